@@ -1,0 +1,136 @@
+"""ctypes binding of libdexbotic_amd.so (C ABI declared in include/dexbotic_amd.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module
+raises at import; every kernel call checks the status code and raises ``DxaError`` with
+``dxa_last_error()``.  Build the library with ``python -m dexbotic_amd.build`` (done by
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdexbotic_amd.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4, 5
+NT, NN, TN = 0, 1, 2
+
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+_int = C.c_int
+
+
+class DxaError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("layout", _i32), ("in_dtype", _i32), ("out_dtype", _i32), ("act", _i32),
+        ("M", _i64), ("N", _i64), ("K", _i64),
+        ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
+        ("bias", _vp), ("residual", _vp), ("ldr", _i64), ("aux_out", _vp), ("mulgrad", _vp), ("ldg", _i64),
+        ("alpha", _f32), ("accumulate", _i32), ("nb", _i32 * 3),
+        ("sA", _i64 * 3), ("sB", _i64 * 3), ("sC", _i64 * 3), ("sR", _i64 * 3), ("sG", _i64 * 3),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("B", _i32), ("Hq", _i32), ("Hkv", _i32), ("Sq", _i32), ("Sk", _i32), ("D", _i32),
+        ("causal", _i32), ("scale", _f32),
+        ("q", _vp), ("q_sb", _i64), ("q_sh", _i64), ("q_ss", _i64),
+        ("k", _vp), ("k_sb", _i64), ("k_sh", _i64), ("k_ss", _i64),
+        ("v", _vp), ("v_sb", _i64), ("v_sh", _i64), ("v_ss", _i64),
+        ("o", _vp), ("o_sb", _i64), ("o_sh", _i64), ("o_ss", _i64),
+        ("lse", _vp), ("kv_start", _vp), ("kv_end", _vp),
+        ("d_o", _vp), ("do_sb", _i64), ("do_sh", _i64), ("do_ss", _i64),
+        ("dq", _vp), ("dq_sb", _i64), ("dq_sh", _i64), ("dq_ss", _i64),
+        ("dk", _vp), ("dk_sb", _i64), ("dk_sh", _i64), ("dk_ss", _i64),
+        ("dv", _vp), ("dv_sb", _i64), ("dv_sh", _i64), ("dv_ss", _i64),
+        ("force_generic", _i32),
+    ]
+
+
+class AdamWDesc(C.Structure):
+    _fields_ = [
+        ("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("shadow", _vp),
+        ("chunk_start", _vp), ("chunk_len", _vp), ("chunk_grp", _vp), ("n_chunks", _i32),
+        ("lr", _f32 * 8), ("wd", _f32 * 8),
+        ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("bc1", _f32), ("bc2", _f32),
+        ("clip_coef", _vp),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/dexbotic_amd.h
+SIGNATURES = {
+    "dxa_last_error": (C.c_char_p, []),
+    "dxa_version": (_int, []),
+    "dxa_gemm": (_int, [C.POINTER(GemmDesc), _vp]),
+    "dxa_rmsnorm_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
+    "dxa_rmsnorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "dxa_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
+    "dxa_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "dxa_norm_bwd_blocks": (_int, [_i64]),
+    "dxa_colsum": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _sz, _vp]),
+    "dxa_rope_split": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "dxa_rope_merge": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "dxa_attn_fwd": (_int, [C.POINTER(AttnDesc), _vp]),
+    "dxa_attn_bwd_workspace": (_sz, [C.POINTER(AttnDesc)]),
+    "dxa_attn_bwd": (_int, [C.POINTER(AttnDesc), _vp, _sz, _vp]),
+    "dxa_swiglu_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_swiglu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_act_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp]),
+    "dxa_act_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "dxa_add": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "dxa_cast": (_int, [_vp, _vp, _i64, _int, _int, _vp]),
+    "dxa_copy2d": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp]),
+    "dxa_splice_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_splice_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "dxa_scatter_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp]),
+    "dxa_im2col": (_int, [_vp, _vp, _int, _int, _int, _int, _i64, _int, _int, _vp]),
+    "dxa_vit_embed_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "dxa_vit_embed_bwd": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "dxa_qsample": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "dxa_timestep_embedding": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "dxa_dit_assemble_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "dxa_dit_assemble_bwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    "dxa_token_drop": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "dxa_token_drop_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_mse_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
+    "dxa_ddim_step": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _f32, _f32, _f32, _vp]),
+    "dxa_adamw": (_int, [C.POINTER(AdamWDesc), _vp]),
+    "dxa_sumsq": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
+    "dxa_clip_coef": (_int, [_vp, _f32, _vp, _vp, _vp]),
+    "dxa_scale": (_int, [_vp, _i64, _f32, _vp]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"dexbotic_amd: native library {LIB_PATH} not found. Build it with "
+            "`python -m dexbotic_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"dexbotic_amd: symbol {name} missing from {LIB_PATH} (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return (lib.dxa_last_error() or b"").decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise DxaError(f"{what}: status {rc}: {last_error()}")

@@ -1,0 +1,479 @@
+// Attention for the CogACT path (see include/dexbotic_amd.h :: dxa_attn_*).
+//
+// FORWARD, bf16, head_dim 64/128 — fused flash kernel:
+//   workgroup = 4 waves = 64 query rows (16 per wave); K/V tiles of 64 keys staged in LDS
+//   (K row-major [key][d], V transposed [d][key] through an in-register 4x8 transpose), both XOR
+//   swizzled so the ds_read_b128 / ds_read_b64 fragment reads are bank-conflict free.
+//   "Swapped" products keep everything lane-local:
+//     S^T = K Q^T  -> lane (q = lane&15, g = lane>>4) holds 16 scores of ONE query (keys 16n+4g+r):
+//                     the row max / row sum are 15 local ops + two wavefront shuffles (xor 16, 32);
+//     O^T = V^T P^T-> the bf16 P fragment of the PV MFMA is exactly the lane's own registers (a
+//                     k-slot permutation shared with the V^T fragment), so P never touches LDS;
+//                     the running rescale of O is one scalar per lane.
+//   fp32 online softmax, fp32 accumulation, saves log-sum-exp for the backward.
+// FORWARD, generic (any dtype / head_dim): one wavefront per query row, fp32 math, scores in LDS.
+// BACKWARD: recompute P = exp(scale*QK^T - lse) and form dQ/dK/dV with five batched MFMA GEMMs
+//   (dxa_gemm: NT scores, NT dP, NN dQ, TN dK, TN dV; fp32 scores/dP) plus three HBM-bound kernels.
+//   With 288 GB of HBM the [B,H,Sq,Sk] probability slab of one layer (74 MB at B16/S287) is cheap;
+//   the GQA group is folded into the GEMM row index so K/V gradients need no separate reduction.
+#include "common.h"
+
+namespace {
+
+struct AttnP {
+  int B, Hq, Hkv, Sq, Sk, D, causal;
+  float scale;
+  const char* q; int64_t q_sb, q_sh, q_ss;
+  const char* k; int64_t k_sb, k_sh, k_ss;
+  const char* v; int64_t v_sb, v_sh, v_ss;
+  char* o; int64_t o_sb, o_sh, o_ss;
+  float* lse;
+  const int32_t* kv_start;
+  const int32_t* kv_end;
+};
+
+// ------------------------------------------------------------------------------------ generic forward
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void attn_fwd_generic_k(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* qs = sm + (size_t)wave * (p.D + p.Sk);
+  float* ps = qs + p.D;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t total = (int64_t)p.B * p.Hq * p.Sq;
+  if (row >= total) return;
+  const int i = (int)(row % p.Sq);
+  const int h = (int)((row / p.Sq) % p.Hq);
+  const int b = (int)(row / ((int64_t)p.Sq * p.Hq));
+  const int hk = h / (p.Hq / p.Hkv);
+  const T* q = reinterpret_cast<const T*>(p.q) + b * p.q_sb + h * p.q_sh + (int64_t)i * p.q_ss;
+  const T* k = reinterpret_cast<const T*>(p.k) + b * p.k_sb + hk * p.k_sh;
+  const T* v = reinterpret_cast<const T*>(p.v) + b * p.v_sb + hk * p.v_sh;
+  T* o = reinterpret_cast<T*>(p.o) + b * p.o_sb + h * p.o_sh + (int64_t)i * p.o_ss;
+  for (int d = lane; d < p.D; d += 64) qs[d] = ldf<T>(q + d);
+  int j0 = p.kv_start ? p.kv_start[b] : 0;
+  int j1 = p.kv_end ? p.kv_end[b] : p.Sk;
+  if (p.causal) j1 = min(j1, i + (p.Sk - p.Sq) + 1);
+  j0 = max(j0, 0);
+  j1 = min(j1, p.Sk);
+  // wave-private LDS: same-wave write->read needs only the LDS counter, __syncthreads not required,
+  // but lanes read values written by other lanes: make it visible
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  float mx = -INFINITY;
+  for (int j = j0 + lane; j < j1; j += 64) {
+    const T* kr = k + (int64_t)j * p.k_ss;
+    float acc = 0.f;
+    for (int d = 0; d < p.D; d += VEC) {
+      float kv[VEC];
+      Vec<T, VEC>::ld(kv, kr + d);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc += qs[d + e] * kv[e];
+    }
+    acc *= p.scale;
+    ps[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = j0 + lane; j < j1; j += 64) {
+    const float e = expf(ps[j] - mx);
+    ps[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const bool any = j1 > j0;
+  const float inv = any ? 1.f / sum : 0.f;
+  for (int j = j0 + lane; j < j1; j += 64) ps[j] = rnd<T>(ps[j] * inv);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < p.D; d += 64) {
+    float acc = 0.f;
+    for (int j = j0; j < j1; ++j) acc += ps[j] * ldf<T>(v + (int64_t)j * p.v_ss + d);
+    stf<T>(o + d, acc);
+  }
+  if (lane == 0 && p.lse) p.lse[row] = any ? mx + logf(sum) : 0.f;
+}
+
+// -------------------------------------------------------------------------------------- flash forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
+  constexpr int NCH = D / 8;          // 16-B chunks per K row
+  constexpr int KROW = D * 2;         // bytes per K row
+  constexpr int KT_BYTES = 64 * KROW; // K tile
+  constexpr int VT_BYTES = D * 128;   // V^T tile: D rows x 64 keys x 2 B
+  __shared__ __attribute__((aligned(16))) char smem[KT_BYTES + VT_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + KT_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int q0 = blockIdx.x * 64;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
+
+  // Q fragments: MFMA second operand, lane (q = l16, k-group lg) holds d = 32*ds + 8*lg .. +7
+  const int qi = q0 + wave * 16 + l16;
+  uint4 qf[D / 32];
+#pragma unroll
+  for (int ds = 0; ds < D / 32; ++ds) {
+    qf[ds] = make_uint4(0, 0, 0, 0);
+    if (qi < p.Sq) qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
+  }
+  f32x4_t oacc[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) oacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int j_lo = p.kv_start ? p.kv_start[b] : 0;
+  int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
+  j_lo = max(j_lo, 0);
+  j_hi = min(j_hi, p.Sk);
+  const int coff = p.Sk - p.Sq;
+  int blk_hi = j_hi;  // exclusive key bound for the whole workgroup
+  if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
+  const int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;  // exclusive bound for this lane's query
+  const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
+
+  for (int kt = t_lo; kt < t_hi; ++kt) {
+    const int key0 = kt * 64;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K tile: [64][D] row-major, chunk ^= row & (NCH-1)
+    {
+      constexpr int RPI = 256 / NCH;       // rows per pass
+      const int c = tid % NCH;
+#pragma unroll
+      for (int i = 0; i < 64 / RPI; ++i) {
+        const int r = tid / NCH + RPI * i;
+        const int key = key0 + r;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (key < p.Sk) val = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + c * 8);
+        *reinterpret_cast<uint4*>(Ks + r * KROW + ((c ^ (r & (NCH - 1))) << 4)) = val;
+      }
+    }
+    // ---- stage V^T tile: thread (kc = key chunk of 8, dg = group of 4 d) transposes 8x4 -> 4x8
+    if (tid < 8 * (D / 4)) {
+      const int kc = tid & 7, dg = tid >> 3;
+      uint2 vv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = key0 + kc * 8 + e;
+        vv[e] = make_uint2(0, 0);
+        if (key < p.Sk) vv[e] = *reinterpret_cast<const uint2*>(vb + (int64_t)key * p.v_ss + dg * 4);
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = dg * 4 + qd;
+        uint32_t w[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const uint32_t lo = (qd & 2) ? vv[2 * m].y : vv[2 * m].x;
+          const uint32_t hi = (qd & 2) ? vv[2 * m + 1].y : vv[2 * m + 1].x;
+          const uint32_t lo16 = (qd & 1) ? (lo >> 16) : (lo & 0xffffu);
+          const uint32_t hi16 = (qd & 1) ? (hi >> 16) : (hi & 0xffffu);
+          w[m] = lo16 | (hi16 << 16);
+        }
+        *reinterpret_cast<uint4*>(Vs + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : sacc[n][r] = score(query l16, key key0 + 16n + 4lg + r)
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      sacc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int r = n * 16 + l16;
+#pragma unroll
+      for (int ds = 0; ds < D / 32; ++ds) {
+        const int c = 4 * ds + lg;
+        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + r * KROW + ((c ^ (r & (NCH - 1))) << 4));
+        sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                          __builtin_bit_cast(bf16x8_t, qf[ds]), sacc[n], 0, 0, 0);
+      }
+    }
+    // ---- online softmax for this lane's query
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + 16 * n + 4 * lg + r;
+        const bool vis = key >= j_lo && key < my_hi;
+        const float s = vis ? sacc[n][r] * p.scale : -INFINITY;
+        sacc[n][r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    float alpha = 1.f;
+    if (m_new > -INFINITY) alpha = expf(m_run - m_new);  // m_run = -inf -> 0
+    float psum = 0.f;
+    uint32_t pk[8];  // bf16 pairs: pk[2*kb2 + ...] see below
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[r] = (m_new > -INFINITY) ? expf(sacc[n][r] - m_new) : 0.f;  // exp(-inf) = 0 for masked keys
+        psum += e[r];
+      }
+      pk[2 * n] = (uint32_t)f2bf(e[0]) | ((uint32_t)f2bf(e[1]) << 16);
+      pk[2 * n + 1] = (uint32_t)f2bf(e[2]) | ((uint32_t)f2bf(e[3]) << 16);
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < D / 16; ++i) {
+      oacc[i][0] *= alpha; oacc[i][1] *= alpha; oacc[i][2] *= alpha; oacc[i][3] *= alpha;
+    }
+    // ---- O^T += V^T P^T.  k-slot (lg, e) of 32-key block kb2 <-> key 32*kb2 + 16*(e>>2) + 4*lg + (e&3):
+    //      P fragment = {sacc[2kb2][0..3], sacc[2kb2+1][0..3]} of this lane (already in pk);
+    //      V^T fragment of row d: two 8-byte reads at keys 32kb2+4lg and 32kb2+16+4lg.
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      const uint4 pf = make_uint4(pk[4 * kb2], pk[4 * kb2 + 1], pk[4 * kb2 + 2], pk[4 * kb2 + 3]);
+#pragma unroll
+      for (int di = 0; di < D / 16; ++di) {
+        const int d = di * 16 + l16;
+        const int sw = (d >> 1) & 7;
+        const int k1 = 32 * kb2 + 4 * lg, k2 = k1 + 16;
+        const uint2 v1 = *reinterpret_cast<const uint2*>(Vs + d * 128 + ((((k1 >> 3)) ^ sw) << 4) + (k1 & 7) * 2);
+        const uint2 v2 = *reinterpret_cast<const uint2*>(Vs + d * 128 + ((((k2 >> 3)) ^ sw) << 4) + (k2 & 7) * 2);
+        const uint4 vf = make_uint4(v1.x, v1.y, v2.x, v2.y);
+        oacc[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                           __builtin_bit_cast(bf16x8_t, pf), oacc[di], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: lane holds O[query l16][d = 16di + 4lg + r]
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (qi < p.Sq) {
+    bf16_t* orow = reinterpret_cast<bf16_t*>(p.o) + b * p.o_sb + h * p.o_sh + (int64_t)qi * p.o_ss;
+#pragma unroll
+    for (int di = 0; di < D / 16; ++di) {
+      uint2 ov;
+      ov.x = (uint32_t)f2bf(oacc[di][0] * inv) | ((uint32_t)f2bf(oacc[di][1] * inv) << 16);
+      ov.y = (uint32_t)f2bf(oacc[di][2] * inv) | ((uint32_t)f2bf(oacc[di][3] * inv) << 16);
+      *reinterpret_cast<uint2*>(orow + di * 16 + 4 * lg) = ov;
+    }
+    if (lg == 0 && p.lse)
+      p.lse[((int64_t)b * p.Hq + h) * p.Sq + qi] = l_tot > 0.f ? m_run + logf(l_tot) : 0.f;
+  }
+}
+
+// -------------------------------------------------------------------------------- backward helpers
+// P[b,h,i,j] = visible ? exp(scale*S - lse) : 0   (S fp32 -> P dtype T)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_k(const float* __restrict__ S, const float* __restrict__ lse,
+                                                    T* __restrict__ P, int B, int H, int Sq, int Sk, float scale, int causal,
+                                                    const int32_t* __restrict__ kv_start, const int32_t* __restrict__ kv_end) {
+  const int64_t total = (int64_t)B * H * Sq * Sk;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int j = (int)(it % Sk);
+    const int64_t row = it / Sk;
+    const int i = (int)(row % Sq);
+    const int b = (int)(row / ((int64_t)Sq * H));
+    int j0 = kv_start ? kv_start[b] : 0, j1 = kv_end ? kv_end[b] : Sk;
+    if (causal) j1 = min(j1, i + (Sk - Sq) + 1);
+    const bool vis = j >= j0 && j < j1;
+    stf<T>(P + it, vis ? expf(S[it] * scale - lse[row]) : 0.f);
+  }
+}
+// delta[b,h,i] = sum_d dO*O ; one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_k(const T* __restrict__ dO, int64_t do_sb, int64_t do_sh, int64_t do_ss,
+                                                    const T* __restrict__ O, int64_t o_sb, int64_t o_sh, int64_t o_ss,
+                                                    float* __restrict__ delta, int B, int H, int Sq, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * H * Sq) return;
+  const int i = (int)(row % Sq);
+  const int h = (int)((row / Sq) % H);
+  const int b = (int)(row / ((int64_t)Sq * H));
+  const T* a = dO + b * do_sb + h * do_sh + (int64_t)i * do_ss;
+  const T* c = O + b * o_sb + h * o_sh + (int64_t)i * o_ss;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += ldf<T>(a + d) * ldf<T>(c + d);
+  s = wave_sum(s);
+  if (lane == 0) delta[row] = s;
+}
+// dS = P * (dP - delta) * scale   (dP fp32 -> dS dtype T)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_ds_k(const T* __restrict__ P, const float* __restrict__ dP,
+                                                 const float* __restrict__ delta, T* __restrict__ dS, int64_t rows, int Sk, float scale) {
+  const int64_t total = rows * Sk;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int64_t row = it / Sk;
+    stf<T>(dS + it, ldf<T>(P + it) * (dP[it] - delta[row]) * scale);
+  }
+}
+
+inline bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+AttnP make_params(const dxa_attn_desc* d) {
+  AttnP p;
+  p.B = d->B; p.Hq = d->Hq; p.Hkv = d->Hkv; p.Sq = d->Sq; p.Sk = d->Sk; p.D = d->D; p.causal = d->causal;
+  p.scale = d->scale;
+  p.q = (const char*)d->q; p.q_sb = d->q_sb; p.q_sh = d->q_sh; p.q_ss = d->q_ss;
+  p.k = (const char*)d->k; p.k_sb = d->k_sb; p.k_sh = d->k_sh; p.k_ss = d->k_ss;
+  p.v = (const char*)d->v; p.v_sb = d->v_sb; p.v_sh = d->v_sh; p.v_ss = d->v_ss;
+  p.o = (char*)d->o; p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_ss = d->o_ss;
+  p.lse = d->lse; p.kv_start = d->kv_start; p.kv_end = d->kv_end;
+  return p;
+}
+
+int check_common(const dxa_attn_desc* d, const char* who) {
+  if (!d) { dxa_set_error("%s: null desc", who); return DXA_ERR_BAD_ARG; }
+  if (!(d->dtype == DXA_F32 || d->dtype == DXA_BF16)) { dxa_set_error("%s: bad dtype", who); return DXA_ERR_BAD_ARG; }
+  if (d->B < 0 || d->Hq <= 0 || d->Hkv <= 0 || d->Hq % d->Hkv != 0 || d->Sq < 0 || d->Sk < 0 || d->D <= 0) {
+    dxa_set_error("%s: bad shape B=%d Hq=%d Hkv=%d Sq=%d Sk=%d D=%d", who, d->B, d->Hq, d->Hkv, d->Sq, d->Sk, d->D);
+    return DXA_ERR_BAD_ARG;
+  }
+  if (!d->q || !d->k || !d->v || !d->o || !d->lse) { dxa_set_error("%s: null tensor", who); return DXA_ERR_BAD_ARG; }
+  return DXA_OK;
+}
+
+}  // namespace
+
+extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
+  if (int rc = check_common(d, "dxa_attn_fwd")) return rc;
+  if (d->B == 0 || d->Sq == 0) return DXA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const AttnP p = make_params(d);
+  const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
+                        d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
+                        d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
+  const bool flash_ok = !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && strides8 &&
+                        al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
+  if (flash_ok) {
+    dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
+    if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_flash_k<64>), grid, dim3(256), 0, st, p);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
+  const size_t lds = 4 * (size_t)(d->D + d->Sk) * sizeof(float);
+  DXA_CHECK_ARG(lds <= 160 * 1024, "dxa_attn_fwd: generic kernel supports Sk+D <= 10240 (got %d)", d->Sk + d->D);
+  const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  const size_t es = d->dtype == DXA_BF16 ? 2 : 4;
+  const bool vec = d->D % 4 == 0 && d->k_ss % 4 == 0 && d->k_sb % 4 == 0 && d->k_sh % 4 == 0 && al(d->k, 4 * es);
+#define LAUNCH_GENERIC(T, V)                                                                                      \
+  do {                                                                                                            \
+    if (lds > 48 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_generic_k<T, V>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipLaunchKernelGGL((attn_fwd_generic_k<T, V>), grid, dim3(256), lds, st, p);                                  \
+  } while (0)
+  if (d->dtype == DXA_BF16) { if (vec) LAUNCH_GENERIC(bf16_t, 4); else LAUNCH_GENERIC(bf16_t, 1); }
+  else { if (vec) LAUNCH_GENERIC(float, 4); else LAUNCH_GENERIC(float, 1); }
+#undef LAUNCH_GENERIC
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" size_t dxa_attn_bwd_workspace(const dxa_attn_desc* d) {
+  if (!d) return 0;
+  const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
+  const size_t es = d->dtype == DXA_BF16 ? 2 : 4;
+  return align_up(n * 4, 256) + 2 * align_up(n * es, 256) + align_up((size_t)d->B * d->Hq * d->Sq * 4, 256);
+}
+
+extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  if (int rc = check_common(d, "dxa_attn_bwd")) return rc;
+  DXA_CHECK_ARG(d->d_o && d->dq && d->dk && d->dv, "dxa_attn_bwd: null gradient tensor");
+  DXA_CHECK_ARG(workspace && workspace_bytes >= dxa_attn_bwd_workspace(d), "dxa_attn_bwd: workspace too small");
+  if (d->B == 0 || d->Sq == 0 || d->Sk == 0) return DXA_OK;
+  const int G = d->Hq / d->Hkv;
+  if (G > 1) {
+    if (d->q_sh != (int64_t)d->Sq * d->q_ss || d->do_sh != (int64_t)d->Sq * d->do_ss) {
+      dxa_set_error("dxa_attn_bwd: GQA needs head-major q and dO (sh == Sq*ss) to fold the group into GEMM rows");
+      return DXA_ERR_UNSUPPORTED;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
+  const size_t es = d->dtype == DXA_BF16 ? 2 : 4;
+  char* w = (char*)workspace;
+  float* Sf = (float*)w; w += align_up(n * 4, 256);
+  void* P = w; w += align_up(n * es, 256);
+  void* dS = w; w += align_up(n * es, 256);
+  float* delta = (float*)w;
+  const int64_t SqSk = (int64_t)d->Sq * d->Sk;
+
+  dxa_gemm_desc g;
+  auto reset = [&](int layout, int out_dtype) {
+    memset(&g, 0, sizeof(g));
+    g.layout = layout; g.in_dtype = d->dtype; g.out_dtype = out_dtype; g.act = DXA_ACT_NONE; g.alpha = 1.f;
+    g.nb[0] = d->B; g.nb[1] = d->Hkv; g.nb[2] = G;
+  };
+  int rc;
+  // 1. S = Q K^T (fp32 out), batch (b, hkv, g)
+  reset(DXA_NT, DXA_F32);
+  g.M = d->Sq; g.N = d->Sk; g.K = d->D;
+  g.A = d->q; g.lda = d->q_ss; g.sA[0] = d->q_sb; g.sA[1] = d->q_sh * G; g.sA[2] = d->q_sh;
+  g.B = d->k; g.ldb = d->k_ss; g.sB[0] = d->k_sb; g.sB[1] = d->k_sh; g.sB[2] = 0;
+  g.C = Sf; g.ldc = d->Sk; g.sC[0] = (int64_t)d->Hq * SqSk; g.sC[1] = (int64_t)G * SqSk; g.sC[2] = SqSk;
+  if ((rc = dxa_gemm(&g, stream))) return rc;
+  // 2. P = exp(scale*S - lse)
+  {
+    dim3 grid(dxa_grid1d((int64_t)n, 256));
+    if (d->dtype == DXA_BF16)
+      hipLaunchKernelGGL((attn_probs_k<bf16_t>), grid, dim3(256), 0, st, Sf, d->lse, (bf16_t*)P, d->B, d->Hq, d->Sq, d->Sk, d->scale, d->causal, d->kv_start, d->kv_end);
+    else
+      hipLaunchKernelGGL((attn_probs_k<float>), grid, dim3(256), 0, st, Sf, d->lse, (float*)P, d->B, d->Hq, d->Sq, d->Sk, d->scale, d->causal, d->kv_start, d->kv_end);
+  }
+  // 3. delta = rowsum(dO * O)
+  {
+    const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (d->dtype == DXA_BF16)
+      hipLaunchKernelGGL((attn_delta_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)d->d_o, d->do_sb, d->do_sh, d->do_ss, (const bf16_t*)d->o, d->o_sb, d->o_sh, d->o_ss, delta, d->B, d->Hq, d->Sq, d->D);
+    else
+      hipLaunchKernelGGL((attn_delta_k<float>), grid, dim3(256), 0, st, (const float*)d->d_o, d->do_sb, d->do_sh, d->do_ss, (const float*)d->o, d->o_sb, d->o_sh, d->o_ss, delta, d->B, d->Hq, d->Sq, d->D);
+  }
+  // 4. dP = dO V^T (fp32 out, reuses the score slab)
+  reset(DXA_NT, DXA_F32);
+  g.M = d->Sq; g.N = d->Sk; g.K = d->D;
+  g.A = d->d_o; g.lda = d->do_ss; g.sA[0] = d->do_sb; g.sA[1] = d->do_sh * G; g.sA[2] = d->do_sh;
+  g.B = d->v; g.ldb = d->v_ss; g.sB[0] = d->v_sb; g.sB[1] = d->v_sh; g.sB[2] = 0;
+  g.C = Sf; g.ldc = d->Sk; g.sC[0] = (int64_t)d->Hq * SqSk; g.sC[1] = (int64_t)G * SqSk; g.sC[2] = SqSk;
+  if ((rc = dxa_gemm(&g, stream))) return rc;
+  // 5. dS = P * (dP - delta) * scale
+  {
+    dim3 grid(dxa_grid1d((int64_t)n, 256));
+    const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
+    if (d->dtype == DXA_BF16)
+      hipLaunchKernelGGL((attn_ds_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)P, Sf, delta, (bf16_t*)dS, rows, d->Sk, d->scale);
+    else
+      hipLaunchKernelGGL((attn_ds_k<float>), grid, dim3(256), 0, st, (const float*)P, Sf, delta, (float*)dS, rows, d->Sk, d->scale);
+  }
+  // 6. dQ = dS K  (NN), batch (b, hkv, g)
+  reset(DXA_NN, d->dtype);
+  g.M = d->Sq; g.N = d->D; g.K = d->Sk;
+  g.A = dS; g.lda = d->Sk; g.sA[0] = (int64_t)d->Hq * SqSk; g.sA[1] = (int64_t)G * SqSk; g.sA[2] = SqSk;
+  g.B = d->k; g.ldb = d->k_ss; g.sB[0] = d->k_sb; g.sB[1] = d->k_sh; g.sB[2] = 0;
+  g.C = d->dq; g.ldc = d->dq_ss; g.sC[0] = d->dq_sb; g.sC[1] = d->dq_sh * G; g.sC[2] = d->dq_sh;
+  if ((rc = dxa_gemm(&g, stream))) return rc;
+  // 7. dK = dS^T Q (TN) and 8. dV = P^T dO (TN): contraction over (g, i) = G*Sq rows, batch (b, hkv)
+  reset(DXA_TN, d->dtype);
+  g.nb[2] = 1;
+  g.M = d->Sk; g.N = d->D; g.K = (int64_t)G * d->Sq;
+  g.A = dS; g.lda = d->Sk; g.sA[0] = (int64_t)d->Hq * SqSk; g.sA[1] = (int64_t)G * SqSk;
+  g.B = d->q; g.ldb = d->q_ss; g.sB[0] = d->q_sb; g.sB[1] = d->q_sh * G;
+  g.C = d->dk; g.ldc = d->dk_ss; g.sC[0] = d->dk_sb; g.sC[1] = d->dk_sh;
+  if ((rc = dxa_gemm(&g, stream))) return rc;
+  g.A = P;
+  g.B = d->d_o; g.ldb = d->do_ss; g.sB[0] = d->do_sb; g.sB[1] = d->do_sh * G;
+  g.C = d->dv; g.ldc = d->dv_ss; g.sC[0] = d->dv_sb; g.sC[1] = d->dv_sh;
+  if ((rc = dxa_gemm(&g, stream))) return rc;
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}

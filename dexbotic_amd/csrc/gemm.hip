@@ -1,0 +1,423 @@
+// MFMA GEMM with fused epilogue for gfx950 (see include/dexbotic_amd.h :: dxa_gemm).
+//
+// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA 16x16 tiles),
+// K-slab of 128 BYTES per row per operand (64 bf16 / 32 fp32) double-buffered in LDS (64 KiB), so
+// two workgroups share a CU.  LDS rows are 8 x 16-byte chunks, XOR-swizzled by (row & 7): the
+// ds_read_b128 fragment reads of a 16-lane group land on 16 distinct 16-B slots (conflict free).
+//
+//   k-contiguous operands (A of NT/NN, B of NT)  : 16-B global loads, straight 16-B LDS stores.
+//   k-strided operands  (A of TN, B of NN/TN)     : each thread loads 4 rows x (8|4) k, transposes
+//                                                  in registers and stores four 16-B chunks.
+// MFMA: bf16 -> v_mfma_f32_16x16x32_bf16 (8 k per lane);  fp32 -> 4 x v_mfma_f32_16x16x4_f32 fed from
+// one 16-B LDS read (lane group g holds k = 4g..4g+3 of a 16-k block; step j uses element j of both
+// operands, i.e. a k-permutation shared by A and B — the sum over the block is unchanged and is an
+// exact fp32 fma chain).
+// Operands are fed swapped (MFMA "A" = B-tile rows = n, MFMA "B" = A-tile rows = m) so that a lane's
+// four accumulator registers are four CONSECUTIVE n for one m: the epilogue does 8/16-byte stores.
+// Workgroup ids are remapped XCD-aware (8 XCDs, private L2s): each XCD walks a contiguous range of
+// a grouped (8 tile-rows) ordering so neighbouring tiles share A/B panels in that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;              // bytes per LDS row (K slab)
+constexpr int TILE_BYTES = BM * ROWB;  // 16 KiB per operand per buffer
+
+struct GemmP {
+  int64_t M, N, K;
+  const char* A; int64_t lda;
+  const char* B; int64_t ldb;
+  char* C; int64_t ldc;
+  const char* bias;
+  const char* R; int64_t ldr;
+  char* aux;
+  const char* G; int64_t ldg;
+  float alpha;
+  int act, accumulate;
+  int nb1, nb2;  // nb[1], nb[2]
+  int64_t sA[3], sB[3], sC[3], sR[3], sG[3];
+  int tm, tn;
+  int vecA, vecB, vecC, vecR, vecG, vecBias;
+};
+
+template <typename T> struct EltTraits;
+template <> struct EltTraits<float> { static constexpr int EPC = 4; };   // elements per 16-B chunk
+template <> struct EltTraits<bf16_t> { static constexpr int EPC = 8; };
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+
+// ---- k-contiguous staging: thread -> (chunk c = tid&7, rows (tid>>3)+32*i) --------------------------
+template <typename T>
+__device__ __forceinline__ void load_kc(uint4 (&r)[4], const T* __restrict__ base, int64_t ld, int64_t row0,
+                                        int64_t rows, int64_t k0, int64_t K, int vec, int tid) {
+  constexpr int EPC = EltTraits<T>::EPC;
+  const int c = tid & 7;
+  const int64_t k = k0 + (int64_t)c * EPC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = row0 + (tid >> 3) + 32 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < rows && k < K) {
+      const T* p = base + row * ld + k;
+      if (vec && k + EPC <= K) {
+        v = *reinterpret_cast<const uint4*>(p);
+      } else {
+        alignas(16) T tmp[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tmp[e] = (k + e < K) ? p[e] : (T)0;
+        v = *reinterpret_cast<const uint4*>(tmp);
+      }
+    }
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void store_kc(const uint4 (&r)[4], char* tile, int tid) {
+  const int c = tid & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    *reinterpret_cast<uint4*>(tile + lds_off(row, c)) = r[i];
+  }
+}
+
+// ---- k-strided staging: element (row, k) at base[k*ld + row]; thread -> (chunk kg = tid&7, rows 4*(tid>>3)+q)
+template <typename T> struct KsRegs;
+template <> struct KsRegs<bf16_t> { uint2 v[8]; };   // v[j] = 4 rows for k_j
+template <> struct KsRegs<float> { uint4 v[4]; };
+
+template <typename T>
+__device__ __forceinline__ void load_ks(KsRegs<T>& r, const T* __restrict__ base, int64_t ld, int64_t row0,
+                                        int64_t rows, int64_t k0, int64_t K, int vec, int tid) {
+  constexpr int EPC = EltTraits<T>::EPC;
+  const int kg = tid & 7;
+  const int64_t rr = row0 + 4 * (tid >> 3);
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    const int64_t k = k0 + kg * EPC + j;
+    alignas(16) T tmp[4] = {(T)0, (T)0, (T)0, (T)0};
+    if (k < K && rr < rows) {
+      const T* p = base + k * ld + rr;
+      if (vec && rr + 3 < rows) {
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<uint2*>(tmp) = *reinterpret_cast<const uint2*>(p);
+        } else {
+          *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(p);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tmp[q] = (rr + q < rows) ? p[q] : (T)0;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      r.v[j] = *reinterpret_cast<const uint2*>(tmp);
+    } else {
+      r.v[j] = *reinterpret_cast<const uint4*>(tmp);
+    }
+  }
+}
+__device__ __forceinline__ uint32_t half_of(const uint2& v, int q) {
+  const uint32_t w = (q & 2) ? v.y : v.x;
+  return (q & 1) ? (w >> 16) : (w & 0xffffu);
+}
+__device__ __forceinline__ void store_ks(const KsRegs<bf16_t>& r, char* tile, int tid) {
+  const int kg = tid & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 4 * (tid >> 3) + q;
+    uint4 o;
+    o.x = half_of(r.v[0], q) | (half_of(r.v[1], q) << 16);
+    o.y = half_of(r.v[2], q) | (half_of(r.v[3], q) << 16);
+    o.z = half_of(r.v[4], q) | (half_of(r.v[5], q) << 16);
+    o.w = half_of(r.v[6], q) | (half_of(r.v[7], q) << 16);
+    *reinterpret_cast<uint4*>(tile + lds_off(row, kg)) = o;
+  }
+}
+__device__ __forceinline__ uint32_t comp_of(const uint4& v, int q) {
+  return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ void store_ks(const KsRegs<float>& r, char* tile, int tid) {
+  const int kg = tid & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 4 * (tid >> 3) + q;
+    uint4 o = make_uint4(comp_of(r.v[0], q), comp_of(r.v[1], q), comp_of(r.v[2], q), comp_of(r.v[3], q));
+    *reinterpret_cast<uint4*>(tile + lds_off(row, kg)) = o;
+  }
+}
+
+template <typename T, bool KS> struct Stager;
+template <typename T> struct Stager<T, false> {
+  uint4 r[4];
+  __device__ __forceinline__ void load(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t k0,
+                                       int64_t K, int vec, int tid) {
+    load_kc<T>(r, base, ld, row0, rows, k0, K, vec, tid);
+  }
+  __device__ __forceinline__ void store(char* tile, int tid) { store_kc(r, tile, tid); }
+};
+template <typename T> struct Stager<T, true> {
+  KsRegs<T> r;
+  __device__ __forceinline__ void load(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t k0,
+                                       int64_t K, int vec, int tid) {
+    load_ks<T>(r, base, ld, row0, rows, k0, K, vec, tid);
+  }
+  __device__ __forceinline__ void store(char* tile, int tid) { store_ks(r, tile, tid); }
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_step(f32x4_t& acc, const uint4& first, const uint4& second);
+template <>
+__device__ __forceinline__ void mma_step<bf16_t>(f32x4_t& acc, const uint4& first, const uint4& second) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, first),
+                                                __builtin_bit_cast(bf16x8_t, second), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(f32x4_t& acc, const uint4& first, const uint4& second) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.x), __uint_as_float(second.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.y), __uint_as_float(second.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.z), __uint_as_float(second.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(first.w), __uint_as_float(second.w), acc, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ void load4(float (&o)[4], const T* p, bool vec, int n_ok);
+template <> __device__ __forceinline__ void load4<float>(float (&o)[4], const float* p, bool vec, int n_ok) {
+  if (vec && n_ok == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = i < n_ok ? p[i] : 0.f;
+  }
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(float (&o)[4], const bf16_t* p, bool vec, int n_ok) {
+  if (vec && n_ok == 4) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = i < n_ok ? bf2f(p[i]) : 0.f;
+  }
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4], bool vec, int n_ok);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4], bool vec, int n_ok) {
+  if (vec && n_ok == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < n_ok) p[i] = v[i];
+  }
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4], bool vec, int n_ok) {
+  if (vec && n_ok == 4) {
+    uint2 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < n_ok) p[i] = f2bf(v[i]);
+  }
+}
+
+template <typename TI, typename TO, bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A,B][TILE_BYTES]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+
+  // ---- XCD-aware, grouped tile order --------------------------------------------------------------
+  const int nt = p.tm * p.tn;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * p.tn;
+  const int group = bid / width;
+  const int first_pm = group * GROUP_M;
+  const int gsz = min(p.tm - first_pm, GROUP_M);
+  const int pm = first_pm + (bid % width) % gsz;
+  const int pn = (bid % width) / gsz;
+  const int64_t m0 = (int64_t)pm * BM, n0 = (int64_t)pn * BN;
+
+  // ---- batch offsets ----------------------------------------------------------------------------------
+  const int z = blockIdx.z;
+  const int b2 = z % p.nb2, b1 = (z / p.nb2) % p.nb1, b0 = z / (p.nb2 * p.nb1);
+  const TI* A = reinterpret_cast<const TI*>(p.A) + b0 * p.sA[0] + b1 * p.sA[1] + b2 * p.sA[2];
+  const TI* B = reinterpret_cast<const TI*>(p.B) + b0 * p.sB[0] + b1 * p.sB[1] + b2 * p.sB[2];
+  const int64_t offC = b0 * p.sC[0] + b1 * p.sC[1] + b2 * p.sC[2];
+
+  constexpr int EPC = EltTraits<TI>::EPC;
+  constexpr int BK = 8 * EPC;
+  const int64_t nk = (p.K + BK - 1) / BK;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  Stager<TI, A_KS> sa;
+  Stager<TI, B_KS> sb;
+  sa.load(A, p.lda, m0, p.M, 0, p.K, p.vecA, tid);
+  sb.load(B, p.ldb, n0, p.N, 0, p.K, p.vecB, tid);
+  sa.store(smem, tid);
+  sb.store(smem + TILE_BYTES, tid);
+  __syncthreads();
+
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int cur = (int)(kt & 1);
+    char* As = smem + cur * 2 * TILE_BYTES;
+    char* Bs = As + TILE_BYTES;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.vecA, tid);
+      sb.load(B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, p.vecB, tid);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + l16, 4 * s + lg));
+        bfr[i] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + i * 16 + l16, 4 * s + lg));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) mma_step<TI>(acc[mi][ni], bfr[ni], af[mi]);
+    }
+    if (more) {
+      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      sa.store(An, tid);
+      sb.store(An + TILE_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per (mi,ni), m = .. + l16 and n = .. + 4*lg + {0..3} ---------------------
+  TO* C = reinterpret_cast<TO*>(p.C) + offC;
+  TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) + offC : nullptr;
+  const TI* R = p.R ? reinterpret_cast<const TI*>(p.R) + b0 * p.sR[0] + b1 * p.sR[1] + b2 * p.sR[2] : nullptr;
+  const TI* G = p.G ? reinterpret_cast<const TI*>(p.G) + b0 * p.sG[0] + b1 * p.sG[1] + b2 * p.sG[2] : nullptr;
+  const TI* bias = reinterpret_cast<const TI*>(p.bias);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 16 + 4 * lg;
+    if (n >= p.N) continue;
+    const int n_ok = (int)min((int64_t)4, p.N - n);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) load4<TI>(bv, bias + n, p.vecBias, n_ok);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int64_t m = m0 + wm * 64 + mi * 16 + l16;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha + bv[r];
+      if (AUX) store4<TO>(AUX + m * p.ldc + n, v, p.vecC, n_ok);
+      if (G) {
+        float g[4];
+        load4<TI>(g, G + m * p.ldg + n, p.vecG, n_ok);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= act_grad(p.act, g[r]);
+      } else if (p.act != DXA_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+      }
+      if (R) {
+        float rr[4];
+        load4<TI>(rr, R + m * p.ldr + n, p.vecR, n_ok);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+      }
+      TO* cp = C + m * p.ldc + n;
+      if (p.accumulate) {
+        float c0[4];
+        load4<TO>(c0, cp, p.vecC, n_ok);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += c0[r];
+      }
+      store4<TO>(cp, v, p.vecC, n_ok);
+    }
+  }
+}
+
+template <typename TI, typename TO>
+int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
+  constexpr size_t LDS = 4 * TILE_BYTES;
+  switch (layout) {
+    case DXA_NT: hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false>), grid, dim3(256), LDS, st, p); break;
+    case DXA_NN: hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true>), grid, dim3(256), LDS, st, p); break;
+    case DXA_TN: hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true>), grid, dim3(256), LDS, st, p); break;
+    default: return DXA_ERR_BAD_ARG;
+  }
+  return DXA_OK;
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline bool strides_mult(const int64_t s[3], int64_t m) { return s[0] % m == 0 && s[1] % m == 0 && s[2] % m == 0; }
+
+}  // namespace
+
+extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
+  DXA_CHECK_ARG(d != nullptr, "dxa_gemm: null desc");
+  DXA_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "dxa_gemm: negative dims");
+  DXA_CHECK_ARG(d->layout >= DXA_NT && d->layout <= DXA_TN, "dxa_gemm: bad layout %d", d->layout);
+  DXA_CHECK_ARG(d->in_dtype == DXA_F32 || d->in_dtype == DXA_BF16, "dxa_gemm: bad in_dtype %d", d->in_dtype);
+  DXA_CHECK_ARG(d->out_dtype == d->in_dtype || d->out_dtype == DXA_F32,
+                "dxa_gemm: out_dtype must equal in_dtype or be fp32");
+  DXA_CHECK_ARG(d->nb[0] >= 1 && d->nb[1] >= 1 && d->nb[2] >= 1, "dxa_gemm: batch extents must be >= 1");
+  if (d->M == 0 || d->N == 0) return DXA_OK;
+  DXA_CHECK_ARG(d->A && d->B && d->C, "dxa_gemm: null operand");
+  const int64_t nbatch = (int64_t)d->nb[0] * d->nb[1] * d->nb[2];
+  DXA_CHECK_ARG(nbatch <= 65535, "dxa_gemm: too many batches (%lld)", (long long)nbatch);
+
+  const size_t es = d->in_dtype == DXA_BF16 ? 2 : 4, os = d->out_dtype == DXA_BF16 ? 2 : 4;
+  const int64_t epc = 16 / es;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = (const char*)d->A; p.lda = d->lda;
+  p.B = (const char*)d->B; p.ldb = d->ldb;
+  p.C = (char*)d->C; p.ldc = d->ldc;
+  p.bias = (const char*)d->bias;
+  p.R = (const char*)d->residual; p.ldr = d->ldr;
+  p.aux = (char*)d->aux_out;
+  p.G = (const char*)d->mulgrad; p.ldg = d->ldg;
+  p.alpha = d->alpha; p.act = d->act; p.accumulate = d->accumulate;
+  p.nb1 = d->nb[1]; p.nb2 = d->nb[2];
+  for (int i = 0; i < 3; ++i) {
+    p.sA[i] = d->sA[i]; p.sB[i] = d->sB[i]; p.sC[i] = d->sC[i]; p.sR[i] = d->sR[i]; p.sG[i] = d->sG[i];
+  }
+  p.tm = dxa_cdiv(d->M, BM);
+  p.tn = dxa_cdiv(d->N, BN);
+  const bool a_ks = d->layout == DXA_TN, b_ks = d->layout != DXA_NT;
+  // vector path: k-contiguous needs 16-B aligned rows; k-strided loads 4 consecutive rows (4*es bytes)
+  p.vecA = a_ks ? (aligned_to(d->A, 4 * es) && d->lda % 4 == 0 && strides_mult(d->sA, 4))
+                : (aligned_to(d->A, 16) && d->lda % epc == 0 && strides_mult(d->sA, epc));
+  p.vecB = b_ks ? (aligned_to(d->B, 4 * es) && d->ldb % 4 == 0 && strides_mult(d->sB, 4))
+                : (aligned_to(d->B, 16) && d->ldb % epc == 0 && strides_mult(d->sB, epc));
+  p.vecC = aligned_to(d->C, 4 * os) && d->ldc % 4 == 0 && strides_mult(d->sC, 4) &&
+           (!d->aux_out || aligned_to(d->aux_out, 4 * os));
+  p.vecR = d->residual && aligned_to(d->residual, 4 * es) && d->ldr % 4 == 0 && strides_mult(d->sR, 4);
+  p.vecG = d->mulgrad && aligned_to(d->mulgrad, 4 * es) && d->ldg % 4 == 0 && strides_mult(d->sG, 4);
+  p.vecBias = d->bias && aligned_to(d->bias, 4 * es);
+
+  dim3 grid((unsigned)(p.tm * p.tn), 1, (unsigned)nbatch);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (d->in_dtype == DXA_BF16) {
+    rc = d->out_dtype == DXA_BF16 ? launch<bf16_t, bf16_t>(p, d->layout, grid, st)
+                                  : launch<bf16_t, float>(p, d->layout, grid, st);
+  } else {
+    rc = launch<float, float>(p, d->layout, grid, st);
+  }
+  if (rc != DXA_OK) return rc;
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}

@@ -1,0 +1,401 @@
+// RMSNorm / LayerNorm forward+backward and column sums (HBM-bound; wave64 shuffle reductions).
+// One wavefront owns one row in the forward (no LDS, no barriers): 16-byte loads, fp32 statistics,
+// row re-read from L1/L2 for the normalise pass.  The backward keeps one row per wavefront too and
+// accumulates the weight/bias gradient partials of a workgroup's rows in a per-workgroup fp32 slab
+// (L2 resident), reduced afterwards by dxa_colsum: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- RMSNorm
+template <typename T, typename TW, int VEC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, const TW* __restrict__ w,
+                                                     T* __restrict__ y, float* __restrict__ rstd_out,
+                                                     int64_t rows, int64_t cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * cols;
+  float ss = 0.f;
+  for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+    float v[VEC];
+    Vec<T, VEC>::ld(v, xr + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ss += v[i] * v[i];
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)cols + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+  T* yr = y + row * cols;
+  for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+    float v[VEC], g[VEC];
+    Vec<T, VEC>::ld(v, xr + c);
+    if (w) {
+      Vec<TW, VEC>::ld(g, w + c);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] = 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = g[i] * rnd<T>(v[i] * rstd);
+    Vec<T, VEC>::st(yr + c, v);
+  }
+}
+
+// partial_dw: [gridDim.x][cols]; every block zeroes its own slab first
+template <typename T, typename TW, int VEC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const TW* __restrict__ w, const float* __restrict__ rstd,
+                                                     T* __restrict__ dx, float* __restrict__ partial,
+                                                     int64_t rows, int64_t cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* slab = w ? partial + (int64_t)blockIdx.x * cols : nullptr;
+  if (w) {
+    for (int64_t c = threadIdx.x; c < cols; c += 256) slab[c] = 0.f;
+    __syncthreads();
+  }
+  // rows are dealt round-robin: block b takes rows b*4+wave + k*gridDim.x*4.  The four waves of a block
+  // add into the same slab columns -> serialise them wave by wave (deterministic order).
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < rows; base += (int64_t)gridDim.x * 4) {
+    const int64_t row = base + wave;
+    const bool ok = row < rows;
+    float rs = 0.f, cterm = 0.f;
+    if (ok) {
+      rs = rstd[row];
+      const T* xr = x + row * cols;
+      const T* gr = dy + row * cols;
+      float s = 0.f;
+      for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+        float xv[VEC], gv[VEC], wv[VEC];
+        Vec<T, VEC>::ld(xv, xr + c);
+        Vec<T, VEC>::ld(gv, gr + c);
+        if (w) Vec<TW, VEC>::ld(wv, w + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s += gv[i] * (w ? wv[i] : 1.f) * (xv[i] * rs);
+      }
+      cterm = wave_sum(s) / (float)cols;
+      T* dxr = dx + row * cols;
+      for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+        float xv[VEC], gv[VEC], wv[VEC], o[VEC];
+        Vec<T, VEC>::ld(xv, xr + c);
+        Vec<T, VEC>::ld(gv, gr + c);
+        if (w) Vec<TW, VEC>::ld(wv, w + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float xh = xv[i] * rs;
+          o[i] = rs * (gv[i] * (w ? wv[i] : 1.f) - xh * cterm);
+        }
+        Vec<T, VEC>::st(dxr + c, o);
+      }
+    }
+    if (w) {
+      for (int turn = 0; turn < 4; ++turn) {
+        if (turn == wave && ok) {
+          const T* xr = x + row * cols;
+          const T* gr = dy + row * cols;
+          for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+            float xv[VEC], gv[VEC];
+            Vec<T, VEC>::ld(xv, xr + c);
+            Vec<T, VEC>::ld(gv, gr + c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) slab[c + i] += gv[i] * rnd<T>(xv[i] * rs);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------- LayerNorm
+template <typename T, typename TW, int VEC>
+__global__ __launch_bounds__(256) void layernorm_fwd_k(const T* __restrict__ x, const TW* __restrict__ w,
+                                                       const TW* __restrict__ b, T* __restrict__ y,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       int64_t rows, int64_t cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * cols;
+  float s = 0.f;
+  for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+    float v[VEC];
+    Vec<T, VEC>::ld(v, xr + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float ss = 0.f;
+  for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+    float v[VEC];
+    Vec<T, VEC>::ld(v, xr + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { const float d = v[i] - mean; ss += d * d; }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)cols + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  T* yr = y + row * cols;
+  for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+    float v[VEC], g[VEC], bb[VEC];
+    Vec<T, VEC>::ld(v, xr + c);
+    if (w) Vec<TW, VEC>::ld(g, w + c);
+    if (b) Vec<TW, VEC>::ld(bb, b + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = (v[i] - mean) * rstd * (w ? g[i] : 1.f) + (b ? bb[i] : 0.f);
+    Vec<T, VEC>::st(yr + c, v);
+  }
+}
+
+// partial: [gridDim.x][2*cols] = (dw | db)
+template <typename T, typename TW, int VEC>
+__global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       const TW* __restrict__ w, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, T* __restrict__ dx,
+                                                       float* __restrict__ partial, int64_t rows, int64_t cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* slab = partial ? partial + (int64_t)blockIdx.x * 2 * cols : nullptr;
+  if (slab) {
+    for (int64_t c = threadIdx.x; c < 2 * cols; c += 256) slab[c] = 0.f;
+    __syncthreads();
+  }
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < rows; base += (int64_t)gridDim.x * 4) {
+    const int64_t row = base + wave;
+    const bool ok = row < rows;
+    float rs = 0.f, mu = 0.f;
+    if (ok) {
+      rs = rstd[row];
+      mu = mean[row];
+      const T* xr = x + row * cols;
+      const T* gr = dy + row * cols;
+      float s1 = 0.f, s2 = 0.f;
+      for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+        float xv[VEC], gv[VEC], wv[VEC];
+        Vec<T, VEC>::ld(xv, xr + c);
+        Vec<T, VEC>::ld(gv, gr + c);
+        if (w) Vec<TW, VEC>::ld(wv, w + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float g = gv[i] * (w ? wv[i] : 1.f);
+          s1 += g;
+          s2 += g * ((xv[i] - mu) * rs);
+        }
+      }
+      const float c1 = wave_sum(s1) / (float)cols, c2 = wave_sum(s2) / (float)cols;
+      T* dxr = dx + row * cols;
+      for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+        float xv[VEC], gv[VEC], wv[VEC], o[VEC];
+        Vec<T, VEC>::ld(xv, xr + c);
+        Vec<T, VEC>::ld(gv, gr + c);
+        if (w) Vec<TW, VEC>::ld(wv, w + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float g = gv[i] * (w ? wv[i] : 1.f);
+          o[i] = rs * (g - c1 - (xv[i] - mu) * rs * c2);
+        }
+        Vec<T, VEC>::st(dxr + c, o);
+      }
+    }
+    if (slab) {
+      for (int turn = 0; turn < 4; ++turn) {
+        if (turn == wave && ok) {
+          const T* xr = x + row * cols;
+          const T* gr = dy + row * cols;
+          for (int64_t c = (int64_t)lane * VEC; c < cols; c += 64 * VEC) {
+            float xv[VEC], gv[VEC];
+            Vec<T, VEC>::ld(xv, xr + c);
+            Vec<T, VEC>::ld(gv, gr + c);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              slab[c + i] += gv[i] * ((xv[i] - mu) * rs);
+              slab[cols + c + i] += gv[i];
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------- colsum
+// stage 1: grid (col tiles of 256, row splits); block 256 = 4 waves; lane owns 4 consecutive columns
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1_k(const T* __restrict__ x, int64_t ld, float* __restrict__ part,
+                                                       int64_t rows, int64_t cols, int vec) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * 256 + lane * 4;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < cols) {
+    const int n_ok = (int)min((int64_t)4, cols - c0);
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      const T* p = x + r * ld + c0;
+      if (vec && n_ok == 4) {
+        float v[4];
+        Vec<T, 4>::ld(v, p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] += v[i];
+      } else {
+        for (int i = 0; i < n_ok; ++i) a[i] += ldf<T>(p + i);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wave][lane * 4 + i] = a[i];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int64_t c = (int64_t)blockIdx.x * 256 + t;
+  if (c < cols) part[(int64_t)blockIdx.y * cols + c] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+__global__ void colsum_stage2_k(const float* __restrict__ part, float* __restrict__ out, int nsplit, int64_t cols,
+                                int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < nsplit; ++i) s += part[(int64_t)i * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+constexpr int NORM_BWD_MAX_BLOCKS = 256;
+
+}  // namespace
+
+extern "C" int dxa_norm_bwd_blocks(int64_t rows) {
+  int64_t g = (rows + 3) / 4;
+  if (g < 1) g = 1;
+  return (int)(g > NORM_BWD_MAX_BLOCKS ? NORM_BWD_MAX_BLOCKS : g);
+}
+
+static int check_norm_dtypes(int dtype, int w_dtype, const char* who) {
+  if (!(dtype == DXA_F32 || dtype == DXA_BF16) || !(w_dtype == DXA_F32 || w_dtype == DXA_BF16) ||
+      (dtype == DXA_F32 && w_dtype == DXA_BF16)) {
+    dxa_set_error("%s: unsupported dtype combination (%d,%d)", who, dtype, w_dtype);
+    return DXA_ERR_UNSUPPORTED;
+  }
+  return DXA_OK;
+}
+
+extern "C" int dxa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t cols,
+                               float eps, int dtype, int w_dtype, dxa_stream_t stream) {
+  if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_rmsnorm_fwd")) return rc;
+  DXA_CHECK_ARG(x && y && rows >= 0 && cols > 0, "dxa_rmsnorm_fwd: bad args");
+  if (rows == 0) return DXA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec_ok = al16(x) && al16(y) && (!w || al16(w));
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_fwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((rmsnorm_fwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, cols, eps);
+  } else if (dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_fwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)w, (bf16_t*)y, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((rmsnorm_fwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)w, (bf16_t*)y, rstd, rows, cols, eps);
+  } else {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_fwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)w, (float*)y, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((rmsnorm_fwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)w, (float*)y, rstd, rows, cols, eps);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
+                               float* partial_dw, int64_t rows, int64_t cols, int dtype, int w_dtype,
+                               dxa_stream_t stream) {
+  if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_rmsnorm_bwd")) return rc;
+  DXA_CHECK_ARG(dy && x && rstd && dx && rows >= 0 && cols > 0, "dxa_rmsnorm_bwd: bad args");
+  DXA_CHECK_ARG(!w || partial_dw, "dxa_rmsnorm_bwd: partial_dw required when w is given");
+  if (rows == 0) return DXA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w));
+  dim3 grid((unsigned)dxa_norm_bwd_blocks(rows));
+  if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
+    else hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
+  } else if (dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
+    else hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
+  } else {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, rstd, (float*)dx, partial_dw, rows, cols);
+    else hipLaunchKernelGGL((rmsnorm_bwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, rstd, (float*)dx, partial_dw, rows, cols);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                                 int64_t rows, int64_t cols, float eps, int dtype, int w_dtype,
+                                 dxa_stream_t stream) {
+  if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_layernorm_fwd")) return rc;
+  DXA_CHECK_ARG(x && y && rows >= 0 && cols > 0, "dxa_layernorm_fwd: bad args");
+  if (rows == 0) return DXA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec_ok = al16(x) && al16(y) && (!w || al16(w)) && (!b || al16(b));
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_fwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((layernorm_fwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, cols, eps);
+  } else if (dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_fwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)w, (const float*)b, (bf16_t*)y, mean, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((layernorm_fwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)w, (const float*)b, (bf16_t*)y, mean, rstd, rows, cols, eps);
+  } else {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_fwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)w, (const float*)b, (float*)y, mean, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((layernorm_fwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)w, (const float*)b, (float*)y, mean, rstd, rows, cols, eps);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
+                                 const float* rstd, void* dx, float* partial_dwdb, int64_t rows, int64_t cols,
+                                 int dtype, int w_dtype, dxa_stream_t stream) {
+  if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_layernorm_bwd")) return rc;
+  DXA_CHECK_ARG(dy && x && mean && rstd && dx && rows >= 0 && cols > 0, "dxa_layernorm_bwd: bad args");
+  DXA_CHECK_ARG(!w || partial_dwdb, "dxa_layernorm_bwd: partial_dwdb required when w is given");
+  if (rows == 0) return DXA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w));
+  dim3 grid((unsigned)dxa_norm_bwd_blocks(rows));
+  float* part = w ? partial_dwdb : nullptr;
+  if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
+    else hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
+  } else if (dtype == DXA_BF16) {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
+    else hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
+  } else {
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, part, rows, cols);
+    else hipLaunchKernelGGL((layernorm_bwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, part, rows, cols);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, int64_t cols, int dtype,
+                          int accumulate, float* scratch, size_t scratch_bytes, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "dxa_colsum: bad args");
+  DXA_CHECK_ARG(dtype == DXA_F32 || dtype == DXA_BF16, "dxa_colsum: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  int nsplit = (int)((rows + 127) / 128);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 64) nsplit = 64;
+  DXA_CHECK_ARG(scratch && scratch_bytes >= (size_t)nsplit * cols * sizeof(float),
+                "dxa_colsum: scratch too small (need %zu bytes)", (size_t)nsplit * cols * sizeof(float));
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nsplit);
+  const size_t es = dtype == DXA_BF16 ? 2 : 4;
+  const int vec = ((reinterpret_cast<uintptr_t>(x) % (4 * es)) == 0) && (ld % 4 == 0);
+  if (dtype == DXA_BF16)
+    hipLaunchKernelGGL((colsum_stage1_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ld, scratch, rows, cols, vec);
+  else
+    hipLaunchKernelGGL((colsum_stage1_k<float>), grid, dim3(256), 0, st, (const float*)x, ld, scratch, rows, cols, vec);
+  hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, scratch, out, nsplit,
+                     cols, accumulate);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}

@@ -1,0 +1,159 @@
+// Fused multi-tensor AdamW over a flat parameter arena + global grad-norm clip helpers (HBM-bound).
+// One launch updates every parameter: the arena is described by a device chunk table (start, len,
+// group), each workgroup owns one chunk; lr / weight-decay come per group, the clip coefficient from a
+// device scalar (no host sync between the norm reduction and the update).  fp32 p/g/m/v with 16-byte
+// accesses; an optional bf16 shadow of the new parameters is written in the same pass, so the next
+// forward reads bf16 weights without a separate cast sweep.
+// Semantics = torch.optim.AdamW (decoupled weight decay) after clip_grad_norm_:
+//   g *= clip; p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+//   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+#include "common.h"
+
+namespace {
+
+struct AdamP {
+  float* p; const float* g; float* m; float* v; bf16_t* shadow;
+  const int64_t* cs; const int32_t* cl; const int32_t* cg;
+  float lr[8], wd[8];
+  float b1, b2, eps, bc1, bc2;
+  const float* clip;
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float wd, const AdamP& a,
+                                      float step_size, float inv_sqrt_bc2) {
+  // same operation order as torch's _single_tensor_adamw (lerp_, mul_+addcmul_, sqrt/ bc2_sqrt + eps, addcdiv_)
+  p *= 1.f - lr * wd;
+  m = m + (1.f - a.b1) * (g - m);
+  v = a.b2 * v + (1.f - a.b2) * (g * g);
+  const float denom = sqrtf(v) / inv_sqrt_bc2 + a.eps;
+  p -= step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
+  const int c = blockIdx.x;
+  const int64_t start = a.cs[c];
+  const int len = a.cl[c];
+  const int grp = a.cg[c];
+  const float lr = a.lr[grp], wd = a.wd[grp];
+  const float clip = a.clip ? a.clip[0] : 1.f;
+  const float step_size = lr / a.bc1;
+  const float inv_sqrt_bc2 = sqrtf(a.bc2);  // (name kept: it is the divisor sqrt(1-beta2^t))
+  float* p = a.p + start;
+  const float* g = a.g + start;
+  float* m = a.m + start;
+  float* v = a.v + start;
+  bf16_t* sh = a.shadow ? a.shadow + start : nullptr;
+  const bool vec = ((start & 3) == 0);
+  const int n4 = vec ? (len >> 2) : 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam1(pv.x, gv.x * clip, mv.x, vv.x, lr, wd, a, step_size, inv_sqrt_bc2);
+    adam1(pv.y, gv.y * clip, mv.y, vv.y, lr, wd, a, step_size, inv_sqrt_bc2);
+    adam1(pv.z, gv.z * clip, mv.z, vv.z, lr, wd, a, step_size, inv_sqrt_bc2);
+    adam1(pv.w, gv.w * clip, mv.w, vv.w, lr, wd, a, step_size, inv_sqrt_bc2);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (sh) {
+      uint2 o;
+      o.x = (uint32_t)f2bf(pv.x) | ((uint32_t)f2bf(pv.y) << 16);
+      o.y = (uint32_t)f2bf(pv.z) | ((uint32_t)f2bf(pv.w) << 16);
+      reinterpret_cast<uint2*>(sh)[i] = o;
+    }
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < len; i += 256) {
+    float pv = p[i], mv = m[i], vv = v[i];
+    adam1(pv, g[i] * clip, mv, vv, lr, wd, a, step_size, inv_sqrt_bc2);
+    p[i] = pv; m[i] = mv; v[i] = vv;
+    if (sh) sh[i] = f2bf(pv);
+  }
+}
+
+// stage 1: up to 4096 blocks, each writes one double partial; stage 2: one block folds them
+__global__ __launch_bounds__(256) void sumsq_stage1_k(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (vec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  }
+  const float t = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = (double)t;
+}
+__global__ __launch_bounds__(256) void sumsq_stage2_k(const double* __restrict__ part, int nparts, float* __restrict__ out,
+                                                      int accumulate) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)red[0] : (float)red[0];
+}
+__global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, float* __restrict__ norm_out,
+                            float* __restrict__ coef_out) {
+  const float norm = sqrtf(sumsq[0]);
+  if (norm_out) norm_out[0] = norm;
+  if (coef_out) {
+    const float c = max_norm / (norm + 1e-6f);
+    coef_out[0] = c < 1.f ? c : 1.f;
+  }
+}
+__global__ __launch_bounds__(256) void scale_k(float* __restrict__ x, int64_t n, float s) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
+}
+
+}  // namespace
+
+extern "C" int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream) {
+  DXA_CHECK_ARG(d && d->p && d->g && d->m && d->v && d->chunk_start && d->chunk_len && d->chunk_grp,
+                "dxa_adamw: null pointer");
+  DXA_CHECK_ARG(d->n_chunks >= 0, "dxa_adamw: negative chunk count");
+  if (d->n_chunks == 0) return DXA_OK;
+  AdamP a;
+  a.p = d->p; a.g = d->g; a.m = d->m; a.v = d->v; a.shadow = (bf16_t*)d->shadow;
+  a.cs = d->chunk_start; a.cl = d->chunk_len; a.cg = d->chunk_grp;
+  for (int i = 0; i < 8; ++i) { a.lr[i] = d->lr[i]; a.wd[i] = d->wd[i]; }
+  a.b1 = d->beta1; a.b2 = d->beta2; a.eps = d->eps; a.bc1 = d->bc1; a.bc2 = d->bc2;
+  a.clip = d->clip_coef;
+  hipLaunchKernelGGL(adamw_k, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_sumsq(const float* x, int64_t n, double* scratch, float* out, int accumulate, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && scratch && out && n >= 0, "dxa_sumsq: bad args");
+  int nb = dxa_grid1d((n + 3) / 4, 256, 4096);
+  hipLaunchKernelGGL(sumsq_stage1_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+  hipLaunchKernelGGL(sumsq_stage2_k, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, out, accumulate);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream) {
+  DXA_CHECK_ARG(sumsq, "dxa_clip_coef: null");
+  hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, norm_out, coef_out);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && n >= 0, "dxa_scale: bad args");
+  if (n == 0) return DXA_OK;
+  hipLaunchKernelGGL(scale_k, dim3(dxa_grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}

@@ -1,0 +1,471 @@
+"""Tensor-level wrappers over the C ABI (no autograd here — see functional.py).
+
+Every function takes torch tensors living on the MI355X, passes raw device pointers + sizes + the
+current HIP stream to libdexbotic_amd.so and returns torch tensors allocated by torch's caching
+allocator (PyTorch = device memory and streams only).  Nothing here computes with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import lib
+
+F32, BF16 = L.F32, L.BF16
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise L.DxaError(f"unsupported dtype {t.dtype} (fp32 / bf16 only)")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.DxaError("dexbotic_amd kernels need device tensors (no CPU fallback exists)")
+    return t.data_ptr()
+
+
+def _row_major(t: torch.Tensor, name: str) -> int:
+    """leading dimension of a 2-D tensor whose last dim is contiguous"""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise L.DxaError(f"{name}: expected a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int,
+         out: torch.Tensor, ldc: int, *, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = L.ACT_NONE,
+         aux_out: Optional[torch.Tensor] = None, mulgrad: Optional[torch.Tensor] = None, ldg: int = 0,
+         alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = (1, 1, 1),
+         sA: Sequence[int] = (0, 0, 0), sB: Sequence[int] = (0, 0, 0), sC: Sequence[int] = (0, 0, 0),
+         sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0)) -> torch.Tensor:
+    d = L.GemmDesc()
+    d.layout, d.in_dtype, d.out_dtype, d.act = layout, dt(a), dt(out), act
+    if dt(b) != d.in_dtype:
+        raise L.DxaError("gemm: A and B dtypes differ")
+    for t, n in ((bias, "bias"), (residual, "residual"), (mulgrad, "mulgrad")):
+        if t is not None and dt(t) != d.in_dtype:
+            raise L.DxaError(f"gemm: {n} dtype must equal the input dtype")
+    if aux_out is not None and dt(aux_out) != d.out_dtype:
+        raise L.DxaError("gemm: aux_out dtype must equal the output dtype")
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc
+    d.bias, d.residual, d.ldr = _ptr(bias), _ptr(residual), ldr
+    d.aux_out, d.mulgrad, d.ldg = _ptr(aux_out), _ptr(mulgrad), ldg
+    d.alpha, d.accumulate = alpha, int(accumulate)
+    for i in range(3):
+        d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
+    L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm")
+    return out
+
+
+def _out2d(M: int, N: int, like: torch.Tensor, out: Optional[torch.Tensor], out_dtype: Optional[torch.dtype]):
+    if out is None:
+        out = torch.empty((M, N), device=like.device, dtype=out_dtype or like.dtype)
+    return out
+
+
+def mm_nt(a: torch.Tensor, b: torch.Tensor, *, out=None, out_dtype=None, **kw) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T  (+ fused epilogue options of gemm())"""
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K, (a.shape, b.shape)
+    out = _out2d(M, N, a, out, out_dtype)
+    kw = _ld_kwargs(kw, out)
+    return gemm(L.NT, a, b, M, N, K, _row_major(a, "a"), _row_major(b, "b"), out, _row_major(out, "out"), **kw)
+
+
+def mm_nn(a: torch.Tensor, b: torch.Tensor, *, out=None, out_dtype=None, **kw) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ b[K,N]"""
+    M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K, (a.shape, b.shape)
+    out = _out2d(M, N, a, out, out_dtype)
+    kw = _ld_kwargs(kw, out)
+    return gemm(L.NN, a, b, M, N, K, _row_major(a, "a"), _row_major(b, "b"), out, _row_major(out, "out"), **kw)
+
+
+def mm_tn(a: torch.Tensor, b: torch.Tensor, *, out=None, out_dtype=None, **kw) -> torch.Tensor:
+    """out[M,N] = a[K,M]^T @ b[K,N]"""
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K, (a.shape, b.shape)
+    out = _out2d(M, N, a, out, out_dtype)
+    kw = _ld_kwargs(kw, out)
+    return gemm(L.TN, a, b, M, N, K, _row_major(a, "a"), _row_major(b, "b"), out, _row_major(out, "out"), **kw)
+
+
+def _ld_kwargs(kw: dict, out: torch.Tensor) -> dict:
+    kw = dict(kw)
+    if kw.get("residual") is not None:
+        kw["ldr"] = _row_major(kw["residual"], "residual")
+    if kw.get("mulgrad") is not None:
+        kw["ldg"] = _row_major(kw["mulgrad"], "mulgrad")
+    if kw.get("aux_out") is not None and _row_major(kw["aux_out"], "aux_out") != _row_major(out, "out"):
+        raise L.DxaError("gemm: aux_out must share the output leading dimension")
+    return kw
+
+
+# ----------------------------------------------------------------------------------------------- norms
+def rmsnorm_fwd(x: torch.Tensor, w: Optional[torch.Tensor], eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous()
+    y = torch.empty_like(x2)
+    rstd = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    L.check(lib.dxa_rmsnorm_fwd(_ptr(x2), _ptr(w), _ptr(y), _ptr(rstd), x2.shape[0], x2.shape[1], eps, dt(x2),
+                                dt(w) if w is not None else dt(x2), _stream()), "dxa_rmsnorm_fwd")
+    return y.view(x.shape), rstd
+
+
+def norm_bwd_blocks(rows: int) -> int:
+    return int(lib.dxa_norm_bwd_blocks(rows))
+
+
+def rmsnorm_bwd(dy, x, w, rstd) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """returns (dx, dw_fp32 or None)"""
+    x2 = x.reshape(-1, x.shape[-1])
+    dy2 = dy.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous() and dy2.is_contiguous()
+    rows, cols = x2.shape
+    dx = torch.empty_like(x2)
+    part = None
+    if w is not None:
+        part = torch.empty((norm_bwd_blocks(rows), cols), device=x.device, dtype=torch.float32)
+    L.check(lib.dxa_rmsnorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(rstd), _ptr(dx), _ptr(part), rows, cols, dt(x2),
+                                dt(w) if w is not None else dt(x2), _stream()), "dxa_rmsnorm_bwd")
+    dw = colsum(part) if part is not None else None
+    return dx.view(x.shape), dw
+
+
+def layernorm_fwd(x, w, b, eps):
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous()
+    y = torch.empty_like(x2)
+    mean = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    L.check(lib.dxa_layernorm_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), x2.shape[0],
+                                  x2.shape[1], eps, dt(x2), dt(w) if w is not None else dt(x2), _stream()),
+            "dxa_layernorm_fwd")
+    return y.view(x.shape), mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd):
+    """returns (dx, dw_fp32 or None, db_fp32 or None)"""
+    x2 = x.reshape(-1, x.shape[-1])
+    dy2 = dy.reshape(-1, x.shape[-1])
+    assert x2.is_contiguous() and dy2.is_contiguous()
+    rows, cols = x2.shape
+    dx = torch.empty_like(x2)
+    part = None
+    if w is not None:
+        part = torch.empty((norm_bwd_blocks(rows), 2 * cols), device=x.device, dtype=torch.float32)
+    L.check(lib.dxa_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(part), rows,
+                                  cols, dt(x2), dt(w) if w is not None else dt(x2), _stream()), "dxa_layernorm_bwd")
+    if part is None:
+        return dx.view(x.shape), None, None
+    s = colsum(part)
+    return dx.view(x.shape), s[:cols], s[cols:]
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[c] (+)= sum_r x[r, c]  (fp32 result)"""
+    ld = _row_major(x, "x")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        accumulate = False
+    nsplit = max(1, min(64, (rows + 127) // 128))
+    scratch = torch.empty(nsplit * cols, device=x.device, dtype=torch.float32)
+    L.check(lib.dxa_colsum(_ptr(x), ld, _ptr(out), rows, cols, dt(x), int(accumulate), _ptr(scratch),
+                           scratch.numel() * 4, _stream()), "dxa_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ RoPE
+def rope_split(qkv: torch.Tensor, cos_t, sin_t, pos, B, S, Hq, Hkv, D):
+    assert qkv.is_contiguous() and qkv.shape == (B * S, (Hq + 2 * Hkv) * D)
+    q = torch.empty((B, Hq, S, D), device=qkv.device, dtype=qkv.dtype)
+    k = torch.empty((B, Hkv, S, D), device=qkv.device, dtype=qkv.dtype)
+    v = torch.empty((B, Hkv, S, D), device=qkv.device, dtype=qkv.dtype)
+    L.check(lib.dxa_rope_split(_ptr(qkv), _ptr(q), _ptr(k), _ptr(v), _ptr(cos_t), _ptr(sin_t), _ptr(pos), B, S, Hq,
+                               Hkv, D, dt(qkv), _stream()), "dxa_rope_split")
+    return q, k, v
+
+
+def rope_merge(dq, dk, dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D):
+    assert dq.is_contiguous() and dk.is_contiguous() and dv.is_contiguous()
+    dqkv = torch.empty((B * S, (Hq + 2 * Hkv) * D), device=dq.device, dtype=dq.dtype)
+    L.check(lib.dxa_rope_merge(_ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqkv), _ptr(cos_t), _ptr(sin_t), _ptr(pos), B, S,
+                               Hq, Hkv, D, dt(dq), _stream()), "dxa_rope_merge")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _bhsd_strides(t: torch.Tensor) -> Tuple[int, int, int]:
+    """t is a [B,H,S,D] VIEW (any memory order) with D contiguous -> (sb, sh, ss)"""
+    assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1), (t.shape, t.stride())
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end) -> L.AttnDesc:
+    d = L.AttnDesc()
+    B, Hq, Sq, D = q.shape
+    _, Hkv, Sk, _ = k.shape
+    d.dtype, d.B, d.Hq, d.Hkv, d.Sq, d.Sk, d.D = dt(q), B, Hq, Hkv, Sq, Sk, D
+    d.causal, d.scale = int(causal), scale
+    d.q, (d.q_sb, d.q_sh, d.q_ss) = _ptr(q), _bhsd_strides(q)
+    d.k, (d.k_sb, d.k_sh, d.k_ss) = _ptr(k), _bhsd_strides(k)
+    d.v, (d.v_sb, d.v_sh, d.v_ss) = _ptr(v), _bhsd_strides(v)
+    d.o, (d.o_sb, d.o_sh, d.o_ss) = _ptr(o), _bhsd_strides(o)
+    d.lse, d.kv_start, d.kv_end = _ptr(lse), _ptr(kv_start), _ptr(kv_end)
+    return d
+
+
+def attn_fwd(q, k, v, o, *, causal: bool, scale: float, kv_start=None, kv_end=None, force_generic=False):
+    """q/k/v/o: [B,H,S,D] views (token-major or head-major memory); returns lse [B,Hq,Sq] fp32"""
+    B, Hq, Sq, _ = q.shape
+    lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32)
+    d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end)
+    d.force_generic = int(force_generic)
+    L.check(lib.dxa_attn_fwd(C.byref(d), _stream()), "dxa_attn_fwd")
+    return lse
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, causal: bool, scale: float, kv_start=None, kv_end=None):
+    d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end)
+    d.d_o, (d.do_sb, d.do_sh, d.do_ss) = _ptr(do), _bhsd_strides(do)
+    d.dq, (d.dq_sb, d.dq_sh, d.dq_ss) = _ptr(dq), _bhsd_strides(dq)
+    d.dk, (d.dk_sb, d.dk_sh, d.dk_ss) = _ptr(dk), _bhsd_strides(dk)
+    d.dv, (d.dv_sb, d.dv_sh, d.dv_ss) = _ptr(dv), _bhsd_strides(dv)
+    nbytes = int(lib.dxa_attn_bwd_workspace(C.byref(d)))
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    L.check(lib.dxa_attn_bwd(C.byref(d), _ptr(ws), nbytes, _stream()), "dxa_attn_bwd")
+
+
+# ----------------------------------------------------------------------------------------- elementwise
+def swiglu_fwd(gu: torch.Tensor) -> torch.Tensor:
+    rows, F2 = gu.shape
+    assert gu.is_contiguous() and F2 % 2 == 0
+    out = torch.empty((rows, F2 // 2), device=gu.device, dtype=gu.dtype)
+    L.check(lib.dxa_swiglu_fwd(_ptr(gu), _ptr(out), rows, F2 // 2, dt(gu), _stream()), "dxa_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    rows, F2 = gu.shape
+    assert gu.is_contiguous() and dout.is_contiguous()
+    dgu = torch.empty_like(gu)
+    L.check(lib.dxa_swiglu_bwd(_ptr(gu), _ptr(dout), _ptr(dgu), rows, F2 // 2, dt(gu), _stream()), "dxa_swiglu_bwd")
+    return dgu
+
+
+def act_fwd(x: torch.Tensor, act: int) -> torch.Tensor:
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    L.check(lib.dxa_act_fwd(_ptr(x), _ptr(y), x.numel(), act, dt(x), _stream()), "dxa_act_fwd")
+    return y
+
+
+def act_bwd(x: torch.Tensor, dy: torch.Tensor, act: int) -> torch.Tensor:
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    L.check(lib.dxa_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), act, dt(x), _stream()), "dxa_act_bwd")
+    return dx
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(lib.dxa_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), dt(a), _stream()), "dxa_add")
+    return out
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert src.is_contiguous()
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=dtype)
+    L.check(lib.dxa_cast(_ptr(src), _ptr(out), src.numel(), dt(src), dt(out), _stream()), "dxa_cast")
+    return out
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor, cols: int, cols_padded: int) -> torch.Tensor:
+    L.check(lib.dxa_copy2d(_ptr(src), _row_major(src, "src"), _ptr(dst), _row_major(dst, "dst"), src.shape[0], cols,
+                           cols_padded, dt(src), dt(dst), _stream()), "dxa_copy2d")
+    return dst
+
+
+def splice_fwd(plan: torch.Tensor, embed: torch.Tensor, img: Optional[torch.Tensor]) -> torch.Tensor:
+    assert plan.dtype == torch.int64 and plan.is_contiguous() and embed.is_contiguous()
+    n, d = plan.numel(), embed.shape[1]
+    out = torch.empty((n, d), device=embed.device, dtype=embed.dtype)
+    L.check(lib.dxa_splice_fwd(_ptr(plan), _ptr(embed), _ptr(img), _ptr(out), n, d, dt(embed), _stream()),
+            "dxa_splice_fwd")
+    return out
+
+
+def splice_bwd(plan: torch.Tensor, dout: torch.Tensor, d_embed: Optional[torch.Tensor],
+               d_img: Optional[torch.Tensor]) -> None:
+    n, d = dout.shape
+    assert dout.is_contiguous() and (d_embed is None or d_embed.dtype == torch.float32)
+    L.check(lib.dxa_splice_bwd(_ptr(plan), _ptr(dout), _ptr(d_embed), _ptr(d_img), n, d, dt(dout), _stream()),
+            "dxa_splice_bwd")
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    assert x.is_contiguous() and idx.dtype == torch.int64
+    out = torch.empty((idx.numel(), x.shape[1]), device=x.device, dtype=dtype)
+    L.check(lib.dxa_gather_rows(_ptr(x), _ptr(idx), _ptr(out), idx.numel(), x.shape[1], dt(x), dt(out), _stream()),
+            "dxa_gather_rows")
+    return out
+
+
+def scatter_rows(dout: torch.Tensor, idx: torch.Tensor, R: int, dtype: torch.dtype) -> torch.Tensor:
+    assert dout.is_contiguous()
+    dx = torch.empty((R, dout.shape[1]), device=dout.device, dtype=dtype)
+    L.check(lib.dxa_scatter_rows(_ptr(dout), _ptr(idx), _ptr(dx), idx.numel(), R, dout.shape[1], dt(dout), dt(dx),
+                                 _stream()), "dxa_scatter_rows")
+    return dx
+
+
+def im2col(images: torch.Tensor, P: int, ld: int, dtype: torch.dtype) -> torch.Tensor:
+    assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    N, _, H, W = images.shape
+    rows = torch.empty((N * (H // P) * (W // P), ld), device=images.device, dtype=dtype)
+    L.check(lib.dxa_im2col(_ptr(images), _ptr(rows), N, H, W, P, ld, dt(images), dt(rows), _stream()), "dxa_im2col")
+    return rows
+
+
+def vit_embed_fwd(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, N: int, np_: int) -> torch.Tensor:
+    C_ = patch.shape[-1]
+    x = torch.empty((N, np_ + 1, C_), device=patch.device, dtype=patch.dtype)
+    L.check(lib.dxa_vit_embed_fwd(_ptr(patch), _ptr(cls), _ptr(pos), _ptr(x), N, np_, C_, dt(patch), dt(cls),
+                                  _stream()), "dxa_vit_embed_fwd")
+    return x
+
+
+def vit_embed_bwd(dx: torch.Tensor, N: int, np_: int) -> torch.Tensor:
+    C_ = dx.shape[-1]
+    assert dx.is_contiguous()
+    dpatch = torch.empty((N * np_, C_), device=dx.device, dtype=dx.dtype)
+    L.check(lib.dxa_vit_embed_bwd(_ptr(dx), _ptr(dpatch), N, np_, C_, dt(dx), _stream()), "dxa_vit_embed_bwd")
+    return dpatch
+
+
+# ------------------------------------------------------------------------------------- diffusion glue
+def qsample(x0, noise, a, s):
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (x0, noise, a, s))
+    xt = torch.empty_like(x0)
+    N = x0.shape[0]
+    L.check(lib.dxa_qsample(_ptr(x0), _ptr(noise), _ptr(a), _ptr(s), _ptr(xt), N, x0.numel() // N, _stream()),
+            "dxa_qsample")
+    return xt
+
+
+def timestep_embedding(t: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float32 and freqs.dtype == torch.float32
+    half = freqs.numel()
+    out = torch.empty((t.numel(), 2 * half), device=t.device, dtype=torch.float32)
+    L.check(lib.dxa_timestep_embedding(_ptr(t), _ptr(freqs), _ptr(out), t.numel(), half, _stream()),
+            "dxa_timestep_embedding")
+    return out
+
+
+def dit_assemble_fwd(xe, te, ze, pos):
+    N, T, hd = xe.shape
+    h = torch.empty((N, T + 1, hd), device=xe.device, dtype=torch.float32)
+    L.check(lib.dxa_dit_assemble_fwd(_ptr(xe), _ptr(te), _ptr(ze), _ptr(pos), _ptr(h), N, T, hd, _stream()),
+            "dxa_dit_assemble_fwd")
+    return h
+
+
+def dit_assemble_bwd(dh):
+    N, T1, hd = dh.shape
+    assert dh.is_contiguous()
+    dxe = torch.empty((N, T1 - 1, hd), device=dh.device, dtype=torch.float32)
+    dc = torch.empty((N, hd), device=dh.device, dtype=torch.float32)
+    L.check(lib.dxa_dit_assemble_bwd(_ptr(dh), _ptr(dxe), _ptr(dc), N, T1 - 1, hd, _stream()), "dxa_dit_assemble_bwd")
+    return dxe, dc
+
+
+def token_drop(z, uncond, drop):
+    N, d = z.shape
+    assert drop.dtype == torch.uint8 and z.is_contiguous()
+    out = torch.empty_like(z)
+    L.check(lib.dxa_token_drop(_ptr(z), _ptr(uncond), _ptr(drop), _ptr(out), N, d, _stream()), "dxa_token_drop")
+    return out
+
+
+def token_drop_bwd(dout, drop, want_dz=True):
+    N, d = dout.shape
+    assert dout.is_contiguous()
+    dz = torch.empty_like(dout) if want_dz else None
+    dunc = torch.empty(d, device=dout.device, dtype=torch.float32)
+    L.check(lib.dxa_token_drop_bwd(_ptr(dout), _ptr(drop), _ptr(dz), _ptr(dunc), N, d, 0, _stream()),
+            "dxa_token_drop_bwd")
+    return dz, dunc
+
+
+def mse_loss(pred, target, gscale: float = 1.0, want_grad: bool = True):
+    assert pred.is_contiguous() and target.is_contiguous() and pred.dtype == torch.float32
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred) if want_grad else None
+    L.check(lib.dxa_mse_loss(_ptr(pred), _ptr(target), _ptr(loss), _ptr(dpred), pred.numel(), gscale, _stream()),
+            "dxa_mse_loss")
+    return loss, dpred
+
+
+def ddim_step(x, model_out, B, use_cfg, cfg_scale, c_recip, c_recipm1, ab_prev):
+    per = x.numel() // x.shape[0]
+    L.check(lib.dxa_ddim_step(_ptr(x), _ptr(model_out), B, per, int(use_cfg), cfg_scale, c_recip, c_recipm1, ab_prev,
+                              _stream()), "dxa_ddim_step")
+    return x
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def sumsq(x: torch.Tensor, out: torch.Tensor, scratch: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    assert x.dtype == torch.float32 and x.is_contiguous() and scratch.dtype == torch.float64 and scratch.numel() >= 4096
+    L.check(lib.dxa_sumsq(_ptr(x), x.numel(), _ptr(scratch), _ptr(out), int(accumulate), _stream()), "dxa_sumsq")
+    return out
+
+
+def clip_coef(sumsq_t, max_norm: float, norm_out, coef_out):
+    L.check(lib.dxa_clip_coef(_ptr(sumsq_t), max_norm, _ptr(norm_out), _ptr(coef_out), _stream()), "dxa_clip_coef")
+
+
+def scale_(x: torch.Tensor, s: float) -> torch.Tensor:
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    L.check(lib.dxa_scale(_ptr(x), x.numel(), s, _stream()), "dxa_scale")
+    return x
+
+
+def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1, beta2, eps, step, clip=None):
+    d = L.AdamWDesc()
+    d.p, d.g, d.m, d.v, d.shadow = _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow)
+    d.chunk_start, d.chunk_len, d.chunk_grp = _ptr(chunk_start), _ptr(chunk_len), _ptr(chunk_grp)
+    d.n_chunks = chunk_start.numel()
+    assert len(lrs) <= 8 and len(lrs) == len(wds)
+    for i, (lr, wd) in enumerate(zip(lrs, wds)):
+        d.lr[i], d.wd[i] = lr, wd
+    d.beta1, d.beta2, d.eps = beta1, beta2, eps
+    d.bc1, d.bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    d.clip_coef = _ptr(clip)
+    L.check(lib.dxa_adamw(C.byref(d), _stream()), "dxa_adamw")

@@ -1,0 +1,257 @@
+/*
+ * dexbotic_amd.h — C ABI of libdexbotic_amd.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * DB-CogACT VLA forward / training hot path (SURVEY.md §8a rows A1–A14).
+ *
+ * The reference (dexmal/dexbotic v0.2.0) is 100 % Python and has NO FFI boundary of its own
+ * (SURVEY.md §0, §8b): every FLOP on the path is executed by torch / transformers / timm underneath
+ * the reference's nn.Module classes.  This header therefore declares the boundary a reference
+ * maintainer would bind *underneath* those classes; each entry point cites the reference call site
+ * (file:line, relative to the reference root; "HF:" = site-packages/transformers/models) whose
+ * third-party arithmetic it replaces.  INTEGRATION.md shows the ctypes binding + module swap.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - every call is asynchronous on the caller's HIP stream (`stream` = hipStream_t) and never
+ *     synchronises, allocates or frees; scratch is passed in by the caller;
+ *   - return 0 on success, <0 on error (dxa_status); dxa_last_error() gives a thread-local message;
+ *   - dtype codes: DXA_F32 (float) / DXA_BF16 (bfloat16 bits, round-to-nearest-even);
+ *   - re-entrant from several host threads / streams; no global mutable state.
+ */
+#ifndef DEXBOTIC_AMD_H_
+#define DEXBOTIC_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dxa_stream_t; /* hipStream_t */
+
+enum dxa_status { DXA_OK = 0, DXA_ERR_BAD_ARG = -1, DXA_ERR_UNSUPPORTED = -2, DXA_ERR_HIP = -3 };
+enum dxa_dtype { DXA_F32 = 0, DXA_BF16 = 1 };
+enum dxa_act {
+  DXA_ACT_NONE = 0,
+  DXA_ACT_GELU_ERF = 1,   /* nn.GELU()            — mm_projector/builder.py:71-79          */
+  DXA_ACT_GELU_TANH = 2,  /* nn.GELU("tanh")      — cogact/action_model/dit.py:151         */
+  DXA_ACT_QUICK_GELU = 3, /* x*sigmoid(1.702x)    — HF:clip/modeling_clip.py (CLIPMLP)     */
+  DXA_ACT_SILU = 4,       /* x*sigmoid(x)         — HF:qwen2/modeling_qwen2.py:35-48, dit.py:30 */
+  DXA_ACT_RELU = 5
+};
+/* operand layouts of dxa_gemm: which operand has the contraction index contiguous in memory */
+enum dxa_layout {
+  DXA_NT = 0, /* C[m,n] = sum_k A[m,k] B[n,k]   y = x W^T      (forward of every nn.Linear)        */
+  DXA_NN = 1, /* C[m,n] = sum_k A[m,k] B[k,n]   dx = dy W      (input gradient)                     */
+  DXA_TN = 2  /* C[m,n] = sum_k A[k,m] B[k,n]   dW = dy^T x    (weight gradient)                    */
+};
+
+const char* dxa_last_error(void);
+int dxa_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue (MFMA: v_mfma_f32_16x16x32_bf16 for bf16, v_mfma_f32_16x16x4_f32 for
+ * exact-fp32).  Replaces torch F.linear / matmul + the adjacent elementwise ops at:
+ *   HF:qwen2/modeling_qwen2.py:35-48,105-235 (q/k/v/o, gate/up/down), HF:clip/modeling_clip.py:259-384,
+ *   mm_projector/builder.py:71-79, cogact/action_model/dit.py:22-64,137-178 (timm Attention/Mlp),
+ *   HF:clip/modeling_clip.py:149-155 (patch-embed conv as a GEMM over im2col rows),
+ *   and the autograd-generated dX / dW matmuls of all of them.
+ *   v = alpha * sum_k(...) ; v += bias[n] ; if aux_out: aux_out[m,n] = v ; v = act(v) ;
+ *   if mulgrad: v *= act'(mulgrad[m,n]) (act given by `act`, v NOT activated in that case) ;
+ *   v += residual[m,n] ; if accumulate: v += C[m,n] ; C[m,n] = v.
+ * Batched over (nb0, nb1, nb2) with element strides per operand (0 = broadcast).
+ * Any M/N/K and any leading dimension are accepted; 16-byte aligned rows take the vector path.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dxa_gemm_desc {
+  int32_t layout;    /* dxa_layout */
+  int32_t in_dtype;  /* dtype of A, B, bias, residual, mulgrad */
+  int32_t out_dtype; /* dtype of C and aux_out */
+  int32_t act;       /* dxa_act */
+  int64_t M, N, K;
+  const void* A;
+  int64_t lda;
+  const void* B;
+  int64_t ldb;
+  void* C;
+  int64_t ldc;
+  const void* bias;     /* [N] or NULL */
+  const void* residual; /* [M,N] (ld = ldr, batch strides = sR*) or NULL */
+  int64_t ldr;
+  void* aux_out; /* pre-activation copy [M,N] (ld = ldc, batch strides as C) or NULL */
+  const void* mulgrad; /* [M,N] pre-activation saved by the forward (ld = ldg) or NULL */
+  int64_t ldg;
+  float alpha;
+  int32_t accumulate; /* C += result */
+  int32_t nb[3];      /* batch extents (>=1) */
+  int64_t sA[3], sB[3], sC[3], sR[3], sG[3]; /* batch strides in elements */
+} dxa_gemm_desc;
+int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation.  w/b are [cols] in w_dtype (NULL = no affine).
+ * RMSNorm follows HF:qwen2/modeling_qwen2.py:238-253: y = w * round_to_dtype(x * rsqrt(mean(x^2)+eps)).
+ * LayerNorm follows torch.nn.LayerNorm as used by HF:clip/modeling_clip.py (eps 1e-5, affine) and
+ * cogact/action_model/dit.py:143-147,170 (eps 1e-6, no affine).  Statistics in fp32, saved for bwd.
+ * Backward writes dx and per-block partial dw/db into `partial` ([nblk, 2*cols] fp32; nblk returned by
+ * dxa_norm_bwd_blocks(rows)); reduce them with dxa_colsum.
+ * ---------------------------------------------------------------------------------------------- */
+int dxa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t cols,
+                    float eps, int dtype, int w_dtype, dxa_stream_t stream);
+int dxa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
+                    float* partial_dw, int64_t rows, int64_t cols, int dtype, int w_dtype,
+                    dxa_stream_t stream);
+int dxa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                      int64_t rows, int64_t cols, float eps, int dtype, int w_dtype, dxa_stream_t stream);
+int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                      void* dx, float* partial_dwdb, int64_t rows, int64_t cols, int dtype, int w_dtype,
+                      dxa_stream_t stream);
+int dxa_norm_bwd_blocks(int64_t rows);
+/* out[c] (+)= sum_r x[r*ld + c]   (bias gradients, norm-weight gradients, pos-emb gradients).
+ * Deterministic two-stage reduction; scratch >= min(64, ceil(rows/128)) * cols floats. */
+int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, int64_t cols, int dtype,
+               int accumulate, float* scratch, size_t scratch_bytes, dxa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RoPE (rotate-half, HF:qwen2/modeling_qwen2.py:107-140) fused with the QKV split into head-major
+ * [B,H,S,D] tensors.  cos/sin: [n_pos, D/2] fp32 tables built on the host exactly like
+ * Qwen2RotaryEmbedding (:52-104); pos: [B*S] int32 row index into the tables (NULL -> s).
+ * dxa_rope_split : qkv [B*S, (Hq+2Hkv)*D] token-major  ->  q [B,Hq,S,D], k [B,Hkv,S,D], v [B,Hkv,S,D]
+ * dxa_rope_merge : inverse rotation (backward): dq,dk,dv head-major -> dqkv token-major
+ * ---------------------------------------------------------------------------------------------- */
+int dxa_rope_split(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
+                   const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int dtype,
+                   dxa_stream_t stream);
+int dxa_rope_merge(const void* dq, const void* dk, const void* dv, void* dqkv, const float* cos_t,
+                   const float* sin_t, const int32_t* pos, int B, int S, int Hq, int Hkv, int D,
+                   int dtype, dxa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention.  Replaces torch SDPA at HF:qwen2/modeling_qwen2.py:143-235 (causal + key padding, GQA),
+ * HF:clip/modeling_clip.py:259-330 (full), timm Attention in dit.py:145-149 (full, 17 tokens).
+ * Element (b,h,s,d) of q/k/v/o lives at base + b*sb + h*sh + s*ss + d (element strides).
+ * softmax in fp32; keys j visible to query i iff kv_start[b] <= j < kv_end[b] and (!causal || j <= i).
+ * Forward: fused flash kernel (bf16, D in {64,128}: K/V tiles staged in LDS, MFMA QK^T and PV,
+ * wavefront-shuffle softmax reductions) or a generic fp32-accumulate kernel (any dtype / D).
+ * Saves lse[b,h,i] = log sum_j exp(scale*s_ij) for the backward.
+ * Backward: dq/dk/dv from (q,k,v,o,do,lse); `workspace` must hold dxa_attn_bwd_workspace(desc) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dxa_attn_desc {
+  int32_t dtype;
+  int32_t B, Hq, Hkv, Sq, Sk, D;
+  int32_t causal;
+  float scale;
+  const void* q; int64_t q_sb, q_sh, q_ss;
+  const void* k; int64_t k_sb, k_sh, k_ss;
+  const void* v; int64_t v_sb, v_sh, v_ss;
+  void* o;       int64_t o_sb, o_sh, o_ss;
+  float* lse;               /* [B,Hq,Sq] */
+  const int32_t* kv_start;  /* [B] or NULL (=0)  */
+  const int32_t* kv_end;    /* [B] or NULL (=Sk) */
+  /* backward only */
+  const void* d_o; int64_t do_sb, do_sh, do_ss;
+  void* dq; int64_t dq_sb, dq_sh, dq_ss;
+  void* dk; int64_t dk_sb, dk_sh, dk_ss;
+  void* dv; int64_t dv_sb, dv_sh, dv_ss;
+  int32_t force_generic;    /* testing: bypass the MFMA kernel */
+} dxa_attn_desc;
+int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream);
+size_t dxa_attn_bwd_workspace(const dxa_attn_desc* d);
+int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / data-movement kernels (HBM-bound; 16-byte vector access).
+ * ---------------------------------------------------------------------------------------------- */
+/* SwiGLU, HF:qwen2/modeling_qwen2.py:46-48.  gu = [rows, 2F]: gate = cols [0,F), up = cols [F,2F). */
+int dxa_swiglu_fwd(const void* gu, void* out, int64_t rows, int64_t F, int dtype, dxa_stream_t stream);
+int dxa_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, int dtype,
+                   dxa_stream_t stream);
+int dxa_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dxa_stream_t stream);
+int dxa_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int act, int dtype, dxa_stream_t stream);
+/* out = a + b (same dtype) */
+int dxa_add(const void* a, const void* b, void* out, int64_t n, int dtype, dxa_stream_t stream);
+int dxa_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, dxa_stream_t stream);
+/* dst[r, 0:cols] = src[r, 0:cols] with independent leading dimensions (padding columns zeroed) */
+int dxa_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols,
+               int64_t cols_padded, int src_dtype, int dst_dtype, dxa_stream_t stream);
+
+/* Token splice (dexbotic_arch.py:182-373).  plan[b*S+s] >= 0: token id; <= -1: image row -1-plan;
+ * INT64_MIN: zero padding.  Forward gathers embed_tokens rows / image-feature rows into
+ * inputs_embeds [B*S, d].  Backward scatters: image rows plain-stored (each used once, untouched rows
+ * must be pre-zeroed), token rows atomically added into the fp32 embedding gradient. */
+int dxa_splice_fwd(const int64_t* plan, const void* embed, const void* img, void* out, int64_t n_rows,
+                   int64_t d, int dtype, dxa_stream_t stream);
+int dxa_splice_bwd(const int64_t* plan, const void* dout, float* d_embed, void* d_img, int64_t n_rows,
+                   int64_t d, int dtype, dxa_stream_t stream);
+/* out[i,:] = x[idx[i],:]   (cognition token, cogact_arch.py:110-120) and its scatter-add backward */
+int dxa_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, int64_t d, int src_dtype,
+                    int dst_dtype, dxa_stream_t stream);
+/* dx [R,d] is written completely: row r = sum_{i: idx[i]==r} dout[i], every other row = 0 */
+int dxa_scatter_rows(const void* dout, const int64_t* idx, void* dx, int64_t n, int64_t R, int64_t d,
+                     int src_dtype, int dst_dtype, dxa_stream_t stream);
+
+/* Patch embedding front-end (HF:clip/modeling_clip.py:138-218).
+ * im2col: images [N,3,H,W] (img_dtype) -> rows [N*g*g, ld] (dtype), column order (c, py, px) = the
+ * flattened Conv2d weight [C, 3*P*P]; columns >= 3*P*P are zero.
+ * vit_embed: x[n,0,:] = cls + pos[0]; x[n,1+p,:] = patch[n,p,:] + pos[1+p]. */
+int dxa_im2col(const void* images, void* rows, int N, int H, int W, int P, int64_t ld, int img_dtype,
+               int dtype, dxa_stream_t stream);
+int dxa_vit_embed_fwd(const void* patch, const void* cls, const void* pos, void* x, int N, int np, int C,
+                      int dtype, int w_dtype, dxa_stream_t stream);
+int dxa_vit_embed_bwd(const void* dx, void* dpatch, int N, int np, int C, int dtype, dxa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Diffusion action expert glue (fp32).  cogact/action_model/{action_models,dit,diffusion}.py.
+ * ---------------------------------------------------------------------------------------------- */
+/* x_t = a[n]*x0 + s[n]*noise   (diffusion.py:308-326; a,s gathered from the float64 tables on host) */
+int dxa_qsample(const float* x0, const float* noise, const float* a, const float* s, float* xt,
+                int64_t N, int64_t per, dxa_stream_t stream);
+/* sinusoidal timestep embedding out[n] = [cos(t_n f) | sin(t_n f)], f = freqs[half] built on the host
+ * exactly as dit.py:45-49 does (exp(-ln(10000) k/half) in fp32) */
+int dxa_timestep_embedding(const float* t, const float* freqs, float* out, int64_t N, int half,
+                           dxa_stream_t stream);
+/* h[n,0,:] = te[n]+ze[n]+pos[0]; h[n,1+t,:] = xe[n,t]+pos[1+t]  (dit.py:281-286) and its backward */
+int dxa_dit_assemble_fwd(const float* xe, const float* te, const float* ze, const float* pos, float* h,
+                         int N, int T, int hd, dxa_stream_t stream);
+int dxa_dit_assemble_bwd(const float* dh, float* dxe, float* dc, int N, int T, int hd, dxa_stream_t stream);
+/* z_out[n] = drop[n] ? uncond : z[n]   (LabelEmbedder.token_drop, dit.py:80-96); bwd masks dz */
+int dxa_token_drop(const float* z, const float* uncond, const uint8_t* drop, float* out, int64_t N,
+                   int64_t d, dxa_stream_t stream);
+/* dz[n] = drop[n] ? 0 : dout[n] (dz may be NULL); duncond[c] (+)= sum over dropped n of dout[n,c] */
+int dxa_token_drop_bwd(const float* dout, const uint8_t* drop, float* dz, float* duncond, int64_t N,
+                       int64_t d, int accumulate, dxa_stream_t stream);
+/* loss = mean((pred-target)^2) (action_models.py:119-121); dpred = 2 (pred-target) / n * gscale */
+int dxa_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int64_t n,
+                 float gscale, dxa_stream_t stream);
+/* One DDIM(eta=0) update with classifier-free guidance (dit.py:294-311, diffusion.py:626-673):
+ * eps = eu + s (ec - eu) with ec = model_out[0:B], eu = model_out[B:2B] (cfg) or eps = model_out;
+ * x0 = c_recip x - c_recipm1 eps ; eps' = (c_recip x - x0)/c_recipm1 ; x <- sqrt(ab_prev) x0 +
+ * sqrt(1-ab_prev) eps'.  x is [B or 2B, per]; with cfg both halves receive the same result. */
+int dxa_ddim_step(float* x, const float* model_out, int64_t B, int64_t per, int use_cfg, float cfg_scale,
+                  float c_recip, float c_recipm1, float ab_prev, dxa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer (trainer.py:25-36,88-124 -> torch.optim.AdamW + clip_grad_norm_(1.0)) over a flat arena.
+ * chunk table (device): chunk c covers elements [start[c], start[c]+len[c]) and uses group grp[c].
+ * Per group: lr, weight_decay.  clip_coef: device float multiplied into every gradient.
+ * shadow (optional): bf16 copy of the updated parameters written in the same pass.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dxa_adamw_desc {
+  float* p; const float* g; float* m; float* v;
+  uint16_t* shadow;            /* or NULL */
+  const int64_t* chunk_start; const int32_t* chunk_len; const int32_t* chunk_grp; int32_t n_chunks;
+  float lr[8]; float wd[8];
+  float beta1, beta2, eps;
+  float bc1, bc2;              /* 1-beta1^t, 1-beta2^t */
+  const float* clip_coef;      /* device scalar or NULL (=1) */
+} dxa_adamw_desc;
+int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream);
+/* out[0] = sum x^2 over n fp32 elements (deterministic two-stage; scratch >= 4096 doubles) */
+int dxa_sumsq(const float* x, int64_t n, double* scratch, float* out, int accumulate, dxa_stream_t stream);
+/* norm = sqrt(sumsq); coef = min(1, max_norm/(norm+1e-6))  (torch.nn.utils.clip_grad_norm_) */
+int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream);
+int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEXBOTIC_AMD_H_ */

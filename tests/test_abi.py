@@ -1,0 +1,74 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, the ctypes table covers all of them, and the product path refuses to run without a GPU
+(no CPU fallback, no oracle import)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dexbotic_amd.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dxa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dexbotic_amd import _lib as L
+    syms = header_symbols()
+    assert len(syms) >= 40
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (dxa_[a-z0-9_]+)", out))
+    missing = [s for s in syms if s not in exported]
+    assert not missing, f"declared in include/dexbotic_amd.h but not exported: {missing}"
+    assert sorted(L.SIGNATURES) == syms, (set(L.SIGNATURES) ^ set(syms))
+    assert L.lib.dxa_version() >= 100
+    assert L.last_error() == ""
+
+
+def test_struct_layouts_match_header_field_order():
+    from dexbotic_amd import _lib as L
+    src = open(HEADER).read()
+    for cname, cls in (("dxa_gemm_desc", L.GemmDesc), ("dxa_attn_desc", L.AttnDesc), ("dxa_adamw_desc", L.AdamWDesc)):
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname, src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[\d+\])?\s*$", part.strip())
+                names.append(m.group(1))
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_cpu_fallback():
+    from dexbotic_amd import _lib as L
+    from dexbotic_amd import kernels as K
+    a = torch.zeros(4, 4)
+    with pytest.raises(L.DxaError):
+        K.mm_nt(a, a)
+    # bad arguments are rejected by the library itself with a message
+    d = L.GemmDesc()
+    d.layout = 7
+    assert L.lib.dxa_gemm(d, None) == -1
+    assert "layout" in L.last_error()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "dexbotic_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+    code = "import sys; import dexbotic_amd; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)

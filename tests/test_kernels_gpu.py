@@ -1,0 +1,467 @@
+"""Kernel-level numerics: every C-ABI entry point against a plain torch fp32/fp64 reference of the
+same op, on the MI355X.  (Model-level parity against the oracle / golden vectors: test_parity_gpu.py.)"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from dexbotic_amd import _lib as L
+    from dexbotic_amd import kernels as K
+
+DEV = "cuda"
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xFFFF))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def assert_close(out, ref, rtol, atol, what=""):
+    out64, ref64 = out.double(), ref.double()
+    err = (out64 - ref64).abs()
+    tol = atol + rtol * ref64.abs()
+    bad = err > tol
+    if bad.any():
+        i = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {err.max().item():.3e} "
+                             f"(ref max {ref64.abs().max().item():.3e}); first at {i}: got {out64[tuple(i)].item():.6e} "
+                             f"want {ref64[tuple(i)].item():.6e}")
+
+
+def tol_for(dtype, K_=1):
+    if dtype == torch.bfloat16:
+        return 1.0 / 128, 1e-2 * math.sqrt(max(K_, 1)) / 16
+    return 2e-5, 2e-6 * math.sqrt(max(K_, 1))
+
+
+ACTS = {0: lambda x: x, 1: lambda x: F.gelu(x), 2: lambda x: F.gelu(x, approximate="tanh"),
+        3: lambda x: x * torch.sigmoid(1.702 * x), 4: F.silu, 5: F.relu}
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 256), (200, 136, 96), (130, 70, 588), (17, 7, 7),
+                                   (1000, 520, 1024), (64, 2304, 768)])
+def test_gemm_plain(dtype, layout, shape):
+    M, N, Kd = shape
+    a = rnd(M, Kd, dtype=dtype, seed=1) if layout != "tn" else rnd(Kd, M, dtype=dtype, seed=1)
+    b = rnd(N, Kd, dtype=dtype, seed=2) if layout == "nt" else rnd(Kd, N, dtype=dtype, seed=2)
+    fn = {"nt": K.mm_nt, "nn": K.mm_nn, "tn": K.mm_tn}[layout]
+    out = fn(a, b)
+    A = a.double() if layout != "tn" else a.double().t()
+    Bm = b.double().t() if layout == "nt" else b.double()
+    ref = A @ Bm
+    rtol, atol = tol_for(dtype, Kd)
+    assert out.shape == (M, N) and out.dtype == dtype
+    assert_close(out, ref, rtol, atol, f"gemm {layout} {shape} {dtype}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm_epilogue(dtype, act):
+    M, N, Kd = 300, 264, 192
+    a, w = rnd(M, Kd, dtype=dtype, seed=3), rnd(N, Kd, dtype=dtype, seed=4, scale=0.1)
+    bias, res = rnd(N, dtype=dtype, seed=5), rnd(M, N, dtype=dtype, seed=6)
+    aux = torch.empty(M, N, device=DEV, dtype=dtype)
+    out = K.mm_nt(a, w, bias=bias, act=act, residual=res, aux_out=aux)
+    pre = a.double() @ w.double().t() + bias.double()
+    ref = ACTS[act](pre) + res.double()
+    rtol, atol = tol_for(dtype, Kd)
+    assert_close(aux, pre, rtol, atol, "aux_out")
+    assert_close(out, ref, 2 * rtol, 2 * atol, f"epilogue act={act}")
+    # mulgrad: out = (dy @ w) * act'(pre)
+    dy = rnd(M, N, dtype=dtype, seed=7)
+    pre_t = pre.to(dtype)
+    g = K.mm_nn(dy, w, mulgrad=rnd(M, Kd, dtype=dtype, seed=8), act=act)
+    xg = rnd(M, Kd, dtype=dtype, seed=8).double().requires_grad_(True)
+    ACTS[act](xg).backward(dy.double() @ w.double())
+    assert_close(g, xg.grad, 3 * rtol, 3 * atol, f"mulgrad act={act}")
+    del pre_t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_accumulate_f32out_strided(dtype):
+    M, N, Kd = 260, 200, 320
+    big_a = rnd(M, Kd + 24, dtype=dtype, seed=9)
+    a = big_a[:, 8:8 + Kd] if dtype == torch.float32 else big_a[:, 8:8 + Kd]   # row stride != K, 16B-aligned offset
+    x = rnd(M, N, dtype=dtype, seed=10)
+    out = rnd(Kd, N, dtype=torch.float32, seed=11)
+    ref = out.double() + a.double().t() @ x.double()
+    K.mm_tn(a, x, out=out, accumulate=True)                     # dW-style: fp32 accumulate into existing grad
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (2e-5, 2e-3)
+    assert_close(out, ref, rtol, atol, "accumulate fp32 out")
+    # unaligned view (offset of 1 element): scalar path
+    a1 = big_a[:, 1:1 + Kd]
+    o2 = K.mm_nt(a1, rnd(N, Kd, dtype=dtype, seed=12))
+    ref2 = a1.double() @ rnd(N, Kd, dtype=dtype, seed=12).double().t()
+    r2, a2 = tol_for(dtype, Kd)
+    assert_close(o2, ref2, r2, a2, "unaligned rows")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_gqa(dtype):
+    B, Hkv, G, S, D = 2, 2, 3, 70, 64
+    q = rnd(B, Hkv * G, S, D, dtype=dtype, seed=13)
+    k = rnd(B, Hkv, S, D, dtype=dtype, seed=14)
+    out = torch.empty(B, Hkv * G, S, S, device=DEV, dtype=torch.float32)
+    K.gemm(L.NT, q, k, S, S, D, D, D, out, S, alpha=0.5, nb=(B, Hkv, G),
+           sA=(Hkv * G * S * D, G * S * D, S * D), sB=(Hkv * S * D, S * D, 0), sC=(Hkv * G * S * S, G * S * S, S * S))
+    ref = 0.5 * torch.einsum("bhgid,bhjd->bhgij", q.double().view(B, Hkv, G, S, D), k.double()).reshape(B, Hkv * G, S, S)
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (2e-5, 1e-4)
+    assert_close(out, ref, rtol, atol, "batched gqa scores")
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype,wdtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                          (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("rows,cols", [(37, 256), (1030, 3584), (5, 130)])
+def test_rmsnorm(dtype, wdtype, rows, cols):
+    x = rnd(rows, cols, dtype=dtype, seed=20)
+    w = (1 + 0.1 * rnd(cols, seed=21)).to(wdtype)
+    dy = rnd(rows, cols, dtype=dtype, seed=22)
+    y, rstd = K.rmsnorm_fwd(x, w, 1e-6)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    normed = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)
+    yr = wr * normed
+    rtol, atol = (1e-5, 1e-5) if dtype == torch.float32 else (1.0 / 64, 1e-2)
+    assert_close(y, yr, rtol, atol, "rmsnorm fwd")
+    yr.backward(dy.double())
+    dx, dw = K.rmsnorm_bwd(dy, x, w, rstd)
+    assert_close(dx, xr.grad, rtol, atol * 2, "rmsnorm dx")
+    assert_close(dw, wr.grad, rtol, atol * math.sqrt(rows), "rmsnorm dw")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("affine", [True, False])
+@pytest.mark.parametrize("rows,cols", [(40, 128), (1028, 1024), (7, 70)])
+def test_layernorm(dtype, affine, rows, cols):
+    x = rnd(rows, cols, dtype=dtype, seed=23) + 0.5
+    w = (1 + 0.1 * rnd(cols, seed=24)) if affine else None
+    b = 0.1 * rnd(cols, seed=25) if affine else None
+    dy = rnd(rows, cols, dtype=dtype, seed=26)
+    y, mean, rstd = K.layernorm_fwd(x, w, b, 1e-5)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True) if affine else None
+    br = b.double().requires_grad_(True) if affine else None
+    yr = F.layer_norm(xr, (cols,), wr, br, 1e-5)
+    rtol, atol = (1e-5, 1e-5) if dtype == torch.float32 else (1.0 / 64, 2e-2)
+    assert_close(y, yr, rtol, atol, "layernorm fwd")
+    yr.backward(dy.double())
+    dx, dw, db = K.layernorm_bwd(dy, x, w, mean, rstd)
+    assert_close(dx, xr.grad, rtol, atol * 2, "layernorm dx")
+    if affine:
+        assert_close(dw, wr.grad, rtol, atol * math.sqrt(rows), "layernorm dw")
+        assert_close(db, br.grad, rtol, atol * math.sqrt(rows), "layernorm db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(4592, 520), (3, 70), (300, 4608)])
+def test_colsum(dtype, rows, cols):
+    x = rnd(rows, cols, dtype=dtype, seed=27)
+    out = K.colsum(x)
+    assert_close(out, x.double().sum(0), 1e-5, 1e-4 * math.sqrt(rows), "colsum")
+    acc = torch.ones(cols, device=DEV)
+    K.colsum(x, out=acc, accumulate=True)
+    assert_close(acc, 1 + x.double().sum(0), 1e-5, 1e-4 * math.sqrt(rows), "colsum accumulate")
+
+
+# ------------------------------------------------------------------------------------------------ RoPE
+def _rope_tables(S, D, theta):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
+    return fr.cos().to(DEV).contiguous(), fr.sin().to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_split_merge(dtype):
+    B, S, Hq, Hkv, D = 2, 37, 4, 2, 128
+    qkv = rnd(B * S, (Hq + 2 * Hkv) * D, dtype=dtype, seed=30)
+    cos_t, sin_t = _rope_tables(S, D, 1e6)
+    q, k, v = K.rope_split(qkv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
+    x = qkv.double().view(B, S, Hq + 2 * Hkv, D)
+    cos = torch.cat([cos_t, cos_t], -1).double()[None, :, None]
+    sin = torch.cat([sin_t, sin_t], -1).double()[None, :, None]
+    rot = lambda t: torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1)
+    qr = (x[:, :, :Hq] * cos + rot(x[:, :, :Hq]) * sin).transpose(1, 2)
+    kr = (x[:, :, Hq:Hq + Hkv] * cos + rot(x[:, :, Hq:Hq + Hkv]) * sin).transpose(1, 2)
+    vr = x[:, :, Hq + Hkv:].transpose(1, 2)
+    rtol, atol = (1e-5, 1e-5) if dtype == torch.float32 else (1.0 / 64, 2e-2)
+    assert_close(q, qr, rtol, atol, "rope q")
+    assert_close(k, kr, rtol, atol, "rope k")
+    assert_close(v, vr, 0, 0, "rope v copy")
+    # merge is the transpose (adjoint) of split: <split(x), g> == <x, merge(g)>
+    gq, gk, gv = rnd(*q.shape, dtype=dtype, seed=31), rnd(*k.shape, dtype=dtype, seed=32), rnd(*v.shape, dtype=dtype, seed=33)
+    dqkv = K.rope_merge(gq, gk, gv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
+    lhs = (qr * gq.double()).sum() + (kr * gk.double()).sum() + (vr * gv.double()).sum()
+    rhs = (qkv.double() * dqkv.double()).sum()
+    assert abs(lhs - rhs) < (1e-6 if dtype == torch.float32 else 3e-2) * (abs(lhs) + 100)
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, causal, scale, kv_start, kv_end):
+    B, Hq, Sq, D = q.shape
+    Hkv, Sk = k.shape[1], k.shape[2]
+    G = Hq // Hkv
+    kk = k.double().repeat_interleave(G, 1)
+    vv = v.double().repeat_interleave(G, 1)
+    s = q.double() @ kk.transpose(-1, -2) * scale
+    j = torch.arange(Sk, device=q.device)[None, None, None, :]
+    i = torch.arange(Sq, device=q.device)[None, None, :, None]
+    vis = torch.ones(B, 1, Sq, Sk, dtype=torch.bool, device=q.device)
+    if kv_start is not None:
+        vis = vis & (j >= kv_start.view(B, 1, 1, 1))
+    if kv_end is not None:
+        vis = vis & (j < kv_end.view(B, 1, 1, 1))
+    if causal:
+        vis = vis & (j <= i + (Sk - Sq))
+    s = s.masked_fill(~vis, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return p @ vv, torch.logsumexp(s, -1)
+
+
+ATTN_CASES = [
+    # B, Hq, Hkv, Sq, D, causal, padded, head_major
+    (2, 4, 2, 150, 128, True, True, True),     # LLM-like GQA causal + right padding
+    (2, 2, 2, 257, 64, False, False, False),   # CLIP-like, token-major fused qkv
+    (3, 2, 2, 17, 64, False, False, False),    # DiT-like
+    (1, 7, 1, 287, 128, True, False, True),    # 7:1 GQA
+    (2, 2, 1, 64, 128, True, True, True),
+]
+
+
+@pytest.mark.parametrize("dtype,force_generic", [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, True)])
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(dtype, force_generic, case):
+    B, Hq, Hkv, S, D, causal, padded, head_major = case
+    scale = D ** -0.5
+    if head_major:
+        q, k, v = rnd(B, Hq, S, D, dtype=dtype, seed=40), rnd(B, Hkv, S, D, dtype=dtype, seed=41), rnd(B, Hkv, S, D, dtype=dtype, seed=42)
+        o_store = torch.empty(B, S, Hq, D, device=DEV, dtype=dtype)       # token-major output (o_proj input)
+        o = o_store.permute(0, 2, 1, 3)
+        do_store = rnd(B, Hq, S, D, dtype=dtype, seed=43)
+        do = do_store
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    else:
+        assert Hq == Hkv
+        qkv = rnd(B, S, 3, Hq, D, dtype=dtype, seed=44)
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        o_store = torch.empty(B, S, Hq, D, device=DEV, dtype=dtype)
+        o = o_store.permute(0, 2, 1, 3)
+        do = rnd(B, S, Hq, D, dtype=dtype, seed=45).permute(0, 2, 1, 3)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = (dqkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    kv_end = None
+    if padded:
+        kv_end = torch.tensor([S - 5 * (b + 1) for b in range(B)], dtype=torch.int32, device=DEV)
+    lse = K.attn_fwd(q, k, v, o, causal=causal, scale=scale, kv_end=kv_end, force_generic=force_generic)
+    ref_o, ref_lse = _attn_ref(q, k, v, causal, scale, None, kv_end)
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (1.0 / 64, 2e-2)
+    assert_close(o, ref_o, rtol, atol, "attn o")
+    assert_close(lse, ref_lse, 1e-4 if dtype == torch.float32 else 1e-2, 1e-4 if dtype == torch.float32 else 3e-2, "attn lse")
+    # backward vs autograd
+    qr, kr, vr = (t.double().detach().clone().requires_grad_(True) for t in (q, k, v))
+    ro, _ = _attn_ref(qr, kr, vr, causal, scale, None, kv_end)
+    ro.backward(do.double())
+    K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=causal, scale=scale, kv_end=kv_end)
+    rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (1.0 / 32, 6e-2)
+    assert_close(dq, qr.grad, rt, at, "attn dq")
+    assert_close(dk, kr.grad, rt, at * 2, "attn dk")
+    assert_close(dv, vr.grad, rt, at * 2, "attn dv")
+
+
+def test_attention_left_padding_and_flash_vs_generic():
+    B, Hq, Hkv, S, D = 2, 4, 4, 200, 64
+    q, k, v = (rnd(B, Hq, S, D, dtype=torch.bfloat16, seed=s) for s in (50, 51, 52))
+    o1, o2 = torch.empty_like(q), torch.empty_like(q)
+    ks = torch.tensor([0, 37], dtype=torch.int32, device=DEV)
+    l1 = K.attn_fwd(q, k, v, o1, causal=True, scale=0.125, kv_start=ks)
+    l2 = K.attn_fwd(q, k, v, o2, causal=True, scale=0.125, kv_start=ks, force_generic=True)
+    assert_close(o1, o2, 1.0 / 64, 1e-2, "flash vs generic")
+    assert_close(l1, l2, 1e-3, 1e-3, "flash vs generic lse")
+    assert torch.all(o1[1, :, :37] == 0)         # rows with no visible key
+
+
+# ----------------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swiglu_and_acts(dtype):
+    rows, Fd = 77, 264
+    gu = rnd(rows, 2 * Fd, dtype=dtype, seed=60)
+    dout = rnd(rows, Fd, dtype=dtype, seed=61)
+    out = K.swiglu_fwd(gu)
+    gr = gu.double().requires_grad_(True)
+    ref = F.silu(gr[:, :Fd]) * gr[:, Fd:]
+    rtol, atol = (1e-5, 1e-5) if dtype == torch.float32 else (1.0 / 64, 1e-2)
+    assert_close(out, ref, rtol, atol, "swiglu fwd")
+    ref.backward(dout.double())
+    assert_close(K.swiglu_bwd(gu, dout), gr.grad, rtol, atol, "swiglu bwd")
+    for act in (1, 2, 3, 4, 5):
+        x = rnd(rows, Fd, dtype=dtype, seed=62)
+        xr = x.double().requires_grad_(True)
+        yr = ACTS[act](xr)
+        assert_close(K.act_fwd(x, act), yr, rtol, atol, f"act {act}")
+        yr.backward(dout.double())
+        assert_close(K.act_bwd(x, dout, act), xr.grad, rtol, atol, f"act bwd {act}")
+    a, b = rnd(5, 70, dtype=dtype, seed=63), rnd(5, 70, dtype=dtype, seed=64)
+    assert_close(K.add(a, b), a.double() + b.double(), rtol, atol, "add")
+    c = K.cast(rnd(33, 12, seed=65), torch.bfloat16)
+    assert torch.equal(c, rnd(33, 12, seed=65).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_splice_gather(dtype):
+    V, d, nimg = 50, 136, 6
+    embed = rnd(V, d, dtype=dtype, seed=70)
+    img = rnd(2 * nimg, d, dtype=dtype, seed=71)
+    PAD = np.iinfo(np.int64).min
+    plan = torch.tensor([3, -1, -2, -3, -4, -5, -6, 7, 3, PAD,
+                         9, -7, -8, -9, -10, -11, -12, 1, PAD, PAD], dtype=torch.int64, device=DEV)
+    out = K.splice_fwd(plan, embed, img)
+    ref = torch.zeros(20, d, device=DEV, dtype=dtype)
+    for r, p in enumerate(plan.tolist()):
+        if p >= 0:
+            ref[r] = embed[p]
+        elif p != PAD:
+            ref[r] = img[-1 - p]
+    assert torch.equal(out, ref)
+    dout = rnd(20, d, dtype=dtype, seed=72)
+    d_embed = torch.zeros(V, d, device=DEV)
+    d_img = torch.zeros_like(img)
+    K.splice_bwd(plan, dout, d_embed, d_img)
+    re = torch.zeros(V, d, device=DEV, dtype=torch.float64)
+    ri = torch.zeros(2 * nimg, d, device=DEV, dtype=dtype)
+    for r, p in enumerate(plan.tolist()):
+        if p >= 0:
+            re[p] += dout[r].double()
+        elif p != PAD:
+            ri[-1 - p] = dout[r]
+    assert_close(d_embed, re, 1e-6, 1e-6, "splice d_embed")
+    assert torch.equal(d_img, ri)
+    idx = torch.tensor([4, 19, 4], dtype=torch.int64, device=DEV)
+    gth = K.gather_rows(out, idx, torch.float32)
+    assert torch.equal(gth, out[idx].float())
+    sc = K.scatter_rows(gth, idx, 20, dtype)
+    rs = torch.zeros(20, d, device=DEV, dtype=torch.float64)
+    rs.index_add_(0, idx, gth.double())
+    assert_close(sc, rs, 1.0 / 128, 1e-6, "scatter rows")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vit_frontend(dtype):
+    N, H, P, Cc = 3, 56, 14, 72
+    img = rnd(N, 3, H, H, seed=80)
+    ld = 592
+    rows = K.im2col(img, P, ld, dtype)
+    ref = F.unfold(img, P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
+    assert torch.equal(rows[:, :588], ref.to(dtype))
+    assert torch.all(rows[:, 588:] == 0)
+    np_ = (H // P) ** 2
+    patch = rnd(N * np_, Cc, dtype=dtype, seed=81)
+    cls, pos = rnd(Cc, seed=82), rnd(np_ + 1, Cc, seed=83)
+    x = K.vit_embed_fwd(patch, cls, pos, N, np_)
+    ref = torch.cat([cls.to(dtype).expand(N, 1, Cc), patch.view(N, np_, Cc)], 1).float() + pos
+    assert_close(x, ref, 1e-6 if dtype == torch.float32 else 1.0 / 128, 1e-6, "vit embed")
+    dx = rnd(N, np_ + 1, Cc, dtype=dtype, seed=84)
+    assert torch.equal(K.vit_embed_bwd(dx, N, np_), dx[:, 1:].reshape(-1, Cc))
+
+
+def test_diffusion_glue():
+    N, T, A, hd, d = 8, 16, 7, 96, 136
+    x0, noise = rnd(N, T, A, seed=90), rnd(N, T, A, seed=91)
+    a, s = torch.rand(N, device=DEV), torch.rand(N, device=DEV)
+    assert_close(K.qsample(x0, noise, a, s), a[:, None, None] * x0 + s[:, None, None] * noise, 1e-6, 1e-7, "qsample")
+    t = torch.tensor([0, 1, 5, 17, 50, 63, 98, 99], dtype=torch.float32, device=DEV)
+    half = 128
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(DEV)
+    emb = K.timestep_embedding(t, freqs)
+    args = t[:, None] * freqs[None]
+    assert_close(emb, torch.cat([args.cos(), args.sin()], -1), 1e-5, 2e-6, "timestep embedding")
+    xe, te, ze, pos = rnd(N, T, hd, seed=92), rnd(N, hd, seed=93), rnd(N, hd, seed=94), rnd(T + 1, hd, seed=95)
+    h = K.dit_assemble_fwd(xe, te, ze, pos)
+    ref = torch.cat([(te + ze)[:, None], xe], 1) + pos
+    assert_close(h, ref, 1e-6, 1e-6, "dit assemble")
+    dh = rnd(N, T + 1, hd, seed=96)
+    dxe, dc = K.dit_assemble_bwd(dh)
+    assert torch.equal(dxe, dh[:, 1:]) and torch.equal(dc, dh[:, 0])
+    z, unc = rnd(N, d, seed=97), rnd(d, seed=98)
+    drop = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0], dtype=torch.uint8, device=DEV)
+    zo = K.token_drop(z, unc, drop)
+    assert torch.equal(zo, torch.where(drop.bool()[:, None], unc[None], z))
+    dz, dunc = K.token_drop_bwd(z, drop)
+    assert torch.equal(dz, torch.where(drop.bool()[:, None], torch.zeros_like(z), z))
+    assert_close(dunc, z[drop.bool()].sum(0), 1e-6, 1e-6, "dunc")
+    pred, tgt = rnd(N, T, A, seed=99), rnd(N, T, A, seed=100)
+    loss, dpred = K.mse_loss(pred, tgt, gscale=0.5)
+    assert_close(loss, ((pred - tgt) ** 2).mean().view(1), 1e-5, 1e-6, "mse")
+    assert_close(dpred, 0.5 * 2 * (pred - tgt) / pred.numel(), 1e-5, 1e-9, "mse grad")
+    # ddim step with CFG
+    Bq, per = 2, T * A
+    x = rnd(2 * Bq, T, A, seed=101)
+    x[Bq:] = x[:Bq]
+    mo = rnd(2 * Bq, T, A, seed=102)
+    xr = x.clone()
+    c1, c2, abp = 1.31, 0.85, 0.77
+    K.ddim_step(x, mo, Bq, True, 1.5, c1, c2, abp)
+    eps = mo[Bq:] + 1.5 * (mo[:Bq] - mo[Bq:])
+    x0p = c1 * xr[:Bq] - c2 * eps
+    e2 = (c1 * xr[:Bq] - x0p) / c2
+    ref = x0p * math.sqrt(abp) + math.sqrt(1 - abp) * e2
+    assert_close(x[:Bq], ref, 1e-5, 1e-6, "ddim step")
+    assert torch.equal(x[:Bq], x[Bq:])
+    del per
+
+
+# --------------------------------------------------------------------------------------------- optimizer
+def test_adamw_matches_torch():
+    torch.manual_seed(0)
+    sizes = [1000, 37, 4096 * 3 + 5, 8, 70000]
+    n = sum(sizes)
+    p = rnd(n, seed=110).contiguous()
+    g = rnd(n, seed=111, scale=0.1).contiguous()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    params = [p[sum(sizes[:i]):sum(sizes[:i + 1])].clone().requires_grad_(True) for i in range(len(sizes))]
+    groups = [dict(params=[params[0], params[2], params[4]], weight_decay=0.01, lr=1e-3),
+              dict(params=[params[1], params[3]], weight_decay=0.0, lr=5e-4)]
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8)
+    # chunk table: chunks of <= 4096 elements aligned to tensor boundaries
+    cs, cl, cg = [], [], []
+    off = 0
+    for i, sz in enumerate(sizes):
+        grp = 0 if i in (0, 2, 4) else 1
+        o = 0
+        while o < sz:
+            ln = min(4096, sz - o)
+            cs.append(off + o); cl.append(ln); cg.append(grp)
+            o += ln
+        off += sz
+    cs_t = torch.tensor(cs, dtype=torch.int64, device=DEV)
+    cl_t = torch.tensor(cl, dtype=torch.int32, device=DEV)
+    cg_t = torch.tensor(cg, dtype=torch.int32, device=DEV)
+    ss = torch.zeros(1, device=DEV)
+    scratch = torch.empty(4096, device=DEV, dtype=torch.float64)
+    norm, coef = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    for step in (1, 2, 3):
+        gs = g * (1 + 0.3 * step)
+        for i, q_ in enumerate(params):
+            q_.grad = gs[sum(sizes[:i]):sum(sizes[:i + 1])].clone()
+        tn = torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        K.sumsq(gs, ss, scratch)
+        K.clip_coef(ss, 1.0, norm, coef)
+        assert abs(norm.item() - tn.item()) < 1e-4 * tn.item()
+        K.adamw(p, gs, m, v, shadow, cs_t, cl_t, cg_t, [1e-3, 5e-4], [0.01, 0.0], 0.9, 0.999, 1e-8, step, clip=coef)
+        ref = torch.cat([q_.detach() for q_ in params])
+        assert_close(p, ref, 1e-5, 2e-6, f"adamw step {step}")
+        assert torch.equal(shadow, p.to(torch.bfloat16))
+    x = rnd(1000, seed=112)
+    K.scale_(x, 0.25)
+    assert_close(x, rnd(1000, seed=112) * 0.25, 0, 0, "scale")
