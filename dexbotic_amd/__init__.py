@@ -1,0 +1,32 @@
+"""dexbotic_amd — MI355X-native (gfx950 / CDNA4) drop-in for the DB-CogACT hot path of dexmal/dexbotic.
+
+Importing the package loads libdexbotic_amd.so through ctypes and fails loudly if it is missing:
+there is no CPU or eager-PyTorch fallback for the compute path.
+
+    from dexbotic_amd.model.cogact.cogact_arch import CogActConfig, CogACTForCausalLM
+
+mirrors ``dexbotic.model.cogact.cogact_arch`` (same class names, ``forward`` / ``inference_action``
+contracts, ``state_dict`` keys and ``model_type`` registry strings).
+"""
+from . import _lib  # noqa: F401  (raises ImportError when the native library is absent)
+
+__version__ = "0.1.0"
+
+
+def model_registry():
+    """``config.model_type`` -> (Config, ForCausalLM): the HF AutoConfig/AutoModel registry strings of the
+    reference (dexbotic_arch.py:18, cogact_arch.py:14)."""
+    from .model.cogact.cogact_arch import CogActConfig, CogACTForCausalLM
+    from .model.dexbotic_arch import DexboticConfig, DexboticForCausalLM
+    return {"dexbotic": (DexboticConfig, DexboticForCausalLM),
+            "dexbotic_cogact": (CogActConfig, CogACTForCausalLM)}
+
+
+def from_pretrained(path: str, **kw):
+    """load any registered policy from a reference-format checkpoint directory"""
+    import json
+    import os
+    with open(os.path.join(path, "config.json")) as f:
+        mt = json.load(f).get("model_type", "dexbotic")
+    _, cls = model_registry()[mt]
+    return cls.from_pretrained(path, **kw)

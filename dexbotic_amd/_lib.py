@@ -105,6 +105,7 @@ SIGNATURES = {
     "dxa_sumsq": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
     "dxa_clip_coef": (_int, [_vp, _f32, _vp, _vp, _vp]),
     "dxa_scale": (_int, [_vp, _i64, _f32, _vp]),
+    "dxa_scale_dev": (_int, [_vp, _i64, _vp, _vp]),
 }
 
 

@@ -116,6 +116,11 @@ __global__ __launch_bounds__(256) void scale_k(float* __restrict__ x, int64_t n,
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
 }
 
+__global__ __launch_bounds__(256) void scale_dev_k(float* __restrict__ x, int64_t n, const float* __restrict__ s) {
+  const float f = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
+}
+
 }  // namespace
 
 extern "C" int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream) {
@@ -154,6 +159,14 @@ extern "C" int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream) {
   DXA_CHECK_ARG(x && n >= 0, "dxa_scale: bad args");
   if (n == 0) return DXA_OK;
   hipLaunchKernelGGL(scale_k, dim3(dxa_grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_scale_dev(float* x, int64_t n, const float* s, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && s && n >= 0, "dxa_scale_dev: bad args");
+  if (n == 0) return DXA_OK;
+  hipLaunchKernelGGL(scale_dev_k, dim3(dxa_grid1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

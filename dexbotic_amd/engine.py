@@ -58,6 +58,7 @@ class ParamStore:
         self.grad_written: Dict[str, bool] = {}
         self.on_bucket_ready: Optional[Callable[[int], None]] = None
         self._bucket_pending: List[int] = []
+        self._micro_written: set = set()
 
     # ---- layout -------------------------------------------------------------------------------------
     def new_bucket(self) -> int:
@@ -93,10 +94,7 @@ class ParamStore:
             p = nn.Parameter(self.master[s.offset:s.offset + s.numel].view(s.shape), requires_grad=True)
             self.params[s.name] = p
             self.grad_written[s.name] = False
-        self._bucket_pending = [0] * nb
-        for s in self.slots.values():
-            self._bucket_pending[s.bucket] += 1
-        self._bucket_total = list(self._bucket_pending)
+        self.set_expected(())
 
     # ---- views --------------------------------------------------------------------------------------
     def _view(self, arena: torch.Tensor, names: Sequence[str], shape: Optional[Sequence[int]]) -> torch.Tensor:
@@ -131,20 +129,39 @@ class ParamStore:
         return self.grad_written[names[0]]
 
     def mark_written(self, *names: str) -> None:
+        """``grad_written`` is sticky for the optimizer step (=> later micro-batches accumulate); the bucket
+        countdown restarts every micro-batch so the reducer can fire on the last one."""
         for nm in names:
-            if not self.grad_written[nm]:
-                self.grad_written[nm] = True
+            self.grad_written[nm] = True
+            if nm not in self._micro_written:
+                self._micro_written.add(nm)
                 b = self.slots[nm].bucket
                 self._bucket_pending[b] -= 1
-                if self._bucket_pending[b] == 0 and self.on_bucket_ready is not None:
+                if self._bucket_pending[b] == 0 and self.on_bucket_ready is not None and not self._bucket_fired[b]:
+                    self._bucket_fired[b] = True
                     self.on_bucket_ready(b)
+
+    def set_expected(self, exclude: Iterable[str] = ()) -> None:
+        """(re)count, per bucket, the slots a backward pass is expected to write: trainable and not in
+        ``exclude`` (parameters the path never touches, e.g. lm_head / the unused last CLIP layer)."""
+        exclude = set(exclude)
+        self._bucket_total = [0] * len(self.bucket_ranges)
+        for s in self.slots.values():
+            if self.params[s.name].requires_grad and s.name not in exclude:
+                self._bucket_total[s.bucket] += 1
+        self.begin_micro()
+
+    def begin_micro(self) -> None:
+        self._micro_written = set()
+        self._bucket_pending = list(self._bucket_total)
+        self._bucket_fired = [False] * len(self._bucket_total)
 
     def begin_step(self, zero_names: Iterable[str] = ()) -> None:
         """Reset per-step state.  Gradients are produced with beta=0 writes by the GEMM kernels, so
         only slots that are accumulated into (embedding rows, never-written slots) need zeroing."""
         for nm in self.grad_written:
             self.grad_written[nm] = False
-        self._bucket_pending = list(self._bucket_total)
+        self.begin_micro()
         for nm in zero_names:
             self.g(nm).zero_()
 
@@ -162,6 +179,36 @@ class ParamStore:
         if self.shadow is not None:
             from . import kernels as K
             K.cast(self.master, self.shadow.dtype, out=self.shadow)
+
+
+class Fp32View:
+    """Same interface as ParamStore but ``w()`` hands out the fp32 masters: used by the diffusion action
+    head, which the reference keeps in fp32 (cogact_arch.py:133, SURVEY.md App. A dtype notes)."""
+
+    def __init__(self, store: ParamStore):
+        self._s = store
+
+    def w(self, *names: str, shape=None):
+        return self._s.w32(*names, shape=shape)
+
+    def __getattr__(self, item):
+        return getattr(self._s, item)
+
+
+def attach_parameters(root: nn.Module, store: ParamStore, containers: Optional[Dict[str, nn.Module]] = None) -> None:
+    """Register every arena view as an nn.Parameter under its dotted name so that ``root.state_dict()``
+    has exactly the reference's keys.  Intermediate modules that do not exist yet
+    are created as empty containers; existing modules (e.g. the backbone / tower objects) are reused."""
+    for name, p in store.params.items():
+        parts = name.split(".")
+        mod = root
+        for part in parts[:-1]:
+            child = mod._modules.get(part)
+            if child is None:
+                child = nn.Module()
+                mod.add_module(part, child)
+            mod = child
+        mod.register_parameter(parts[-1], p)
 
 
 # ------------------------------------------------------------------------------------------ optimizer
@@ -192,9 +239,13 @@ class OptimConfig:
 class FusedAdamW:
     """One-launch AdamW over the arena + device-side global-norm clipping."""
 
-    def __init__(self, store: ParamStore, cfg: OptimConfig, prefixes: Dict[str, str] | None = None):
+    def __init__(self, store: ParamStore, cfg: OptimConfig, prefixes: Dict[str, str] | None = None,
+                 exclude: Iterable[str] = ()):
+        """``exclude``: parameters that never receive a gradient (torch.optim skips ``grad is None``
+        parameters entirely — no weight decay either)."""
         from . import kernels as K  # noqa: F401  (fail early if the library is missing)
         self.store, self.cfg = store, cfg
+        exclude = set(exclude)
         dev = store.device
         self.m = torch.zeros_like(store.master)
         self.v = torch.zeros_like(store.master)
@@ -204,7 +255,7 @@ class FusedAdamW:
         self.group_keys: List[Tuple[str, bool]] = []
         cs, cl, cg = [], [], []
         for s in sorted(store.slots.values(), key=lambda s: s.offset):
-            if not store.params[s.name].requires_grad:
+            if not store.params[s.name].requires_grad or s.name in exclude:
                 continue
             lr_key = "base"
             if cfg.mm_projector_lr is not None and prefixes["mm_projector"] in s.name:
@@ -335,6 +386,11 @@ class GradReducer:
 
     def finish(self) -> None:
         """flush the tail bucket and make the compute stream wait for all collectives"""
+        st = self.store
+        for b in reversed(range(len(st.bucket_ranges))):   # buckets a frozen/unused slot kept from firing
+            if not st._bucket_fired[b] and st._bucket_pending[b] < st._bucket_total[b]:
+                st._bucket_fired[b] = True
+                self.bucket_ready(b)
         self._flush()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)

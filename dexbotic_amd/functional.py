@@ -1,0 +1,496 @@
+"""Block-level autograd Functions of the CogACT path.
+
+Each Function is one transformer block (or one front-end / head stage): its forward is a fixed
+sequence of libdexbotic_amd kernel launches, its backward the hand-scheduled reverse sequence.
+Weight gradients are NOT returned to autograd: the dW GEMMs (TN layout, fp32 output) write — or
+accumulate, for gradient accumulation — straight into the fp32 gradient arena of the ParamStore
+(engine.py), which then notifies the data-parallel reducer that the block's bucket is complete.
+An ``anchor`` parameter (any trainable tensor of the block) is passed through ``apply`` only so that
+autograd schedules the backward even when the activations upstream do not require grad.
+
+With 288 GB of HBM per MI355X every block keeps its activations (no recompute): the reference's
+gradient checkpointing (base_exp.py:243) exists to fit 80 GB parts and costs a 4th forward.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import kernels as K
+from .engine import ParamStore
+
+
+def _names(x) -> Tuple[str, ...]:
+    return (x,) if isinstance(x, str) else tuple(x)
+
+
+def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) -> None:
+    """dW (+)= dy^T x into the gradient arena (fused view over `names`)"""
+    names = _names(names)
+    if not all(st.trainable(n) for n in names):
+        if any(st.trainable(n) for n in names):
+            raise L.DxaError(f"fused parameters {names} must be frozen/unfrozen together")
+        return
+    K.mm_tn(dy2d, x2d, out=st.g(*names, shape=shape), accumulate=st.accum_flag(*names))
+    st.mark_written(*names)
+
+
+def _bgrad(st: ParamStore, names, dy2d: torch.Tensor) -> None:
+    names = _names(names)
+    if not all(st.trainable(n) for n in names):
+        return
+    n = sum(st.slots[nm].numel for nm in names)
+    K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
+    st.mark_written(*names)
+
+
+def _vgrad(st: ParamStore, name: str, val: torch.Tensor) -> None:
+    """small fp32 gradient vector/matrix (already reduced) into the arena"""
+    if not st.trainable(name):
+        return
+    g = st.g(name)
+    flat = g.view(-1)
+    v = val.reshape(-1)
+    if st.accum_flag(name):
+        K.add(flat, v.contiguous(), out=flat)
+    else:
+        K.cast(v.contiguous(), torch.float32, out=flat)
+    st.mark_written(name)
+
+
+# ------------------------------------------------------------------------------------------- Qwen2 layer
+@dataclass
+class Qwen2LayerSpec:
+    ln1: str
+    qkv_w: Tuple[str, str, str]
+    qkv_b: Tuple[str, str, str]
+    o_w: str
+    ln2: str
+    gu_w: Tuple[str, str]
+    down_w: str
+    B: int = 0
+    S: int = 0
+    Hq: int = 0
+    Hkv: int = 0
+    D: int = 0
+    d: int = 0
+    F: int = 0
+    eps: float = 1e-6
+
+
+class Qwen2LayerFn(Function):
+    """HF Qwen2DecoderLayer (HF:qwen2/modeling_qwen2.py:258-300) called from cogact_arch.py:97-106:
+    x + o_proj(attn(rope(qkv(rmsnorm(x))))) ; then + down(silu(gate)*up) of rmsnorm."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, sp: Qwen2LayerSpec, cos_t, sin_t, kv_start, kv_end):
+        B, S, Hq, Hkv, D, d, F_ = sp.B, sp.S, sp.Hq, sp.Hkv, sp.D, sp.d, sp.F
+        M = B * S
+        nq = (Hq + 2 * Hkv) * D
+        h1, rstd1 = K.rmsnorm_fwd(x, st.w(sp.ln1), sp.eps)
+        qkv = K.mm_nt(h1, st.w(*sp.qkv_w, shape=(nq, d)), bias=st.w(*sp.qkv_b, shape=(nq,)))
+        q, k, v = K.rope_split(qkv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
+        del qkv
+        o = torch.empty((B, S, Hq, D), device=x.device, dtype=x.dtype)
+        lse = K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=True, scale=D ** -0.5, kv_start=kv_start, kv_end=kv_end)
+        x2 = K.mm_nt(o.view(M, Hq * D), st.w(sp.o_w), residual=x)
+        h2, rstd2 = K.rmsnorm_fwd(x2, st.w(sp.ln2), sp.eps)
+        gu = K.mm_nt(h2, st.w(*sp.gu_w, shape=(2 * F_, d)))
+        a = K.swiglu_fwd(gu)
+        y = K.mm_nt(a, st.w(sp.down_w), residual=x2)
+        ctx.st, ctx.sp = st, sp
+        ctx.aux = (cos_t, sin_t, kv_start, kv_end)
+        ctx.save_for_backward(x, rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, sp = ctx.st, ctx.sp
+        cos_t, sin_t, kv_start, kv_end = ctx.aux
+        x, rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a = ctx.saved_tensors
+        B, S, Hq, Hkv, D, d, F_ = sp.B, sp.S, sp.Hq, sp.Hkv, sp.D, sp.d, sp.F
+        M = B * S
+        nq = (Hq + 2 * Hkv) * D
+        dy = dy.contiguous()
+        # ---- MLP
+        da = K.mm_nn(dy, st.w(sp.down_w))
+        _wgrad(st, sp.down_w, dy, a, (d, F_))
+        dgu = K.swiglu_bwd(gu, da)
+        del da
+        dh2 = K.mm_nn(dgu, st.w(*sp.gu_w, shape=(2 * F_, d)))
+        _wgrad(st, sp.gu_w, dgu, h2, (2 * F_, d))
+        del dgu
+        tr2 = st.trainable(sp.ln2)
+        dx2n, _ = K.rmsnorm_bwd(dh2, x2, st.w(sp.ln2), rstd2, dw_out=st.g(sp.ln2) if tr2 else None,
+                                accumulate=st.accum_flag(sp.ln2), want_dw=tr2)
+        if tr2:
+            st.mark_written(sp.ln2)
+        dx2 = K.add(dy, dx2n)
+        del dx2n, dh2
+        # ---- attention: dO written head-major by a (b, h)-batched NN GEMM so the GQA group folds into
+        #      the rows of the dK/dV GEMMs (attention.hip)
+        wo = st.w(sp.o_w)                                        # [d, Hq*D]
+        do = torch.empty((B, Hq, S, D), device=x.device, dtype=x.dtype)
+        K.gemm(L.NN, dx2, wo, S, D, d, d, Hq * D, do, D, nb=(B, Hq, 1),
+               sA=(S * d, 0, 0), sB=(0, D, 0), sC=(Hq * S * D, S * D, 0))
+        _wgrad(st, sp.o_w, dx2, o.view(M, Hq * D), (d, Hq * D))
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do, dq, dk, dv, causal=True, scale=D ** -0.5,
+                   kv_start=kv_start, kv_end=kv_end)
+        dqkv = K.rope_merge(dq, dk, dv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
+        del dq, dk, dv, do
+        dh1 = K.mm_nn(dqkv, st.w(*sp.qkv_w, shape=(nq, d)))
+        _wgrad(st, sp.qkv_w, dqkv, h1, (nq, d))
+        _bgrad(st, sp.qkv_b, dqkv)
+        del dqkv
+        tr1 = st.trainable(sp.ln1)
+        dxn, _ = K.rmsnorm_bwd(dh1, x, st.w(sp.ln1), rstd1, dw_out=st.g(sp.ln1) if tr1 else None,
+                               accumulate=st.accum_flag(sp.ln1), want_dw=tr1)
+        if tr1:
+            st.mark_written(sp.ln1)
+        dx = K.add(dx2, dxn)
+        return dx, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------- ViT-style block (CLIP layer, DiT block)
+@dataclass
+class VitBlockSpec:
+    ln1_w: Optional[str]
+    ln1_b: Optional[str]
+    qkv_w: Tuple[str, ...]      # 3 adjacent tensors (CLIP) or the single fused one (timm)
+    qkv_b: Tuple[str, ...]
+    out_w: str
+    out_b: str
+    ln2_w: Optional[str]
+    ln2_b: Optional[str]
+    fc1_w: str
+    fc1_b: str
+    fc2_w: str
+    fc2_b: str
+    act: int
+    eps: float
+    N: int = 0      # sequences
+    T: int = 0      # tokens per sequence
+    H: int = 0
+    D: int = 0
+    I: int = 0      # mlp width
+
+
+class VitBlockFn(Function):
+    """Pre-LN block: x + out(attn(qkv(LN(x)))) ; + fc2(act(fc1(LN(.)))).
+    CLIP encoder layer (HF:clip/modeling_clip.py:259-384; affine LN eps 1e-5, quick_gelu) and DiTBlock
+    (cogact/action_model/dit.py:137-162 with timm Attention/Mlp; LN without affine eps 1e-6, tanh-GELU)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, sp: VitBlockSpec):
+        N, T, H, D, I = sp.N, sp.T, sp.H, sp.D, sp.I
+        C_ = H * D
+        M = N * T
+        w = lambda n: st.w(n) if n is not None else None
+        x = x.reshape(M, C_)
+        h1, mean1, rstd1 = K.layernorm_fwd(x, w(sp.ln1_w), w(sp.ln1_b), sp.eps)
+        qkv = K.mm_nt(h1, st.w(*sp.qkv_w, shape=(3 * C_, C_)), bias=st.w(*sp.qkv_b, shape=(3 * C_,)))
+        q5 = qkv.view(N, T, 3, H, D)
+        q, k, v = (q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        o = torch.empty((N, T, H, D), device=x.device, dtype=x.dtype)
+        lse = K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=False, scale=D ** -0.5)
+        x2 = K.mm_nt(o.view(M, C_), st.w(sp.out_w), bias=st.w(sp.out_b), residual=x)
+        h2, mean2, rstd2 = K.layernorm_fwd(x2, w(sp.ln2_w), w(sp.ln2_b), sp.eps)
+        pre = torch.empty((M, I), device=x.device, dtype=x.dtype)
+        a = K.mm_nt(h2, st.w(sp.fc1_w), bias=st.w(sp.fc1_b), act=sp.act, aux_out=pre)
+        y = K.mm_nt(a, st.w(sp.fc2_w), bias=st.w(sp.fc2_b), residual=x2)
+        ctx.st, ctx.sp = st, sp
+        ctx.save_for_backward(x, mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a)
+        return y.view(N, T, C_)
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, sp = ctx.st, ctx.sp
+        x, mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a = ctx.saved_tensors
+        N, T, H, D, I = sp.N, sp.T, sp.H, sp.D, sp.I
+        C_ = H * D
+        M = N * T
+        w = lambda n: st.w(n) if n is not None else None
+        dy = dy.reshape(M, C_).contiguous()
+        # ---- MLP (activation gradient fused into the dX GEMM epilogue)
+        dpre = K.mm_nn(dy, st.w(sp.fc2_w), mulgrad=pre, act=sp.act)
+        _wgrad(st, sp.fc2_w, dy, a, (C_, I))
+        _bgrad(st, sp.fc2_b, dy)
+        dh2 = K.mm_nn(dpre, st.w(sp.fc1_w))
+        _wgrad(st, sp.fc1_w, dpre, h2, (I, C_))
+        _bgrad(st, sp.fc1_b, dpre)
+        del dpre
+        dx2 = K.add(dy, _ln_bwd(st, dh2, x2, sp.ln2_w, sp.ln2_b, mean2, rstd2))
+        del dh2
+        # ---- attention
+        do = K.mm_nn(dx2, st.w(sp.out_w))                       # [M, C] token-major
+        _wgrad(st, sp.out_w, dx2, o.view(M, C_), (C_, C_))
+        _bgrad(st, sp.out_b, dx2)
+        dqkv = torch.empty_like(qkv)
+        q5, d5 = qkv.view(N, T, 3, H, D), dqkv.view(N, T, 3, H, D)
+        q, k, v = (q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        dq, dk, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.view(N, T, H, D).permute(0, 2, 1, 3), dq, dk, dv,
+                   causal=False, scale=D ** -0.5)
+        dh1 = K.mm_nn(dqkv, st.w(*sp.qkv_w, shape=(3 * C_, C_)))
+        _wgrad(st, sp.qkv_w, dqkv, h1, (3 * C_, C_))
+        _bgrad(st, sp.qkv_b, dqkv)
+        del dqkv
+        dx = K.add(dx2, _ln_bwd(st, dh1, x, sp.ln1_w, sp.ln1_b, mean1, rstd1))
+        return dx.view(N, T, C_), None, None, None
+
+
+def _ln_bwd(st: ParamStore, dy, x, wn: Optional[str], bn: Optional[str], mean, rstd) -> torch.Tensor:
+    if wn is None:
+        dx, _, _ = K.layernorm_bwd(dy, x, None, mean, rstd)
+        return dx
+    tr = st.trainable(wn)
+    dx, _, _ = K.layernorm_bwd(dy, x, st.w(wn), mean, rstd, dw_out=st.g(wn) if tr else None,
+                               db_out=st.g(bn) if tr else None, accumulate=st.accum_flag(wn), want_dw=tr)
+    if tr:
+        st.mark_written(wn, bn)
+    return dx
+
+
+# --------------------------------------------------------------------------------------- generic pieces
+class LinearFn(Function):
+    """y = act(x W^T + b) (+ residual).  nn.Linear call sites of the path that are not inside a block:
+    patch embedding (HF:clip/modeling_clip.py:149-155 as a GEMM over im2col rows), DiT embedders and final
+    layer (dit.py:22-64,106-135,165-178)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, wn: str, bn: Optional[str], act: int, wshape):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous() and not (x2.stride(1) == 1):
+            x2 = x2.contiguous()
+        W = st.w(wn, shape=wshape)
+        pre = None
+        if act != L.ACT_NONE:
+            pre = torch.empty((x2.shape[0], W.shape[0]), device=x.device, dtype=x.dtype)
+        y = K.mm_nt(x2[:, :W.shape[1]] if x2.shape[1] != W.shape[1] else x2, W,
+                    bias=st.w(bn) if bn else None, act=act, aux_out=pre)
+        ctx.st, ctx.wn, ctx.bn, ctx.act, ctx.wshape, ctx.xshape = st, wn, bn, act, wshape, x.shape
+        ctx.save_for_backward(x2, pre if pre is not None else x2.new_empty(0))
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        x2, pre = ctx.saved_tensors
+        W = st.w(ctx.wn, shape=ctx.wshape)
+        dy2 = dy.reshape(-1, W.shape[0]).contiguous()
+        if ctx.act != L.ACT_NONE:
+            dy2 = K.act_bwd(pre, dy2, ctx.act)
+        xk = x2[:, :W.shape[1]] if x2.shape[1] != W.shape[1] else x2
+        _wgrad(st, ctx.wn, dy2, xk, W.shape)
+        if ctx.bn:
+            _bgrad(st, ctx.bn, dy2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.mm_nn(dy2, W)
+            if x2.shape[1] != W.shape[1]:
+                raise L.DxaError("LinearFn: padded input cannot receive a gradient")
+            dx = dx.view(ctx.xshape)
+        return dx, None, None, None, None, None, None
+
+
+class MlpFn(Function):
+    """y = (act(x W1^T + b1)) W2^T + b2 : mm_projector mlp2x_gelu (mm_projector/builder.py:71-79) and the
+    TimestepEmbedder MLP (dit.py:27-31)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, w1, b1, w2, b2, act: int):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        W1, W2 = st.w(w1), st.w(w2)
+        pre = torch.empty((x2.shape[0], W1.shape[0]), device=x.device, dtype=x.dtype)
+        a = K.mm_nt(x2, W1, bias=st.w(b1), act=act, aux_out=pre)
+        y = K.mm_nt(a, W2, bias=st.w(b2))
+        ctx.st, ctx.names, ctx.act, ctx.xshape = st, (w1, b1, w2, b2), act, x.shape
+        ctx.save_for_backward(x2, pre, a)
+        return y.view(*x.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        w1, b1, w2, b2 = ctx.names
+        x2, pre, a = ctx.saved_tensors
+        W1, W2 = st.w(w1), st.w(w2)
+        dy2 = dy.reshape(-1, W2.shape[0]).contiguous()
+        dpre = K.mm_nn(dy2, W2, mulgrad=pre, act=ctx.act)
+        _wgrad(st, w2, dy2, a, W2.shape)
+        _bgrad(st, b2, dy2)
+        _wgrad(st, w1, dpre, x2, W1.shape)
+        _bgrad(st, b1, dpre)
+        dx = K.mm_nn(dpre, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None, None
+
+
+class NormFn(Function):
+    """stand-alone LayerNorm / RMSNorm: CLIP pre_layrnorm, Qwen2 final norm, DiT final LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, kind: str, wn: Optional[str], bn: Optional[str], eps: float):
+        if kind == "rms":
+            y, rstd = K.rmsnorm_fwd(x.contiguous(), st.w(wn), eps)
+            mean = rstd.new_empty(0)
+        else:
+            y, mean, rstd = K.layernorm_fwd(x.contiguous(), st.w(wn) if wn else None, st.w(bn) if bn else None, eps)
+        ctx.st, ctx.kind, ctx.wn, ctx.bn = st, kind, wn, bn
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        x, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.kind == "rms":
+            tr = st.trainable(ctx.wn)
+            dx, _ = K.rmsnorm_bwd(dy, x.contiguous(), st.w(ctx.wn), rstd, dw_out=st.g(ctx.wn) if tr else None,
+                                  accumulate=st.accum_flag(ctx.wn), want_dw=tr)
+            if tr:
+                st.mark_written(ctx.wn)
+        else:
+            dx = _ln_bwd(st, dy, x.contiguous(), ctx.wn, ctx.bn, mean, rstd).view(x.shape)
+        return dx, None, None, None, None, None, None
+
+
+class VitEmbedFn(Function):
+    """CLS + position embeddings (HF:clip/modeling_clip.py:206-217)."""
+
+    @staticmethod
+    def forward(ctx, patch, anchor, st: ParamStore, cls_n: str, pos_n: str, N: int, np_: int):
+        x = K.vit_embed_fwd(patch.contiguous(), st.w(cls_n), st.w(pos_n), N, np_)
+        ctx.st, ctx.cls_n, ctx.pos_n, ctx.N, ctx.np_ = st, cls_n, pos_n, N, np_
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        st, N, np_ = ctx.st, ctx.N, ctx.np_
+        dx = dx.contiguous()
+        C_ = dx.shape[-1]
+        dpatch = K.vit_embed_bwd(dx, N, np_)
+        if st.trainable(ctx.pos_n) or st.trainable(ctx.cls_n):
+            s = K.colsum(dx.view(N, (np_ + 1) * C_))
+            _vgrad(st, ctx.pos_n, s)
+            _vgrad(st, ctx.cls_n, s[:C_])
+        return dpatch, None, None, None, None, None, None
+
+
+class DropClsFn(Function):
+    """feature_select: hidden_states[-2][:, 1:] (mm_vision/clip/clip_encoder.py:31-36)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, T, C_ = x.shape
+        ctx.shape = (N, T, C_)
+        return K.vit_embed_bwd(x.contiguous(), N, T - 1).view(N, T - 1, C_)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, T, C_ = ctx.shape
+        dx = torch.zeros((N, T * C_), device=dy.device, dtype=dy.dtype)
+        K.copy2d(dy.reshape(N, (T - 1) * C_).contiguous(), dx[:, C_:], (T - 1) * C_, (T - 1) * C_)
+        return dx.view(N, T, C_)
+
+
+class SpliceFn(Function):
+    """_prepare_inputs_labels_for_multimodal (dexbotic_arch.py:182-373): embed_tokens gather + image
+    block insertion + zero padding, driven by the integer plan built on the host (splice.py)."""
+
+    @staticmethod
+    def forward(ctx, img_feats, anchor, st: ParamStore, embed_n: str, plan: torch.Tensor):
+        d = img_feats.shape[-1]
+        out = K.splice_fwd(plan, st.w(embed_n), img_feats.reshape(-1, d).contiguous())
+        ctx.st, ctx.embed_n, ctx.ishape = st, embed_n, img_feats.shape
+        ctx.save_for_backward(plan)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        st = ctx.st
+        (plan,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        d_img = None
+        if ctx.needs_input_grad[0]:
+            d_img = torch.zeros(ctx.ishape, device=dout.device, dtype=dout.dtype)
+        d_embed = None
+        if st.trainable(ctx.embed_n):
+            d_embed = st.g(ctx.embed_n)
+            if not st.accum_flag(ctx.embed_n):
+                d_embed.zero_()                                 # dense nn.Embedding gradient: only B*S_text rows hit
+            st.mark_written(ctx.embed_n)
+        K.splice_bwd(plan, dout, d_embed, d_img)
+        return d_img, None, None, None, None
+
+
+class GatherRowsFn(Function):
+    """cognition feature = hidden state of the last un-padded token (cogact_arch.py:110-120); output fp32
+    (the action head runs in fp32, cogact_arch.py:133)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.R, ctx.dtype = x.shape[0], x.dtype
+        ctx.save_for_backward(idx)
+        return K.gather_rows(x.contiguous(), idx, torch.float32)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return K.scatter_rows(dout.contiguous(), idx, ctx.R, ctx.dtype), None
+
+
+class TokenDropFn(Function):
+    """LabelEmbedder.token_drop (dit.py:80-96)."""
+
+    @staticmethod
+    def forward(ctx, z, anchor, st: ParamStore, unc_n: str, drop: torch.Tensor):
+        ctx.st, ctx.unc_n = st, unc_n
+        ctx.save_for_backward(drop)
+        return K.token_drop(z.contiguous(), st.w32(unc_n).view(-1), drop)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (drop,) = ctx.saved_tensors
+        dz, dunc = K.token_drop_bwd(dout.contiguous(), drop, want_dz=ctx.needs_input_grad[0])
+        _vgrad(ctx.st, ctx.unc_n, dunc)
+        return dz, None, None, None, None
+
+
+class DitAssembleFn(Function):
+    """x = cat(t_emb + z_emb, x_emb) + positional_embedding (dit.py:281-286)."""
+
+    @staticmethod
+    def forward(ctx, xe, te, ze, anchor, st: ParamStore, pos_n: str):
+        ctx.st, ctx.pos_n = st, pos_n
+        return K.dit_assemble_fwd(xe.contiguous(), te.contiguous(), ze.contiguous(), st.w32(pos_n))
+
+    @staticmethod
+    def backward(ctx, dh):
+        dh = dh.contiguous()
+        N, T1, hd = dh.shape
+        dxe, dc = K.dit_assemble_bwd(dh)
+        if ctx.st.trainable(ctx.pos_n):
+            _vgrad(ctx.st, ctx.pos_n, K.colsum(dh.view(N, T1 * hd)))
+        return dxe, dc, dc, None, None, None
+
+
+class MseLossFn(Function):
+    """loss = ((eps_hat - eps)**2).mean()  (action_models.py:119-121)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, dpred = K.mse_loss(pred.contiguous(), target.contiguous(), 1.0, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        # g is the scalar upstream gradient (1.0 for loss.backward(); 1/accum under gradient
+        # accumulation): applied on the device, no host sync
+        return K.scale_dev_(dpred.clone(), g.reshape(1).float().contiguous()), None

@@ -139,19 +139,24 @@ def norm_bwd_blocks(rows: int) -> int:
     return int(lib.dxa_norm_bwd_blocks(rows))
 
 
-def rmsnorm_bwd(dy, x, w, rstd) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """returns (dx, dw_fp32 or None)"""
+def rmsnorm_bwd(dy, x, w, rstd, dw_out: Optional[torch.Tensor] = None, accumulate: bool = False,
+                want_dw: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """returns (dx, dw_fp32 or None); dw is (accumulated) into dw_out when given"""
     x2 = x.reshape(-1, x.shape[-1])
     dy2 = dy.reshape(-1, x.shape[-1])
     assert x2.is_contiguous() and dy2.is_contiguous()
     rows, cols = x2.shape
     dx = torch.empty_like(x2)
     part = None
-    if w is not None:
+    if w is not None and want_dw:
         part = torch.empty((norm_bwd_blocks(rows), cols), device=x.device, dtype=torch.float32)
+    # w is still needed for dx even when its gradient is not (frozen norm): pass a throw-away slab
+    if w is not None and part is None:
+        part = torch.empty((norm_bwd_blocks(rows), cols), device=x.device, dtype=torch.float32)
+        want_dw = False
     L.check(lib.dxa_rmsnorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(rstd), _ptr(dx), _ptr(part), rows, cols, dt(x2),
                                 dt(w) if w is not None else dt(x2), _stream()), "dxa_rmsnorm_bwd")
-    dw = colsum(part) if part is not None else None
+    dw = colsum(part, out=dw_out, accumulate=accumulate) if (part is not None and want_dw) else None
     return dx.view(x.shape), dw
 
 
@@ -167,8 +172,8 @@ def layernorm_fwd(x, w, b, eps):
     return y.view(x.shape), mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd):
-    """returns (dx, dw_fp32 or None, db_fp32 or None)"""
+def layernorm_bwd(dy, x, w, mean, rstd, dw_out=None, db_out=None, accumulate: bool = False, want_dw: bool = True):
+    """returns (dx, dw_fp32 or None, db_fp32 or None); dw/db are (accumulated) into dw_out/db_out when given"""
     x2 = x.reshape(-1, x.shape[-1])
     dy2 = dy.reshape(-1, x.shape[-1])
     assert x2.is_contiguous() and dy2.is_contiguous()
@@ -179,8 +184,12 @@ def layernorm_bwd(dy, x, w, mean, rstd):
         part = torch.empty((norm_bwd_blocks(rows), 2 * cols), device=x.device, dtype=torch.float32)
     L.check(lib.dxa_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(part), rows,
                                   cols, dt(x2), dt(w) if w is not None else dt(x2), _stream()), "dxa_layernorm_bwd")
-    if part is None:
+    if part is None or not want_dw:
         return dx.view(x.shape), None, None
+    if dw_out is not None:
+        colsum(part[:, :cols], out=dw_out, accumulate=accumulate)
+        colsum(part[:, cols:], out=db_out, accumulate=accumulate)
+        return dx.view(x.shape), dw_out, db_out
     s = colsum(part)
     return dx.view(x.shape), s[:cols], s[cols:]
 
@@ -454,6 +463,13 @@ def clip_coef(sumsq_t, max_norm: float, norm_out, coef_out):
 def scale_(x: torch.Tensor, s: float) -> torch.Tensor:
     assert x.dtype == torch.float32 and x.is_contiguous()
     L.check(lib.dxa_scale(_ptr(x), x.numel(), s, _stream()), "dxa_scale")
+    return x
+
+
+def scale_dev_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """x *= s[0], s a device fp32 scalar"""
+    assert x.dtype == torch.float32 and x.is_contiguous() and s.dtype == torch.float32 and s.numel() == 1
+    L.check(lib.dxa_scale_dev(_ptr(x), x.numel(), _ptr(s), _stream()), "dxa_scale_dev")
     return x
 
 

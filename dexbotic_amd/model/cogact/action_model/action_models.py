@@ -1,0 +1,72 @@
+"""Diffusion action model (mirror of dexbotic/model/cogact/action_model/action_models.py:63-135)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .... import functional as Fn
+from ....engine import ParamStore
+from .diffusion import create_diffusion
+from .dit import DiT
+
+
+def DiT_S(**kw):
+    return DiT(depth=6, hidden_size=384, num_heads=4, **kw)
+
+
+def DiT_B(**kw):
+    return DiT(depth=12, hidden_size=768, num_heads=12, **kw)
+
+
+def DiT_L(**kw):
+    return DiT(depth=24, hidden_size=1024, num_heads=16, **kw)
+
+
+# model-size registry (action_models.py:60); tests may register tiny sizes the same way
+DiT_models = {"DiT-S": DiT_S, "DiT-B": DiT_B, "DiT-L": DiT_L}
+
+
+class ActionModel(nn.Module):
+    def __init__(self, store: ParamStore, prefix: str, token_size: int, model_type: str, in_channels: int,
+                 future_action_window_size: int, past_action_window_size: int, diffusion_steps: int = 100,
+                 noise_schedule: str = "squaredcos_cap_v2"):
+        super().__init__()
+        self.in_channels = in_channels
+        self.noise_schedule = noise_schedule
+        self.diffusion_steps = diffusion_steps
+        self.diffusion = create_diffusion(timestep_respacing="", noise_schedule=noise_schedule,
+                                          diffusion_steps=diffusion_steps, sigma_small=True, learn_sigma=False)
+        self.ddim_diffusion = None
+        self.past_action_window_size = past_action_window_size
+        self.future_action_window_size = future_action_window_size
+        self.net = DiT_models[model_type](store=store, prefix=prefix + "net.", token_size=token_size,
+                                          in_channels=in_channels, class_dropout_prob=0.1, learn_sigma=False,
+                                          future_action_window_size=future_action_window_size,
+                                          past_action_window_size=past_action_window_size)
+
+    def loss(self, x: torch.Tensor, z: torch.Tensor, reduction: str = "mean", *, noise: Optional[torch.Tensor] = None,
+             timestep: Optional[torch.Tensor] = None, drop_ids: Optional[torch.Tensor] = None):
+        """x (N,T,A) ground-truth chunk, z (N,1,token) condition.  The three random draws of the reference
+        (action_models.py:106-109 noise/timestep, dit.py:85-87 CFG drop) can be injected for parity tests;
+        otherwise they come from torch's device RNG exactly where the reference draws them."""
+        assert reduction == "mean", "the CogACT path uses the mean reduction (cogact_arch.py:134)"
+        x = x.float()
+        if noise is None:
+            noise = torch.randn_like(x)
+        if timestep is None:
+            timestep = torch.randint(0, self.diffusion.num_timesteps, (x.size(0),), device=x.device)
+        if drop_ids is None and self.training and self.net.class_dropout_prob > 0:
+            drop_ids = torch.rand(x.shape[0], device=x.device) < self.net.class_dropout_prob
+        x_t = self.diffusion.q_sample(x, timestep, noise)
+        noise_pred = self.net(x_t, timestep, z, drop_ids=drop_ids)
+        assert noise_pred.shape == noise.shape == x.shape
+        return Fn.MseLossFn.apply(noise_pred, noise.float())
+
+    def create_ddim(self, ddim_step: int = 10):
+        self.ddim_diffusion = create_diffusion(timestep_respacing="ddim" + str(ddim_step),
+                                               noise_schedule=self.noise_schedule,
+                                               diffusion_steps=self.diffusion_steps, sigma_small=True,
+                                               learn_sigma=False)
+        return self.ddim_diffusion

@@ -1,0 +1,21 @@
+"""Action-model factory (mirror of dexbotic/model/cogact/action_model/builder.py:5-27)."""
+from __future__ import annotations
+
+from ....engine import ParamStore
+from .action_models import ActionModel
+
+REQUIRED = ("action_model_type", "hidden_size", "action_dim", "chunk_size")
+
+
+def build_action_model(config, store: ParamStore, prefix: str = "model.action_head."):
+    missing = [k for k in REQUIRED if not hasattr(config, k)]
+    if missing:                                     # exp/utils.py:43-52 require_config_keys
+        raise ValueError(f"Missing required config keys: {missing}")
+    model_type = config.action_model_type
+    if "DiT" in model_type:
+        return ActionModel(store=store, prefix=prefix, model_type=model_type, token_size=config.hidden_size,
+                           in_channels=config.action_dim, future_action_window_size=config.chunk_size - 1,
+                           past_action_window_size=0)
+    if "Linear" in model_type:
+        raise NotImplementedError("LinearModel head (action_models.py:15-45) is not on the DB-CogACT path")
+    raise ValueError(f"Unknown action model type: {model_type}")

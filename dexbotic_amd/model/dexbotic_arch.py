@@ -1,0 +1,347 @@
+"""Base VLM classes: host-side mirror of dexbotic/model/dexbotic_arch.py on libdexbotic_amd kernels.
+
+Same public surface as the reference: ``DexboticConfig`` (:17-23),
+``CausalLMOutputDexbotic`` (:26-34), ``DexboticVLMModel`` with the ``_build_*`` factories, module /
+prefix properties, ``_extract_vision_features`` (:157-180) and
+``_prepare_inputs_labels_for_multimodal`` (:182-373), ``DexboticForCausalLM`` (:415-542) and
+``ActionOutputForCausalLM._denorm`` (:546-563).  What differs is underneath: parameters live in the
+flat arenas of engine.ParamStore, arithmetic is libdexbotic_amd.so.
+"""
+from __future__ import annotations
+
+import json
+import os
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import kernels as K
+from ..constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+from ..engine import ParamStore, attach_parameters
+from ..splice import SplicePlan, build_splice_plan
+from .llm.qwen2 import Qwen2Backbone, Qwen2Config
+from .modules.mm_projector.builder import build_vision_projector
+from .modules.mm_vision.builder import build_vision_tower
+from .modules.mm_vision.clip.clip_encoder import CLIPVisionConfig
+
+_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, torch.float32: torch.float32,
+           torch.bfloat16: torch.bfloat16}
+
+
+class DexboticConfig:
+    """Plain-Python mirror of the HF ``PretrainedConfig`` subclass of the reference.  ``llm_config`` may be a
+    Qwen2Config, a dict, an HF config object or a directory with config.json; its keys are merged in
+    (``_merge_llm``, dexbotic_arch.py:79-85) so ``hidden_size`` / ``vocab_size`` are top-level."""
+    model_type = "dexbotic"
+
+    def __init__(self, llm_config=None, mm_projector_type: Optional[str] = "mlp2x_gelu", mm_vision_tower=None,
+                 chat_template: Optional[str] = "dexbotic", init_llm_weights: bool = False,
+                 compute_dtype="float32", **kwargs):
+        if isinstance(llm_config, str):
+            with open(os.path.join(llm_config, "config.json")) as f:
+                llm_config = json.load(f)
+        self.llm_config = Qwen2Config.from_any(llm_config if llm_config is not None else {})
+        self.mm_projector_type = mm_projector_type
+        self.mm_vision_tower = mm_vision_tower
+        self.chat_template = chat_template
+        self.init_llm_weights = False
+        self.compute_dtype = compute_dtype if isinstance(compute_dtype, str) else str(compute_dtype).replace("torch.", "")
+        self.tokenizer_model_max_length = kwargs.pop("tokenizer_model_max_length", None)
+        self.tokenizer_padding_side = kwargs.pop("tokenizer_padding_side", "right")
+        self.image_aspect_ratio = kwargs.pop("image_aspect_ratio", "pad")
+        self.use_cache = kwargs.pop("use_cache", True)
+        for k, v in self.llm_config.to_dict().items():          # _merge_llm: only add missing keys
+            if not hasattr(self, k):
+                setattr(self, k, v)
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    # ---- (de)serialisation compatible with the reference's config.json ------------------------------
+    def to_dict(self) -> Dict[str, Any]:
+        d = {}
+        for k, v in self.__dict__.items():
+            if k.startswith("_"):
+                continue
+            if hasattr(v, "to_dict"):
+                v = v.to_dict()
+            d[k] = v
+        d["model_type"] = self.model_type
+        return d
+
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]):
+        d = dict(d)
+        d.pop("model_type", None)
+        d.pop("architectures", None)
+        return cls(**d)
+
+    @classmethod
+    def from_pretrained(cls, path: str):
+        with open(os.path.join(path, "config.json")) as f:
+            return cls.from_dict(json.load(f))
+
+    def save_pretrained(self, path: str) -> None:
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, default=str)
+
+
+@dataclass
+class CausalLMOutputDexbotic:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[Any] = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Optional[Tuple[torch.Tensor, ...]] = None
+    text_loss: Optional[torch.Tensor] = None
+    action_loss: Optional[torch.Tensor] = None
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else tuple(v for v in self.__dict__.values() if v is not None)[k]
+
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None]
+
+
+class DexboticVLMModel(nn.Module):
+    """vision tower -> projector -> splice into LLM embeddings -> LLM backbone."""
+    supports_gradient_checkpointing = True
+
+    def __init__(self, config: DexboticConfig, store: ParamStore):
+        super().__init__()
+        self.config = config
+        self.store = store
+        # registration order = forward order = arena order (the DP reducer walks it backwards)
+        self.mm_vision_tower = None
+        self.mm_projector = None
+        if getattr(config, "mm_vision_tower", None) is not None:
+            self.mm_vision_tower = self._build_mm_vision_module(config.mm_vision_tower)
+            self.mm_projector = self._build_mm_projector_module(config)
+        self.llm = Qwen2Backbone(store, "model.llm.", config.llm_config)
+        self._last_plan: Optional[SplicePlan] = None
+
+    def initialize_model(self, extra_config: dict):
+        for key, value in extra_config.items():
+            setattr(self.config, key, value)
+
+    def _build_mm_projector_module(self, config) -> nn.Module:
+        if getattr(self, "mm_projector", None) is not None:
+            return self.mm_projector
+        self.mm_projector = build_vision_projector(config, self.store, "model.mm_projector.")
+        return self.mm_projector
+
+    def _build_mm_vision_module(self, config) -> nn.Module:
+        if getattr(self, "mm_vision_tower", None) is not None:
+            return self.mm_vision_tower
+        self.mm_vision_tower = build_vision_tower(config, self.store, "model.mm_vision_tower.")
+        self.config.mm_hidden_size = self.mm_vision_tower.hidden_size
+        return self.mm_vision_tower
+
+    @property
+    def mm_projector_module(self) -> nn.Module:
+        return self.mm_projector
+
+    @property
+    def mm_projector_prefix(self) -> str:
+        return "mm_projector"
+
+    @property
+    def mm_vision_module(self) -> nn.Module:
+        return self.mm_vision_tower
+
+    @property
+    def mm_vision_prefix(self) -> str:
+        return "mm_vision"
+
+    @property
+    def backbone(self) -> nn.Module:
+        return self.llm
+
+    @property
+    def device(self):
+        return self.store.device
+
+    @property
+    def dtype(self):
+        return self.store.compute_dtype
+
+    def _extract_vision_features(self, images: torch.Tensor) -> torch.Tensor:
+        """[B,3,H,W] or [B,V,3,H,W] -> [B, V*N_v, d]; the views of a sample are concatenated along tokens."""
+        if images.ndim == 5:
+            B, V = images.shape[:2]
+            feats = self.mm_projector_module(self.mm_vision_module(images.flatten(0, 1)))
+            return feats.view(B, V * feats.shape[1], feats.shape[2])
+        return self.mm_projector_module(self.mm_vision_module(images))
+
+    def _prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                              cache_position, images) -> tuple:
+        """Same contract as the reference (returns input_ids=None and the spliced inputs_embeds); the plan
+        (kv ranges, last-token index) is kept in ``self._last_plan`` for the backbone / cognition gather."""
+        if input_ids.shape[1] == 1:
+            raise NotImplementedError("KV-cache decode (discrete VLA, SURVEY.md §8f rank 3) is not built yet")
+        if self.mm_vision_module is None or images is None:
+            raise NotImplementedError("text-only forward is outside the VLA path")
+        image_features = self._extract_vision_features(images)                          # [B, V*N_v, d]
+        ids_np = input_ids.detach().cpu().numpy()
+        am_np = None if attention_mask is None else attention_mask.detach().cpu().numpy()
+        lb_np = None if labels is None else labels.detach().cpu().numpy()
+        plan = build_splice_plan(ids_np, am_np, lb_np, image_features.shape[1],
+                                 getattr(self.config, "tokenizer_model_max_length", None),
+                                 getattr(self.config, "tokenizer_padding_side", "right"))
+        self._last_plan = plan
+        dev = image_features.device
+        plan_t = torch.from_numpy(plan.plan.reshape(-1)).to(dev)
+        B, S = plan.plan.shape
+        embeds = Fn.SpliceFn.apply(image_features, self.store.params[self.llm.embed_name], self.store,
+                                   self.llm.embed_name, plan_t).view(B, S, -1)
+        new_labels = None if labels is None else torch.from_numpy(plan.labels).to(dev)
+        new_mask = None if attention_mask is None else torch.from_numpy(plan.attention_mask).to(
+            device=dev, dtype=attention_mask.dtype)
+        return None, position_ids, new_mask, past_key_values, embeds, new_labels, cache_position
+
+    def run_llm(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+        """HF Qwen2Model(inputs_embeds, attention_mask) -> hidden_states[-1]; key-padding ranges come from the
+        splice plan (causal AND padding mask, position_ids = arange(S))."""
+        kv_start = kv_end = None
+        plan = self._last_plan
+        if attention_mask is not None and plan is not None and not plan.attention_mask.all():
+            kv_start = torch.from_numpy(plan.kv_start).to(inputs_embeds.device)
+            kv_end = torch.from_numpy(plan.kv_end).to(inputs_embeds.device)
+        return self.llm(inputs_embeds, kv_start, kv_end)
+
+
+class NativePreTrainedMixin:
+    """from_pretrained / save_pretrained / state_dict plumbing shared by the *ForCausalLM classes."""
+    config_class = DexboticConfig
+
+    def _finish_init(self, train: bool) -> None:
+        self.store.finalize(train=train)
+        attach_parameters(self, self.store)
+
+    def post_load(self) -> None:
+        self.store.sync_shadow()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        # checkpoints written under transformers 4.51 carry ".vision_tower.vision_model." 
+        sd = {k.replace(".vision_tower.vision_model.", ".vision_tower."): v for k, v in state_dict.items()}
+        out = nn.Module.load_state_dict(self, sd, strict=strict)
+        self.post_load()
+        return out
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, device=None, train: bool = False, **kw):
+        from safetensors.torch import load_file
+        config = cls.config_class.from_pretrained(path)
+        if torch_dtype is not None:
+            config.compute_dtype = str(torch_dtype).replace("torch.", "")
+        model = cls(config, device=device, train=train)
+        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        sd = {}
+        for f in files:
+            sd.update(load_file(os.path.join(path, f)))
+        model.load_state_dict(sd, strict=True)
+        return model
+
+    def save_pretrained(self, path: str) -> None:
+        from safetensors.torch import save_file
+        self.config.save_pretrained(path)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(path, "model.safetensors"))
+
+    @torch.no_grad()
+    def init_random_(self, seed: int = 0, std: float = 0.02) -> None:
+        """synthetic weights for benchmarks (no checkpoints offline): N(0, std) matrices, unit norm weights,
+        zero biases — same families HF's _init_weights uses for these modules."""
+        g = torch.Generator(device=self.store.device)
+        g.manual_seed(seed)
+        self.store.master.normal_(0.0, std, generator=g)
+        for name in self.store.slots:
+            t = self.store.w32(name)
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "bias":
+                t.zero_()
+            elif leaf == "weight" and t.dim() == 1:
+                t.fill_(1.0)
+        self.post_load()
+
+
+class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
+    config_class = DexboticConfig
+
+    def __init__(self, config: DexboticConfig, device=None, train: bool = True):
+        super().__init__()
+        self.config = config
+        config.model_type = self.config_class.model_type
+        device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        self.store = ParamStore(device, _DTYPES[config.compute_dtype])
+        self._real_init(config)
+        self._finish_init(train)
+
+    def _real_init(self, config):
+        self.model = DexboticVLMModel(config, self.store)
+        self.store.new_bucket()
+        self.store.register([("lm_head.weight", (config.vocab_size, config.hidden_size))])
+
+    @property
+    def device(self):
+        return self.store.device
+
+    @property
+    def dtype(self):
+        return self.store.compute_dtype
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                return_dict=None, cache_position=None, actions=None, states=None) -> CausalLMOutputDexbotic:
+        (_, position_ids, attention_mask, past_key_values, inputs_embeds, labels, cache_position
+         ) = self.model._prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                               labels, cache_position, images)
+        hidden = self.model.run_llm(inputs_embeds, attention_mask)
+        B, S, d = hidden.shape
+        with torch.no_grad():
+            logits = K.mm_nt(hidden.reshape(B * S, d).contiguous(), self.store.w("lm_head.weight")).view(B, S, -1)
+        if labels is not None:
+            raise NotImplementedError("LM cross-entropy training (discrete VLA / hybrid, SURVEY.md §8f rank 3)")
+        return CausalLMOutputDexbotic(loss=None, logits=logits, hidden_states=(hidden,))
+
+    def process_images(self, images):
+        """expand-to-square with the mean colour + CLIP preprocessing (host side; dexbotic_arch.py:498-529)."""
+        proc = self.model.mm_vision_module.image_processor
+        if getattr(self.config, "image_aspect_ratio", "pad") != "pad":
+            return proc(images, return_tensors="pt")["pixel_values"]
+        out = []
+        for im in images:
+            im = self.expand2square(im, tuple(int(x * 255) for x in proc.image_mean))
+            out.append(proc.preprocess(im, return_tensors="pt")["pixel_values"][0])
+        if all(x.shape == out[0].shape for x in out):
+            out = torch.stack(out, dim=0)
+        return out
+
+    @staticmethod
+    def expand2square(pil_img, background_color):
+        from PIL import Image
+        w, h = pil_img.size
+        if w == h:
+            return pil_img
+        side = max(w, h)
+        canvas = Image.new(pil_img.mode, (side, side), background_color)
+        canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
+        return canvas
+
+
+class ActionOutputForCausalLM(ABC):
+    @abstractmethod
+    def inference_action(self, input_ids, image_tensor, inference_args={}, **kwargs):
+        ...
+
+    def _denorm(self, actions, action_norms) -> np.ndarray:
+        """[-1,1] -> physical units; host numpy like the reference (bit-exact contract)."""
+        lo = np.array(action_norms["min"]).reshape(1, -1)
+        hi = np.array(action_norms["max"]).reshape(1, -1)
+        a = np.clip(actions, -1, 1)
+        return lo + (a + 1) * 0.5 * (hi - lo)

@@ -1,0 +1,119 @@
+"""Qwen2 decoder backbone on libdexbotic_amd kernels.
+
+Stands in for the HF ``Qwen2Model`` the reference instantiates through ``AutoModel.from_config``
+(dexbotic/model/dexbotic_arch.py:52-62) and calls at cogact_arch.py:97-106; arithmetic per
+HF:qwen2/modeling_qwen2.py (RMSNorm :238-253, attention + rotate-half RoPE :105-235, SwiGLU :35-48,
+final norm — ``hidden_states[-1]`` is post-norm).  Parameter names are HF's.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import functional as Fn
+from ...engine import ParamStore
+
+
+@dataclass
+class Qwen2Config:
+    """subset of HF Qwen2Config that defines the arithmetic (defaults = Qwen2.5-7B)"""
+    vocab_size: int = 152064
+    hidden_size: int = 3584
+    intermediate_size: int = 18944
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 28
+    num_key_value_heads: int = 4
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    max_position_embeddings: int = 32768
+    model_type: str = "qwen2"
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    def to_dict(self):
+        return asdict(self)
+
+    @classmethod
+    def from_any(cls, obj) -> "Qwen2Config":
+        if isinstance(obj, cls):
+            return obj
+        d = obj if isinstance(obj, dict) else (obj.to_dict() if hasattr(obj, "to_dict") else vars(obj))
+        rp = d.get("rope_parameters") or {}
+        theta = d.get("rope_theta", rp.get("rope_theta", 1e6))
+        keys = {f for f in cls.__dataclass_fields__}
+        kw = {k: v for k, v in d.items() if k in keys and v is not None}
+        kw["rope_theta"] = theta
+        if kw.get("model_type", "qwen2") != "qwen2":
+            raise NotImplementedError(f"llm_config.model_type={kw['model_type']!r}: only the Qwen2 backbone of "
+                                      "DB-CogACT is implemented natively")
+        return cls(**kw)
+
+
+class Qwen2Backbone(nn.Module):
+    def __init__(self, store: ParamStore, prefix: str, config: Qwen2Config):
+        super().__init__()
+        self.store, self.p, self.config = store, prefix, config
+        c = config
+        d, f, hd = c.hidden_size, c.intermediate_size, c.head_dim
+        Hq, Hkv = c.num_attention_heads, c.num_key_value_heads
+        store.new_bucket()
+        store.register([(prefix + "embed_tokens.weight", (c.vocab_size, d))])
+        self.layer_specs = []
+        for i in range(c.num_hidden_layers):
+            lp = f"{prefix}layers.{i}."
+            store.new_bucket()
+            qkv_w = tuple(lp + f"self_attn.{n}_proj.weight" for n in "qkv")
+            qkv_b = tuple(lp + f"self_attn.{n}_proj.bias" for n in "qkv")
+            store.register([(lp + "input_layernorm.weight", (d,))])
+            store.register([(qkv_w[0], (Hq * hd, d)), (qkv_w[1], (Hkv * hd, d)), (qkv_w[2], (Hkv * hd, d))])
+            store.register([(qkv_b[0], (Hq * hd,)), (qkv_b[1], (Hkv * hd,)), (qkv_b[2], (Hkv * hd,))])
+            store.register([(lp + "self_attn.o_proj.weight", (d, Hq * hd))])
+            store.register([(lp + "post_attention_layernorm.weight", (d,))])
+            gu = (lp + "mlp.gate_proj.weight", lp + "mlp.up_proj.weight")
+            store.register([(gu[0], (f, d)), (gu[1], (f, d))])
+            store.register([(lp + "mlp.down_proj.weight", (d, f))])
+            self.layer_specs.append(Fn.Qwen2LayerSpec(
+                ln1=lp + "input_layernorm.weight", qkv_w=qkv_w, qkv_b=qkv_b, o_w=lp + "self_attn.o_proj.weight",
+                ln2=lp + "post_attention_layernorm.weight", gu_w=gu, down_w=lp + "mlp.down_proj.weight",
+                Hq=Hq, Hkv=Hkv, D=hd, d=d, F=f, eps=c.rms_norm_eps))
+        store.new_bucket()
+        store.register([(prefix + "norm.weight", (d,))])
+        self._rope = {}
+
+    @property
+    def embed_name(self) -> str:
+        return self.p + "embed_tokens.weight"
+
+    @property
+    def vocab_size(self) -> int:
+        return self.config.vocab_size
+
+    def rope_tables(self, S: int, device):
+        """cos/sin [S, hd/2] fp32 built with the same torch ops as Qwen2RotaryEmbedding
+        (HF:qwen2/modeling_qwen2.py:52-104; position_ids = arange(S), dexbotic_arch.py:251)."""
+        key = (S, str(device))
+        if key not in self._rope:
+            hd = self.config.head_dim
+            inv_freq = 1.0 / (self.config.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+            freqs = torch.arange(S, dtype=torch.float32)[:, None] * inv_freq[None, :]
+            self._rope[key] = (freqs.cos().contiguous().to(device), freqs.sin().contiguous().to(device))
+        return self._rope[key]
+
+    def forward(self, inputs_embeds: torch.Tensor, kv_start: Optional[torch.Tensor] = None,
+                kv_end: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """inputs_embeds [B,S,d] (compute dtype) -> last hidden state [B,S,d] (post final RMSNorm)."""
+        B, S, d = inputs_embeds.shape
+        cos_t, sin_t = self.rope_tables(S, inputs_embeds.device)
+        st = self.store
+        x = inputs_embeds.reshape(B * S, d)
+        for sp in self.layer_specs:
+            sp.B, sp.S = B, S
+            x = Fn.Qwen2LayerFn.apply(x, st.params[sp.ln1], st, sp, cos_t, sin_t, kv_start, kv_end)
+        x = Fn.NormFn.apply(x, st.params[self.p + "norm.weight"], st, "rms", self.p + "norm.weight", None,
+                            self.config.rms_norm_eps)
+        return x.view(B, S, d)

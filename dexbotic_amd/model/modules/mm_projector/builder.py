@@ -1,0 +1,62 @@
+"""Vision-projector factory (mirror of dexbotic/model/modules/mm_projector/builder.py:36-81)."""
+from __future__ import annotations
+
+import re
+
+import torch
+import torch.nn as nn
+
+from .... import _lib as L
+from .... import functional as Fn
+from ....engine import ParamStore
+
+REQUIRED = ("mm_projector_type", "mm_hidden_size", "hidden_size")
+
+
+class MlpProjector(nn.Module):
+    """`mlpNx_gelu`: Linear -> (GELU(erf) -> Linear) x (N-1); state_dict names `0.weight`, `2.weight`, ..."""
+
+    def __init__(self, store: ParamStore, prefix: str, depth: int, in_dim: int, out_dim: int):
+        super().__init__()
+        if depth not in (1, 2):
+            raise NotImplementedError("native projector: linear and mlp2x_gelu (the DB-CogACT default)")
+        self.store, self.p, self.depth = store, prefix, depth
+        store.new_bucket()
+        store.register([(prefix + "0.weight", (out_dim, in_dim)), (prefix + "0.bias", (out_dim,))])
+        if depth == 2:
+            store.register([(prefix + "2.weight", (out_dim, out_dim)), (prefix + "2.bias", (out_dim,))])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        st, p = self.store, self.p
+        anchor = st.params[p + "0.weight"]
+        if self.depth == 1:
+            return Fn.LinearFn.apply(x, anchor, st, p + "0.weight", p + "0.bias", L.ACT_NONE, None)
+        return Fn.MlpFn.apply(x, anchor, st, p + "0.weight", p + "0.bias", p + "2.weight", p + "2.bias",
+                              L.ACT_GELU_ERF)
+
+
+class LinearProjector(nn.Module):
+    def __init__(self, store: ParamStore, prefix: str, in_dim: int, out_dim: int):
+        super().__init__()
+        self.store, self.p = store, prefix
+        store.new_bucket()
+        store.register([(prefix + "weight", (out_dim, in_dim)), (prefix + "bias", (out_dim,))])
+
+    def forward(self, x):
+        st, p = self.store, self.p
+        return Fn.LinearFn.apply(x, st.params[p + "weight"], st, p + "weight", p + "bias", L.ACT_NONE, None)
+
+
+def build_vision_projector(config, store: ParamStore, prefix: str = "model.mm_projector."):
+    missing = [k for k in REQUIRED if not hasattr(config, k)]
+    if missing:
+        raise ValueError(f"Missing required config keys: {missing}")
+    projector_type = getattr(config, "mm_projector_type", "mlp2x_gelu")
+    if projector_type == "linear":
+        return LinearProjector(store, prefix, config.mm_hidden_size, config.hidden_size)
+    m = re.match(r"^mlp(\d+)x_gelu$", projector_type)
+    if m:
+        return MlpProjector(store, prefix, int(m.group(1)), config.mm_hidden_size, config.hidden_size)
+    if projector_type.startswith("linear") or projector_type == "mlp_downsample":
+        raise NotImplementedError(f"projector {projector_type!r} is not used by the north-star configs")
+    raise ValueError(f"Unknown projector type: {projector_type}")

@@ -1,0 +1,68 @@
+"""Minimal fine-tune driver for the native policy: what HF ``Trainer.training_step`` + ``optimizer.step`` do
+for the reference (exp/trainer.py:25-36,88-138; exp/base_exp.py:865-871), on the flat arenas.
+
+    step(batch):  begin_step -> model(**batch).loss.backward() -> [DP all-reduce finishes] ->
+                  global-norm clip + fused AdamW (+ bf16 shadow refresh) -> cosine lr
+
+One process per GPU; with ``torch.distributed`` initialised (backend "nccl" = RCCL over xGMI) the gradient
+arena is averaged across ranks by engine.GradReducer, overlapped with the backward.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .engine import FusedAdamW, GradReducer, OptimConfig, cosine_lr_scale
+
+
+class NativeTrainer:
+    def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
+                 grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20):
+        import torch.distributed as dist
+        self.model = model
+        self.store = model.store
+        self.cfg = optim or OptimConfig()
+        unused = list(model.unused_parameter_names()) if hasattr(model, "unused_parameter_names") else []
+        self.opt = FusedAdamW(self.store, self.cfg, exclude=unused)
+        self.total_steps, self.warmup_steps, self.grad_accum = total_steps, warmup_steps, grad_accum
+        self.global_step = 0
+        self.micro = 0
+        self.store.set_expected(unused)
+        use_dist = (dist.is_available() and dist.is_initialized()) if distributed is None else distributed
+        self.reducer = None
+        if use_dist and dist.get_world_size() > 1:
+            self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused)
+        self.store.attach_grads()
+        self._zeroed_unused = False
+
+    def lr_scale(self) -> float:
+        if self.total_steps <= 0:
+            return 1.0
+        return cosine_lr_scale(self.global_step, self.total_steps, self.warmup_steps)
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """one micro-batch; the optimizer runs every ``grad_accum`` calls.  Returns the (detached) loss."""
+        first = self.micro % self.grad_accum == 0
+        last = (self.micro + 1) % self.grad_accum == 0
+        if first:
+            self.store.begin_step()
+        else:
+            self.store.begin_micro()
+        # with accumulation, communication happens on the last micro-batch only (like DDP.no_sync)
+        self.store.on_bucket_ready = self.reducer.bucket_ready if (self.reducer is not None and last) else None
+        out = self.model(**batch)
+        loss = out.loss
+        (loss / self.grad_accum if self.grad_accum > 1 else loss).backward()
+        self.micro += 1
+        if last:
+            if not self._zeroed_unused:
+                # slots no kernel ever writes (lm_head, unused CLIP layer, history_embedder) stay exactly zero
+                for nm in self.store.never_written():
+                    self.store.g(nm).zero_()
+                self._zeroed_unused = True
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.opt.step(self.lr_scale())
+            self.global_step += 1
+        return loss.detach()

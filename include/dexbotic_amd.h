@@ -250,6 +250,8 @@ int dxa_sumsq(const float* x, int64_t n, double* scratch, float* out, int accumu
 /* norm = sqrt(sumsq); coef = min(1, max_norm/(norm+1e-6))  (torch.nn.utils.clip_grad_norm_) */
 int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream);
 int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream);
+/* x *= s[0] with s a DEVICE scalar (upstream loss gradient; no host sync) */
+int dxa_scale_dev(float* x, int64_t n, const float* s, dxa_stream_t stream);
 
 #ifdef __cplusplus
 }

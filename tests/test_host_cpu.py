@@ -1,0 +1,128 @@
+"""CPU tests of the host side of the product: construction, state_dict key map, splice plan, diffusion
+tables, integer action rows, optimizer grouping, registry.  No kernel is launched here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cogact_oracle as O
+from oracle.weights import cogact_shapes
+from tests.helpers import CFGS, build_product, load_golden, product_config
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_state_dict_key_map_matches_reference(golden_dir, tag):
+    # oracle.weights.cogact_shapes is asserted equal to the live reference's state_dict by gen_golden.py
+    g, cfg, w = load_golden(golden_dir, tag)
+    m = build_product(cfg, w, device="cpu", train=False)
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == cogact_shapes(cfg)
+    for k, v in w.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    # every parameter is a view into ONE arena; fused groups are adjacent
+    st = m.store
+    base = st.master.data_ptr()
+    for name, p in m.named_parameters():
+        assert base <= p.data_ptr() < base + st.master.numel() * 4, name
+    lp = "model.llm.layers.0.self_attn."
+    fused = st.w32(lp + "q_proj.weight", lp + "k_proj.weight", lp + "v_proj.weight",
+                   shape=((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim, cfg.hidden_size))
+    assert torch.equal(fused[:cfg.num_attention_heads * cfg.head_dim], sd[lp + "q_proj.weight"])
+    assert torch.equal(fused[-cfg.num_key_value_heads * cfg.head_dim:], sd[lp + "v_proj.weight"])
+    # the 4.51-style checkpoint key layout is accepted too
+    old = {k.replace(".vision_tower.", ".vision_tower.vision_model."): torch.from_numpy(v) for k, v in w.items()}
+    m.load_state_dict(old, strict=True)
+
+
+def test_unused_parameters_match_reference(golden_dir):
+    g, cfg, w = load_golden(golden_dir, "t1")
+    m = build_product(cfg, w, device="cpu", train=False)
+    assert sorted(m.unused_parameter_names()) == sorted(g["no_grad_params"].tolist())
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_splice_plan_matches_reference_and_oracle(golden_dir, tag):
+    from dexbotic_amd.splice import build_splice_plan
+    g, cfg, _ = load_golden(golden_dir, tag)
+    views = g["images"].shape[1] if g["images"].ndim == 5 else 1
+    n_img = cfg.num_patches * views
+    plan = build_splice_plan(g["input_ids"], g["attention_mask"], g["input_ids"], n_img)
+    assert np.array_equal(plan.attention_mask, g["new_attention_mask"])          # reference output
+    src, mask, lengths = O.splice_plan(g["input_ids"], g["attention_mask"], n_img)
+    assert np.array_equal(plan.plan, src) and np.array_equal(plan.lengths, lengths)
+    # cognition index = last un-padded token (cogact_arch.py:110-120)
+    assert np.array_equal(plan.last_index, lengths - 1)
+    assert np.array_equal(plan.kv_end, lengths.astype(np.int32)) and not plan.kv_start.any()
+
+
+def test_splice_plan_edge_cases():
+    from dexbotic_amd.splice import PLAN_PAD, build_splice_plan
+    ids = np.array([[5, -200, 7, 8, 0, 0], [9, 10, 11, 12, 13, 14], [1, -200, -200, 2, 3, 0]])
+    mask = np.array([[1, 1, 1, 1, 0, 0], [1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 0]], dtype=bool)
+    for side in ("right", "left"):
+        for max_len in (None, 7):
+            p = build_splice_plan(ids, mask, None, 3, max_len, side)
+            src, m2, lengths = O.splice_plan(ids, mask, 3, max_len, side)
+            assert np.array_equal(p.plan, src), (side, max_len)
+            assert np.array_equal(p.attention_mask, m2)
+            assert (p.plan[~p.attention_mask] == PLAN_PAD).all()
+    # sample 1 has no placeholder but still consumes image block 1; sample 2 uses blocks 2 and 3
+    p = build_splice_plan(ids, mask, None, 3)
+    assert p.plan[0, 1:4].tolist() == [-1, -2, -3]
+    assert p.plan[2, 1:7].tolist() == [-7, -8, -9, -10, -11, -12]
+    assert (p.labels == -100).all()
+    empty = build_splice_plan(np.zeros((2, 4), dtype=np.int64), np.zeros((2, 4), dtype=bool), None, 3)
+    assert empty.plan.shape == (2, 0)
+
+
+def test_diffusion_tables_match_reference(golden_dir):
+    from dexbotic_amd.model.cogact.action_model.diffusion import create_diffusion
+    g = np.load(os.path.join(golden_dir, "diffusion_tables.npz"))
+    tr = create_diffusion("", "squaredcos_cap_v2", diffusion_steps=100, sigma_small=True, learn_sigma=False)
+    assert np.array_equal(tr.betas, g["betas"]) and np.array_equal(tr.alphas_cumprod, g["alphas_cumprod"])
+    assert np.array_equal(tr.sqrt_alphas_cumprod, g["sqrt_alphas_cumprod"])
+    assert np.array_equal(tr.sqrt_one_minus_alphas_cumprod, g["sqrt_one_minus_alphas_cumprod"])
+    for n in (1, 2, 5, 10, 20, 25, 50):
+        dd = create_diffusion(f"ddim{n}", "squaredcos_cap_v2", diffusion_steps=100, sigma_small=True, learn_sigma=False)
+        assert dd.timestep_map == g[f"ddim{n}/timestep_map"].tolist()
+        for k in ("alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+            assert np.array_equal(getattr(dd, k), g[f"ddim{n}/{k}"]), (n, k)
+    with pytest.raises(ValueError):
+        create_diffusion("ddim30", "squaredcos_cap_v2", diffusion_steps=100, sigma_small=True, learn_sigma=False)
+
+
+def test_denorm_bit_exact(golden_dir):
+    from dexbotic_amd.model.dexbotic_arch import ActionOutputForCausalLM
+
+    class _D(ActionOutputForCausalLM):
+        def inference_action(self, *a, **k):
+            pass
+    g = np.load(os.path.join(golden_dir, "action_bins.npz"))
+    den = _D()._denorm(g["normed_all"], {"min": g["mn"].tolist(), "max": g["mx"].tolist()})
+    assert np.array_equal(den, g["denorm"])
+
+
+def test_optimizer_groups_and_schedule(golden_dir):
+    from dexbotic_amd.engine import FusedAdamW, OptimConfig, cosine_lr_scale, no_decay_name
+    from oracle.gen_golden import no_decay_name as ref_rule
+    g, cfg, w = load_golden(golden_dir, "t1")
+    for name in w:
+        assert no_decay_name(name) == ref_rule(name), name
+    assert cosine_lr_scale(0, 100) == 1.0 and abs(cosine_lr_scale(50, 100) - 0.5) < 1e-12
+    assert cosine_lr_scale(100, 100) == 0.0 and cosine_lr_scale(5, 100, 10) == 0.5
+
+
+def test_registry_and_config_roundtrip(tmp_path):
+    import dexbotic_amd
+    reg = dexbotic_amd.model_registry()
+    assert set(reg) >= {"dexbotic", "dexbotic_cogact"}
+    c = product_config(CFGS["t1"])
+    assert c.model_type == "dexbotic_cogact" and c.hidden_size == 256 and c.vocab_size == 512
+    c.save_pretrained(str(tmp_path))
+    c2 = type(c).from_pretrained(str(tmp_path))
+    assert c2.llm_config.to_dict() == c.llm_config.to_dict()
+    assert c2.action_model_type == "DiT-T" and c2.chunk_size == 16
+    from dexbotic_amd.model.cogact.action_model.builder import build_action_model
+    with pytest.raises(ValueError):
+        build_action_model(object(), None)

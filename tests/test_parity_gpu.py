@@ -1,0 +1,156 @@
+"""Model-level parity on the MI355X: the product (dexbotic_amd, HIP kernels through the C ABI) against
+  (1) the golden vectors produced by the live reference (tests/golden, oracle/gen_golden.py) and
+  (2) the CPU oracle on fresh seeded inputs (shapes the fixtures do not cover).
+Bar (BASELINE.json north_star): 7-DoF action chunks / losses / activations within 1e-3 relative in fp32;
+bf16 compute is held to a stated looser tolerance against the same fp32 reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cogact_oracle as O
+from tests.helpers import CFGS, build_product, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP32_TOL = 1e-3          # north-star tolerance
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _batch(g):
+    drop = T(g["drop_u"]) < 0.1
+    return dict(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]),
+                actions=T(g["actions"]), labels=T(g["input_ids"]), noise=T(g["noise"]), timesteps=T(g["timesteps"]),
+                drop_ids=drop)
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_fp32_forward_backward_step_match_reference(golden_dir, tag):
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    g, cfg, w = load_golden(golden_dir, tag)
+    m = build_product(cfg, w, "float32", DEV, train=True)
+    m.train()
+    tr = NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=0.01, max_grad_norm=1.0))
+    m.store.begin_step()
+    out = m(**_batch(g))
+    assert np.array_equal(m.model._last_plan.attention_mask, g["new_attention_mask"])
+    assert rel_err(out.logits.float().cpu().numpy(), g["logits"]) < FP32_TOL
+    assert abs(out.loss.item() - float(g["loss"])) < FP32_TOL * abs(float(g["loss"]))
+    out.loss.backward()
+    st = m.store
+    assert sorted(st.never_written()) == sorted(g["no_grad_params"].tolist())
+    for key in g.files:
+        if key.startswith("grad/"):
+            n = key[5:]
+            assert rel_err(st.g(n).cpu().numpy(), g[key]) < FP32_TOL, n
+        elif key.startswith("gradS/"):
+            n = key[6:]
+            assert rel_err(st.g(n).reshape(-1)[::97].cpu().numpy(), g[key]) < FP32_TOL, n
+            assert abs(st.g(n).double().norm().item() - float(g["gradN/" + n])) < FP32_TOL * float(g["gradN/" + n]), n
+    # one optimizer step through the trainer (fresh backward inside), then compare parameters + 2nd-step loss
+    loss1 = tr.step(_batch(g))
+    assert abs(loss1.item() - float(g["loss"])) < FP32_TOL * abs(float(g["loss"]))
+    assert abs(tr.opt.norm.item() - float(g["grad_norm"])) < FP32_TOL * float(g["grad_norm"])
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("param1/"):
+            n = key[7:]
+            big = np.abs(g["grad/" + n]) > 1e-5       # Adam's first step is sign-like: skip ~0 gradients
+            assert np.abs(sd[n].cpu().numpy() - g[key])[big].max() < 5e-6, n
+    m.store.begin_step()
+    loss2 = m(**_batch(g)).loss.item()
+    assert abs(loss2 - float(g["loss_step2"])) < 5e-3 * abs(float(g["loss_step2"]))
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_fp32_inference_action_matches_reference(golden_dir, tag):
+    g, cfg, w = load_golden(golden_dir, tag)
+    m = build_product(cfg, w, "float32", DEV, train=False)
+    m.eval()
+    norms = {"min": g["norm_min"].tolist(), "max": g["norm_max"].tolist()}
+    acts, samples, traj = m.inference_action(T(g["infer_ids"]), T(g["images"][:1]),
+                                             {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms},
+                                             noise=T(g["init_noise"]), return_trajectory=True)
+    for i in range(len(traj)):
+        assert rel_err(traj[i].cpu().numpy(), g["ddim_traj"][i]) < FP32_TOL, i
+    assert rel_err(np.array(acts), g["infer_actions"]) < FP32_TOL
+    assert isinstance(acts, list) and len(acts) == cfg.chunk_size and len(acts[0]) == cfg.action_dim
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_bf16_tracks_fp32_reference(golden_dir, tag):
+    """bf16 MFMA path (flash attention, bf16 GEMMs, fp32 head): stated tolerance 3e-2 on hidden states,
+    2e-2 on the loss, against the fp32 reference outputs."""
+    g, cfg, w = load_golden(golden_dir, tag)
+    m = build_product(cfg, w, "bfloat16", DEV, train=True)
+    m.train()
+    m.store.begin_step()
+    out = m(**_batch(g))
+    assert rel_err(out.logits.float().cpu().numpy(), g["logits"]) < 3e-2
+    assert abs(out.loss.item() - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    out.loss.backward()
+    st = m.store
+    for n in ("model.llm.layers.0.self_attn.q_proj.weight", "model.mm_projector.0.weight",
+              "model.action_head.net.blocks.1.mlp.fc1.weight"):
+        gn = float(g["gradN/" + n])
+        assert abs(st.g(n).double().norm().item() - gn) < 6e-2 * gn, n
+
+
+def test_fp32_matches_oracle_on_fresh_inputs_with_left_padding_and_views():
+    """shapes/flags the fixtures do not cover: left padding, 2 views + padding, no CFG drop, R=2."""
+    from oracle.weights import cogact_shapes, make_weights
+    cfg = O.OracleConfig(vocab_size=300, hidden_size=256, intermediate_size=384, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=2, v_hidden=128, v_inter=192, v_layers=3,
+                         v_heads=2, dit_hidden=128, dit_depth=2, dit_heads=2, tokenizer_padding_side="left")
+    w = make_weights(cogact_shapes(cfg), 77)
+    rs = np.random.RandomState(5)
+    B, L, V, R = 3, 10, 2, 2
+    ids = rs.randint(5, 290, size=(B, L)).astype(np.int64)
+    ids[:, 2] = -200
+    mask = np.ones((B, L), dtype=bool)
+    mask[1, 7:] = False
+    mask[2, 9:] = False
+    images = np.clip(rs.standard_normal((B, V, 3, 56, 56)), -2.5, 2.5).astype(np.float32)
+    actions = rs.uniform(-1, 1, size=(B, 112)).astype(np.float32)
+    noise = rs.standard_normal((R * B, 16, 7)).astype(np.float32)
+    ts = rs.randint(0, 100, size=(R * B,)).astype(np.int64)
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    ref = O.cogact_forward(sd, cfg, torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(images),
+                           torch.from_numpy(actions), torch.from_numpy(noise), torch.from_numpy(ts), None, R)
+    ref["loss"].backward()
+    m = build_product(cfg, w, "float32", DEV, train=True)
+    m.config.tokenizer_padding_side = "left"
+    m.eval()                              # no CFG token drop
+    m.store.begin_step()
+    out = m(input_ids=T(ids), attention_mask=T(mask), images=T(images), actions=T(actions), noise=T(noise),
+            timesteps=T(ts), repeated_diffusion_steps=R)
+    valid = ref["attention_mask"].numpy()
+    got = out.logits.float().cpu().numpy()
+    assert rel_err(got[valid], ref["logits"].detach().numpy()[valid]) < FP32_TOL
+    assert abs(out.loss.item() - ref["loss"].item()) < FP32_TOL * ref["loss"].item()
+    out.loss.backward()
+    for n in ("model.llm.layers.1.mlp.down_proj.weight", "model.mm_projector.2.weight",
+              "model.mm_vision_tower.vision_tower.embeddings.position_embedding.weight",
+              "model.llm.embed_tokens.weight", "model.action_head.net.z_embedder.linear.weight"):
+        assert rel_err(m.store.g(n).cpu().numpy(), sd[n].grad.numpy()) < FP32_TOL, n
+
+
+def test_gradient_accumulation_equals_big_batch(golden_dir):
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    g, cfg, w = load_golden(golden_dir, "t1")
+    b = _batch(g)
+    m1 = build_product(cfg, w, "float32", DEV, train=True)
+    m1.store.begin_step()
+    m1(**b).loss.backward()
+    g_full = m1.store.grad.clone()
+    m2 = build_product(cfg, w, "float32", DEV, train=True)
+    tr = NativeTrainer(m2, OptimConfig(base_lr=0.0), grad_accum=3)
+    R, B = 4, 3
+    for i in range(B):                       # one sample per micro-batch, same injected draws
+        sel = torch.arange(R, device=DEV) * B + i
+        mb = dict(input_ids=b["input_ids"][i:i + 1], attention_mask=b["attention_mask"][i:i + 1],
+                  images=b["images"][i:i + 1], actions=b["actions"][i:i + 1], noise=b["noise"][sel],
+                  timesteps=b["timesteps"][sel], drop_ids=b["drop_ids"][sel])
+        tr.step(mb)
+    assert rel_err(m2.store.grad.cpu().numpy(), g_full.cpu().numpy()) < 1e-4
