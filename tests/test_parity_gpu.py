@@ -34,7 +34,7 @@ def test_fp32_forward_backward_step_match_reference(golden_dir, tag):
     m.store.begin_step()
     out = m(**_batch(g))
     assert np.array_equal(m.model._last_plan.attention_mask, g["new_attention_mask"])
-    assert rel_err(out.logits.float().cpu().numpy(), g["logits"]) < FP32_TOL
+    assert rel_err(out.logits.detach().float().cpu().numpy(), g["logits"]) < FP32_TOL
     assert abs(out.loss.item() - float(g["loss"])) < FP32_TOL * abs(float(g["loss"]))
     out.loss.backward()
     st = m.store
@@ -86,7 +86,7 @@ def test_bf16_tracks_fp32_reference(golden_dir, tag):
     m.train()
     m.store.begin_step()
     out = m(**_batch(g))
-    assert rel_err(out.logits.float().cpu().numpy(), g["logits"]) < 3e-2
+    assert rel_err(out.logits.detach().float().cpu().numpy(), g["logits"]) < 3e-2
     assert abs(out.loss.item() - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
     out.loss.backward()
     st = m.store
@@ -125,7 +125,7 @@ def test_fp32_matches_oracle_on_fresh_inputs_with_left_padding_and_views():
     out = m(input_ids=T(ids), attention_mask=T(mask), images=T(images), actions=T(actions), noise=T(noise),
             timesteps=T(ts), repeated_diffusion_steps=R)
     valid = ref["attention_mask"].numpy()
-    got = out.logits.float().cpu().numpy()
+    got = out.logits.detach().float().cpu().numpy()
     assert rel_err(got[valid], ref["logits"].detach().numpy()[valid]) < FP32_TOL
     assert abs(out.loss.item() - ref["loss"].item()) < FP32_TOL * ref["loss"].item()
     out.loss.backward()
