@@ -10,6 +10,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7; whichever copy of that soname is
+# mapped first serves the whole process, and device pointers / streams handed to our kernels belong to
+# torch's runtime.  Loading libdexbotic_amd.so before torch would bind everything to /opt/rocm's copy,
+# which then fails to see the device torch initialised ("no ROCm-capable device").
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdexbotic_amd.so")
 

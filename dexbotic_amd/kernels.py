@@ -73,8 +73,39 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
     d.alpha, d.accumulate = alpha, int(accumulate)
     for i in range(3):
         d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
+    prof = GEMM_PROFILE
+    if prof is not None and prof.wants(layout, d.in_dtype, d.out_dtype):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm")
+        e1.record()
+        prof.add(e0, e1, 2.0 * M * N * K * nb[0] * nb[1] * nb[2])
+        return out
     L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm")
     return out
+
+
+class GemmProfile:
+    """HIP-event timing of every launch of ONE gemm kernel instantiation (layout, in dtype, out dtype) on
+    the stream it is launched on — bench.py's live roofline measurement."""
+
+    def __init__(self, layout: int, in_dtype: int, out_dtype: int):
+        self.key = (layout, in_dtype, out_dtype)
+        self.events = []
+
+    def wants(self, layout, in_dtype, out_dtype) -> bool:
+        return (layout, in_dtype, out_dtype) == self.key
+
+    def add(self, e0, e1, flops: float) -> None:
+        self.events.append((e0, e1, flops))
+
+    def summary(self):
+        """(launches, total_ms, total_flops) — call after a device synchronize"""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
+        return len(self.events), ms, sum(f for _, _, f in self.events)
+
+
+GEMM_PROFILE: Optional[GemmProfile] = None
 
 
 def _out2d(M: int, N: int, like: torch.Tensor, out: Optional[torch.Tensor], out_dtype: Optional[torch.dtype]):

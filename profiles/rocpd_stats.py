@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average duration.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o NAME -- python bench.py ...
+    python profiles/rocpd_stats.py gpurun_out/prof/NAME_results.db > profiles/NAME_kernel_stats.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"void ", "", name)
+    return name[:110]
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                       "from kernels group by name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    print(f"# {path}: {sum(r[1] for r in rows)} dispatches, {total/1e6:.1f} ms GPU kernel time; columns {cols[:4]}...")
+    print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
+    for n, c, s, a, mn, mx in rows[:45]:
+        print(f"{short(n):110s} {c:7d} {s/1e6:10.2f} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f} {100*s/total:6.2f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
