@@ -92,6 +92,8 @@ SIGNATURES = {
     "dxa_add": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "dxa_cast": (_int, [_vp, _vp, _i64, _int, _int, _vp]),
     "dxa_copy2d": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp]),
+    "dxa_transpose": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
+    "dxa_permute_bshd": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "dxa_splice_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "dxa_splice_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "dxa_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),

@@ -667,3 +667,98 @@ extern "C" int dxa_ddim_step(float* x, const float* model_out, int64_t B, int64_
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
+
+// ------------------------------------------------------------------------------------ transpose / permute
+// dst[c, r] = src[r, c] for r < R, c < C; dst columns R..Rp-1 are zero-filled (padding the contraction
+// dimension of the dW GEMMs to a multiple of the K slab).  64x64 tiles through LDS, 16-byte global accesses
+// on both sides (bf16: 8 elements), rows of the LDS tile padded by 2 elements against bank conflicts.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int64_t ldd,
+                                                   int64_t R, int64_t C, int64_t Rp, int vec) {
+  constexpr int TS = 64;
+  constexpr int EPV = 16 / sizeof(T);          // elements per 16-byte vector
+  __shared__ T tile[TS][TS + 2];
+  const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+  const int tid = threadIdx.x;
+  constexpr int VPR = TS / EPV;                 // vectors per tile row
+  for (int v = tid; v < TS * VPR; v += 256) {
+    const int rr = v / VPR, cc = (v % VPR) * EPV;
+    const int64_t r = r0 + rr, c = c0 + cc;
+    alignas(16) T tmp[EPV];
+    if (r < R && vec && c + EPV <= C) {
+      *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(src + r * lds_ + c);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) tmp[e] = (r < R && c + e < C) ? src[r * lds_ + c + e] : (T)0;
+    }
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) tile[rr][cc + e] = tmp[e];
+  }
+  __syncthreads();
+  for (int v = tid; v < TS * VPR; v += 256) {
+    const int cc = v / VPR, rr = (v % VPR) * EPV;   // dst row = src col cc, dst cols = src rows rr..rr+EPV-1
+    const int64_t c = c0 + cc, r = r0 + rr;
+    if (c >= C || r >= Rp) continue;
+    alignas(16) T tmp[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) tmp[e] = tile[rr + e][cc];   // rows >= R were loaded as zeros
+    if (vec && r + EPV <= Rp) {
+      *reinterpret_cast<uint4*>(dst + c * ldd + r) = *reinterpret_cast<const uint4*>(tmp);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) if (r + e < Rp) dst[c * ldd + r + e] = tmp[e];
+    }
+  }
+}
+// [B,S,H,D] -> [B,H,S,D] (to_head=1) or back (to_head=0); 16-byte pieces
+template <typename T>
+__global__ __launch_bounds__(256) void permute_bshd_k(const T* __restrict__ src, T* __restrict__ dst, int B, int S, int H, int D,
+                                                      int to_head) {
+  constexpr int EPV = 16 / sizeof(T);
+  const int dv = D / EPV;
+  const int64_t total = (int64_t)B * S * H * dv;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+    const int v = (int)(it % dv);
+    const int h = (int)((it / dv) % H);
+    const int s = (int)((it / ((int64_t)dv * H)) % S);
+    const int b = (int)(it / ((int64_t)dv * H * S));
+    const int64_t tok = (((int64_t)b * S + s) * H + h) * D + v * EPV;
+    const int64_t head = (((int64_t)b * H + h) * S + s) * D + v * EPV;
+    if (to_head) *reinterpret_cast<uint4*>(dst + head) = *reinterpret_cast<const uint4*>(src + tok);
+    else *reinterpret_cast<uint4*>(dst + tok) = *reinterpret_cast<const uint4*>(src + head);
+  }
+}
+}  // namespace
+
+extern "C" int dxa_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t R, int64_t C, int64_t R_padded,
+                             int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(src && dst && R >= 0 && C >= 0 && R_padded >= R && ld_src >= C && ld_dst >= R_padded && ok_dtype(dtype),
+                "dxa_transpose: bad args");
+  if (R_padded == 0 || C == 0) return DXA_OK;
+  const size_t es = dtype == DXA_BF16 ? 2 : 4;
+  const int64_t epv = 16 / es;
+  const int vec = al(src, 16) && al(dst, 16) && ld_src % epv == 0 && ld_dst % epv == 0;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R_padded + 63) / 64));
+  DXA_CHECK_ARG(grid.y <= 65535, "dxa_transpose: too many row tiles");
+  if (dtype == DXA_BF16)
+    hipLaunchKernelGGL((transpose_k<bf16_t>), grid, dim3(256), 0, ST, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, R_padded, vec);
+  else
+    hipLaunchKernelGGL((transpose_k<float>), grid, dim3(256), 0, ST, (const float*)src, ld_src, (float*)dst, ld_dst, R, C, R_padded, vec);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_permute_bshd(const void* src, void* dst, int B, int S, int H, int D, int to_head, int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(src && dst && ok_dtype(dtype), "dxa_permute_bshd: bad args");
+  const size_t es = dtype == DXA_BF16 ? 2 : 4;
+  DXA_CHECK_ARG(D % (int)(16 / es) == 0 && al(src, 16) && al(dst, 16), "dxa_permute_bshd: head_dim must be a multiple of %d", (int)(16 / es));
+  const int64_t total = (int64_t)B * S * H * (D / (int)(16 / es));
+  if (total == 0) return DXA_OK;
+  if (dtype == DXA_BF16)
+    hipLaunchKernelGGL((permute_bshd_k<bf16_t>), dim3(dxa_grid1d(total, 256)), dim3(256), 0, ST, (const bf16_t*)src, (bf16_t*)dst, B, S, H, D, to_head);
+  else
+    hipLaunchKernelGGL((permute_bshd_k<float>), dim3(dxa_grid1d(total, 256)), dim3(256), 0, ST, (const float*)src, (float*)dst, B, S, H, D, to_head);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}

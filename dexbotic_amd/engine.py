@@ -59,6 +59,9 @@ class ParamStore:
         self.on_bucket_ready: Optional[Callable[[int], None]] = None
         self._bucket_pending: List[int] = []
         self._micro_written: set = set()
+        self.shadow_t: Optional[torch.Tensor] = None
+        self._wt_groups: List[Tuple[Tuple[str, ...], int, int]] = []
+        self.wt_index: set = set()
 
     # ---- layout -------------------------------------------------------------------------------------
     def new_bucket(self) -> int:
@@ -85,6 +88,8 @@ class ParamStore:
             self.shadow = torch.zeros(total, device=self.device, dtype=self.compute_dtype)
         if train:
             self.grad = torch.zeros(total, device=self.device, dtype=torch.float32)
+            if self.shadow is not None and self._wt_groups and self.device.type == "cuda":
+                self.shadow_t = torch.zeros(total, device=self.device, dtype=self.compute_dtype)
         nb = self._bucket + 1
         self.bucket_ranges = [[total, 0] for _ in range(nb)]
         for s in self.slots.values():
@@ -179,11 +184,34 @@ class ParamStore:
         if self.shadow is not None:
             from . import kernels as K
             K.cast(self.master, self.shadow.dtype, out=self.shadow)
+        self.sync_transposed()
+
+    # ---- transposed bf16 weight shadows: dX = dY W runs as an NT product on the fast MFMA path -------------
+    def register_wt(self, names: Sequence[str], rows: int, cols: int) -> None:
+        """the (fused) weight `names` = [rows, cols] also needs a [cols, rows] copy for its input gradient"""
+        self._wt_groups.append((tuple(names), int(rows), int(cols)))
+        self.wt_index.add(tuple(names))
+
+    @property
+    def has_wt(self) -> bool:
+        return self.shadow_t is not None
+
+    def wt(self, *names: str, shape: Sequence[int]) -> torch.Tensor:
+        return self._view(self.shadow_t, names, shape)
+
+    def sync_transposed(self) -> None:
+        if self.shadow_t is None:
+            return
+        from . import kernels as K
+        for names, rows, cols in self._wt_groups:
+            K.transpose(self.w(*names, shape=(rows, cols)), out=self.wt(*names, shape=(cols, rows)))
 
 
 class Fp32View:
     """Same interface as ParamStore but ``w()`` hands out the fp32 masters: used by the diffusion action
     head, which the reference keeps in fp32 (cogact_arch.py:133, SURVEY.md App. A dtype notes)."""
+
+    has_wt = False        # fp32 GEMMs use the exact NN / TN kernels
 
     def __init__(self, store: ParamStore):
         self._s = store
@@ -304,6 +332,7 @@ class FusedAdamW:
         lrs, wds = self._lrs_wds(lr_scale)
         K.adamw(st.master, st.grad, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
                 lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
+        st.sync_transposed()
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:

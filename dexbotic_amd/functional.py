@@ -28,6 +28,24 @@ def _names(x) -> Tuple[str, ...]:
     return (x,) if isinstance(x, str) else tuple(x)
 
 
+KPAD = 64   # the transposed activations pad the token axis (= contraction axis of dW) to the GEMM K slab
+
+
+def _use_nt(st: ParamStore, names) -> bool:
+    """bf16 training runs EVERY large GEMM as an NT product on the fast MFMA kernel: dX = dY (W^T)^T against the
+    transposed bf16 weight shadow, dW = (dY^T)(X^T)^T on explicitly transposed activations (a ~2 % HBM-bound
+    extra pass).  fp32 mode / the fp32 action head keep the exact NN / TN kernels."""
+    return bool(getattr(st, "has_wt", False)) and _names(names) in st.wt_index
+
+
+def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor:
+    """dX = dY W for W = fused view over `names` of shape wshape = (out, in)"""
+    names = _names(names)
+    if _use_nt(st, names):
+        return K.mm_nt(dy2d, st.wt(*names, shape=(wshape[1], wshape[0])), **kw)
+    return K.mm_nn(dy2d, st.w(*names, shape=tuple(wshape)), **kw)
+
+
 def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) -> None:
     """dW (+)= dy^T x into the gradient arena (fused view over `names`)"""
     names = _names(names)
@@ -35,7 +53,11 @@ def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) 
         if any(st.trainable(n) for n in names):
             raise L.DxaError(f"fused parameters {names} must be frozen/unfrozen together")
         return
-    K.mm_tn(dy2d, x2d, out=st.g(*names, shape=shape), accumulate=st.accum_flag(*names))
+    out = st.g(*names, shape=shape)
+    if _use_nt(st, names) and dy2d.dtype == torch.bfloat16:
+        K.mm_nt(K.transpose(dy2d, KPAD), K.transpose(x2d, KPAD), out=out, accumulate=st.accum_flag(*names))
+    else:
+        K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names))
     st.mark_written(*names)
 
 
@@ -117,11 +139,11 @@ class Qwen2LayerFn(Function):
         nq = (Hq + 2 * Hkv) * D
         dy = dy.contiguous()
         # ---- MLP
-        da = K.mm_nn(dy, st.w(sp.down_w))
+        da = _dx(st, sp.down_w, (d, F_), dy)
         _wgrad(st, sp.down_w, dy, a, (d, F_))
         dgu = K.swiglu_bwd(gu, da)
         del da
-        dh2 = K.mm_nn(dgu, st.w(*sp.gu_w, shape=(2 * F_, d)))
+        dh2 = _dx(st, sp.gu_w, (2 * F_, d), dgu)
         _wgrad(st, sp.gu_w, dgu, h2, (2 * F_, d))
         del dgu
         tr2 = st.trainable(sp.ln2)
@@ -133,17 +155,20 @@ class Qwen2LayerFn(Function):
         del dx2n, dh2
         # ---- attention: dO written head-major by a (b, h)-batched NN GEMM so the GQA group folds into
         #      the rows of the dK/dV GEMMs (attention.hip)
-        wo = st.w(sp.o_w)                                        # [d, Hq*D]
-        do = torch.empty((B, Hq, S, D), device=x.device, dtype=x.dtype)
-        K.gemm(L.NN, dx2, wo, S, D, d, d, Hq * D, do, D, nb=(B, Hq, 1),
-               sA=(S * d, 0, 0), sB=(0, D, 0), sC=(Hq * S * D, S * D, 0))
+        if _use_nt(st, sp.o_w):
+            do = K.permute_bshd(_dx(st, sp.o_w, (d, Hq * D), dx2), B, S, Hq, D, True)
+        else:
+            wo = st.w(sp.o_w)                                    # [d, Hq*D]
+            do = torch.empty((B, Hq, S, D), device=x.device, dtype=x.dtype)
+            K.gemm(L.NN, dx2, wo, S, D, d, d, Hq * D, do, D, nb=(B, Hq, 1),
+                   sA=(S * d, 0, 0), sB=(0, D, 0), sC=(Hq * S * D, S * D, 0))
         _wgrad(st, sp.o_w, dx2, o.view(M, Hq * D), (d, Hq * D))
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do, dq, dk, dv, causal=True, scale=D ** -0.5,
                    kv_start=kv_start, kv_end=kv_end)
         dqkv = K.rope_merge(dq, dk, dv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
         del dq, dk, dv, do
-        dh1 = K.mm_nn(dqkv, st.w(*sp.qkv_w, shape=(nq, d)))
+        dh1 = _dx(st, sp.qkv_w, (nq, d), dqkv)
         _wgrad(st, sp.qkv_w, dqkv, h1, (nq, d))
         _bgrad(st, sp.qkv_b, dqkv)
         del dqkv
@@ -217,17 +242,17 @@ class VitBlockFn(Function):
         w = lambda n: st.w(n) if n is not None else None
         dy = dy.reshape(M, C_).contiguous()
         # ---- MLP (activation gradient fused into the dX GEMM epilogue)
-        dpre = K.mm_nn(dy, st.w(sp.fc2_w), mulgrad=pre, act=sp.act)
+        dpre = _dx(st, sp.fc2_w, (C_, I), dy, mulgrad=pre, act=sp.act)
         _wgrad(st, sp.fc2_w, dy, a, (C_, I))
         _bgrad(st, sp.fc2_b, dy)
-        dh2 = K.mm_nn(dpre, st.w(sp.fc1_w))
+        dh2 = _dx(st, sp.fc1_w, (I, C_), dpre)
         _wgrad(st, sp.fc1_w, dpre, h2, (I, C_))
         _bgrad(st, sp.fc1_b, dpre)
         del dpre
         dx2 = K.add(dy, _ln_bwd(st, dh2, x2, sp.ln2_w, sp.ln2_b, mean2, rstd2))
         del dh2
         # ---- attention
-        do = K.mm_nn(dx2, st.w(sp.out_w))                       # [M, C] token-major
+        do = _dx(st, sp.out_w, (C_, C_), dx2)                   # [M, C] token-major
         _wgrad(st, sp.out_w, dx2, o.view(M, C_), (C_, C_))
         _bgrad(st, sp.out_b, dx2)
         dqkv = torch.empty_like(qkv)
@@ -236,7 +261,7 @@ class VitBlockFn(Function):
         dq, dk, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.view(N, T, H, D).permute(0, 2, 1, 3), dq, dk, dv,
                    causal=False, scale=D ** -0.5)
-        dh1 = K.mm_nn(dqkv, st.w(*sp.qkv_w, shape=(3 * C_, C_)))
+        dh1 = _dx(st, sp.qkv_w, (3 * C_, C_), dqkv)
         _wgrad(st, sp.qkv_w, dqkv, h1, (3 * C_, C_))
         _bgrad(st, sp.qkv_b, dqkv)
         del dqkv
@@ -291,7 +316,7 @@ class LinearFn(Function):
             _bgrad(st, ctx.bn, dy2)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = K.mm_nn(dy2, W)
+            dx = _dx(st, ctx.wn, W.shape, dy2)
             if x2.shape[1] != W.shape[1]:
                 raise L.DxaError("LinearFn: padded input cannot receive a gradient")
             dx = dx.view(ctx.xshape)
@@ -320,12 +345,12 @@ class MlpFn(Function):
         x2, pre, a = ctx.saved_tensors
         W1, W2 = st.w(w1), st.w(w2)
         dy2 = dy.reshape(-1, W2.shape[0]).contiguous()
-        dpre = K.mm_nn(dy2, W2, mulgrad=pre, act=ctx.act)
+        dpre = _dx(st, w2, W2.shape, dy2, mulgrad=pre, act=ctx.act)
         _wgrad(st, w2, dy2, a, W2.shape)
         _bgrad(st, b2, dy2)
         _wgrad(st, w1, dpre, x2, W1.shape)
         _bgrad(st, b1, dpre)
-        dx = K.mm_nn(dpre, W1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = _dx(st, w1, W1.shape, dpre).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None, None, None, None
 
 

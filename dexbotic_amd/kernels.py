@@ -353,6 +353,24 @@ def copy2d(src: torch.Tensor, dst: torch.Tensor, cols: int, cols_padded: int) ->
     return dst
 
 
+def transpose(x: torch.Tensor, pad_to: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R, C] -> [C, Rp] with Rp = R rounded up to `pad_to` (zero filled)"""
+    R, C_ = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    if out is None:
+        out = torch.empty((C_, Rp), device=x.device, dtype=x.dtype)
+    L.check(lib.dxa_transpose(_ptr(x), _row_major(x, "x"), _ptr(out), _row_major(out, "out"), R, C_, Rp, dt(x), _stream()),
+            "dxa_transpose")
+    return out
+
+
+def permute_bshd(x: torch.Tensor, B: int, S: int, H: int, D: int, to_head: bool) -> torch.Tensor:
+    assert x.is_contiguous() and x.numel() == B * S * H * D
+    out = torch.empty((B, H, S, D) if to_head else (B, S, H, D), device=x.device, dtype=x.dtype)
+    L.check(lib.dxa_permute_bshd(_ptr(x), _ptr(out), B, S, H, D, int(to_head), dt(x), _stream()), "dxa_permute_bshd")
+    return out
+
+
 def splice_fwd(plan: torch.Tensor, embed: torch.Tensor, img: Optional[torch.Tensor]) -> torch.Tensor:
     assert plan.dtype == torch.int64 and plan.is_contiguous() and embed.is_contiguous()
     n, d = plan.numel(), embed.shape[1]

@@ -174,6 +174,14 @@ int dxa_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype
 int dxa_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols,
                int64_t cols_padded, int src_dtype, int dst_dtype, dxa_stream_t stream);
 
+/* dst[c, r] = src[r, c] (r < R, c < C); dst columns R..R_padded-1 are zero.  Feeds the weight-gradient GEMMs
+ * (dW = dY^T X) and the transposed bf16 weight shadows (dX = dY W) as NT products into the fast MFMA path. */
+int dxa_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t R, int64_t C,
+                  int64_t R_padded, int dtype, dxa_stream_t stream);
+/* [B,S,H,D] <-> [B,H,S,D] (to_head = 1: token-major -> head-major) */
+int dxa_permute_bshd(const void* src, void* dst, int B, int S, int H, int D, int to_head, int dtype,
+                     dxa_stream_t stream);
+
 /* Token splice (dexbotic_arch.py:182-373).  plan[b*S+s] >= 0: token id; <= -1: image row -1-plan;
  * INT64_MIN: zero padding.  Forward gathers embed_tokens rows / image-feature rows into
  * inputs_embeds [B*S, d].  Backward scatters: image rows plain-stored (each used once, untouched rows

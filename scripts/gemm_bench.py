@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""GEMM micro-benchmark for kernel tuning: times dxa_gemm on the shapes of the DB-CogACT step.
+
+    python scripts/gemm_bench.py                 # default (fast path where eligible)
+    DXA_GEMM_NO_FAST=1 python scripts/gemm_bench.py
+    DXA_GEMM_FAST_BN=128 python scripts/gemm_bench.py
+Random bf16 operands (uniform [-1,1): zero-filled inputs clock ~20 % higher, cdna guide rule 25)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dexbotic_amd import kernels as K  # noqa: E402
+
+M = 4592
+SHAPES = [  # (name, layout, M, N, K)
+    ("qkv     fwd", "nt", M, 4608, 3584), ("o_proj  fwd", "nt", M, 3584, 3584),
+    ("gate_up fwd", "nt", M, 37888, 3584), ("down    fwd", "nt", M, 3584, 18944),
+    ("gate_up dX ", "nn", M, 3584, 37888), ("down    dX ", "nn", M, 18944, 3584),
+    ("gate_up dW ", "tn", 37888, 3584, M), ("down    dW ", "tn", 3584, 18944, M),
+    ("square 4096", "nt", 4096, 4096, 4096), ("square 8192", "nt", 8192, 8192, 8192),
+]
+
+
+def main():
+    dev = "cuda"
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    for name, lay, m, n, k in SHAPES:
+        if only and only not in lay and only not in name:
+            continue
+        if lay == "nt":
+            a = (torch.rand(m, k, device=dev) * 2 - 1).bfloat16()
+            b = (torch.rand(n, k, device=dev) * 2 - 1).bfloat16()
+            fn = K.mm_nt
+        elif lay == "nn":
+            a = (torch.rand(m, k, device=dev) * 2 - 1).bfloat16()
+            b = (torch.rand(k, n, device=dev) * 2 - 1).bfloat16()
+            fn = K.mm_nn
+        else:
+            a = (torch.rand(k, m, device=dev) * 2 - 1).bfloat16()
+            b = (torch.rand(k, n, device=dev) * 2 - 1).bfloat16()
+            fn = K.mm_tn
+        out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        for _ in range(3):
+            fn(a, b, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            fn(a, b, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print(f"{name} {lay} M={m:6d} N={n:6d} K={k:6d}  {ms*1e3:9.1f} us  {2*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

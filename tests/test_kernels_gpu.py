@@ -465,3 +465,21 @@ def test_adamw_matches_torch():
     x = rnd(1000, seed=112)
     K.scale_(x, 0.25)
     assert_close(x, rnd(1000, seed=112) * 0.25, 0, 0, "scale")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(4592, 3584), (70, 130), (64, 64), (1, 7), (287, 18944)])
+def test_transpose_and_permute(dtype, R, C):
+    x = rnd(R, C, dtype=dtype, seed=120)
+    y = K.transpose(x, 64)
+    Rp = (R + 63) // 64 * 64
+    assert y.shape == (C, Rp)
+    assert torch.equal(y[:, :R], x.t())
+    assert torch.all(y[:, R:] == 0)
+    v = rnd(R, C + 8, dtype=dtype, seed=121)[:, 8:]          # strided source view
+    assert torch.equal(K.transpose(v, 1), v.t())
+    B, S, H, D = 2, 37, 3, 64
+    t = rnd(B, S, H, D, dtype=dtype, seed=122)
+    hm = K.permute_bshd(t, B, S, H, D, True)
+    assert torch.equal(hm, t.permute(0, 2, 1, 3))
+    assert torch.equal(K.permute_bshd(hm, B, S, H, D, False), t)
