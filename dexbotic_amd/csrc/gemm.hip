@@ -39,7 +39,6 @@ struct GemmP {
   int64_t sA[3], sB[3], sC[3], sR[3], sG[3];
   int tm, tn;
   int vecA, vecB, vecC, vecR, vecG, vecBias;
-  int abl;  // tuning-only ablation mask (env DXA_GEMM_ABL): 1 = no LDS-DMA in the loop, 2 = no ds_reads, 4 = no MFMA
 };
 
 template <typename T> struct EltTraits;
@@ -356,371 +355,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
 }
 
-// =====================================================================================================
-// Fast path: bf16 NT, 256 x BN_ tile, 512 threads (8 waves as 2 x 4), direct-to-LDS loads.
-//
-//   * global -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA): no VGPR round trip, no staging VALU; the
-//     buffer descriptor bounds-checks rows >= M/N to zero.  The LDS image is lane-linear (one wave
-//     instruction = 8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk and again
-//     on the fragment reads (chunk ^ ((row>>1)&7): the 16-lane groups of ds_read_b128 then hit 16 distinct
-//     16-B slots for the 32-row MFMA fragments).
-//   * two LDS stages (2 x 64 KiB at BN_=256), K slab 64: the loads of slab t+1 are issued before the
-//     MFMAs of slab t and stay in flight across the barrier (counted s_waitcnt vmcnt, raw s_barrier).
-//   * v_mfma_f32_32x32x16_bf16, wave tile 128 x BN_/4; operands swapped so a lane's accumulator quads are
-//     4 consecutive n of one m (same vector epilogue as the generic kernel).
-// Requirements (checked by the host): K % 64 == 0, 16-byte aligned A/B rows, no batching.
-// =====================================================================================================
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <typename TO, int BN_>
-__global__ __launch_bounds__(512) void gemm_nt_fast_kernel(const GemmP p) {
-  // The body uses device-only builtins (buffer resources, LDS-DMA): the host pass of hipcc silently drops
-  // the whole kernel stub if it has to parse them, so it only sees an empty body.
-#if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BMF = 256;
-  constexpr int A_BYTES = BMF * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int NA = A_BYTES / 1024 / 8;   // LDS-DMA wave-instructions per wave for A (4)
-  constexpr int NB = B_BYTES / 1024 / 8;   // ... for B (4 or 2)
-  constexpr int FN = BN_ / 4 / 32;         // 32-wide n fragments per wave (2 or 1)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l32 = lane & 31, lh = lane >> 5;
-
-  const int nt = p.tm * p.tn;
-  int bid = blockIdx.x;
-  {
-    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 4;
-  const int width = GROUP_M * p.tn;
-  const int group = bid / width;
-  const int first_pm = group * GROUP_M;
-  const int gsz = min(p.tm - first_pm, GROUP_M);
-  const int pm = first_pm + (bid % width) % gsz;
-  const int pn = (bid % width) / gsz;
-  const int64_t m0 = (int64_t)pm * BMF, n0 = (int64_t)pn * BN_;
-
-  // buffer descriptors (wave-uniform by construction: kernel arguments only)
-  const uint32_t bytesA = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2);
-  const uint32_t bytesB = (uint32_t)(((p.N - 1) * p.ldb + p.K) * 2);
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
-
-  // per-lane source offsets: wave-instruction i covers tile rows 8i..8i+7; lane -> (row = 8i + lane/8, slot = lane%8)
-  uint32_t offA[NA], offB[NB];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int row = (wave * NA + j) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int64_t grow = m0 + row;
-    offA[j] = grow < p.M ? (uint32_t)((grow * p.lda) * 2 + chunk * 16) : 0x80000000u;   // >= num_records -> zeros
-  }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int row = (wave * NB + j) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int64_t grow = n0 + row;
-    offB[j] = grow < p.N ? (uint32_t)((grow * p.ldb) * 2 + chunk * 16) : 0x80000000u;
-  }
-  auto issue = [&](int stage, int kt) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + A_BYTES;
-    const int soff = kt * 128;   // 64 bf16 per slab
-#pragma unroll
-    for (int j = 0; j < NA; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(sA + (wave * NA + j) * 1024), 16, offA[j], soff, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(sB + (wave * NB + j) * 1024), 16, offB[j], soff, 0, 0);
-  };
-
-  f32x16_t acc[4][FN];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (int)(p.K / 64);
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      issue(cur ^ 1, kt + 1);
-      if constexpr (NA + NB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();            // every wave's slab-kt pieces have landed
-    const char* sA = smem + cur * STAGE;
-    const char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c = 2 * ks + lh;
-      uint4 af[4], bfr[FN];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 128 + i * 32 + l32;
-        af[i] = *reinterpret_cast<const uint4*>(sA + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int row = wn * (BN_ / 4) + j * 32 + l32;
-        bfr[j] = *reinterpret_cast<const uint4*>(sB + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[j]),
-                                                              __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // stage `cur` may be overwritten by the next iteration's issue
-  }
-
-  // epilogue: D[i = n][j = m]: lane holds m = l32, n = 8*(r>>2) + 4*lh + (r&3)
-  TO* C = reinterpret_cast<TO*>(p.C);
-  TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
-  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
-  const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t n = n0 + wn * (BN_ / 4) + j * 32 + 8 * q + 4 * lh;
-      if (n >= p.N) continue;
-      const int n_ok = (int)min((int64_t)4, p.N - n);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 32 + l32;
-        if (m >= p.M) continue;
-        const float a4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
-      }
-    }
-  }
-#endif  // __HIP_DEVICE_COMPILE__
-}
-
 // =====================================================================================================
-// Staggered variant of the fast path (same tile, same LDS image, same epilogue).
-//
-// The lock-step kernel above leaves the matrix pipe idle while all 8 waves issue LDS-DMA / ds_reads and
-// leaves the LDS idle while all 8 waves run MFMAs.  Here the two wave rows (waves 0-3 / 4-7: one wave of
-// each row per SIMD) run ONE barrier interval apart, so on every SIMD one wave is in a "load" phase
-// (fragment ds_reads of its next quadrant + LDS-DMA issue for the next K slab) while its partner is in
-// an "MFMA" phase (8 x v_mfma_f32_32x32x16_bf16 = one 64x32 quadrant x K=64).
-//   per K slab and wave: 4 x { load phase ; s_barrier ; MFMA phase ; s_barrier }
-//   quadrant order (ma,nb) = (0,0) (0,1) (1,1) (1,0): reads A0+B0 | B1 | A1 | none
-//   LDS-DMA of slab t+1 is issued in load phases 0,1,2 (2+3+3 pieces per wave) and retired by
-//   s_waitcnt vmcnt(0) at the end of load phase 3, i.e. two intervals before the first consumer:
-//     RAW  every wave passes that wait at least one full interval before any wave reads slab t+1;
-//     WAR  a slab's last fragment read is in load phase 2, >= 3 intervals before it is overwritten.
-// Row 1 executes one extra s_barrier before the loop, row 0 one after it: equal barrier counts.
-// =====================================================================================================
-template <typename TO>
-__global__ __launch_bounds__(512) void gemm_nt_stag_kernel(const GemmP p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = 256 * 128, STAGE = 2 * A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int l32 = lane & 31, lh = lane >> 5;
-
-  const int nt = p.tm * p.tn;
-  int bid = blockIdx.x;
-  {
-    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 4;
-  const int width = GROUP_M * p.tn;
-  const int group = bid / width;
-  const int first_pm = group * GROUP_M;
-  const int gsz = min(p.tm - first_pm, GROUP_M);
-  const int pm = first_pm + (bid % width) % gsz;
-  const int pn = (bid % width) / gsz;
-  const int64_t m0 = (int64_t)pm * 256, n0 = (int64_t)pn * 256;
-
-  const uint32_t bytesA = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2);
-  const uint32_t bytesB = (uint32_t)(((p.N - 1) * p.ldb + p.K) * 2);
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
-  uint32_t offA[4], offB[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int64_t ga = m0 + row, gb = n0 + row;
-    offA[j] = ga < p.M ? (uint32_t)((ga * p.lda) * 2 + chunk * 16) : 0x80000000u;
-    offB[j] = gb < p.N ? (uint32_t)((gb * p.ldb) * 2 + chunk * 16) : 0x80000000u;
-  }
-#define DMA_A(stage, kt, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + (stage) * STAGE + (wave * 4 + (j)) * 1024), 16, offA[j], (kt) * 128, 0, 0)
-#define DMA_B(stage, kt, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + (stage) * STAGE + A_BYTES + (wave * 4 + (j)) * 1024), 16, offB[j], (kt) * 128, 0, 0)
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (int)(p.K / 64);
-  // prologue: slab 0, everybody
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { DMA_A(0, 0, j); DMA_B(0, 0, j); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();       // stagger: row 1 runs one interval behind row 0
-
-  // Fragment reads are inline-asm ds_read_b128: for a C++ LDS load hipcc cannot prove that it does not alias
-  // the LDS-DMA in flight and drains it with s_waitcnt vmcnt(0) before every read (kills the prefetch).
-  // Per-lane byte address = stage base + row*128 + ((2ks+lh) ^ ((row>>1)&7))*16; the XOR term is the same for
-  // every fragment row of a lane (rows differ by multiples of 32), so 4+4 address VGPRs + immediates suffice.
-  u32x4_t af[2][4], bf0[4], bf1[4];
-  for (int i = 0; i < 2; ++i) for (int ks = 0; ks < 4; ++ks) af[i][ks] = (u32x4_t){(uint32_t)lane, 1u, 2u, 3u};
-  for (int ks = 0; ks < 4; ++ks) { bf0[ks] = (u32x4_t){(uint32_t)lane, 4u, 5u, 6u}; bf1[ks] = bf0[ks]; }
-  const int arow = wm * 128 + l32, brow = wn * 64 + l32;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  uint32_t abase[4], bbase[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    abase[ks] = lds0 + arow * 128 + (((2 * ks + lh) ^ ((arow >> 1) & 7)) << 4);
-    bbase[ks] = lds0 + A_BYTES + brow * 128 + (((2 * ks + lh) ^ ((brow >> 1) & 7)) << 4);
-  }
-#define DS_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
-#define RD_A(soff, ma)                                                                        \
-  do {                                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                        \
-      const uint32_t a_ = abase[ks] + (soff);                                                 \
-      DS_READ(af[0][ks], a_, (ma) * 8192);                                                    \
-      DS_READ(af[1][ks], a_, (ma) * 8192 + 4096);                                             \
-    }                                                                                         \
-  } while (0)
-#define RD_B(soff, nb, dst)                                                                   \
-  do {                                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                        \
-      const uint32_t b_ = bbase[ks] + (soff);                                                 \
-      DS_READ(dst[ks], b_, (nb) * 4096);                                                      \
-    }                                                                                         \
-  } while (0)
-#define MFMA_Q(ma, nb, bsrc)                                                                                   \
-  do {                                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int i = 0; i < 2; ++i)             \
-      acc[(ma) * 2 + i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bsrc[ks]),  \
-                                                                      __builtin_bit_cast(bf16x8_t, af[i][ks]), \
-                                                                      acc[(ma) * 2 + i][nb], 0, 0, 0);         \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
-  } while (0)
-#define MFMA_PAIR(ma, nb, bsrc, ks)                                                                            \
-  do {                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-      acc[(ma) * 2 + i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bsrc[ks]),  \
-                                                                      __builtin_bit_cast(bf16x8_t, af[i][ks]), \
-                                                                      acc[(ma) * 2 + i][nb], 0, 0, 0);         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-  } while (0)
-#define MFMA_Q_DMA(ma, nb, bsrc, D1, D2, D3)                                                                   \
-  do {                                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    MFMA_PAIR(ma, nb, bsrc, 0);                                                                                \
-    D1;                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    MFMA_PAIR(ma, nb, bsrc, 1);                                                                                \
-    D2;                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    MFMA_PAIR(ma, nb, bsrc, 2);                                                                                \
-    D3;                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    MFMA_PAIR(ma, nb, bsrc, 3);                                                                                \
-  } while (0)
-#define PHASE_END() do { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1, nxt = cur ^ 1;
-    const uint32_t soff = (uint32_t)(cur * STAGE);
-    const bool more = kt + 1 < nk && !(p.abl & 1);
-    const bool rd = !(p.abl & 2), mm = !(p.abl & 4);
-    // The LDS-DMA pieces of slab kt+1 are issued from INSIDE the MFMA phases (one piece after every pair of
-    // MFMAs): their issue cost hides in the 32-cycle MFMA gaps instead of stretching the load phases.
-    // ---- phase 0: quadrant (0,0)
-    if (rd) { RD_A(soff, 0); RD_B(soff, 0, bf0); }
-    PHASE_END();
-    if (mm) MFMA_Q_DMA(0, 0, bf0, if (more) DMA_A(nxt, kt + 1, 0), if (more) DMA_A(nxt, kt + 1, 1), if (more) DMA_A(nxt, kt + 1, 2));
-    PHASE_END();
-    // ---- phase 1: quadrant (0,1)
-    if (rd) { RD_B(soff, 1, bf1); }
-    PHASE_END();
-    if (mm) MFMA_Q_DMA(0, 1, bf1, if (more) DMA_A(nxt, kt + 1, 3), if (more) DMA_B(nxt, kt + 1, 0), if (more) DMA_B(nxt, kt + 1, 1));
-    PHASE_END();
-    // ---- phase 2: quadrant (1,1)
-    if (rd) { RD_A(soff, 1); }
-    PHASE_END();
-    if (mm) MFMA_Q_DMA(1, 1, bf1, if (more) DMA_B(nxt, kt + 1, 2), if (more) DMA_B(nxt, kt + 1, 3), (void)0);
-    PHASE_END();
-    // ---- phase 3: quadrant (1,0); retire this wave's LDS-DMA of slab kt+1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_END();
-    if (mm) MFMA_Q(1, 0, bf0);
-    PHASE_END();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();
-#undef DMA_A
-#undef DMA_B
-#undef MFMA_Q
-#undef MFMA_Q_DMA
-#undef MFMA_PAIR
-#undef PHASE_END
-#undef RD_A
-#undef RD_B
-#undef DS_READ
-
-  TO* C = reinterpret_cast<TO*>(p.C);
-  TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
-  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
-  const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t n = n0 + wn * 64 + j * 32 + 8 * q + 4 * lh;
-      if (n >= p.N) continue;
-      const int n_ok = (int)min((int64_t)4, p.N - n);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 32 + l32;
-        if (m >= p.M) continue;
-        const float a4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
-      }
-    }
-  }
-#endif  // __HIP_DEVICE_COMPILE__
-}
-template __global__ void gemm_nt_stag_kernel<bf16_t>(const GemmP);
-template __global__ void gemm_nt_stag_kernel<float>(const GemmP);
-
-// =====================================================================================================
-// Ring variant of the fast path: ONE workgroup barrier per K slab.
+// Fast path: bf16 NT "ring" kernel — 256x256 tile, 512 threads, LDS-DMA ring, ONE barrier per K slab.
 //
 // Measured on MI355X (8192^3, ablation builds of the staggered kernel): an s_barrier over 8 waves costs
 // ~100-200 cycles, so its 8 barriers per 64-deep slab cap that skeleton near 1.4 PF even with no loads.
@@ -862,40 +502,57 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #undef MFMA1
 #undef SB
 
-  TO* C = reinterpret_cast<TO*>(p.C);
-  TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
-  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
-  const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+  // ---- epilogue: accumulators -> wave-private LDS slab (fp32, padded rows) -> row-contiguous global stores.
+  // The MFMA layout gives each lane 4 consecutive n of 32 different rows: stored directly that is 8-byte
+  // pieces at a row stride (measured: 0.6 TB/s, 58 us per tile).  Re-read from LDS, 16 lanes cover one
+  // 64-column row segment, so stores (and the residual / mulgrad / accumulate reads) are full 128/256-byte
+  // lines.  Two passes of 64 rows; the slab is private to the wave, so no workgroup barrier is needed (the
+  // loop's last barrier already retired every ring read and LDS-DMA).
+  {
+    constexpr int ROWP = 64 * 4 + 16;
+    char* slab = smem + wave * (64 * ROWP);
+    TO* C = reinterpret_cast<TO*>(p.C);
+    TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
+    const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
+    const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
+    const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+    const int cr = lane >> 4, cc = (lane & 15) * 4;
+    const int64_t n = n0 + wn * 64 + cc;
+    const int n_ok = (int)max((int64_t)0, min((int64_t)4, p.N - n));
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias && n_ok > 0) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t n = n0 + wn * 64 + j * 32 + 8 * q + 4 * lh;
-      if (n >= p.N) continue;
-      const int n_ok = (int)min((int64_t)4, p.N - n);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 32 + l32;
-        if (m >= p.M) continue;
-        const float a4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = 2 * pass + ii;
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            *reinterpret_cast<float4*>(slab + (ii * 32 + l32) * ROWP + (j * 32 + 8 * q + 4 * lh) * 4) = v;
+          }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = cr + 4 * it;
+        const int64_t m = m0 + wm * 128 + pass * 64 + row;
+        const float4 v = *reinterpret_cast<const float4*>(slab + row * ROWP + cc * 4);
+        if (m < p.M && n_ok > 0) {
+          const float a4[4] = {v.x, v.y, v.z, v.w};
+          epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 template __global__ void gemm_nt_ring_kernel<bf16_t>(const GemmP);
 template __global__ void gemm_nt_ring_kernel<float>(const GemmP);
-
-// explicit instantiations: hipcc (ROCm 7.2) otherwise emits the device code but no host stub for this
-// template when it is only referenced through hipFuncSetAttribute + hipLaunchKernelGGL in a macro
-template __global__ void gemm_nt_fast_kernel<bf16_t, 256>(const GemmP);
-template __global__ void gemm_nt_fast_kernel<bf16_t, 128>(const GemmP);
-template __global__ void gemm_nt_fast_kernel<float, 256>(const GemmP);
-template __global__ void gemm_nt_fast_kernel<float, 128>(const GemmP);
 
 template <typename TI, typename TO>
 int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
@@ -959,67 +616,28 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
   p.vecBias = d->bias && aligned_to(d->bias, 4 * es);
 
   hipStream_t st = (hipStream_t)stream;
-  // ---- fast path: bf16 NT, K % 64 == 0, aligned rows, no batching, operands < 2 GiB
+  // ---- fast path (ring kernel): bf16 NT, K % 32 == 0, 16-byte aligned rows, no batching, operands < 2 GiB
   const int64_t bytesA = ((d->M - 1) * d->lda + d->K) * 2, bytesB = ((d->N - 1) * d->ldb + d->K) * 2;
   static const bool fast_off = getenv("DXA_GEMM_NO_FAST") != nullptr;
-  static const char* force_bn_env = getenv("DXA_GEMM_FAST_BN");
-  if (!fast_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->K >= 64 && d->K % 64 == 0 &&
-      p.vecA && p.vecB && d->M >= 128 && d->N >= 128 && bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
-    // tile choice: 256x256 unless that leaves the 256 CUs badly quantised and 256x128 does better
-    auto eff = [&](int bn) {
-      const int64_t t = (int64_t)dxa_cdiv(d->M, 256) * dxa_cdiv(d->N, bn);
-      const int64_t rounds = (t + 255) / 256;
-      return (double)t / (double)(rounds * 256);
-    };
-    int bn = (d->N <= 128 || eff(128) > eff(256) + 0.12) ? 128 : 256;
-    if (force_bn_env) bn = atoi(force_bn_env) == 128 ? 128 : 256;
+  if (!fast_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->K >= 32 && d->K % 32 == 0 &&
+      p.vecA && p.vecB && d->M >= 64 && d->N >= 64 && (int64_t)d->M * d->N >= 128 * 128 &&
+      bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
     p.tm = dxa_cdiv(d->M, 256);
-    p.tn = dxa_cdiv(d->N, bn);
+    p.tn = dxa_cdiv(d->N, 256);
     dim3 fgrid((unsigned)(p.tm * p.tn));
-    const size_t lds = 2 * (size_t)(256 * 128 + bn * 128);
-#define LAUNCH_FAST(TO_, BN_)                                                                                   \
-  do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_fast_kernel<TO_, BN_>),                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<TO_, BN_>), fgrid, dim3(512), lds, st, p);                          \
-  } while (0)
-    static const char* abl_env = getenv("DXA_GEMM_ABL");
-    p.abl = abl_env ? atoi(abl_env) : 0;
-    static const char* kern_env = getenv("DXA_GEMM_KERNEL");
-    const bool use_stag = bn == 256 && !(kern_env && strcmp(kern_env, "fast") == 0);
-#define LAUNCH_STAG(TO_)                                                                                        \
-  do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_stag_kernel<TO_>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);                            \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
-    hipLaunchKernelGGL((gemm_nt_stag_kernel<TO_>), fgrid, dim3(512), 131072, st, p);                            \
-  } while (0)
-    const bool use_ring = bn == 256 && !kern_env;
+    constexpr int RING_LDS = 139264;   // max(4 x 32 KiB ring, 8 waves x 64 x 272 B epilogue slabs)
 #define LAUNCH_RING(TO_)                                                                                        \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<TO_>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_>), fgrid, dim3(512), 131072, st, p);                            \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_>), fgrid, dim3(512), RING_LDS, st, p);                          \
   } while (0)
-    if (use_ring) {
-      if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t); else LAUNCH_RING(float);
-    } else if (use_stag) {
-      if (d->out_dtype == DXA_BF16) LAUNCH_STAG(bf16_t); else LAUNCH_STAG(float);
-    } else if (d->out_dtype == DXA_BF16) { if (bn == 256) LAUNCH_FAST(bf16_t, 256); else LAUNCH_FAST(bf16_t, 128); }
-    else { if (bn == 256) LAUNCH_FAST(float, 256); else LAUNCH_FAST(float, 128); }
-#undef LAUNCH_STAG
-#undef LAUNCH_FAST
+    if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t); else LAUNCH_RING(float);
+#undef LAUNCH_RING
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
