@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--llm-layers", dest="llm_layers", type=int, default=28)
     ap.add_argument("--vit-layers", dest="vit_layers", type=int, default=24)
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="debug: run the RCCL gradient reducer even at world size 1 (exercises the DP code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -168,8 +170,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the native path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -181,7 +186,7 @@ def main():
     model, cfg, llm, vis = build_model(args, device)
     model.train()
     trainer = NativeTrainer(model, OptimConfig(base_lr=2e-5, weight_decay=0.0, max_grad_norm=1.0),
-                            total_steps=1000)
+                            total_steps=1000, force_reducer=args.force_reducer)
     batch = synthetic_batch(args.batch, args.views, args.s_text, device, seed=1234 + rank)
 
     def sync():
@@ -223,6 +228,8 @@ def main():
         "tflops_per_gpu_model": round(value * 3 * f_fwd / world / 1e12, 1),
         "mfu_bf16": round(value * 3 * f_fwd / world / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
+    if trainer.reducer is not None:
+        result["allreduce_gb_per_step"] = round(trainer.reducer.bytes_reduced / (args.steps + args.warmup) / 1e9, 3)
     if rank == 0:
         n, ms, fl = prof.summary()
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -264,14 +264,108 @@ __global__ void colsum_stage2_k(const float* __restrict__ part, float* __restric
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
-constexpr int NORM_BWD_MAX_BLOCKS = 256;
+// Fast backward (cols % 4 == 0, cols <= 4096): a wave owns whole rows, keeps its weight/bias-gradient partial
+// sums in REGISTERS (16 x 4 columns per lane) over all its rows and writes ONE partial row at the end:
+// no LDS, no barriers, no serialisation between the waves of a workgroup; x/dy are read twice (second pass
+// from L1/L2).  partial: [4*gridDim.x][(LN ? 2 : 1) * cols].
+template <typename T, typename TW, bool LN>
+__global__ __launch_bounds__(256) void norm_bwd_fast_k(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       const TW* __restrict__ w, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, T* __restrict__ dx,
+                                                       float* __restrict__ partial, int64_t rows, int64_t cols) {
+  constexpr int NIT = 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t prow = (int64_t)blockIdx.x * 4 + wave;
+  float aw[NIT][4], ab[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { aw[it][i] = 0.f; ab[it][i] = 0.f; }
+  for (int64_t row = prow; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float rs = rstd[row];
+    const float mu = LN ? mean[row] : 0.f;
+    const T* xr = x + row * cols;
+    const T* gr = dy + row * cols;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t c = ((int64_t)it * 64 + lane) * 4;
+      if (c < cols) {
+        float xv[4], gv[4], wv[4] = {1.f, 1.f, 1.f, 1.f};
+        Vec<T, 4>::ld(xv, xr + c);
+        Vec<T, 4>::ld(gv, gr + c);
+        if (w) Vec<TW, 4>::ld(wv, w + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float g = gv[i] * wv[i];
+          s1 += g;
+          s2 += g * ((xv[i] - mu) * rs);
+        }
+      }
+    }
+    const float c1 = LN ? wave_sum(s1) / (float)cols : 0.f;
+    const float c2 = wave_sum(s2) / (float)cols;
+    T* dxr = dx + row * cols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t c = ((int64_t)it * 64 + lane) * 4;
+      if (c < cols) {
+        float xv[4], gv[4], wv[4] = {1.f, 1.f, 1.f, 1.f}, o[4];
+        Vec<T, 4>::ld(xv, xr + c);
+        Vec<T, 4>::ld(gv, gr + c);
+        if (w) Vec<TW, 4>::ld(wv, w + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xh = (xv[i] - mu) * rs;
+          o[i] = rs * (gv[i] * wv[i] - c1 - xh * c2);
+          aw[it][i] += gv[i] * (LN ? xh : rnd<T>(xh));
+          ab[it][i] += gv[i];
+        }
+        Vec<T, 4>::st(dxr + c, o);
+      }
+    }
+  }
+  if (partial) {
+    float* pr = partial + prow * (LN ? 2 : 1) * cols;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t c = ((int64_t)it * 64 + lane) * 4;
+      if (c < cols) {
+        *reinterpret_cast<float4*>(pr + c) = make_float4(aw[it][0], aw[it][1], aw[it][2], aw[it][3]);
+        if (LN) *reinterpret_cast<float4*>(pr + cols + c) = make_float4(ab[it][0], ab[it][1], ab[it][2], ab[it][3]);
+      }
+    }
+  }
+}
+
+constexpr int NORM_BWD_MAX_BLOCKS = 512;
+constexpr int64_t NORM_BWD_FAST_MAX_COLS = 4096;
+
+template <bool LN>
+bool launch_norm_bwd_fast(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
+                          float* partial, int64_t rows, int64_t cols, int dtype, int w_dtype, bool vec_ok, hipStream_t st) {
+  if (!vec_ok || cols % 4 != 0 || cols > NORM_BWD_FAST_MAX_COLS) return false;
+  int64_t g = (rows + 3) / 4;
+  if (g > NORM_BWD_MAX_BLOCKS) g = NORM_BWD_MAX_BLOCKS;
+  dim3 grid((unsigned)g);
+  if (dtype == DXA_BF16 && w_dtype == DXA_BF16)
+    hipLaunchKernelGGL((norm_bwd_fast_k<bf16_t, bf16_t, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, partial, rows, cols);
+  else if (dtype == DXA_BF16)
+    hipLaunchKernelGGL((norm_bwd_fast_k<bf16_t, float, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, partial, rows, cols);
+  else
+    hipLaunchKernelGGL((norm_bwd_fast_k<float, float, LN>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, partial, rows, cols);
+  return true;
+}
 
 }  // namespace
 
+// number of partial rows both backward kernels write: 4 per workgroup of the fast kernel; the generic
+// fallback launches that many workgroups (one slab each)
 extern "C" int dxa_norm_bwd_blocks(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   if (g < 1) g = 1;
-  return (int)(g > NORM_BWD_MAX_BLOCKS ? NORM_BWD_MAX_BLOCKS : g);
+  if (g > NORM_BWD_MAX_BLOCKS) g = NORM_BWD_MAX_BLOCKS;
+  return (int)(4 * g);
 }
 
 static int check_norm_dtypes(int dtype, int w_dtype, const char* who) {
@@ -313,7 +407,11 @@ extern "C" int dxa_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   DXA_CHECK_ARG(!w || partial_dw, "dxa_rmsnorm_bwd: partial_dw required when w is given");
   if (rows == 0) return DXA_OK;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w));
+  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w)) && (!partial_dw || al16(partial_dw));
+  if (launch_norm_bwd_fast<false>(dy, x, w, nullptr, rstd, dx, w ? partial_dw : nullptr, rows, cols, dtype, w_dtype, vec_ok, st)) {
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   dim3 grid((unsigned)dxa_norm_bwd_blocks(rows));
   if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
     if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
@@ -360,7 +458,11 @@ extern "C" int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, c
   DXA_CHECK_ARG(!w || partial_dwdb, "dxa_layernorm_bwd: partial_dwdb required when w is given");
   if (rows == 0) return DXA_OK;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w));
+  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w)) && (!partial_dwdb || al16(partial_dwdb));
+  if (launch_norm_bwd_fast<true>(dy, x, w, mean, rstd, dx, w ? partial_dwdb : nullptr, rows, cols, dtype, w_dtype, vec_ok, st)) {
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   dim3 grid((unsigned)dxa_norm_bwd_blocks(rows));
   float* part = w ? partial_dwdb : nullptr;
   if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {

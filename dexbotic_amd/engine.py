@@ -356,9 +356,10 @@ class GradReducer:
     """
 
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
-                 skip: Iterable[str] = ()):
+                 skip: Iterable[str] = (), force: bool = False):
         import torch.distributed as dist
         self.dist = dist
+        self.force = force          # run the collectives even at world size 1 (exercises the RCCL path)
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -380,7 +381,7 @@ class GradReducer:
         store.on_bucket_ready = self.bucket_ready
 
     def _flush(self) -> None:
-        if self._pending_lo is None or self.world == 1:
+        if self._pending_lo is None or (self.world == 1 and not self.force):
             self._pending_lo = self._pending_hi = None
             return
         lo, hi = self._pending_lo, self._pending_hi
