@@ -48,14 +48,14 @@ template <> struct EltTraits<bf16_t> { static constexpr int EPC = 8; };
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
 // ---- k-contiguous staging: thread -> (chunk c = tid&7, rows (tid>>3)+32*i) --------------------------
-template <typename T>
+template <typename T, int NR>
 __device__ __forceinline__ void load_kc(uint4 (&r)[4], const T* __restrict__ base, int64_t ld, int64_t row0,
                                         int64_t rows, int64_t k0, int64_t K, int vec, int tid) {
   constexpr int EPC = EltTraits<T>::EPC;
   const int c = tid & 7;
   const int64_t k = k0 + (int64_t)c * EPC;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR / 32; ++i) {
     const int64_t row = row0 + (tid >> 3) + 32 * i;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < rows && k < K) {
@@ -72,10 +72,11 @@ __device__ __forceinline__ void load_kc(uint4 (&r)[4], const T* __restrict__ bas
     r[i] = v;
   }
 }
+template <int NR>
 __device__ __forceinline__ void store_kc(const uint4 (&r)[4], char* tile, int tid) {
   const int c = tid & 7;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR / 32; ++i) {
     const int row = (tid >> 3) + 32 * i;
     *reinterpret_cast<uint4*>(tile + lds_off(row, c)) = r[i];
   }
@@ -86,7 +87,7 @@ template <typename T> struct KsRegs;
 template <> struct KsRegs<bf16_t> { uint2 v[8]; };   // v[j] = 4 rows for k_j
 template <> struct KsRegs<float> { uint4 v[4]; };
 
-template <typename T>
+template <typename T, int NR>
 __device__ __forceinline__ void load_ks(KsRegs<T>& r, const T* __restrict__ base, int64_t ld, int64_t row0,
                                         int64_t rows, int64_t k0, int64_t K, int vec, int tid) {
   constexpr int EPC = EltTraits<T>::EPC;
@@ -96,7 +97,7 @@ __device__ __forceinline__ void load_ks(KsRegs<T>& r, const T* __restrict__ base
   for (int j = 0; j < EPC; ++j) {
     const int64_t k = k0 + kg * EPC + j;
     alignas(16) T tmp[4] = {(T)0, (T)0, (T)0, (T)0};
-    if (k < K && rr < rows) {
+    if (k < K && rr < rows && 4 * (tid >> 3) < NR) {
       const T* p = base + k * ld + rr;
       if (vec && rr + 3 < rows) {
         if constexpr (sizeof(T) == 2) {
@@ -120,8 +121,10 @@ __device__ __forceinline__ uint32_t half_of(const uint2& v, int q) {
   const uint32_t w = (q & 2) ? v.y : v.x;
   return (q & 1) ? (w >> 16) : (w & 0xffffu);
 }
+template <int NR>
 __device__ __forceinline__ void store_ks(const KsRegs<bf16_t>& r, char* tile, int tid) {
   const int kg = tid & 7;
+  if (4 * (tid >> 3) >= NR) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = 4 * (tid >> 3) + q;
@@ -136,8 +139,10 @@ __device__ __forceinline__ void store_ks(const KsRegs<bf16_t>& r, char* tile, in
 __device__ __forceinline__ uint32_t comp_of(const uint4& v, int q) {
   return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
 }
+template <int NR>
 __device__ __forceinline__ void store_ks(const KsRegs<float>& r, char* tile, int tid) {
   const int kg = tid & 7;
+  if (4 * (tid >> 3) >= NR) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = 4 * (tid >> 3) + q;
@@ -146,22 +151,22 @@ __device__ __forceinline__ void store_ks(const KsRegs<float>& r, char* tile, int
   }
 }
 
-template <typename T, bool KS> struct Stager;
-template <typename T> struct Stager<T, false> {
+template <typename T, bool KS, int NR> struct Stager;
+template <typename T, int NR> struct Stager<T, false, NR> {
   uint4 r[4];
   __device__ __forceinline__ void load(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t k0,
                                        int64_t K, int vec, int tid) {
-    load_kc<T>(r, base, ld, row0, rows, k0, K, vec, tid);
+    load_kc<T, NR>(r, base, ld, row0, rows, k0, K, vec, tid);
   }
-  __device__ __forceinline__ void store(char* tile, int tid) { store_kc(r, tile, tid); }
+  __device__ __forceinline__ void store(char* tile, int tid) { store_kc<NR>(r, tile, tid); }
 };
-template <typename T> struct Stager<T, true> {
+template <typename T, int NR> struct Stager<T, true, NR> {
   KsRegs<T> r;
   __device__ __forceinline__ void load(const T* base, int64_t ld, int64_t row0, int64_t rows, int64_t k0,
                                        int64_t K, int vec, int tid) {
-    load_ks<T>(r, base, ld, row0, rows, k0, K, vec, tid);
+    load_ks<T, NR>(r, base, ld, row0, rows, k0, K, vec, tid);
   }
-  __device__ __forceinline__ void store(char* tile, int tid) { store_ks(r, tile, tid); }
+  __device__ __forceinline__ void store(char* tile, int tid) { store_ks<NR>(r, tile, tid); }
 };
 
 template <typename T>
@@ -253,9 +258,13 @@ __device__ __forceinline__ void epilogue4(const GemmP& p, TO* C, TO* AUX, const 
   store4<TO>(cp, v, p.vecC, n_ok);
 }
 
-template <typename TI, typename TO, bool A_KS, bool B_KS>
+// TM = 16x16 fragments per wave per dimension: 4 -> 128x128 tile (default), 2 -> 64x64 tile (small problems that
+// would otherwise leave most of the 256 CUs idle, e.g. the fp32 DiT head GEMMs with M = 1088)
+template <typename TI, typename TO, bool A_KS, bool B_KS, int TM>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A,B][TILE_BYTES]
+  constexpr int BT = 32 * TM;                 // tile rows / cols
+  constexpr int TILE_B = BT * ROWB;           // bytes per operand per buffer
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A,B][TILE_B]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int gsz = min(p.tm - first_pm, GROUP_M);
   const int pm = first_pm + (bid % width) % gsz;
   const int pn = (bid % width) / gsz;
-  const int64_t m0 = (int64_t)pm * BM, n0 = (int64_t)pn * BN;
+  const int64_t m0 = (int64_t)pm * BT, n0 = (int64_t)pn * BT;
 
   // ---- batch offsets ----------------------------------------------------------------------------------
   const int z = blockIdx.z;
@@ -288,24 +297,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   constexpr int BK = 8 * EPC;
   const int64_t nk = (p.K + BK - 1) / BK;
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  Stager<TI, A_KS> sa;
-  Stager<TI, B_KS> sb;
+  Stager<TI, A_KS, BT> sa;
+  Stager<TI, B_KS, BT> sb;
   sa.load(A, p.lda, m0, p.M, 0, p.K, p.vecA, tid);
   sb.load(B, p.ldb, n0, p.N, 0, p.K, p.vecB, tid);
   sa.store(smem, tid);
-  sb.store(smem + TILE_BYTES, tid);
+  sb.store(smem + TILE_B, tid);
   __syncthreads();
 
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int cur = (int)(kt & 1);
-    char* As = smem + cur * 2 * TILE_BYTES;
-    char* Bs = As + TILE_BYTES;
+    char* As = smem + cur * 2 * TILE_B;
+    char* Bs = As + TILE_B;
     const bool more = kt + 1 < nk;
     if (more) {
       sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, p.K, p.vecA, tid);
@@ -313,21 +322,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      uint4 af[4], bfr[4];
+      uint4 af[TM], bfr[TM];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + l16, 4 * s + lg));
-        bfr[i] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + i * 16 + l16, 4 * s + lg));
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 16 * TM + i * 16 + l16, 4 * s + lg));
+        bfr[i] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 16 * TM + i * 16 + l16, 4 * s + lg));
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) mma_step<TI>(acc[mi][ni], bfr[ni], af[mi]);
+        for (int ni = 0; ni < TM; ++ni) mma_step<TI>(acc[mi][ni], bfr[ni], af[mi]);
     }
     if (more) {
-      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      char* An = smem + (cur ^ 1) * 2 * TILE_B;
       sa.store(An, tid);
-      sb.store(An + TILE_BYTES, tid);
+      sb.store(An + TILE_B, tid);
     }
     __syncthreads();
   }
@@ -339,15 +348,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const TI* G = p.G ? reinterpret_cast<const TI*>(p.G) + b0 * p.sG[0] + b1 * p.sG[1] + b2 * p.sG[2] : nullptr;
   const TI* bias = reinterpret_cast<const TI*>(p.bias);
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int64_t n = n0 + wn * 64 + ni * 16 + 4 * lg;
+  for (int ni = 0; ni < TM; ++ni) {
+    const int64_t n = n0 + wn * 16 * TM + ni * 16 + 4 * lg;
     if (n >= p.N) continue;
     const int n_ok = (int)min((int64_t)4, p.N - n);
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) load4<TI>(bv, bias + n, p.vecBias, n_ok);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int64_t m = m0 + wm * 64 + mi * 16 + l16;
+    for (int mi = 0; mi < TM; ++mi) {
+      const int64_t m = m0 + wm * 16 * TM + mi * 16 + l16;
       if (m >= p.M) continue;
       const float a4[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
       epilogue4<TI, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
@@ -554,13 +563,13 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 template __global__ void gemm_nt_ring_kernel<bf16_t>(const GemmP);
 template __global__ void gemm_nt_ring_kernel<float>(const GemmP);
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, int TM>
 int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
-  constexpr size_t LDS = 4 * TILE_BYTES;
+  constexpr size_t LDS = 4 * (32 * TM) * ROWB;
   switch (layout) {
-    case DXA_NT: hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false>), grid, dim3(256), LDS, st, p); break;
-    case DXA_NN: hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true>), grid, dim3(256), LDS, st, p); break;
-    case DXA_TN: hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true>), grid, dim3(256), LDS, st, p); break;
+    case DXA_NT: hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, TM>), grid, dim3(256), LDS, st, p); break;
+    case DXA_NN: hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, TM>), grid, dim3(256), LDS, st, p); break;
+    case DXA_TN: hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, TM>), grid, dim3(256), LDS, st, p); break;
     default: return DXA_ERR_BAD_ARG;
   }
   return DXA_OK;
@@ -641,13 +650,19 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
+  // generic kernel: 128x128 tiles, or 64x64 when 128-tiles would occupy less than ~one wave of the 256 CUs
+  const bool small = (int64_t)p.tm * p.tn * nbatch < 192;
+  if (small) {
+    p.tm = dxa_cdiv(d->M, 64);
+    p.tn = dxa_cdiv(d->N, 64);
+  }
   dim3 grid((unsigned)(p.tm * p.tn), 1, (unsigned)nbatch);
   int rc;
   if (d->in_dtype == DXA_BF16) {
-    rc = d->out_dtype == DXA_BF16 ? launch<bf16_t, bf16_t>(p, d->layout, grid, st)
-                                  : launch<bf16_t, float>(p, d->layout, grid, st);
+    if (small) rc = d->out_dtype == DXA_BF16 ? launch<bf16_t, bf16_t, 2>(p, d->layout, grid, st) : launch<bf16_t, float, 2>(p, d->layout, grid, st);
+    else rc = d->out_dtype == DXA_BF16 ? launch<bf16_t, bf16_t, 4>(p, d->layout, grid, st) : launch<bf16_t, float, 4>(p, d->layout, grid, st);
   } else {
-    rc = launch<float, float>(p, d->layout, grid, st);
+    rc = small ? launch<float, float, 2>(p, d->layout, grid, st) : launch<float, float, 4>(p, d->layout, grid, st);
   }
   if (rc != DXA_OK) return rc;
   DXA_CHECK_LAUNCH();

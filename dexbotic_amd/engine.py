@@ -62,6 +62,8 @@ class ParamStore:
         self.shadow_t: Optional[torch.Tensor] = None
         self._wt_groups: List[Tuple[Tuple[str, ...], int, int]] = []
         self.wt_index: set = set()
+        self._t_stream = None
+        self._t_pending = False
 
     # ---- layout -------------------------------------------------------------------------------------
     def new_bucket(self) -> int:
@@ -199,12 +201,29 @@ class ParamStore:
     def wt(self, *names: str, shape: Sequence[int]) -> torch.Tensor:
         return self._view(self.shadow_t, names, shape)
 
-    def sync_transposed(self) -> None:
+    def sync_transposed(self, overlap: bool = False) -> None:
+        """refresh the W^T shadows.  With ``overlap`` the ~200 HBM-bound transposes run on a side HIP stream
+        (they are first needed by the NEXT backward, so they hide under the next forward's MFMA work);
+        consumers call wait_transposed()."""
         if self.shadow_t is None:
             return
         from . import kernels as K
+        if overlap and self.device.type == "cuda":
+            if self._t_stream is None:
+                self._t_stream = torch.cuda.Stream(device=self.device)
+            self._t_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._t_stream):
+                for names, rows, cols in self._wt_groups:
+                    K.transpose(self.w(*names, shape=(rows, cols)), out=self.wt(*names, shape=(cols, rows)))
+            self._t_pending = True
+            return
         for names, rows, cols in self._wt_groups:
             K.transpose(self.w(*names, shape=(rows, cols)), out=self.wt(*names, shape=(cols, rows)))
+
+    def wait_transposed(self) -> None:
+        if self._t_pending:
+            torch.cuda.current_stream().wait_stream(self._t_stream)
+            self._t_pending = False
 
 
 class Fp32View:
@@ -332,7 +351,7 @@ class FusedAdamW:
         lrs, wds = self._lrs_wds(lr_scale)
         K.adamw(st.master, st.grad, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
                 lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
-        st.sync_transposed()
+        st.sync_transposed(overlap=True)
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:

@@ -42,6 +42,7 @@ def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor
     """dX = dY W for W = fused view over `names` of shape wshape = (out, in)"""
     names = _names(names)
     if _use_nt(st, names):
+        st.wait_transposed()
         return K.mm_nt(dy2d, st.wt(*names, shape=(wshape[1], wshape[0])), **kw)
     return K.mm_nn(dy2d, st.w(*names, shape=tuple(wshape)), **kw)
 
