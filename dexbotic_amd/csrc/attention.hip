@@ -314,6 +314,286 @@ __global__ __launch_bounds__(256) void attn_ds_k(const T* __restrict__ P, const 
   }
 }
 
+// ------------------------------------------------------------------------------ fused flash backward (bf16)
+// Same building blocks as the forward kernel: 64-row tiles staged in LDS either row-major ([row][d], XOR
+// swizzled, read as 16-byte MFMA fragments) or transposed ([d][row], built by an in-register 8x4 transpose,
+// read as two 8-byte pieces per fragment with the k-slot permutation (lg,e) <-> 32*kb2 + 16*(e>>2) + 4*lg + (e&3)
+// that makes a lane's own 16 score registers the matching MFMA operand).  P is recomputed from the saved
+// log-sum-exp; nothing of size S x S ever goes to HBM.
+//   dQ kernel  : workgroup = 64 queries of one head, waves own 16 queries; loops over K/V tiles:
+//                S^T = K Q^T, dP^T = V dO^T (lane = one query), dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
+//   dKV kernel : workgroup = 64 keys of one kv head, waves own 16 keys; loops over the G query heads of the
+//                group and over query tiles: S = Q K^T, dP = dO V^T (lane = one key), dV^T += dO^T P, dK^T += Q^T dS
+template <int D> struct FlashTile {
+  static constexpr int NCH = D / 8;
+  static constexpr int ROW = D * 2;
+  static constexpr int RM_BYTES = 64 * ROW;   // row-major tile
+  static constexpr int TR_BYTES = D * 128;    // transposed tile
+};
+
+template <int D>
+__device__ __forceinline__ void stage_rm(char* dst, const bf16_t* base, int64_t stride, int row0, int nrows, int tid) {
+  constexpr int NCH = FlashTile<D>::NCH, ROW = FlashTile<D>::ROW, RPI = 256 / NCH;
+  const int c = tid % NCH;
+#pragma unroll
+  for (int i = 0; i < 64 / RPI; ++i) {
+    const int r = tid / NCH + RPI * i;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nrows) val = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + r) * stride + c * 8);
+    *reinterpret_cast<uint4*>(dst + r * ROW + ((c ^ (r & (NCH - 1))) << 4)) = val;
+  }
+}
+template <int D>
+__device__ __forceinline__ void stage_tr(char* dst, const bf16_t* base, int64_t stride, int row0, int nrows, int tid) {
+  if (tid < 8 * (D / 4)) {
+    const int kc = tid & 7, dg = tid >> 3;
+    uint2 vv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = row0 + kc * 8 + e;
+      vv[e] = make_uint2(0, 0);
+      if (r < nrows) vv[e] = *reinterpret_cast<const uint2*>(base + (int64_t)r * stride + dg * 4);
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int d = dg * 4 + qd;
+      uint32_t w[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const uint32_t lo = (qd & 2) ? vv[2 * m].y : vv[2 * m].x;
+        const uint32_t hi = (qd & 2) ? vv[2 * m + 1].y : vv[2 * m + 1].x;
+        const uint32_t lo16 = (qd & 1) ? (lo >> 16) : (lo & 0xffffu);
+        const uint32_t hi16 = (qd & 1) ? (hi >> 16) : (hi & 0xffffu);
+        w[m] = lo16 | (hi16 << 16);
+      }
+      *reinterpret_cast<uint4*>(dst + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+template <int D>
+__device__ __forceinline__ uint4 frag_rm(const char* tile, int r, int c) {
+  return *reinterpret_cast<const uint4*>(tile + r * FlashTile<D>::ROW + ((c ^ (r & (FlashTile<D>::NCH - 1))) << 4));
+}
+__device__ __forceinline__ uint4 frag_tr(const char* tile, int d, int kb2, int lg) {
+  const int sw = (d >> 1) & 7;
+  const int k1 = 32 * kb2 + 4 * lg, k2 = k1 + 16;
+  const uint2 v1 = *reinterpret_cast<const uint2*>(tile + d * 128 + (((k1 >> 3) ^ sw) << 4) + (k1 & 7) * 2);
+  const uint2 v2 = *reinterpret_cast<const uint2*>(tile + d * 128 + (((k2 >> 3) ^ sw) << 4) + (k2 & 7) * 2);
+  return make_uint4(v1.x, v1.y, v2.x, v2.y);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+struct AttnBwdP {
+  AttnP f;                 // forward tensors (q,k,v,o unused here) + lse
+  const float* delta;      // [B,Hq,Sq]
+  const char* d_o; int64_t do_sb, do_sh, do_ss;
+  char* dq; int64_t dq_sb, dq_sh, dq_ss;
+  char* dk; int64_t dk_sb, dk_sh, dk_ss;
+  char* dv; int64_t dv_sb, dv_sh, dv_ss;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
+  const AttnP& p = bp.f;
+  using FT = FlashTile<D>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES + FT::TR_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + FT::RM_BYTES;
+  char* Kt = smem + 2 * FT::RM_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int q0 = blockIdx.x * 64;
+  const int qi = q0 + wave * 16 + l16;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
+  const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
+  uint4 qf[D / 32], dof[D / 32];
+#pragma unroll
+  for (int ds = 0; ds < D / 32; ++ds) {
+    qf[ds] = dof[ds] = make_uint4(0, 0, 0, 0);
+    if (qi < p.Sq) {
+      qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
+      dof[ds] = *reinterpret_cast<const uint4*>(dob + (int64_t)qi * bp.do_ss + 32 * ds + 8 * lg);
+    }
+  }
+  const int64_t rowid = ((int64_t)b * p.Hq + h) * p.Sq + qi;
+  const float lse = qi < p.Sq ? p.lse[rowid] : 0.f;
+  const float dlt = qi < p.Sq ? bp.delta[rowid] : 0.f;
+  f32x4_t acc[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  int j_lo = p.kv_start ? p.kv_start[b] : 0;
+  int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
+  j_lo = max(j_lo, 0);
+  j_hi = min(j_hi, p.Sk);
+  const int coff = p.Sk - p.Sq;
+  int blk_hi = j_hi;
+  if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
+  const int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;
+  for (int kt = j_lo / 64; kt < (blk_hi + 63) / 64; ++kt) {
+    const int key0 = kt * 64;
+    __syncthreads();
+    stage_rm<D>(Ks, kb, p.k_ss, key0, p.Sk, tid);
+    stage_rm<D>(Vs, vb, p.v_ss, key0, p.Sk, tid);
+    stage_tr<D>(Kt, kb, p.k_ss, key0, p.Sk, tid);
+    __syncthreads();
+    uint32_t dsp[8];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int r = n * 16 + l16;
+#pragma unroll
+      for (int ds = 0; ds < D / 32; ++ds) {
+        const uint4 kf = frag_rm<D>(Ks, r, 4 * ds + lg);
+        const uint4 vf = frag_rm<D>(Vs, r, 4 * ds + lg);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ds]), s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, dof[ds]), dp, 0, 0, 0);
+      }
+      float dsv[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int key = key0 + 16 * n + 4 * lg + rr;
+        const bool vis = key >= j_lo && key < my_hi;
+        const float pr = vis ? expf(s[rr] * p.scale - lse) : 0.f;
+        dsv[rr] = pr * (dp[rr] - dlt) * p.scale;
+      }
+      dsp[2 * n] = pack_bf16(dsv[0], dsv[1]);
+      dsp[2 * n + 1] = pack_bf16(dsv[2], dsv[3]);
+    }
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
+#pragma unroll
+      for (int di = 0; di < D / 16; ++di) {
+        const uint4 ktf = frag_tr(Kt, di * 16 + l16, kb2, lg);
+        acc[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ktf), __builtin_bit_cast(bf16x8_t, dsf), acc[di], 0, 0, 0);
+      }
+    }
+  }
+  if (qi < p.Sq) {
+    bf16_t* row = reinterpret_cast<bf16_t*>(bp.dq) + b * bp.dq_sb + h * bp.dq_sh + (int64_t)qi * bp.dq_ss;
+#pragma unroll
+    for (int di = 0; di < D / 16; ++di) {
+      uint2 ov;
+      ov.x = pack_bf16(acc[di][0], acc[di][1]);
+      ov.y = pack_bf16(acc[di][2], acc[di][3]);
+      *reinterpret_cast<uint2*>(row + di * 16 + 4 * lg) = ov;
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
+  const AttnP& p = bp.f;
+  using FT = FlashTile<D>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES + 2 * FT::TR_BYTES];
+  char* Qs = smem;
+  char* Os = smem + FT::RM_BYTES;
+  char* Qt = smem + 2 * FT::RM_BYTES;
+  char* Ot = Qt + FT::TR_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, hk = blockIdx.y;
+  const int G = p.Hq / p.Hkv;
+  const int key0 = blockIdx.x * 64;
+  const int key = key0 + wave * 16 + l16;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
+  uint4 kf[D / 32], vf[D / 32];
+#pragma unroll
+  for (int ds = 0; ds < D / 32; ++ds) {
+    kf[ds] = vf[ds] = make_uint4(0, 0, 0, 0);
+    if (key < p.Sk) {
+      kf[ds] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + 32 * ds + 8 * lg);
+      vf[ds] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * p.v_ss + 32 * ds + 8 * lg);
+    }
+  }
+  f32x4_t dka[D / 16], dva[D / 16];
+#pragma unroll
+  for (int i = 0; i < D / 16; ++i) { dka[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dva[i] = dka[i]; }
+  int j_lo = p.kv_start ? p.kv_start[b] : 0;
+  int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
+  j_lo = max(j_lo, 0);
+  j_hi = min(j_hi, p.Sk);
+  const int coff = p.Sk - p.Sq;
+  const bool key_ok = key >= j_lo && key < j_hi;
+  // queries that can see any key of this workgroup: q >= key0 - coff (causal)
+  const int qt_lo = p.causal ? max(0, key0 - coff) / 64 : 0;
+  const bool blk_live = key0 < j_hi && key0 + 64 > j_lo;
+  for (int g = 0; g < G && blk_live; ++g) {
+    const int h = hk * G + g;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
+    const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
+    const float* lse_h = p.lse + ((int64_t)b * p.Hq + h) * p.Sq;
+    const float* dlt_h = bp.delta + ((int64_t)b * p.Hq + h) * p.Sq;
+    for (int qt = qt_lo; qt < (p.Sq + 63) / 64; ++qt) {
+      const int q0 = qt * 64;
+      __syncthreads();
+      stage_rm<D>(Qs, qb, p.q_ss, q0, p.Sq, tid);
+      stage_rm<D>(Os, dob, bp.do_ss, q0, p.Sq, tid);
+      stage_tr<D>(Qt, qb, p.q_ss, q0, p.Sq, tid);
+      stage_tr<D>(Ot, dob, bp.do_ss, q0, p.Sq, tid);
+      __syncthreads();
+      uint32_t pp[8], dsp[8];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int r = n * 16 + l16;
+#pragma unroll
+        for (int ds = 0; ds < D / 32; ++ds) {
+          const uint4 qfr = frag_rm<D>(Qs, r, 4 * ds + lg);
+          const uint4 ofr = frag_rm<D>(Os, r, 4 * ds + lg);
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qfr), __builtin_bit_cast(bf16x8_t, kf[ds]), s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ofr), __builtin_bit_cast(bf16x8_t, vf[ds]), dp, 0, 0, 0);
+        }
+        // lane holds its key against queries q0 + 16n + 4lg + {0..3}
+        const int qq = q0 + 16 * n + 4 * lg;
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int q = qq + rr;
+          const bool vis = key_ok && q < p.Sq && (!p.causal || key <= q + coff);
+          const float lse = q < p.Sq ? lse_h[q] : 0.f;
+          const float dl = q < p.Sq ? dlt_h[q] : 0.f;
+          pv[rr] = vis ? expf(s[rr] * p.scale - lse) : 0.f;
+          dsv[rr] = pv[rr] * (dp[rr] - dl) * p.scale;
+        }
+        pp[2 * n] = pack_bf16(pv[0], pv[1]);
+        pp[2 * n + 1] = pack_bf16(pv[2], pv[3]);
+        dsp[2 * n] = pack_bf16(dsv[0], dsv[1]);
+        dsp[2 * n + 1] = pack_bf16(dsv[2], dsv[3]);
+      }
+#pragma unroll
+      for (int kb2 = 0; kb2 < 2; ++kb2) {
+        const uint4 pf = make_uint4(pp[4 * kb2], pp[4 * kb2 + 1], pp[4 * kb2 + 2], pp[4 * kb2 + 3]);
+        const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
+#pragma unroll
+        for (int di = 0; di < D / 16; ++di) {
+          const uint4 otf = frag_tr(Ot, di * 16 + l16, kb2, lg);
+          const uint4 qtf = frag_tr(Qt, di * 16 + l16, kb2, lg);
+          dva[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, otf), __builtin_bit_cast(bf16x8_t, pf), dva[di], 0, 0, 0);
+          dka[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qtf), __builtin_bit_cast(bf16x8_t, dsf), dka[di], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (key < p.Sk) {
+    bf16_t* krow = reinterpret_cast<bf16_t*>(bp.dk) + b * bp.dk_sb + hk * bp.dk_sh + (int64_t)key * bp.dk_ss;
+    bf16_t* vrow = reinterpret_cast<bf16_t*>(bp.dv) + b * bp.dv_sb + hk * bp.dv_sh + (int64_t)key * bp.dv_ss;
+#pragma unroll
+    for (int di = 0; di < D / 16; ++di) {
+      uint2 ok, ov;
+      ok.x = pack_bf16(dka[di][0], dka[di][1]); ok.y = pack_bf16(dka[di][2], dka[di][3]);
+      ov.x = pack_bf16(dva[di][0], dva[di][1]); ov.y = pack_bf16(dva[di][2], dva[di][3]);
+      *reinterpret_cast<uint2*>(krow + di * 16 + 4 * lg) = ok;
+      *reinterpret_cast<uint2*>(vrow + di * 16 + 4 * lg) = ov;
+    }
+  }
+}
+
 inline bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -379,8 +659,20 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
   return DXA_OK;
 }
 
+// fused flash backward eligibility: bf16, D in {64,128}, 16-byte aligned rows of q/k/v/dO, 8-byte rows of dq/dk/dv
+static bool bwd_flash_ok(const dxa_attn_desc* d) {
+  auto s8 = [](int64_t a, int64_t b, int64_t c) { return a % 8 == 0 && b % 8 == 0 && c % 8 == 0; };
+  auto s4 = [](int64_t a, int64_t b, int64_t c) { return a % 4 == 0 && b % 4 == 0 && c % 4 == 0; };
+  return !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && d->B <= 65535 && d->Hq <= 65535 &&
+         s8(d->q_sb, d->q_sh, d->q_ss) && s8(d->k_sb, d->k_sh, d->k_ss) && s8(d->v_sb, d->v_sh, d->v_ss) &&
+         s8(d->do_sb, d->do_sh, d->do_ss) && s4(d->o_sb, d->o_sh, d->o_ss) && s4(d->dq_sb, d->dq_sh, d->dq_ss) &&
+         s4(d->dk_sb, d->dk_sh, d->dk_ss) && s4(d->dv_sb, d->dv_sh, d->dv_ss) && al(d->q, 16) && al(d->k, 16) &&
+         al(d->v, 16) && al(d->d_o, 16) && al(d->o, 8) && al(d->dq, 8) && al(d->dk, 8) && al(d->dv, 8);
+}
+
 extern "C" size_t dxa_attn_bwd_workspace(const dxa_attn_desc* d) {
   if (!d) return 0;
+  if (bwd_flash_ok(d)) return align_up((size_t)d->B * d->Hq * d->Sq * 4, 256);
   const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
   const size_t es = d->dtype == DXA_BF16 ? 2 : 4;
   return align_up(n * 4, 256) + 2 * align_up(n * es, 256) + align_up((size_t)d->B * d->Hq * d->Sq * 4, 256);
@@ -391,6 +683,32 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
   DXA_CHECK_ARG(d->d_o && d->dq && d->dk && d->dv, "dxa_attn_bwd: null gradient tensor");
   DXA_CHECK_ARG(workspace && workspace_bytes >= dxa_attn_bwd_workspace(d), "dxa_attn_bwd: workspace too small");
   if (d->B == 0 || d->Sq == 0 || d->Sk == 0) return DXA_OK;
+  if (bwd_flash_ok(d)) {
+    hipStream_t st = (hipStream_t)stream;
+    float* delta = (float*)workspace;
+    const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
+    hipLaunchKernelGGL((attn_delta_k<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)d->d_o,
+                       d->do_sb, d->do_sh, d->do_ss, (const bf16_t*)d->o, d->o_sb, d->o_sh, d->o_ss, delta, d->B, d->Hq,
+                       d->Sq, d->D);
+    AttnBwdP bp;
+    bp.f = make_params(d);
+    bp.delta = delta;
+    bp.d_o = (const char*)d->d_o; bp.do_sb = d->do_sb; bp.do_sh = d->do_sh; bp.do_ss = d->do_ss;
+    bp.dq = (char*)d->dq; bp.dq_sb = d->dq_sb; bp.dq_sh = d->dq_sh; bp.dq_ss = d->dq_ss;
+    bp.dk = (char*)d->dk; bp.dk_sb = d->dk_sb; bp.dk_sh = d->dk_sh; bp.dk_ss = d->dk_ss;
+    bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
+    dim3 gq((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
+    dim3 gk((unsigned)((d->Sk + 63) / 64), (unsigned)d->Hkv, (unsigned)d->B);
+    if (d->D == 128) {
+      hipLaunchKernelGGL((attn_bwd_dq_k<128>), gq, dim3(256), 0, st, bp);
+      hipLaunchKernelGGL((attn_bwd_dkv_k<128>), gk, dim3(256), 0, st, bp);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_k<64>), gq, dim3(256), 0, st, bp);
+      hipLaunchKernelGGL((attn_bwd_dkv_k<64>), gk, dim3(256), 0, st, bp);
+    }
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   const int G = d->Hq / d->Hkv;
   if (G > 1) {
     if (d->q_sh != (int64_t)d->Sq * d->q_ss || d->do_sh != (int64_t)d->Sq * d->do_ss) {

@@ -289,8 +289,10 @@ def attn_fwd(q, k, v, o, *, causal: bool, scale: float, kv_start=None, kv_end=No
     return lse
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, causal: bool, scale: float, kv_start=None, kv_end=None):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, causal: bool, scale: float, kv_start=None, kv_end=None,
+             force_generic=False):
     d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end)
+    d.force_generic = int(force_generic)
     d.d_o, (d.do_sb, d.do_sh, d.do_ss) = _ptr(do), _bhsd_strides(do)
     d.dq, (d.dq_sb, d.dq_sh, d.dq_ss) = _ptr(dq), _bhsd_strides(dq)
     d.dk, (d.dk_sb, d.dk_sh, d.dk_ss) = _ptr(dk), _bhsd_strides(dk)

@@ -271,7 +271,7 @@ def test_attention_fwd_bwd(dtype, force_generic, case):
     qr, kr, vr = (t.double().detach().clone().requires_grad_(True) for t in (q, k, v))
     ro, _ = _attn_ref(qr, kr, vr, causal, scale, None, kv_end)
     ro.backward(do.double())
-    K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=causal, scale=scale, kv_end=kv_end)
+    K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=causal, scale=scale, kv_end=kv_end, force_generic=force_generic)
     rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (1.0 / 32, 6e-2)
     assert_close(dq, qr.grad, rt, at, "attn dq")
     assert_close(dk, kr.grad, rt, at * 2, "attn dk")
@@ -288,6 +288,14 @@ def test_attention_left_padding_and_flash_vs_generic():
     assert_close(o1, o2, 1.0 / 64, 1e-2, "flash vs generic")
     assert_close(l1, l2, 1e-3, 1e-3, "flash vs generic lse")
     assert torch.all(o1[1, :, :37] == 0)         # rows with no visible key
+    # fused flash backward vs the GEMM-composed backward under the same left-padding mask
+    do = rnd(B, Hq, S, D, dtype=torch.bfloat16, seed=53)
+    g1 = [torch.empty_like(q) for _ in range(3)]
+    g2 = [torch.empty_like(q) for _ in range(3)]
+    K.attn_bwd(q, k, v, o1, l1, do, *g1, causal=True, scale=0.125, kv_start=ks)
+    K.attn_bwd(q, k, v, o1, l1, do, *g2, causal=True, scale=0.125, kv_start=ks, force_generic=True)
+    for a, b, name in zip(g1, g2, ("dq", "dk", "dv")):
+        assert_close(a, b, 1.0 / 32, 6e-2, f"flash bwd vs generic {name}")
 
 
 # ----------------------------------------------------------------------------------------- elementwise
