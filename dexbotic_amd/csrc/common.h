@@ -144,6 +144,15 @@ void dxa_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+#define DXA_CHECK_HIP(expr)                                                \
+  do {                                                                     \
+    hipError_t e_ = (expr);                                                \
+    if (e_ != hipSuccess) {                                                \
+      dxa_set_error("%s:%d HIP error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return DXA_ERR_HIP;                                                  \
+    }                                                                      \
+  } while (0)
+
 static inline int dxa_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int dxa_grid1d(int64_t n, int block, int cap = 256 * 16) {
   int64_t g = (n + block - 1) / block;

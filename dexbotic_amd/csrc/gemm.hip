@@ -18,6 +18,11 @@
 // a grouped (8 tile-rows) ordering so neighbouring tiles share A/B panels in that XCD's L2.
 #include "common.h"
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -39,6 +44,10 @@ struct GemmP {
   int64_t sA[3], sB[3], sC[3], sR[3], sG[3];
   int tm, tn;
   int vecA, vecB, vecC, vecR, vecG, vecBias;
+  // ring kernel, split-K tail: tiles [0, full) run whole; the last tail_r tiles are cut into split_s K-ranges
+  int full, tail_r, split_s;
+  float* ws;    // fp32 partial accumulators, tail_r * (split_s - 1) slots of 256x256
+  int* flags;   // per tail tile arrival counter (self-resetting)
 };
 
 template <typename T> struct EltTraits;
@@ -396,11 +405,20 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int l32 = lane & 31, lh = lane >> 5;
 
-  const int nt = p.tm * p.tn;
+  // tiles [0, full): one workgroup each, block ids dealt round-robin to the 8 XCDs are remapped so every XCD
+  // walks a contiguous run of tiles.  Tail tiles (the partial last round of the 256 CUs) are cut along K into
+  // split_s workgroups each; the last split gathers the others' fp32 partials and runs the epilogue.
   int bid = blockIdx.x;
-  {
-    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+  int split_j = 0, split_s = 1, tail_i = 0;
+  if (bid < p.full) {
+    const int q = p.full >> 3, r = p.full & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  } else {
+    const int idx = bid - p.full;
+    tail_i = idx % p.tail_r;
+    split_j = idx / p.tail_r;
+    split_s = p.split_s;
+    bid = p.full + tail_i;
   }
   constexpr int GROUP_M = 4;
   const int width = GROUP_M * p.tn;
@@ -425,8 +443,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     offA[j] = ga < p.M ? (uint32_t)((ga * p.lda) * 2 + chunk * 16) : 0x80000000u;
     offB[j] = gb < p.N ? (uint32_t)((gb * p.ldb) * 2 + chunk * 16) : 0x80000000u;
   }
-#define DMA_A(slab, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + ((slab) & 3) * STAGE + (wave * 2 + (j)) * 1024), 16, offA[j], (slab) * 64, 0, 0)
-#define DMA_B(slab, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + ((slab) & 3) * STAGE + A_ST + (wave * 2 + (j)) * 1024), 16, offB[j], (slab) * 64, 0, 0)
+  const int nk_tot = (int)(p.K / 32);
+  const int k_lo = (int)((int64_t)split_j * nk_tot / split_s);
+  const int nk = (int)((int64_t)(split_j + 1) * nk_tot / split_s) - k_lo;   // slabs of this workgroup
+#define DMA_A(slab, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + ((slab) & 3) * STAGE + (wave * 2 + (j)) * 1024), 16, offA[j], (k_lo + (slab)) * 64, 0, 0)
+#define DMA_B(slab, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + ((slab) & 3) * STAGE + A_ST + (wave * 2 + (j)) * 1024), 16, offB[j], (k_lo + (slab)) * 64, 0, 0)
 #define DMA_SLAB(slab) do { DMA_A(slab, 0); DMA_A(slab, 1); DMA_B(slab, 0); DMA_B(slab, 1); } while (0)
 
   f32x16_t acc[4][2];
@@ -437,7 +458,6 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (int)(p.K / 32);
   // ---- prologue: slabs 0,1,2 in flight; slabs 0 and 1 complete before the loop
   DMA_SLAB(0);
   if (nk > 1) DMA_SLAB(1);
@@ -511,6 +531,43 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #undef MFMA1
 #undef SB
 
+  // ---- split-K tail: partial accumulators travel through a lane-linear fp32 slot (1 KiB per wave store).
+  if (split_s > 1) {
+    float4* slot0 = reinterpret_cast<float4*>(p.ws) + (size_t)tail_i * (split_s - 1) * 16384;
+    if (split_j < split_s - 1) {
+      // agent-scope relaxed atomics write through the XCD-private L2, so no cache-wide write-back is needed
+      float* dst = reinterpret_cast<float*>(slot0 + (size_t)split_j * 16384) + tid;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(dst + ((i * 2 + j) * 16 + r) * 512, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.flags + tail_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // gatherer: it has the highest block ids of its tile, so its partners were dispatched before it
+    if (tid == 0) {
+      while (__hip_atomic_load(p.flags + tail_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_s - 1)
+        __builtin_amdgcn_s_sleep(4);
+      __hip_atomic_store(p.flags + tail_i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int sj = 0; sj < split_s - 1; ++sj) {
+      const float* src = reinterpret_cast<const float*>(slot0 + (size_t)sj * 16384) + tid;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += __hip_atomic_load(src + ((i * 2 + j) * 16 + r) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
   // ---- epilogue: accumulators -> wave-private LDS slab (fp32, padded rows) -> row-contiguous global stores.
   // The MFMA layout gives each lane 4 consecutive n of 32 different rows: stored directly that is 8-byte
   // pieces at a row stride (measured: 0.6 TB/s, 58 us per tile).  Re-read from LDS, 16 lanes cover one
@@ -575,6 +632,29 @@ int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
   return DXA_OK;
 }
 
+// Split-K scratch of the ring kernel: < 256 slots of 256 KiB + 256 counters per (device, stream), allocated on
+// first use (so the first dxa_gemm on a stream must not run under stream capture) and kept for the process.
+constexpr int NUM_CU = 256;
+struct SplitWs { float* ws; int* flags; };
+int get_split_ws(hipStream_t st, SplitWs* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SplitWs> tab;
+  int dev = 0;
+  DXA_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tab.find({dev, st});
+  if (it == tab.end()) {
+    char* base = nullptr;
+    const size_t ws_bytes = (size_t)NUM_CU * 256 * 256 * 4;
+    DXA_CHECK_HIP(hipMalloc((void**)&base, ws_bytes + NUM_CU * sizeof(int)));
+    DXA_CHECK_HIP(hipMemset(base + ws_bytes, 0, NUM_CU * sizeof(int)));
+    DXA_CHECK_HIP(hipDeviceSynchronize());
+    it = tab.emplace(std::make_pair(dev, st), SplitWs{(float*)base, (int*)(base + ws_bytes)}).first;
+  }
+  *out = it->second;
+  return DXA_OK;
+}
+
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 inline bool strides_mult(const int64_t s[3], int64_t m) { return s[0] % m == 0 && s[1] % m == 0 && s[2] % m == 0; }
 
@@ -633,7 +713,21 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
       bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
     p.tm = dxa_cdiv(d->M, 256);
     p.tn = dxa_cdiv(d->N, 256);
-    dim3 fgrid((unsigned)(p.tm * p.tn));
+    const int nt = p.tm * p.tn, nk_tot = (int)(d->K / 32);
+    p.full = nt; p.tail_r = 0; p.split_s = 1;
+    static const bool split_off = getenv("DXA_GEMM_NO_SPLIT") != nullptr;
+    const int tail = nt % NUM_CU;
+    if (!split_off && tail > 0) {
+      // the last round would leave NUM_CU - tail CUs idle: cut its tiles along K (>= 16 slabs per piece)
+      // (measured: each fp32 partial slot costs ~0.25 us of write-through traffic, so short K does not pay)
+      const int s = nk_tot >= 64 ? std::min(std::min(NUM_CU / tail, 8), nk_tot / 16) : 1;
+      if (s >= 2) {
+        SplitWs w;
+        if (int rc = get_split_ws(st, &w)) return rc;
+        p.full = nt - tail; p.tail_r = tail; p.split_s = s; p.ws = w.ws; p.flags = w.flags;
+      }
+    }
+    dim3 fgrid((unsigned)(p.full + p.tail_r * p.split_s));
     constexpr int RING_LDS = 139264;   // max(4 x 32 KiB ring, 8 waves x 64 x 272 B epilogue slabs)
 #define LAUNCH_RING(TO_)                                                                                        \
   do {                                                                                                          \

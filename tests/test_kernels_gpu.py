@@ -105,6 +105,25 @@ def test_gemm_accumulate_f32out_strided(dtype):
     assert_close(o2, ref2, r2, a2, "unaligned rows")
 
 
+@pytest.mark.parametrize("shape", [(1100, 530, 2048), (700, 300, 4096), (4592, 4608, 2048), (4112, 1024, 4096)])
+@pytest.mark.parametrize("f32out", [False, True])
+def test_gemm_ring_split_tail(shape, f32out):
+    """bf16 NT ring kernel when the last round of 256x256 tiles is cut along K (fp32 partials + gatherer)"""
+    M, N, Kd = shape
+    a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=15), rnd(N, Kd, dtype=torch.bfloat16, seed=16, scale=0.1)
+    ref = a.double() @ w.double().t()
+    for rep in range(3):                                   # the arrival counters must reset themselves
+        if f32out:
+            out = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+            K.mm_nt(a, w, out=out, accumulate=True)
+            assert_close(out, ref + 0.5, 2e-5, 2e-3 * math.sqrt(Kd / 320), f"split tail f32 accumulate rep {rep}")
+        else:
+            bias, res = rnd(N, dtype=torch.bfloat16, seed=17), rnd(M, N, dtype=torch.bfloat16, seed=18)
+            out = K.mm_nt(a, w, bias=bias, residual=res)
+            rtol, atol = tol_for(torch.bfloat16, Kd)
+            assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"split tail bf16 rep {rep}")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_batched_gqa(dtype):
     B, Hkv, G, S, D = 2, 2, 3, 70, 64
