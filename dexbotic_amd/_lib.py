@@ -17,7 +17,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdexbotic_amd.so")
+LIB_PATH = os.environ.get("DXA_LIB") or os.path.join(_HERE, "libdexbotic_amd.so")   # DXA_LIB: kernel-tuning builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4, 5

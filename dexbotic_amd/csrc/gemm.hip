@@ -478,20 +478,32 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   const uint32_t abase1 = lds0 + (wm * 128 + l32) * 64 + (((2 + lh) ^ sw) << 4);
   const uint32_t bbase0 = lds0 + A_ST + (wn * 64 + l32) * 64 + (((0 + lh) ^ sw) << 4);
   const uint32_t bbase1 = lds0 + A_ST + (wn * 64 + l32) * 64 + (((2 + lh) ^ sw) << 4);
+#if defined(DXA_ABL) && DXA_ABL == 3
+#define DS_READ(dst, addr, imm) asm volatile("" : "+v"(dst) : "v"(addr))
+#else
 #define DS_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#endif
 #define RD_SET(A_, B_, abase, bbase, soff)                                                      \
   do {                                                                                          \
     const uint32_t ax_ = (abase) + (soff), bx_ = (bbase) + (soff);                              \
     DS_READ(A_[0], ax_, 0); DS_READ(A_[1], ax_, 2048); DS_READ(A_[2], ax_, 4096); DS_READ(A_[3], ax_, 6144); \
     DS_READ(B_[0], bx_, 0); DS_READ(B_[1], bx_, 2048);                                          \
   } while (0)
+#if defined(DXA_ABL) && DXA_ABL == 4
+#define MFMA1(A_, B_, i, j) asm volatile("" : "+v"(acc[i][j]) : "v"(A_[i]), "v"(B_[j]))
+#else
 #define MFMA1(A_, B_, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, B_[j]), __builtin_bit_cast(bf16x8_t, A_[i]), acc[i][j], 0, 0, 0)
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
   RD_SET(a0, b0, abase0, bbase0, 0u);       // k-step 0 of slab 0
   for (int t = 0; t < nk; ++t) {
     const uint32_t soff = (uint32_t)((t & 3) * STAGE), soff_n = (uint32_t)(((t + 1) & 3) * STAGE);
+#if defined(DXA_ABL) && DXA_ABL == 1
+    const bool dma = false;
+#else
     const bool dma = t + 3 < nk;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SB();
     MFMA1(a0, b0, 0, 0); MFMA1(a0, b0, 0, 1);
@@ -520,7 +532,9 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     SB();
     if (dma) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of slab t+2 have landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(DXA_ABL) && DXA_ABL == 2)
     __builtin_amdgcn_s_barrier();
+#endif
     SB();
   }
 #undef DMA_A
