@@ -45,24 +45,51 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   bf16_t* sh = a.shadow ? a.shadow + start : nullptr;
   const bool vec = ((start & 3) == 0);
   const int n4 = vec ? (len >> 2) : 0;
-  for (int i = threadIdx.x; i < n4; i += 256) {
-    float4 pv = reinterpret_cast<float4*>(p)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
-    adam1(pv.x, gv.x * clip, mv.x, vv.x, lr, wd, a, step_size, inv_sqrt_bc2);
-    adam1(pv.y, gv.y * clip, mv.y, vv.y, lr, wd, a, step_size, inv_sqrt_bc2);
-    adam1(pv.z, gv.z * clip, mv.z, vv.z, lr, wd, a, step_size, inv_sqrt_bc2);
-    adam1(pv.w, gv.w * clip, mv.w, vv.w, lr, wd, a, step_size, inv_sqrt_bc2);
-    reinterpret_cast<float4*>(p)[i] = pv;
-    reinterpret_cast<float4*>(m)[i] = mv;
-    reinterpret_cast<float4*>(v)[i] = vv;
+  // two float4 groups per thread in flight (8 independent 16-B loads); g, m, v and the stores stream through HBM
+  // exactly once per step, so they carry the nontemporal hint and leave L2/MALL to the master weights' neighbours
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  auto upd = [&](f4& pv, const f4& gv, f4& mv, f4& vv) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pv[e], me = mv[e], ve = vv[e];
+      adam1(pe, gv[e] * clip, me, ve, lr, wd, a, step_size, inv_sqrt_bc2);
+      pv[e] = pe; mv[e] = me; vv[e] = ve;
+    }
+  };
+  auto put = [&](int i, const f4& pv, const f4& mv, const f4& vv) {
+    __builtin_nontemporal_store(pv, reinterpret_cast<f4*>(p) + i);
+    __builtin_nontemporal_store(mv, reinterpret_cast<f4*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f4*>(v) + i);
     if (sh) {
-      uint2 o;
+      u2 o;
       o.x = (uint32_t)f2bf(pv.x) | ((uint32_t)f2bf(pv.y) << 16);
       o.y = (uint32_t)f2bf(pv.z) | ((uint32_t)f2bf(pv.w) << 16);
-      reinterpret_cast<uint2*>(sh)[i] = o;
+      __builtin_nontemporal_store(o, reinterpret_cast<u2*>(sh) + i);
     }
+  };
+  int i = threadIdx.x;
+  for (; i + 256 < n4; i += 512) {
+    f4 p0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + i);
+    f4 p1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + i + 256);
+    const f4 g0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i);
+    const f4 g1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i + 256);
+    f4 m0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i);
+    f4 m1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i + 256);
+    f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i);
+    f4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i + 256);
+    upd(p0, g0, m0, v0);
+    upd(p1, g1, m1, v1);
+    put(i, p0, m0, v0);
+    put(i + 256, p1, m1, v1);
+  }
+  for (; i < n4; i += 256) {
+    f4 p0 = reinterpret_cast<const f4*>(p)[i];
+    const f4 g0 = reinterpret_cast<const f4*>(g)[i];
+    f4 m0 = reinterpret_cast<const f4*>(m)[i];
+    f4 v0 = reinterpret_cast<const f4*>(v)[i];
+    upd(p0, g0, m0, v0);
+    put(i, p0, m0, v0);
   }
   for (int i = (n4 << 2) + threadIdx.x; i < len; i += 256) {
     float pv = p[i], mv = m[i], vv = v[i];
@@ -79,10 +106,24 @@ __global__ __launch_bounds__(256) void sumsq_stage1_k(const float* __restrict__ 
   const int64_t n4 = n >> 2;
   const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   if (vec) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-      const float4 v = reinterpret_cast<const float4*>(x)[i];
-      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* x4 = reinterpret_cast<const f4*>(x);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; i + 3 * stride < n4; i += 4 * stride) {     // four independent 16-B loads in flight per thread
+      const f4 a = __builtin_nontemporal_load(x4 + i), b = __builtin_nontemporal_load(x4 + i + stride);
+      const f4 c = __builtin_nontemporal_load(x4 + i + 2 * stride), d = __builtin_nontemporal_load(x4 + i + 3 * stride);
+      s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+      s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+      s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
     }
+    for (; i < n4; i += stride) {
+      const f4 a = x4[i];
+      s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+    s += s1 + s2 + s3;
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
