@@ -711,6 +711,32 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ src, in
     }
   }
 }
+// bf16 fast path: no LDS.  A lane owns an 8x8 block: eight 16-byte row loads (a wave instruction covers 8 rows x
+// 128 B, whole cache lines), an in-register 16-bit transpose with v_perm_b32, eight 16-byte stores (8 dst rows x
+// 128 B per wave instruction).  Workgroup = 128 x 128 (waves 2 x 2): 256-B runs on both sides, 8 independent
+// loads in flight per lane.  Needs 16-byte aligned rows, C % 8 == 0 and R_padded % 8 == 0.
+__global__ __launch_bounds__(256) void transpose8_bf16_k(const bf16_t* __restrict__ src, int64_t lds_, bf16_t* __restrict__ dst,
+                                                         int64_t ldd, int64_t R, int64_t C, int64_t Rp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int64_t c0 = (int64_t)blockIdx.x * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  if (c0 >= C || r0 >= Rp) return;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  u4 in[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    in[i] = (u4){0u, 0u, 0u, 0u};
+    if (r0 + i < R) in[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + (r0 + i) * lds_ + c0));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      o[d] = __builtin_amdgcn_perm(in[2 * d + 1][j >> 1], in[2 * d][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+    __builtin_nontemporal_store(o, reinterpret_cast<u4*>(dst + (c0 + j) * ldd + r0));
+  }
+}
 // [B,S,H,D] -> [B,H,S,D] (to_head=1) or back (to_head=0); 16-byte pieces
 template <typename T>
 __global__ __launch_bounds__(256) void permute_bshd_k(const T* __restrict__ src, T* __restrict__ dst, int B, int S, int H, int D,
@@ -739,6 +765,13 @@ extern "C" int dxa_transpose(const void* src, int64_t ld_src, void* dst, int64_t
   const size_t es = dtype == DXA_BF16 ? 2 : 4;
   const int64_t epv = 16 / es;
   const int vec = al(src, 16) && al(dst, 16) && ld_src % epv == 0 && ld_dst % epv == 0;
+  if (dtype == DXA_BF16 && vec && C % 8 == 0 && R_padded % 8 == 0) {
+    dim3 g8((unsigned)((C + 127) / 128), (unsigned)((R_padded + 127) / 128));
+    DXA_CHECK_ARG(g8.y <= 65535, "dxa_transpose: too many row tiles");
+    hipLaunchKernelGGL(transpose8_bf16_k, g8, dim3(256), 0, ST, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, C, R_padded);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R_padded + 63) / 64));
   DXA_CHECK_ARG(grid.y <= 65535, "dxa_transpose: too many row tiles");
   if (dtype == DXA_BF16)
