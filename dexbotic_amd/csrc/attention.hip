@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_k(const AttnP p) {
   if (lane == 0 && p.lse) p.lse[row] = any ? mx + logf(sum) : 0.f;
 }
 
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+constexpr float LOG2E = 1.4426950408889634f;
+
 // -------------------------------------------------------------------------------------- flash forward
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
@@ -126,6 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) oacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
+  const float sc2 = p.scale * LOG2E;   // softmax in base 2: exp(x) = 2^(x log2 e), one v_exp_f32 per score
 
   int j_lo = p.kv_start ? p.kv_start[b] : 0;
   int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + 16 * n + 4 * lg + r;
         const bool vis = key >= j_lo && key < my_hi;
-        const float s = vis ? sacc[n][r] * p.scale : -INFINITY;
+        const float s = vis ? sacc[n][r] * sc2 : -INFINITY;          // scores in log2 units
         sacc[n][r] = s;
         tmax = fmaxf(tmax, s);
       }
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
     float alpha = 1.f;
-    if (m_new > -INFINITY) alpha = expf(m_run - m_new);  // m_run = -inf -> 0
+    if (m_new > -INFINITY) alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0
     float psum = 0.f;
     uint32_t pk[8];  // bf16 pairs: pk[2*kb2 + ...] see below
 #pragma unroll
@@ -218,11 +226,11 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
       float e[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        e[r] = (m_new > -INFINITY) ? expf(sacc[n][r] - m_new) : 0.f;  // exp(-inf) = 0 for masked keys
+        e[r] = (m_new > -INFINITY) ? __builtin_amdgcn_exp2f(sacc[n][r] - m_new) : 0.f;  // 2^-inf = 0 for masked keys
         psum += e[r];
       }
-      pk[2 * n] = (uint32_t)f2bf(e[0]) | ((uint32_t)f2bf(e[1]) << 16);
-      pk[2 * n + 1] = (uint32_t)f2bf(e[2]) | ((uint32_t)f2bf(e[3]) << 16);
+      pk[2 * n] = pack_bf16(e[0], e[1]);
+      pk[2 * n + 1] = pack_bf16(e[2], e[3]);
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -258,12 +266,12 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
 #pragma unroll
     for (int di = 0; di < D / 16; ++di) {
       uint2 ov;
-      ov.x = (uint32_t)f2bf(oacc[di][0] * inv) | ((uint32_t)f2bf(oacc[di][1] * inv) << 16);
-      ov.y = (uint32_t)f2bf(oacc[di][2] * inv) | ((uint32_t)f2bf(oacc[di][3] * inv) << 16);
+      ov.x = pack_bf16(oacc[di][0] * inv, oacc[di][1] * inv);
+      ov.y = pack_bf16(oacc[di][2] * inv, oacc[di][3] * inv);
       *reinterpret_cast<uint2*>(orow + di * 16 + 4 * lg) = ov;
     }
     if (lg == 0 && p.lse)
-      p.lse[((int64_t)b * p.Hq + h) * p.Sq + qi] = l_tot > 0.f ? m_run + logf(l_tot) : 0.f;
+      p.lse[((int64_t)b * p.Hq + h) * p.Sq + qi] = l_tot > 0.f ? m_run * 0.6931471805599453f + logf(l_tot) : 0.f;
   }
 }
 
@@ -315,77 +323,85 @@ __global__ __launch_bounds__(256) void attn_ds_k(const T* __restrict__ P, const 
 }
 
 // ------------------------------------------------------------------------------ fused flash backward (bf16)
-// Same building blocks as the forward kernel: 64-row tiles staged in LDS either row-major ([row][d], XOR
-// swizzled, read as 16-byte MFMA fragments) or transposed ([d][row], built by an in-register 8x4 transpose,
-// read as two 8-byte pieces per fragment with the k-slot permutation (lg,e) <-> 32*kb2 + 16*(e>>2) + 4*lg + (e&3)
-// that makes a lane's own 16 score registers the matching MFMA operand).  P is recomputed from the saved
-// log-sum-exp; nothing of size S x S ever goes to HBM.
+// 64-row tiles of Q/dO (or K/V) are staged ROW-major in LDS ([row][d], 16-byte chunks XOR-swizzled by row) and
+// feed both MFMA operand shapes:
+//   * "row" fragments (k = d): one 16-byte read per lane                         -> S = Q K^T, dP = dO V^T
+//   * "column" fragments (k = tile row): two ds_read_b64_tr_b16 per lane.  Within a 16-lane group lane i passes
+//     the address of 4 contiguous d of row (i>>2) and receives column i of that [4 rows][16 d] block, i.e. 4
+//     consecutive tile rows of ONE d — the MFMA operand of dV^T += dO^T P, dK^T += Q^T dS, dQ^T += K^T dS^T
+//     (measured semantics: scripts/probes/tr_read_probe.hip).
+// The k-slot order of those products is (lg,e) <-> row 32*kb2 + 16*(e>>2) + 4*lg + (e&3), which makes a lane's
+// own 16 score registers the other operand.  P is recomputed from the saved log-sum-exp; nothing S x S touches
+// HBM.  The next tile's global loads are issued before the current tile's MFMAs (register prefetch).
 //   dQ kernel  : workgroup = 64 queries of one head, waves own 16 queries; loops over K/V tiles:
 //                S^T = K Q^T, dP^T = V dO^T (lane = one query), dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
 //   dKV kernel : workgroup = 64 keys of one kv head, waves own 16 keys; loops over the G query heads of the
 //                group and over query tiles: S = Q K^T, dP = dO V^T (lane = one key), dV^T += dO^T P, dK^T += Q^T dS
 template <int D> struct FlashTile {
-  static constexpr int NCH = D / 8;
-  static constexpr int ROW = D * 2;
-  static constexpr int RM_BYTES = 64 * ROW;   // row-major tile
-  static constexpr int TR_BYTES = D * 128;    // transposed tile
+  static constexpr int NCH = D / 8;             // 16-byte chunks per row
+  static constexpr int ROW = D * 2;             // bytes per row
+  static constexpr int RM_BYTES = 64 * ROW;
+  static constexpr int RPI = 256 / NCH;         // rows covered by one pass of the 256 threads
+  static constexpr int NPASS = 64 / RPI;        // 16-byte loads per thread per tile
 };
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t tile_reg_t __attribute__((ext_vector_type(4)));   // 16 bytes of a staged tile row
 
+// global -> registers: thread (c = tid % NCH, r = tid / NCH + RPI*i) holds chunk c of row r.  Rows past the end
+// are clamped to the last row (finite data; the score mask zeroes whatever they produce) — no divergent loads.
 template <int D>
-__device__ __forceinline__ void stage_rm(char* dst, const bf16_t* base, int64_t stride, int row0, int nrows, int tid) {
-  constexpr int NCH = FlashTile<D>::NCH, ROW = FlashTile<D>::ROW, RPI = 256 / NCH;
-  const int c = tid % NCH;
+__device__ __forceinline__ void tile_gload(tile_reg_t (&reg)[FlashTile<D>::NPASS], const bf16_t* base, int64_t stride, int row0,
+                                           int nrows, int tid) {
+  using FT = FlashTile<D>;
+  const bf16_t* src = base + (tid % FT::NCH) * 8;
 #pragma unroll
-  for (int i = 0; i < 64 / RPI; ++i) {
-    const int r = tid / NCH + RPI * i;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nrows) val = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + r) * stride + c * 8);
-    *reinterpret_cast<uint4*>(dst + r * ROW + ((c ^ (r & (NCH - 1))) << 4)) = val;
+  for (int i = 0; i < FT::NPASS; ++i) {
+    const int r = min(row0 + tid / FT::NCH + FT::RPI * i, nrows - 1);
+    reg[i] = *reinterpret_cast<const tile_reg_t*>(src + (int64_t)r * stride);
   }
 }
 template <int D>
-__device__ __forceinline__ void stage_tr(char* dst, const bf16_t* base, int64_t stride, int row0, int nrows, int tid) {
-  if (tid < 8 * (D / 4)) {
-    const int kc = tid & 7, dg = tid >> 3;
-    uint2 vv[8];
+__device__ __forceinline__ void tile_sstore(char* dst, const tile_reg_t (&reg)[FlashTile<D>::NPASS], int tid) {
+  using FT = FlashTile<D>;
+  const int c = tid % FT::NCH, r0 = tid / FT::NCH;
+  // RPI is a multiple of NCH's swizzle period only when RPI >= NCH; the row's low bits are those of r0 then
+  char* d0 = dst + r0 * FT::ROW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int r = row0 + kc * 8 + e;
-      vv[e] = make_uint2(0, 0);
-      if (r < nrows) vv[e] = *reinterpret_cast<const uint2*>(base + (int64_t)r * stride + dg * 4);
-    }
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int d = dg * 4 + qd;
-      uint32_t w[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const uint32_t lo = (qd & 2) ? vv[2 * m].y : vv[2 * m].x;
-        const uint32_t hi = (qd & 2) ? vv[2 * m + 1].y : vv[2 * m + 1].x;
-        const uint32_t lo16 = (qd & 1) ? (lo >> 16) : (lo & 0xffffu);
-        const uint32_t hi16 = (qd & 1) ? (hi >> 16) : (hi & 0xffffu);
-        w[m] = lo16 | (hi16 << 16);
-      }
-      *reinterpret_cast<uint4*>(dst + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
+  for (int i = 0; i < FT::NPASS; ++i) {
+    const int r = r0 + FT::RPI * i;
+    *reinterpret_cast<tile_reg_t*>(d0 + FT::RPI * i * FT::ROW + ((c ^ (r & (FT::NCH - 1))) << 4)) = reg[i];
   }
 }
+// Per-lane byte offsets into a swizzled row-major tile, split so that everything that varies inside the MFMA
+// loops is a compile-time immediate:
+//   row fragment (tile row 16n + l16, d = 32ds + 8lg ..)      : row[ds] + n * 16 * ROW
+//   column fragment (d = 16di + l16, rows 32kb2 + 4lg + {0..3}) : col[di] + kb2 * 32 * ROW, and + 16 * ROW
+template <int D> struct FragAddr {
+  using FT = FlashTile<D>;
+  uint32_t row[D / 32], col[D / 16];
+  __device__ __forceinline__ FragAddr(int l16, int lg) {
+    const int xr = l16 & (FT::NCH - 1);
+#pragma unroll
+    for (int ds = 0; ds < D / 32; ++ds) row[ds] = l16 * FT::ROW + ((((ds ^ (xr >> 2)) << 2) | (lg ^ (xr & 3))) << 4);
+    const int rl = 4 * lg + (l16 >> 2), xc = rl & (FT::NCH - 1), b = (l16 & 3) >> 1;
+#pragma unroll
+    for (int di = 0; di < D / 16; ++di)
+      col[di] = rl * FT::ROW + ((((di ^ (xc >> 1)) << 1) | (b ^ (xc & 1))) << 4) + (l16 & 1) * 8;
+  }
+};
+__device__ __forceinline__ uint4 lds_frag(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 template <int D>
-__device__ __forceinline__ uint4 frag_rm(const char* tile, int r, int c) {
-  return *reinterpret_cast<const uint4*>(tile + r * FlashTile<D>::ROW + ((c ^ (r & (FlashTile<D>::NCH - 1))) << 4));
+__device__ __forceinline__ uint4 lds_frag_col(const char* p) {
+  typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+  const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+  const s16x4_t v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 16 * FlashTile<D>::ROW));
+  const uint2 u1 = __builtin_bit_cast(uint2, v1), u2 = __builtin_bit_cast(uint2, v2);
+  return make_uint4(u1.x, u1.y, u2.x, u2.y);
 }
-__device__ __forceinline__ uint4 frag_tr(const char* tile, int d, int kb2, int lg) {
-  const int sw = (d >> 1) & 7;
-  const int k1 = 32 * kb2 + 4 * lg, k2 = k1 + 16;
-  const uint2 v1 = *reinterpret_cast<const uint2*>(tile + d * 128 + (((k1 >> 3) ^ sw) << 4) + (k1 & 7) * 2);
-  const uint2 v2 = *reinterpret_cast<const uint2*>(tile + d * 128 + (((k2 >> 3) ^ sw) << 4) + (k2 & 7) * 2);
-  return make_uint4(v1.x, v1.y, v2.x, v2.y);
-}
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
 struct AttnBwdP {
-  AttnP f;                 // forward tensors (q,k,v,o unused here) + lse
-  const float* delta;      // [B,Hq,Sq]
+  AttnP f;                 // forward tensors (o unused here) + lse
+  float* delta;            // [B,Hq,Sq] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   const char* d_o; int64_t do_sb, do_sh, do_ss;
   char* dq; int64_t dq_sb, dq_sh, dq_ss;
   char* dk; int64_t dk_sb, dk_sh, dk_ss;
@@ -396,12 +412,12 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
   using FT = FlashTile<D>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES + FT::TR_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES];
   char* Ks = smem;
   char* Vs = smem + FT::RM_BYTES;
-  char* Kt = smem + 2 * FT::RM_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
+  const FragAddr<D> fa(l16, lg);
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int q0 = blockIdx.x * 64;
@@ -410,18 +426,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
   const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
+  const bf16_t* ob = reinterpret_cast<const bf16_t*>(p.o) + b * p.o_sb + h * p.o_sh;
   uint4 qf[D / 32], dof[D / 32];
+  float dlt = 0.f;   // delta = rowsum(dO * O): this lane's 8-wide slices, folded over the 4 lane groups below
 #pragma unroll
   for (int ds = 0; ds < D / 32; ++ds) {
     qf[ds] = dof[ds] = make_uint4(0, 0, 0, 0);
     if (qi < p.Sq) {
       qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
       dof[ds] = *reinterpret_cast<const uint4*>(dob + (int64_t)qi * bp.do_ss + 32 * ds + 8 * lg);
+      const uint2 o0 = *reinterpret_cast<const uint2*>(ob + (int64_t)qi * p.o_ss + 32 * ds + 8 * lg);
+      const uint2 o1 = *reinterpret_cast<const uint2*>(ob + (int64_t)qi * p.o_ss + 32 * ds + 8 * lg + 4);
+      const uint32_t ow[4] = {o0.x, o0.y, o1.x, o1.y}, dw[4] = {dof[ds].x, dof[ds].y, dof[ds].z, dof[ds].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dlt += __uint_as_float(ow[e] << 16) * __uint_as_float(dw[e] << 16) +
+               __uint_as_float(ow[e] & 0xffff0000u) * __uint_as_float(dw[e] & 0xffff0000u);
     }
   }
+  dlt += __shfl_xor(dlt, 16, 64);
+  dlt += __shfl_xor(dlt, 32, 64);
   const int64_t rowid = ((int64_t)b * p.Hq + h) * p.Sq + qi;
-  const float lse = qi < p.Sq ? p.lse[rowid] : 0.f;
-  const float dlt = qi < p.Sq ? bp.delta[rowid] : 0.f;
+  if (qi < p.Sq && lg == 0) bp.delta[rowid] = dlt;               // the dK/dV kernel (launched next) reads it
+  const float lse2 = (qi < p.Sq ? p.lse[rowid] : 0.f) * LOG2E;   // exp(x) = 2^(x log2 e): one v_exp_f32
+  const float sc2 = p.scale * LOG2E;
   f32x4_t acc[D / 16];
 #pragma unroll
   for (int i = 0; i < D / 16; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -433,22 +461,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
   int blk_hi = j_hi;
   if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
   const int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;
-  for (int kt = j_lo / 64; kt < (blk_hi + 63) / 64; ++kt) {
+  const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
+  tile_reg_t rk[FT::NPASS], rv[FT::NPASS];
+  if (t_lo < t_hi) {
+    tile_gload<D>(rk, kb, p.k_ss, t_lo * 64, p.Sk, tid);
+    tile_gload<D>(rv, vb, p.v_ss, t_lo * 64, p.Sk, tid);
+  }
+  for (int kt = t_lo; kt < t_hi; ++kt) {
     const int key0 = kt * 64;
+    __syncthreads();                       // previous tile fully consumed
+    tile_sstore<D>(Ks, rk, tid);
+    tile_sstore<D>(Vs, rv, tid);
     __syncthreads();
-    stage_rm<D>(Ks, kb, p.k_ss, key0, p.Sk, tid);
-    stage_rm<D>(Vs, vb, p.v_ss, key0, p.Sk, tid);
-    stage_tr<D>(Kt, kb, p.k_ss, key0, p.Sk, tid);
-    __syncthreads();
+    if (kt + 1 < t_hi) {                   // next tile's loads fly during this tile's MFMAs
+      tile_gload<D>(rk, kb, p.k_ss, key0 + 64, p.Sk, tid);
+      tile_gload<D>(rv, vb, p.v_ss, key0 + 64, p.Sk, tid);
+    }
     uint32_t dsp[8];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const int r = n * 16 + l16;
 #pragma unroll
       for (int ds = 0; ds < D / 32; ++ds) {
-        const uint4 kf = frag_rm<D>(Ks, r, 4 * ds + lg);
-        const uint4 vf = frag_rm<D>(Vs, r, 4 * ds + lg);
+        const uint4 kf = lds_frag(Ks + fa.row[ds] + n * 16 * FT::ROW);
+        const uint4 vf = lds_frag(Vs + fa.row[ds] + n * 16 * FT::ROW);
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ds]), s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, dof[ds]), dp, 0, 0, 0);
       }
@@ -457,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
       for (int rr = 0; rr < 4; ++rr) {
         const int key = key0 + 16 * n + 4 * lg + rr;
         const bool vis = key >= j_lo && key < my_hi;
-        const float pr = vis ? expf(s[rr] * p.scale - lse) : 0.f;
+        const float pr = vis ? __builtin_amdgcn_exp2f(s[rr] * sc2 - lse2) : 0.f;
         dsv[rr] = pr * (dp[rr] - dlt) * p.scale;
       }
       dsp[2 * n] = pack_bf16(dsv[0], dsv[1]);
@@ -468,7 +504,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
       const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
 #pragma unroll
       for (int di = 0; di < D / 16; ++di) {
-        const uint4 ktf = frag_tr(Kt, di * 16 + l16, kb2, lg);
+        const uint4 ktf = lds_frag_col<D>(Ks + fa.col[di] + kb2 * 32 * FT::ROW);
         acc[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ktf), __builtin_bit_cast(bf16x8_t, dsf), acc[di], 0, 0, 0);
       }
     }
@@ -489,13 +525,13 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
   using FT = FlashTile<D>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES + 2 * FT::TR_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES];
+  __shared__ __attribute__((aligned(16))) float stat[2][64];      // lse and delta of the staged queries
   char* Qs = smem;
   char* Os = smem + FT::RM_BYTES;
-  char* Qt = smem + 2 * FT::RM_BYTES;
-  char* Ot = Qt + FT::TR_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
+  const FragAddr<D> fa(l16, lg);
   const int b = blockIdx.z, hk = blockIdx.y;
   const int G = p.Hq / p.Hkv;
   const int key0 = blockIdx.x * 64;
@@ -520,63 +556,76 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
   j_hi = min(j_hi, p.Sk);
   const int coff = p.Sk - p.Sq;
   const bool key_ok = key >= j_lo && key < j_hi;
+  const float sc2 = p.scale * LOG2E;
   // queries that can see any key of this workgroup: q >= key0 - coff (causal)
   const int qt_lo = p.causal ? max(0, key0 - coff) / 64 : 0;
+  const int nqt = (p.Sq + 63) / 64 - qt_lo;
   const bool blk_live = key0 < j_hi && key0 + 64 > j_lo;
-  for (int g = 0; g < G && blk_live; ++g) {
-    const int h = hk * G + g;
+  const int total = (blk_live && nqt > 0) ? G * nqt : 0;     // iterations: (query head of the group, query tile)
+
+  tile_reg_t rq[FT::NPASS], ro[FT::NPASS];
+  float rs = 0.f;
+  auto gload = [&](int it) {
+    const int h = hk * G + it / nqt, q0 = (qt_lo + it % nqt) * 64;
     const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
     const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
-    const float* lse_h = p.lse + ((int64_t)b * p.Hq + h) * p.Sq;
-    const float* dlt_h = bp.delta + ((int64_t)b * p.Hq + h) * p.Sq;
-    for (int qt = qt_lo; qt < (p.Sq + 63) / 64; ++qt) {
-      const int q0 = qt * 64;
-      __syncthreads();
-      stage_rm<D>(Qs, qb, p.q_ss, q0, p.Sq, tid);
-      stage_rm<D>(Os, dob, bp.do_ss, q0, p.Sq, tid);
-      stage_tr<D>(Qt, qb, p.q_ss, q0, p.Sq, tid);
-      stage_tr<D>(Ot, dob, bp.do_ss, q0, p.Sq, tid);
-      __syncthreads();
-      uint32_t pp[8], dsp[8];
+    tile_gload<D>(rq, qb, p.q_ss, q0, p.Sq, tid);
+    tile_gload<D>(ro, dob, bp.do_ss, q0, p.Sq, tid);
+    if (tid < 128) {
+      const int q = q0 + (tid & 63);
+      const float* src = (tid < 64 ? p.lse : bp.delta) + ((int64_t)b * p.Hq + h) * p.Sq;
+      rs = q < p.Sq ? src[q] : 0.f;
+      if (tid < 64) rs *= LOG2E;
+    }
+  };
+  if (total > 0) gload(0);
+  for (int it = 0; it < total; ++it) {
+    const int q0 = (qt_lo + it % nqt) * 64;
+    __syncthreads();                       // previous tile fully consumed
+    tile_sstore<D>(Qs, rq, tid);
+    tile_sstore<D>(Os, ro, tid);
+    if (tid < 128) stat[tid >> 6][tid & 63] = rs;
+    __syncthreads();
+    if (it + 1 < total) gload(it + 1);     // next tile's loads fly during this tile's MFMAs
+    uint32_t pp[8], dsp[8];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const int r = n * 16 + l16;
+    for (int n = 0; n < 4; ++n) {
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ds = 0; ds < D / 32; ++ds) {
-          const uint4 qfr = frag_rm<D>(Qs, r, 4 * ds + lg);
-          const uint4 ofr = frag_rm<D>(Os, r, 4 * ds + lg);
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qfr), __builtin_bit_cast(bf16x8_t, kf[ds]), s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ofr), __builtin_bit_cast(bf16x8_t, vf[ds]), dp, 0, 0, 0);
-        }
-        // lane holds its key against queries q0 + 16n + 4lg + {0..3}
-        const int qq = q0 + 16 * n + 4 * lg;
-        float pv[4], dsv[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int q = qq + rr;
-          const bool vis = key_ok && q < p.Sq && (!p.causal || key <= q + coff);
-          const float lse = q < p.Sq ? lse_h[q] : 0.f;
-          const float dl = q < p.Sq ? dlt_h[q] : 0.f;
-          pv[rr] = vis ? expf(s[rr] * p.scale - lse) : 0.f;
-          dsv[rr] = pv[rr] * (dp[rr] - dl) * p.scale;
-        }
-        pp[2 * n] = pack_bf16(pv[0], pv[1]);
-        pp[2 * n + 1] = pack_bf16(pv[2], pv[3]);
-        dsp[2 * n] = pack_bf16(dsv[0], dsv[1]);
-        dsp[2 * n + 1] = pack_bf16(dsv[2], dsv[3]);
+      for (int ds = 0; ds < D / 32; ++ds) {
+        const uint4 qfr = lds_frag(Qs + fa.row[ds] + n * 16 * FT::ROW);
+        const uint4 ofr = lds_frag(Os + fa.row[ds] + n * 16 * FT::ROW);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qfr), __builtin_bit_cast(bf16x8_t, kf[ds]), s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ofr), __builtin_bit_cast(bf16x8_t, vf[ds]), dp, 0, 0, 0);
       }
+      // lane holds its key against queries q0 + 16n + 4lg + {0..3}
+      const int ql = 16 * n + 4 * lg;
+      const float4 lse4 = *reinterpret_cast<const float4*>(&stat[0][ql]);
+      const float4 dl4 = *reinterpret_cast<const float4*>(&stat[1][ql]);
+      const float lse[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+      float pv[4], dsv[4];
 #pragma unroll
-      for (int kb2 = 0; kb2 < 2; ++kb2) {
-        const uint4 pf = make_uint4(pp[4 * kb2], pp[4 * kb2 + 1], pp[4 * kb2 + 2], pp[4 * kb2 + 3]);
-        const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int q = q0 + ql + rr;
+        const bool vis = key_ok && q < p.Sq && (!p.causal || key <= q + coff);
+        pv[rr] = vis ? __builtin_amdgcn_exp2f(s[rr] * sc2 - lse[rr]) : 0.f;      // stat[0] holds lse * log2(e)
+        dsv[rr] = pv[rr] * (dp[rr] - dl[rr]) * p.scale;
+      }
+      pp[2 * n] = pack_bf16(pv[0], pv[1]);
+      pp[2 * n + 1] = pack_bf16(pv[2], pv[3]);
+      dsp[2 * n] = pack_bf16(dsv[0], dsv[1]);
+      dsp[2 * n + 1] = pack_bf16(dsv[2], dsv[3]);
+    }
 #pragma unroll
-        for (int di = 0; di < D / 16; ++di) {
-          const uint4 otf = frag_tr(Ot, di * 16 + l16, kb2, lg);
-          const uint4 qtf = frag_tr(Qt, di * 16 + l16, kb2, lg);
-          dva[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, otf), __builtin_bit_cast(bf16x8_t, pf), dva[di], 0, 0, 0);
-          dka[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qtf), __builtin_bit_cast(bf16x8_t, dsf), dka[di], 0, 0, 0);
-        }
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      const uint4 pf = make_uint4(pp[4 * kb2], pp[4 * kb2 + 1], pp[4 * kb2 + 2], pp[4 * kb2 + 3]);
+      const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
+#pragma unroll
+      for (int di = 0; di < D / 16; ++di) {
+        const uint4 otf = lds_frag_col<D>(Os + fa.col[di] + kb2 * 32 * FT::ROW);
+        const uint4 qtf = lds_frag_col<D>(Qs + fa.col[di] + kb2 * 32 * FT::ROW);
+        dva[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, otf), __builtin_bit_cast(bf16x8_t, pf), dva[di], 0, 0, 0);
+        dka[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qtf), __builtin_bit_cast(bf16x8_t, dsf), dka[di], 0, 0, 0);
       }
     }
   }
@@ -686,10 +735,6 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
   if (bwd_flash_ok(d)) {
     hipStream_t st = (hipStream_t)stream;
     float* delta = (float*)workspace;
-    const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
-    hipLaunchKernelGGL((attn_delta_k<bf16_t>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)d->d_o,
-                       d->do_sb, d->do_sh, d->do_ss, (const bf16_t*)d->o, d->o_sb, d->o_sh, d->o_ss, delta, d->B, d->Hq,
-                       d->Sq, d->D);
     AttnBwdP bp;
     bp.f = make_params(d);
     bp.delta = delta;
