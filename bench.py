@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--vit-layers", dest="vit_layers", type=int, default=24)
     ap.add_argument("--force-reducer", action="store_true",
                     help="debug: run the RCCL gradient reducer even at world size 1 (exercises the DP code path)")
+    ap.add_argument("--grad-comm", dest="grad_comm", default="bfloat16", choices=["bfloat16", "float32"],
+                    help="dtype of the data-parallel gradient all-reduce (the reference's DeepSpeed bf16 run reduces bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -186,7 +188,8 @@ def main():
     model, cfg, llm, vis = build_model(args, device)
     model.train()
     trainer = NativeTrainer(model, OptimConfig(base_lr=2e-5, weight_decay=0.0, max_grad_norm=1.0),
-                            total_steps=1000, force_reducer=args.force_reducer)
+                            total_steps=1000, force_reducer=args.force_reducer,
+                            grad_comm_dtype=getattr(torch, args.grad_comm))
     batch = synthetic_batch(args.batch, args.views, args.s_text, device, seed=1234 + rank)
 
     def sync():
@@ -229,6 +232,7 @@ def main():
         "mfu_bf16": round(value * 3 * f_fwd / world / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
     if trainer.reducer is not None:
+        result["grad_comm_dtype"] = args.grad_comm
         result["allreduce_gb_per_step"] = round(trainer.reducer.bytes_reduced / (args.steps + args.warmup) / 1e9, 3)
     if rank == 0:
         n, ms, fl = prof.summary()
@@ -256,7 +260,7 @@ def main():
             except Exception as e:  # noqa: BLE001  (the baseline must never break the bench line)
                 result["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

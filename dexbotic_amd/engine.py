@@ -375,10 +375,15 @@ class GradReducer:
     """
 
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
-                 skip: Iterable[str] = (), force: bool = False):
+                 skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32):
         import torch.distributed as dist
         self.dist = dist
         self.force = force          # run the collectives even at world size 1 (exercises the RCCL path)
+        # fp32: the arena slice is averaged in place.  bf16: the slice is cast to a bf16 staging buffer on the
+        # communication stream, averaged, and cast back — half the xGMI bytes; this is what the reference's
+        # DeepSpeed ZeRO-2 bf16 run reduces (its gradients are bf16 tensors, script/deepspeed/zero2.json).
+        assert comm_dtype in (torch.float32, torch.bfloat16)
+        self.comm_dtype = comm_dtype
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -406,14 +411,26 @@ class GradReducer:
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
         buf = self.store.grad[lo:hi]
-        self.bytes_reduced += buf.numel() * 4
+        half = self.comm_dtype == torch.bfloat16
+        self.bytes_reduced += buf.numel() * (2 if half else 4)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self.dist.all_reduce(buf, op=self.dist.ReduceOp.AVG, group=self.group)
+                if half:
+                    from . import kernels as K
+                    stage = K.cast(buf, torch.bfloat16)      # allocated and freed on the communication stream
+                    self.dist.all_reduce(stage, op=self.dist.ReduceOp.AVG, group=self.group)
+                    K.cast(stage, torch.float32, out=buf)
+                else:
+                    self.dist.all_reduce(buf, op=self.dist.ReduceOp.AVG, group=self.group)
         else:  # CPU / gloo: no AVG op
-            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
-            buf.div_(self.world)
+            if half:
+                stage = buf.to(torch.bfloat16)
+                self.dist.all_reduce(stage, op=self.dist.ReduceOp.SUM, group=self.group)
+                buf.copy_(stage.float() / self.world)
+            else:
+                self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+                buf.div_(self.world)
 
     def bucket_ready(self, b: int) -> None:
         if b in self.skip_buckets:

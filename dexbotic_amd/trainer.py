@@ -19,7 +19,7 @@ from .engine import FusedAdamW, GradReducer, OptimConfig, cosine_lr_scale
 class NativeTrainer:
     def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
-                 force_reducer: bool = False):
+                 force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32):
         import torch.distributed as dist
         self.model = model
         self.store = model.store
@@ -33,7 +33,8 @@ class NativeTrainer:
         use_dist = (dist.is_available() and dist.is_initialized()) if distributed is None else distributed
         self.reducer = None
         if use_dist and (dist.get_world_size() > 1 or force_reducer):
-            self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer)
+            self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
+                                       comm_dtype=grad_comm_dtype)
         self.store.attach_grads()
         self._zeroed_unused = False
 

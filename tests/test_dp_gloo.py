@@ -101,6 +101,25 @@ def _worker(rank, world, port, tmp):
             st.mark_written(n)
         red.finish()
         assert torch.allclose(st.g("blk2.w"), torch.full((7, 5), (world - 1) / 2.0))
+        # --- bf16 gradient communication (what the reference's DeepSpeed bf16 run reduces): half the bytes,
+        #     result = mean of the bf16-rounded local gradients
+        st.params["blk2.b"].requires_grad_(True)
+        st.set_expected(["unused.w"])
+        red16 = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"], comm_dtype=torch.bfloat16)
+        st.begin_step()
+        st.on_bucket_ready = red16.bucket_ready
+        local = {}
+        for n in reversed(names):
+            g = torch.randn(st.slots[n].shape)
+            st.g(n).copy_(g)
+            local[n] = g.to(torch.bfloat16).float()
+            st.mark_written(n)
+        red16.finish()
+        dist.all_gather_object(gathered, local)
+        for n in names:
+            mean = (sum(g[n] for g in gathered)).to(torch.bfloat16).float() / world
+            assert torch.allclose(st.g(n), mean, rtol=1e-2, atol=1e-6), n
+        assert red16.bytes_reduced >= sum(st.slots[n].numel for n in names) * 2     # 2 bytes per element sent
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
