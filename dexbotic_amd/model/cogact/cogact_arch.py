@@ -6,6 +6,7 @@ cognition feature of the last un-padded token -> 4x repeated diffusion loss in f
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -13,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ...splice import build_splice_plan
 from ..dexbotic_arch import (ActionOutputForCausalLM, CausalLMOutputDexbotic, DexboticConfig, DexboticForCausalLM,
                              DexboticVLMModel)
 from .action_model.builder import build_action_model
@@ -94,21 +96,18 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
 
     __call__ = nn.Module.__call__
 
-    @torch.no_grad()
-    def inference_action(self, input_ids, image_tensor, inference_args={}, **kwargs):
-        cfg_scale = inference_args.get("cfg_scale", 1.5)
-        num_ddim_steps = inference_args.get("num_ddim_steps", 10)
-        action_norms = inference_args.get("action_norms")
-        out = self(input_ids=input_ids, images=image_tensor, use_cache=True)
-        cognition = out.logits[:, -1, :].float().unsqueeze(1)                               # [B,1,d]
-        B = cognition.size(0)
+    # ------------------------------------------------------------------------------------------ inference
+    def _sample_actions(self, images: torch.Tensor, plan_t: torch.Tensor, B: int, S: int, noise: torch.Tensor,
+                        cfg_scale: float, num_ddim_steps: int, return_trajectory: bool = False):
+        """Device-only part of inference_action (cogact_arch.py:151-204): vision tower -> projector -> splice ->
+        decoder -> cognition token -> DDIM loop over the DiT head.  No host synchronisation and no host->device
+        copies, so the whole thing can be captured in one HIP graph."""
+        image_features = self.model._extract_vision_features(images)
+        embeds = Fn.SpliceFn.apply(image_features, self.store.params[self.model.llm.embed_name], self.store,
+                                   self.model.llm.embed_name, plan_t).view(B, S, -1)
+        hidden = self.model.llm(embeds, None, None)
+        cognition = hidden[:, -1, :].float().unsqueeze(1)                                    # [B,1,d]
         head = self.model.action_head
-        noise = kwargs.get("noise")
-        if noise is None:
-            noise = torch.randn(B, self.config.chunk_size, self.config.action_dim, device=cognition.device,
-                                dtype=cognition.dtype)
-        if head.ddim_diffusion is None or head.ddim_diffusion.num_timesteps != num_ddim_steps:
-            head.create_ddim(ddim_step=num_ddim_steps)
         if cfg_scale > 1.0:
             noise = torch.cat([noise, noise], 0)
             unc = self.store.w32("model.action_head.net.z_embedder.uncondition")          # [1,d]
@@ -120,11 +119,78 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             sample_fn = head.net.forward
         res = head.ddim_diffusion.ddim_sample_loop(sample_fn, noise.shape, noise, clip_denoised=False,
                                                    model_kwargs=model_kwargs, eta=0.0, device=cognition.device,
-                                                   return_trajectory=bool(kwargs.get("return_trajectory")))
+                                                   return_trajectory=return_trajectory)
         samples, traj = (res if isinstance(res, tuple) else (res, None))
-        if cfg_scale > 1.0:
-            samples = samples[:B]
+        return samples[:B], traj
+
+    @torch.no_grad()
+    def inference_action(self, input_ids, image_tensor, inference_args={}, **kwargs):
+        """Reference contract (cogact_arch.py:151-204).  On a GPU the device work of a given request shape is
+        captured once into a HIP graph (second call with that shape) and replayed afterwards: a 10-step DDIM
+        sample is ~3k small launches, and the graph removes their per-launch host cost.
+        ``inference_args["use_graph"]`` (default: env DXA_INFER_GRAPH != "0") turns this off."""
+        cfg_scale = inference_args.get("cfg_scale", 1.5)
+        num_ddim_steps = inference_args.get("num_ddim_steps", 10)
+        action_norms = inference_args.get("action_norms")
+        return_traj = bool(kwargs.get("return_trajectory"))
+        head = self.model.action_head
+        if head.ddim_diffusion is None or head.ddim_diffusion.num_timesteps != num_ddim_steps:
+            head.create_ddim(ddim_step=num_ddim_steps)
+        dev = self.store.device
+        images = image_tensor.to(device=dev, dtype=self.store.compute_dtype)
+        if input_ids.shape[1] == 1:
+            raise NotImplementedError("KV-cache decode (discrete VLA, SURVEY.md §8f rank 3) is not built yet")
+        n_img_tokens = self.model.num_image_tokens(images)
+        plan = build_splice_plan(input_ids.detach().cpu().numpy(), None, None, n_img_tokens,
+                                 getattr(self.config, "tokenizer_model_max_length", None),
+                                 getattr(self.config, "tokenizer_padding_side", "right"))
+        B, S = plan.plan.shape
+        noise = kwargs.get("noise")
+        if noise is None:
+            noise = torch.randn(B, self.config.chunk_size, self.config.action_dim, device=dev, dtype=torch.float32)
+        noise = noise.to(device=dev, dtype=torch.float32)
+        use_graph = inference_args.get("use_graph", os.environ.get("DXA_INFER_GRAPH", "1") != "0")
+        if dev.type == "cuda" and use_graph and not return_traj:
+            samples = self._graph_sample(images, plan.plan.reshape(-1), B, S, noise, float(cfg_scale), int(num_ddim_steps))
+            traj = None
+        else:
+            plan_t = torch.from_numpy(plan.plan.reshape(-1)).to(dev)
+            samples, traj = self._sample_actions(images, plan_t, B, S, noise, float(cfg_scale), int(num_ddim_steps),
+                                                 return_traj)
         actions = self._denorm(samples[0].cpu().numpy(), action_norms).tolist()
         if traj is not None:
             return actions, samples, traj
         return actions
+
+    def _graph_sample(self, images, plan_np, B, S, noise, cfg_scale, num_ddim_steps):
+        key = (tuple(images.shape), B, S, cfg_scale, num_ddim_steps)
+        cache = self.__dict__.setdefault("_infer_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            # first request of this shape: eager on a private stream (this also lets every lazily created
+            # resource — split-K scratch of that stream, device tables, kernel attributes — come into being)
+            ent = {"stream": torch.cuda.Stream(device=images.device), "graph": None,
+                   "images": images.clone(), "noise": noise.clone(),
+                   "plan_host": torch.from_numpy(plan_np.copy()).pin_memory(),
+                   "plan": torch.from_numpy(plan_np).to(images.device)}
+            cache[key] = ent
+            ent["stream"].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ent["stream"]):
+                out, _ = self._sample_actions(ent["images"], ent["plan"], B, S, ent["noise"], cfg_scale, num_ddim_steps)
+            torch.cuda.current_stream().wait_stream(ent["stream"])
+            return out
+        ent["plan_host"].copy_(torch.from_numpy(plan_np))
+        ent["stream"].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ent["stream"]):
+            ent["images"].copy_(images, non_blocking=True)
+            ent["noise"].copy_(noise, non_blocking=True)
+            ent["plan"].copy_(ent["plan_host"], non_blocking=True)
+            if ent["graph"] is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=ent["stream"]):
+                    ent["out"], _ = self._sample_actions(ent["images"], ent["plan"], B, S, ent["noise"], cfg_scale,
+                                                         num_ddim_steps)
+                ent["graph"] = g
+            ent["graph"].replay()
+        torch.cuda.current_stream().wait_stream(ent["stream"])
+        return ent["out"]

@@ -178,6 +178,11 @@ class DexboticVLMModel(nn.Module):
             return feats.view(B, V * feats.shape[1], feats.shape[2])
         return self.mm_projector_module(self.mm_vision_module(images))
 
+    def num_image_tokens(self, images: torch.Tensor) -> int:
+        """tokens one sample's image placeholder expands to (views concatenated along tokens)"""
+        views = images.shape[1] if images.ndim == 5 else 1
+        return views * self.mm_vision_module.num_patches
+
     def _prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
                                               cache_position, images) -> tuple:
         """Same contract as the reference (returns input_ids=None and the spliced inputs_embeds); the plan

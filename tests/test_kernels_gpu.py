@@ -124,6 +124,24 @@ def test_gemm_ring_split_tail(shape, f32out):
             assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"split tail bf16 rep {rep}")
 
 
+@pytest.mark.parametrize("shape", [(1, 768, 64), (17, 100, 768), (36, 3072, 768), (36, 768, 3072), (64, 2304, 768)])
+def test_gemm_skinny_f32(shape):
+    """fp32 NT with M <= 64 (DiT head at inference): 16-column workgroups, 8-way K split inside the workgroup"""
+    M, N, Kd = shape
+    a, w = rnd(M, Kd, seed=19), rnd(N, Kd, seed=20, scale=0.1)
+    bias, res = rnd(N, seed=21), rnd(M, N, seed=22)
+    pre = a.double() @ w.double().t() + bias.double()
+    rtol, atol = tol_for(torch.float32, Kd)
+    assert_close(K.mm_nt(a, w), a.double() @ w.double().t(), rtol, atol, f"skinny plain {shape}")
+    aux = torch.empty(M, N, device=DEV)
+    out = K.mm_nt(a, w, bias=bias, act=2, residual=res, aux_out=aux)
+    assert_close(aux, pre, rtol, atol, "skinny aux")
+    assert_close(out, ACTS[2](pre) + res.double(), 2 * rtol, 2 * atol, f"skinny epilogue {shape}")
+    acc = torch.full((M, N), 0.25, device=DEV)
+    K.mm_nt(a, w, out=acc, accumulate=True)
+    assert_close(acc, a.double() @ w.double().t() + 0.25, rtol, atol, "skinny accumulate")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_batched_gqa(dtype):
     B, Hkv, G, S, D = 2, 2, 3, 70, 64

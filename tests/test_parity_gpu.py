@@ -77,6 +77,31 @@ def test_fp32_inference_action_matches_reference(golden_dir, tag):
     assert isinstance(acts, list) and len(acts) == cfg.chunk_size and len(acts[0]) == cfg.action_dim
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_inference_action_graph_replay_equals_eager(golden_dir, dtype):
+    """the HIP-graph path (captured on the 2nd request of a shape, replayed afterwards) runs the same kernels as
+    the eager path: identical actions, also for new inputs fed through the static buffers"""
+    g, cfg, w = load_golden(golden_dir, "t1")
+    m = build_product(cfg, w, dtype, DEV, train=False)
+    m.eval()
+    norms = {"min": g["norm_min"].tolist(), "max": g["norm_max"].tolist()}
+    args = {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms}
+    ids, img, noise = T(g["infer_ids"]), T(g["images"][:1]), T(g["init_noise"])
+    eager = m.inference_action(ids, img, dict(args, use_graph=False), noise=noise)
+    if dtype == "float32":
+        assert rel_err(np.array(eager), g["infer_actions"]) < FP32_TOL
+    for call in range(4):                                   # 1: eager warm-up, 2: capture + replay, 3-4: replay
+        acts = m.inference_action(ids, img, dict(args, use_graph=True), noise=noise)
+        assert acts == eager, call
+    assert next(iter(m._infer_graphs.values()))["graph"] is not None
+    ids2 = ids.clone()
+    ids2[0, -1] = (ids2[0, -1] + 1) % cfg.vocab_size        # same shape, different prompt / image / noise
+    img2, noise2 = img * 0.5, noise * 0.9
+    want = m.inference_action(ids2, img2, dict(args, use_graph=False), noise=noise2)
+    assert m.inference_action(ids2, img2, dict(args, use_graph=True), noise=noise2) == want
+    assert want != eager
+
+
 @pytest.mark.parametrize("tag", ["t1", "t2"])
 def test_bf16_tracks_fp32_reference(golden_dir, tag):
     """bf16 MFMA path (flash attention, bf16 GEMMs, fp32 head): stated tolerance 3e-2 on hidden states,
