@@ -201,7 +201,7 @@ def main():
         trainer.step(batch)
     sync()
     in_dt = L.BF16 if args.dtype == "bfloat16" else L.F32
-    prof = K.GemmProfile(L.NT, in_dt, in_dt)       # dominant kernel: gemm_kernel<T,T,NT> (all forward linears)
+    prof = K.GemmProfile(L.NT, in_dt, in_dt)       # dominant kernel: the bf16 NT ring GEMM (forward linears + dX)
     K.GEMM_PROFILE = prof if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -237,14 +237,23 @@ def main():
     if rank == 0:
         n, ms, fl = prof.summary()
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<bf16,bf16,NT> (dxa_gemm, all forward linears)",
+        # HBM bytes per launch of that kernel come from the committed rocprofv3 PMC passes over this same command
+        # (separate --pmc runs, FETCH_SIZE doubled as the gfx950 note prescribes): profiles/r01_pmc.json
+        traffic = None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+        if os.path.exists(pmc_path) and in_dt == L.BF16:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        result["roofline"] = {"bound": "mfma",
+                              "kernel": "gemm_nt_ring_kernel<bf16 out> (dxa_gemm bf16 NT: every forward linear and dX product)",
                               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                              "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                              "traffic_source": "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)",
                               "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
                               "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 2)}
         if not args.no_latency and world == 1:
             model.eval()
-            b1 = synthetic_batch(1, args.views, args.s_text, device, seed=7)
+            b1 = synthetic_batch(1, 2, args.s_text, device, seed=7)     # BASELINE.json configs[1]: batch 1, 2 views
             norms = {"min": [-1.0] * 7, "max": [1.0] * 7}
             lat = []
             for i in range(25):
@@ -254,6 +263,8 @@ def main():
                                                                         "action_norms": norms})
                 lat.append(1e3 * (time.perf_counter() - t1))       # inference_action ends with a .cpu() sync
             result["p50_action_inference_ms"] = round(float(np.median(lat[5:])), 2)
+            result["config"]["inference_workload"] = ("DB-CogACT bf16 action inference, batch 1, 2 views 224x224, "
+                                                      "32-token instruction (S=543), CFG 1.5, 10 DDIM steps, HIP-graph replay")
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, llm, vis)

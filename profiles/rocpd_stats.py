@@ -28,5 +28,24 @@ def main(path):
         print(f"{short(n):110s} {c:7d} {s/1e6:10.2f} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f} {100*s/total:6.2f}")
 
 
+def pmc(path):
+    """per-kernel sums of the hardware counters of a `rocprofv3 --pmc ... --kernel-trace` run (view counters_collection)"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    kcol = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else cols[0])
+    ccol = "counter_name" if "counter_name" in cols else "pmc_name"
+    vcol = "value" if "value" in cols else "counter_value"
+    print(f"# {path}: counters_collection columns {cols}")
+    rows = cur.execute(f"select {kcol}, {ccol}, count(distinct dispatch_id), sum({vcol}) from counters_collection "
+                       f"group by {kcol}, {ccol} order by 4 desc").fetchall()
+    print(f"{'kernel':90s} {'counter':28s} {'dispatches':>10s} {'sum':>16s} {'per_dispatch':>16s}")
+    for n, c, k, v in rows[:60]:
+        print(f"{short(n)[:90]:90s} {c:28s} {k:10d} {v:16.4g} {v / max(k, 1):16.4g}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if "--pmc" in sys.argv:
+        pmc([a for a in sys.argv[1:] if a != "--pmc"][0])
+    else:
+        main(sys.argv[1])

@@ -20,7 +20,8 @@ def main():
     args = types.SimpleNamespace(llm_layers=28, vit_layers=24, dtype="bfloat16")
     model, cfg, _, _ = bench.build_model(args, dev)
     model.eval()
-    b1 = bench.synthetic_batch(1, 1, 32, dev, seed=7)
+    views = int(os.environ.get("VIEWS", "2"))                  # BASELINE.json configs[1]: 2 views
+    b1 = bench.synthetic_batch(1, views, 32, dev, seed=7)
     norms = {"min": [-1.0] * 7, "max": [1.0] * 7}
     for use_graph in ([False, True] if mode == "both" else [mode == "graph"]):
         lat = []
