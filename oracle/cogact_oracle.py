@@ -576,3 +576,91 @@ def cogact_inference_action(sd: SD, cfg: OracleConfig, input_ids: torch.Tensor, 
     samples, traj = ddim_sample(sd, cfg, cog, noise, cfg_scale, num_ddim_steps, return_traj=True)
     acts = denorm(samples[0].numpy(), action_norms)
     return acts, samples, traj, cog
+
+
+# --------------------------------------------------------------------------- LM head / discrete decode (row A10)
+IGNORE_INDEX = -100
+
+
+def splice_labels(input_ids: np.ndarray, attention_mask: Optional[np.ndarray], labels: np.ndarray,
+                  n_img_tokens: int, max_length: Optional[int] = None, padding_side: str = "right") -> np.ndarray:
+    """labels after _prepare_inputs_labels_for_multimodal (dexbotic_arch.py:219-373): text positions keep their
+    label, every image row and every padding position is IGNORE_INDEX.  Same walk as splice_plan."""
+    B, L = input_ids.shape
+    if attention_mask is None:
+        attention_mask = np.ones((B, L), dtype=bool)
+    attention_mask = attention_mask.astype(bool)
+    rows: List[np.ndarray] = []
+    for b in range(B):
+        ids = input_ids[b][attention_mask[b]]
+        lab = labels[b][attention_mask[b]]
+        pos = np.nonzero(ids == IMAGE_TOKEN_INDEX)[0]
+        out: List[np.ndarray] = []
+        prev = -1
+        for p_ in pos:
+            out.append(lab[prev + 1:p_].astype(np.int64))
+            out.append(np.full(n_img_tokens, IGNORE_INDEX, dtype=np.int64))
+            prev = p_
+        out.append(lab[prev + 1:].astype(np.int64))
+        rows.append(np.concatenate(out))
+    if max_length is not None:
+        rows = [r[:max_length] for r in rows]
+    S = max(len(r) for r in rows)
+    new = np.full((B, S), IGNORE_INDEX, dtype=np.int64)
+    for b, r in enumerate(rows):
+        if padding_side == "left":
+            new[b, S - len(r):] = r
+        else:
+            new[b, :len(r)] = r
+    return new
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """HF ForCausalLMLoss (transformers/loss/loss_utils.py, called at dexbotic_arch.py:488): logits upcast to
+    fp32, labels shifted left by one (position t predicts token t+1, the last position predicts IGNORE), mean
+    cross-entropy over the non-ignored positions."""
+    V = logits.shape[-1]
+    lg = logits.float()
+    shifted = torch.nn.functional.pad(labels, (0, 1), value=IGNORE_INDEX)[..., 1:].contiguous()
+    return torch.nn.functional.cross_entropy(lg.view(-1, V), shifted.view(-1), ignore_index=IGNORE_INDEX,
+                                             reduction="mean")
+
+
+def lm_forward(sd: SD, cfg: OracleConfig, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+               images: torch.Tensor, labels: Optional[torch.Tensor] = None) -> dict:
+    """DexboticForCausalLM.forward (dexbotic_arch.py:429-496): VLM prefill -> lm_head logits (-> CE loss)."""
+    feats = extract_vision_features(sd, cfg, images)
+    am = None if attention_mask is None else attention_mask.numpy()
+    src, new_mask, _ = splice_plan(input_ids.numpy(), am, feats.shape[1], cfg.tokenizer_model_max_length,
+                                   cfg.tokenizer_padding_side)
+    embeds = splice_embeds(sd, src, feats)
+    mask_t = torch.from_numpy(new_mask)
+    hidden = qwen2_forward(sd, cfg, embeds, mask_t if attention_mask is not None else None)
+    logits = hidden @ sd["lm_head.weight"].t()
+    out = dict(hidden=hidden, logits=logits, attention_mask=mask_t)
+    if labels is not None:
+        new_labels = splice_labels(input_ids.numpy(), am, labels.numpy(), feats.shape[1],
+                                   cfg.tokenizer_model_max_length, cfg.tokenizer_padding_side)
+        out["labels"] = torch.from_numpy(new_labels)
+        out["loss"] = causal_lm_loss(logits, out["labels"])
+    return out
+
+
+def greedy_decode(sd: SD, cfg: OracleConfig, input_ids: torch.Tensor, images: torch.Tensor, max_new_tokens: int,
+                  eos_token_id: Optional[int] = None) -> Tuple[np.ndarray, torch.Tensor]:
+    """Greedy continuation (GenerationMixin.generate(do_sample=False) as DiscreteVLAForCausalLM drives it,
+    discrete_vla_arch.py:33-41), restated as full-prefix recompute: append argmax(logits[:, -1]) and run the
+    whole prefix again — token-for-token what a KV cache must reproduce.  Batch 1.  Returns (new ids, the
+    fp32 logits each new token was chosen from)."""
+    cur = input_ids.clone()
+    new, rows = [], []
+    for _ in range(max_new_tokens):
+        out = lm_forward(sd, cfg, cur, None, images)
+        row = out["logits"][0, -1].float()
+        nxt = int(torch.argmax(row))
+        new.append(nxt)
+        rows.append(row)
+        cur = torch.cat([cur, torch.tensor([[nxt]], dtype=cur.dtype)], dim=1)
+        if eos_token_id is not None and nxt == eos_token_id:
+            break
+    return np.array(new, dtype=np.int64), torch.stack(rows)

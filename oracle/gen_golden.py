@@ -314,6 +314,85 @@ def gen_cogact(tag: str, cfg, seed: int, B: int, L: int, lengths, views: int):
           "no-grad params:", len(never))
 
 
+def gen_lm(tag: str, cfg, seed: int, B: int, L: int, lengths, n_new: int):
+    """Row A10: DexboticForCausalLM.forward with labels (lm_head + HF causal-LM cross-entropy, dexbotic_arch.py:
+    429-496) and a greedy continuation.  generate() itself does not run under this container's transformers
+    (SURVEY.md §8c shim iii), so the greedy ids come from a full-prefix recompute loop over the reference's own
+    forward — the token sequence a KV-cached decode has to reproduce exactly."""
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel, Qwen2Config
+    from dexbotic.model.dexbotic_arch import DexboticConfig, DexboticForCausalLM
+    from oracle.weights import cogact_shapes, make_weights, weights_crc
+    w = {k: v for k, v in make_weights(cogact_shapes(cfg), seed).items() if ".action_head." not in k}
+    d = os.path.join(tempfile.mkdtemp(), "tiny_clip")
+    vcfg = CLIPVisionConfig(hidden_size=cfg.v_hidden, intermediate_size=cfg.v_inter, num_hidden_layers=cfg.v_layers,
+                            num_attention_heads=cfg.v_heads, image_size=cfg.v_image, patch_size=cfg.v_patch,
+                            layer_norm_eps=cfg.v_eps)
+    CLIPVisionModel(vcfg).save_pretrained(d)
+    CLIPImageProcessor(size={"shortest_edge": cfg.v_image},
+                       crop_size={"height": cfg.v_image, "width": cfg.v_image}).save_pretrained(d)
+    llm = Qwen2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                      num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                      num_key_value_heads=cfg.num_key_value_heads, max_position_embeddings=4096,
+                      rope_theta=cfg.rope_theta, rms_norm_eps=cfg.rms_norm_eps)
+    m = DexboticForCausalLM(DexboticConfig(llm_config=llm, mm_vision_tower=d, mm_projector_type="mlp2x_gelu"))
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: v.shape for k, v in w.items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    for p_ in m.parameters():
+        p_.requires_grad = True
+    m.train()
+    rs = np.random.RandomState(seed + 7)
+    ids = rs.randint(10, cfg.vocab_size - 10, size=(B, L)).astype(np.int64)
+    ids[:, 1] = -200
+    mask = np.zeros((B, L), dtype=bool)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = True
+    labels = ids.copy()
+    labels[:, :4] = -100                                   # prompt part is not supervised (like the SFT collator)
+    labels[~mask] = -100
+    images = np.clip(rs.standard_normal((B, 3, cfg.v_image, cfg.v_image)), -2.5, 2.5).astype(np.float32)
+    t = torch.from_numpy
+    out = m(input_ids=t(ids), attention_mask=t(mask), labels=t(labels), images=t(images))
+    out.loss.backward()
+    sd = dict(m.named_parameters())
+    keep = ["lm_head.weight", "model.llm.norm.weight", "model.llm.layers.0.self_attn.q_proj.weight",
+            "model.llm.layers.0.self_attn.k_proj.bias", "model.mm_projector.2.weight"]
+    res = dict(weights_crc=np.uint32(weights_crc(w)), seed=np.int64(seed), input_ids=ids, attention_mask=mask,
+               labels=labels, images=images, loss=np.float32(out.loss.item()),
+               logits=out.logits.detach().numpy().astype(np.float32))
+    gsq = 0.0
+    for n, p_ in sd.items():
+        if p_.grad is not None:
+            gsq += float(p_.grad.double().pow(2).sum())
+            res["gradN/" + n] = np.float64(p_.grad.double().norm().item())
+    res["grad_norm"] = np.float64(gsq ** 0.5)
+    for n in keep:
+        res["grad/" + n] = sd[n].grad.numpy().astype(np.float32)
+    emb_g = sd["model.llm.embed_tokens.weight"].grad
+    rows = np.unique(ids[ids >= 0])[:6]
+    res["embed_rows"] = rows
+    res["grad_embed_rows"] = emb_g[t(rows)].numpy().astype(np.float32)
+    # greedy continuation (batch 1, no padding) by full-prefix recompute through the reference forward
+    m.eval()
+    cur = t(ids[:1, :lengths[0]]).clone()
+    img1 = t(images[:1])
+    new, rows_l = [], []
+    with torch.no_grad():
+        for _ in range(n_new):
+            lg = m(input_ids=cur, images=img1).logits[0, -1].float()
+            nxt = int(torch.argmax(lg))
+            new.append(nxt)
+            rows_l.append(lg.numpy().astype(np.float32))
+            cur = torch.cat([cur, torch.tensor([[nxt]], dtype=cur.dtype)], dim=1)
+    res["decode_prompt"] = ids[:1, :lengths[0]]
+    res["decode_new_ids"] = np.array(new, dtype=np.int64)
+    res["decode_logits"] = np.stack(rows_l)
+    top2 = np.sort(res["decode_logits"], axis=1)[:, -2:]
+    res["decode_margin"] = (top2[:, 1] - top2[:, 0]).astype(np.float32)   # argmax gap: how decisive each choice is
+    np.savez_compressed(os.path.join(GOLD, f"lm_{tag}.npz"), **res)
+    print(f"[gen_golden] lm_{tag}: loss {res['loss']:.5f} |g| {res['grad_norm']:.4f} new ids {new} "
+          f"min margin {res['decode_margin'].min():.4g}")
+
+
 def gen_action_bins():
     """Integer rows (A9): run the reference transform + _denorm + discrete decode."""
     from dexbotic.data.dataset.transform.action import ActionNormAnd2String
@@ -378,6 +457,7 @@ def main():
                         num_attention_heads=4, num_key_value_heads=2, v_hidden=192, v_inter=384,
                         v_layers=4, v_heads=3, dit_hidden=192, dit_depth=3, dit_heads=3)
     gen_cogact("t2", cfg2, seed=4321, B=2, L=16, lengths=[16, 13], views=2)
+    gen_lm("t1", OracleConfig(), seed=1234, B=3, L=12, lengths=[12, 9, 11], n_new=6)
 
 
 if __name__ == "__main__":

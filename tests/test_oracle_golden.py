@@ -149,3 +149,29 @@ def test_action_integer_rows_bit_exact(golden_dir):
     assert np.array_equal(den, g["denorm"])
     dec = np.concatenate([O.discrete_action_to_continuous(s, V) for s in g["strings"].tolist()])
     assert np.array_equal(dec, g["decoded"])
+
+
+def test_lm_loss_grads_and_greedy_ids_match_reference(golden_dir):
+    """row A10: lm_head + HF causal-LM cross-entropy (loss, logits, gradients) and the greedy continuation
+    (token ids bit-exact) against the reference's DexboticForCausalLM"""
+    g = np.load(os.path.join(golden_dir, "lm_t1.npz"), allow_pickle=False)
+    cfg = CFGS["t1"]
+    w = {k: v for k, v in make_weights(cogact_shapes(cfg), int(g["seed"])).items() if ".action_head." not in k}
+    assert weights_crc(w) == int(g["weights_crc"])
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    t = torch.from_numpy
+    out = O.lm_forward(sd, cfg, t(g["input_ids"]), t(g["attention_mask"]), t(g["images"]), t(g["labels"]))
+    assert rel(out["logits"].detach().numpy(), g["logits"]) < 2e-5
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    out["loss"].backward()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel(sd[key[5:]].grad.numpy(), g[key]) < 5e-5, key
+    assert rel(sd["model.llm.embed_tokens.weight"].grad[t(g["embed_rows"])].numpy(), g["grad_embed_rows"]) < 5e-5
+    gsq = sum(float(v.grad.double().pow(2).sum()) for v in sd.values() if v.grad is not None)
+    assert abs(gsq ** 0.5 - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
+    with torch.no_grad():
+        sd0 = {k: v.detach() for k, v in sd.items()}
+        ids, rows = O.greedy_decode(sd0, cfg, t(g["decode_prompt"]), t(g["images"][:1]), len(g["decode_new_ids"]))
+    assert np.array_equal(ids, g["decode_new_ids"])
+    assert rel(rows.numpy(), g["decode_logits"]) < 2e-5
