@@ -111,6 +111,9 @@ SIGNATURES = {
     "dxa_ddim_step": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _f32, _f32, _f32, _vp]),
     "dxa_adamw": (_int, [C.POINTER(AdamWDesc), _vp]),
     "dxa_sumsq": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
+    "dxa_cross_entropy_fwd": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "dxa_cross_entropy_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
+    "dxa_argmax_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),
     "dxa_clip_coef": (_int, [_vp, _f32, _vp, _vp, _vp]),
     "dxa_scale": (_int, [_vp, _i64, _f32, _vp]),
     "dxa_scale_dev": (_int, [_vp, _i64, _vp, _vp]),

@@ -536,3 +536,38 @@ def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1
     d.bc1, d.bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
     d.clip_coef = _ptr(clip)
     L.check(lib.dxa_adamw(C.byref(d), _stream()), "dxa_adamw")
+
+
+# ------------------------------------------------------------------------------------- LM head (row A10)
+def cross_entropy_fwd(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100):
+    """logits [rows, V] (fp32/bf16, rows contiguous), labels [rows] int64 (already shifted) ->
+    (row_loss [rows] fp32, lse [rows] fp32)"""
+    rows, V = logits.shape
+    assert logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == rows
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    L.check(lib.dxa_cross_entropy_fwd(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(row_loss), _ptr(lse), rows, V,
+                                      ignore_index, dt(logits), _stream()), "dxa_cross_entropy_fwd")
+    return row_loss, lse
+
+
+def cross_entropy_bwd(logits: torch.Tensor, labels: torch.Tensor, lse: torch.Tensor, gscale: Optional[torch.Tensor],
+                      scale: float, out: Optional[torch.Tensor] = None, ignore_index: int = -100) -> torch.Tensor:
+    """dlogits = (softmax - onehot) * gscale[0] * scale; ``out`` may be ``logits`` itself (in place)"""
+    rows, V = logits.shape
+    if out is None:
+        out = torch.empty_like(logits)
+    assert out.shape == logits.shape and out.dtype == logits.dtype and out.stride(1) == 1
+    L.check(lib.dxa_cross_entropy_bwd(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(lse), _ptr(gscale), float(scale),
+                                      _ptr(out), out.stride(0), rows, V, ignore_index, dt(logits), _stream()),
+            "dxa_cross_entropy_bwd")
+    return out
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """first index of each row's maximum (torch.argmax semantics) -> int64 [rows]"""
+    rows, cols = x.shape
+    assert x.stride(1) == 1
+    out = torch.empty(rows, device=x.device, dtype=torch.int64)
+    L.check(lib.dxa_argmax_rows(_ptr(x), x.stride(0), _ptr(out), rows, cols, dt(x), _stream()), "dxa_argmax_rows")
+    return out

@@ -261,6 +261,27 @@ int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream);
 /* x *= s[0] with s a DEVICE scalar (upstream loss gradient; no host sync) */
 int dxa_scale_dev(float* x, int64_t n, const float* s, dxa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * LM head: causal-LM cross-entropy and greedy token choice.
+ * dxa_cross_entropy_fwd/bwd: HF ForCausalLMLoss (transformers/loss/loss_utils.py) as called from
+ *   dexbotic/model/dexbotic_arch.py:483-488 on logits = lm_head(hidden_states[-1]).  `labels[r]` is the label of
+ *   row r AFTER the one-position shift; rows with labels == ignore_index contribute nothing.
+ *   fwd: row_loss[r] = logsumexp(logits[r]) - logits[r, label] (fp32 math on fp32 or bf16 logits), lse[r] saved.
+ *        loss = sum(row_loss) / #non-ignored rows is taken by the caller (dxa_colsum).
+ *   bwd: dlogits[r, v] = (exp(logits[r, v] - lse[r]) - [v == label]) * gscale[0] * scale  (gscale: device scalar
+ *        = upstream gradient or NULL for 1; scale = 1 / #non-ignored rows).  dlogits may alias logits.
+ * dxa_argmax_rows: out[r] = first index of the row maximum — torch.argmax, the greedy choice inside
+ *   GenerationMixin.generate(do_sample=False) that DiscreteVLAForCausalLM decodes with
+ *   (dexbotic/model/discrete_vla/discrete_vla_arch.py:33-41).  Integer result, must equal the reference's.
+ * ---------------------------------------------------------------------------------------------- */
+int dxa_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* labels, float* row_loss, float* lse,
+                          int64_t rows, int64_t V, int64_t ignore_index, int dtype, dxa_stream_t stream);
+int dxa_cross_entropy_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* lse,
+                          const float* gscale, float scale, void* dlogits, int64_t ldd, int64_t rows, int64_t V,
+                          int64_t ignore_index, int dtype, dxa_stream_t stream);
+int dxa_argmax_rows(const void* x, int64_t ld, int64_t* out, int64_t rows, int64_t cols, int dtype,
+                    dxa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

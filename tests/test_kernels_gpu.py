@@ -528,3 +528,36 @@ def test_transpose_and_permute(dtype, R, C):
     hm = K.permute_bshd(t, B, S, H, D, True)
     assert torch.equal(hm, t.permute(0, 2, 1, 3))
     assert torch.equal(K.permute_bshd(hm, B, S, H, D, False), t)
+
+
+# ------------------------------------------------------------------------------------- LM head (row A10)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,V", [(37, 1000), (5, 152064), (9, 131)])
+def test_cross_entropy_and_argmax(dtype, rows, V):
+    x = rnd(rows, V, dtype=dtype, seed=130, scale=3.0)
+    labels = torch.randint(0, V, (rows,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    labels[1] = -100
+    labels[rows - 1] = -100
+    row_loss, lse = K.cross_entropy_fwd(x, labels)
+    xr = x.double().requires_grad_(True)
+    ref_rows = F.cross_entropy(xr, labels, ignore_index=-100, reduction="none")
+    tol = 1e-5 if dtype == torch.float32 else 1e-5       # the kernel computes in fp32 from the stored values
+    assert_close(lse, torch.logsumexp(xr, dim=1), tol, tol, "ce lse")
+    assert_close(row_loss, ref_rows, tol, 1e-5, "ce row loss")
+    n_valid = int((labels != -100).sum())
+    g = torch.tensor([0.5], device=DEV)
+    (ref_rows.sum() / n_valid * 0.5).backward()
+    d = K.cross_entropy_bwd(x, labels, lse, g, 1.0 / n_valid)
+    rt, at = (1e-5, 1e-7) if dtype == torch.float32 else (1.0 / 128, 1e-6)
+    assert_close(d, xr.grad, rt, at, "ce dlogits")
+    assert torch.all(d[1] == 0) and torch.all(d[rows - 1] == 0)
+    inplace = x.clone()
+    K.cross_entropy_bwd(inplace, labels, lse, g, 1.0 / n_valid, out=inplace)
+    assert torch.equal(inplace, d)
+    # argmax: first index among ties, any column count
+    y = x.clone()
+    y[0, 7] = y[0].max() + 1
+    y[0, V - 3] = y[0, 7]                                  # tie: index 7 wins
+    y[2] = 0                                               # all equal: index 0
+    assert torch.equal(K.argmax_rows(y), torch.argmax(y.float(), dim=1))
+    assert int(K.argmax_rows(y)[0]) == 7 and int(K.argmax_rows(y)[2]) == 0
