@@ -22,6 +22,13 @@ def model_registry():
             "dexbotic_cogact": (CogActConfig, CogACTForCausalLM)}
 
 
+def discrete_vla():
+    """DiscreteVLAForCausalLM shares model_type "dexbotic" with the base class in the reference
+    (discrete_vla_arch.py:12-13); exps pick it by class, so it is exported by name here."""
+    from .model.discrete_vla.discrete_vla_arch import DiscreteVLAForCausalLM
+    return DiscreteVLAForCausalLM
+
+
 def from_pretrained(path: str, **kw):
     """load any registered policy from a reference-format checkpoint directory"""
     import json

@@ -520,3 +520,47 @@ class MseLossFn(Function):
         # g is the scalar upstream gradient (1.0 for loss.backward(); 1/accum under gradient
         # accumulation): applied on the device, no host sync
         return K.scale_dev_(dpred.clone(), g.reshape(1).float().contiguous()), None
+
+
+class LmHeadLossFn(Function):
+    """logits = lm_head(hidden) and the HF causal-LM cross-entropy over the (already shifted) labels
+    (dexbotic_arch.py:483-488; transformers/loss/loss_utils.py ForCausalLMLoss): loss = mean over the non-ignored
+    rows of logsumexp(logits) - logits[label], in fp32 on the stored logits.  Returns (loss, logits).  The vocabulary
+    GEMMs are the only other large contractions of the path (4592 x 152064 x 3584 at the CogACT batch): bf16 runs them
+    on the NT ring kernel — dW = (dZ^T)(H^T)^T and dH = dZ (W^T)^T through explicit transposes."""
+
+    @staticmethod
+    def forward(ctx, hidden, anchor, st: ParamStore, wn: str, labels_shifted: torch.Tensor, n_valid: int):
+        h2 = hidden.reshape(-1, hidden.shape[-1]).contiguous()
+        W = st.w(wn)
+        logits = K.mm_nt(h2, W)
+        row_loss, lse = K.cross_entropy_fwd(logits, labels_shifted)
+        loss = K.colsum(row_loss.view(-1, 1))
+        if n_valid > 0:
+            K.scale_(loss, 1.0 / n_valid)
+        else:
+            loss = loss * float("nan")                          # F.cross_entropy(mean) over zero targets
+        ctx.st, ctx.wn, ctx.n_valid, ctx.hshape = st, wn, n_valid, hidden.shape
+        ctx.save_for_backward(h2, logits, lse, labels_shifted)
+        ctx.mark_non_differentiable(logits)
+        return loss.view(()), logits.view(*hidden.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, g, _g_logits):
+        st, wn = ctx.st, ctx.wn
+        h2, logits, lse, labels = ctx.saved_tensors
+        W = st.w(wn)
+        dz = K.cross_entropy_bwd(logits, labels, lse, g.reshape(1).float().contiguous(), 1.0 / max(ctx.n_valid, 1))
+        half = dz.dtype == torch.bfloat16
+        if st.trainable(wn):
+            out = st.g(wn)
+            if half:
+                K.mm_nt(K.transpose(dz, KPAD), K.transpose(h2, KPAD), out=out, accumulate=st.accum_flag(wn))
+            else:
+                K.mm_tn(dz, h2, out=out, accumulate=st.accum_flag(wn))
+            st.mark_written(wn)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = K.mm_nt(dz, K.transpose(W, KPAD)) if half else K.mm_nn(dz, W)
+            dh = dh.view(ctx.hshape)
+        return dh, None, None, None, None, None

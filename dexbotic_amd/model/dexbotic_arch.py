@@ -308,11 +308,69 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
                                                                labels, cache_position, images)
         hidden = self.model.run_llm(inputs_embeds, attention_mask)
         B, S, d = hidden.shape
-        with torch.no_grad():
-            logits = K.mm_nt(hidden.reshape(B * S, d).contiguous(), self.store.w("lm_head.weight")).view(B, S, -1)
-        if labels is not None:
-            raise NotImplementedError("LM cross-entropy training (discrete VLA / hybrid, SURVEY.md §8f rank 3)")
-        return CausalLMOutputDexbotic(loss=None, logits=logits, hidden_states=(hidden,))
+        if labels is None:
+            with torch.no_grad():
+                logits = K.mm_nt(hidden.reshape(B * S, d).contiguous(), self.store.w("lm_head.weight")).view(B, S, -1)
+            return CausalLMOutputDexbotic(loss=None, logits=logits, hidden_states=(hidden,))
+        # HF ForCausalLMLoss (dexbotic_arch.py:488): position t is scored against label t+1, the last one is ignored
+        lab = self.model._last_plan.labels
+        shifted = np.full_like(lab, IGNORE_INDEX)
+        shifted[:, :-1] = lab[:, 1:]
+        n_valid = int((shifted != IGNORE_INDEX).sum())
+        loss, logits = Fn.LmHeadLossFn.apply(hidden, self.store.params["lm_head.weight"], self.store, "lm_head.weight",
+                                             torch.from_numpy(shifted.reshape(-1)).to(hidden.device), n_valid)
+        return CausalLMOutputDexbotic(loss=loss, logits=logits, hidden_states=(hidden,))
+
+    def unused_parameter_names(self) -> List[str]:
+        """parameters that get no gradient from the LM loss (the CLIP layer after hidden_states[-2], post_layernorm)"""
+        return self.model.mm_vision_tower.unused_parameter_names()
+
+    @torch.no_grad()
+    def generate(self, input_ids, images=None, max_new_tokens: int = 64, do_sample: bool = False,
+                 temperature: float = 1.0, eos_token_id: Optional[int] = None, stopping_criteria=None,
+                 return_dict_in_generate: bool = False, generator: Optional[torch.Generator] = None, **kwargs):
+        """Token-by-token continuation over a KV cache — the subset of GenerationMixin.generate the reference uses
+        (discrete_vla_arch.py:33-41: batch 1, greedy or temperature sampling, stopping criteria on the decoded tail).
+        Prefill = vision tower + splice + decoder with the cache filled; each step = one cached decoder pass on the
+        new token, lm_head on its hidden state, argmax (first maximal index) or a multinomial draw."""
+        dev = self.store.device
+        imgs = images.to(device=dev, dtype=self.store.compute_dtype)
+        feats = self.model._extract_vision_features(imgs)
+        plan = build_splice_plan(input_ids.detach().cpu().numpy(), None, None, feats.shape[1],
+                                 getattr(self.config, "tokenizer_model_max_length", None),
+                                 getattr(self.config, "tokenizer_padding_side", "right"))
+        B, S = plan.plan.shape
+        if not plan.attention_mask.all():
+            raise NotImplementedError("generate(): prompts of unequal length need per-sample key ranges in the cache")
+        llm = self.model.llm
+        embed = self.store.params[llm.embed_name]
+        x = Fn.SpliceFn.apply(feats, embed, self.store, llm.embed_name,
+                              torch.from_numpy(plan.plan.reshape(-1)).to(dev)).view(B, S, -1)
+        cache = llm.new_cache(B, S + max_new_tokens, dev, x.dtype)
+        last = llm.forward_cached(x, cache)[:, -1].contiguous()
+        W_lm, W_emb = self.store.w("lm_head.weight"), self.store.w(llm.embed_name)
+        seq = input_ids.to(dev)
+        new_tokens, step_logits = [], []
+        for _ in range(max_new_tokens):
+            logits = K.mm_nt(last, W_lm)                                       # [B, V]
+            if do_sample:
+                probs = torch.softmax(logits.float() / max(temperature, 1e-6), dim=-1)
+                nxt = torch.multinomial(probs, 1, generator=generator).view(-1)
+            else:
+                nxt = K.argmax_rows(logits)
+            new_tokens.append(nxt)
+            if kwargs.get("output_logits"):
+                step_logits.append(logits.float())
+            seq = torch.cat([seq, nxt.view(B, 1)], dim=1)
+            done = eos_token_id is not None and bool((nxt == eos_token_id).all())
+            if not done and stopping_criteria:
+                done = any(bool(torch.as_tensor(sc(seq, None)).all()) for sc in stopping_criteria)
+            if done:
+                break
+            last = llm.forward_cached(W_emb[nxt].view(B, 1, -1), cache)[:, -1].contiguous()
+        if return_dict_in_generate:
+            return GenerateOutput(sequences=seq, logits=tuple(step_logits) if step_logits else None)
+        return seq
 
     def process_images(self, images):
         """expand-to-square with the mean colour + CLIP preprocessing (host side; dexbotic_arch.py:498-529)."""
@@ -337,6 +395,12 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         canvas = Image.new(pil_img.mode, (side, side), background_color)
         canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
         return canvas
+
+
+@dataclass
+class GenerateOutput:
+    sequences: torch.Tensor
+    logits: Optional[tuple] = None
 
 
 class ActionOutputForCausalLM(ABC):

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ... import kernels as K
 from ...engine import ParamStore
 
 
@@ -121,3 +122,53 @@ class Qwen2Backbone(nn.Module):
         x = Fn.NormFn.apply(x, st.params[self.p + "norm.weight"], st, "rms", self.p + "norm.weight", None,
                             self.config.rms_norm_eps)
         return x.view(B, S, d)
+
+
+    # ------------------------------------------------------------------------------- KV-cached inference
+    def new_cache(self, batch: int, max_len: int, device, dtype) -> "KVCache":
+        c = self.config
+        return KVCache(c.num_hidden_layers, batch, c.num_key_value_heads, max_len, c.head_dim, device, dtype)
+
+    @torch.no_grad()
+    def forward_cached(self, inputs_embeds: torch.Tensor, cache: "KVCache") -> torch.Tensor:
+        """Prefill (S > 1) or decode (S = 1) step over a key/value cache: the use_cache=True path of HF Qwen2Model
+        that GenerationMixin.generate drives (discrete_vla_arch.py:33-41).  Post-RoPE keys and values of every
+        layer are appended at positions [cache.length, cache.length + S); attention is causal over the whole cache
+        (queries sit at the END of the key range).  No padding support: generation runs at batch 1 or on equal-length
+        prompts, like the reference's single-request inference."""
+        B, S, d = inputs_embeds.shape
+        past, total = cache.length, cache.length + S
+        if total > cache.max_len:
+            raise ValueError(f"KV cache of {cache.max_len} positions cannot take {total}")
+        cos_all, sin_all = self.rope_tables(total, inputs_embeds.device)
+        cos_t, sin_t = cos_all[past:total], sin_all[past:total]
+        st = self.store
+        x = inputs_embeds.reshape(B * S, d).contiguous()
+        for i, sp in enumerate(self.layer_specs):
+            Hq, Hkv, D, F_ = sp.Hq, sp.Hkv, sp.D, sp.F
+            nq = (Hq + 2 * Hkv) * D
+            h1, _ = K.rmsnorm_fwd(x, st.w(sp.ln1), sp.eps)
+            qkv = K.mm_nt(h1, st.w(*sp.qkv_w, shape=(nq, d)), bias=st.w(*sp.qkv_b, shape=(nq,)))
+            q, k, v = K.rope_split(qkv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
+            cache.k[i][:, :, past:total].copy_(k)
+            cache.v[i][:, :, past:total].copy_(v)
+            o = torch.empty((B, S, Hq, D), device=x.device, dtype=x.dtype)
+            K.attn_fwd(q, cache.k[i][:, :, :total], cache.v[i][:, :, :total], o.permute(0, 2, 1, 3), causal=True,
+                       scale=D ** -0.5)
+            x2 = K.mm_nt(o.view(B * S, Hq * D), st.w(sp.o_w), residual=x)
+            h2, _ = K.rmsnorm_fwd(x2, st.w(sp.ln2), sp.eps)
+            a = K.swiglu_fwd(K.mm_nt(h2, st.w(*sp.gu_w, shape=(2 * F_, d))))
+            x = K.mm_nt(a, st.w(sp.down_w), residual=x2)
+        x, _ = K.rmsnorm_fwd(x, st.w(self.p + "norm.weight"), self.config.rms_norm_eps)
+        cache.length = total
+        return x.view(B, S, d)
+
+
+class KVCache:
+    """per-layer post-RoPE keys / values, head-major [B, Hkv, max_len, D] (the layout the attention kernels read)"""
+
+    def __init__(self, layers: int, batch: int, kv_heads: int, max_len: int, head_dim: int, device, dtype):
+        self.k = [torch.empty((batch, kv_heads, max_len, head_dim), device=device, dtype=dtype) for _ in range(layers)]
+        self.v = [torch.empty((batch, kv_heads, max_len, head_dim), device=device, dtype=dtype) for _ in range(layers)]
+        self.max_len = max_len
+        self.length = 0

@@ -55,3 +55,22 @@ def rel_err(a, b) -> float:
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def load_lm_golden(golden_dir, tag="t1"):
+    g = np.load(os.path.join(golden_dir, f"lm_{tag}.npz"), allow_pickle=False)
+    cfg = CFGS[tag]
+    w = {k: v for k, v in make_weights(cogact_shapes(cfg), int(g["seed"])).items() if ".action_head." not in k}
+    assert weights_crc(w) == int(g["weights_crc"])
+    return g, cfg, w
+
+
+def build_lm_product(cfg: O.OracleConfig, weights, compute_dtype="float32", device="cuda", train=True, cls=None):
+    """DexboticForCausalLM (or a subclass such as DiscreteVLAForCausalLM) at an OracleConfig shape"""
+    from dexbotic_amd.model.dexbotic_arch import DexboticConfig, DexboticForCausalLM
+    c = product_config(cfg, compute_dtype)
+    dc = DexboticConfig(llm_config=c.llm_config, mm_vision_tower=c.mm_vision_tower, mm_projector_type="mlp2x_gelu",
+                        compute_dtype=compute_dtype)
+    m = (cls or DexboticForCausalLM)(dc, device=device, train=train)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    return m
