@@ -25,6 +25,7 @@
 
 namespace {
 
+typedef uint32_t u32x4n_t __attribute__((ext_vector_type(4)));   // native 16-byte vector (nontemporal builtins)
 constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 128;              // bytes per LDS row (K slab)
 constexpr int TILE_BYTES = BM * ROWB;  // 16 KiB per operand per buffer
@@ -438,6 +439,63 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(const GemmP p) {
                           reinterpret_cast<const float*>(p.R), reinterpret_cast<const float*>(p.G), bv, m, n, n_ok, a4);
 }
 
+// bf16 twin of the skinny kernel (M <= 64): KV-cached decode (M = batch) and other few-row products are a pure
+// stream over the weight matrix.  Same decomposition — 16 output columns per workgroup, 8 waves splitting K in
+// 64-k blocks — with v_mfma_f32_16x16x32_bf16: a lane's 16-byte load IS its MFMA operand (8 consecutive k).
+template <int MB, typename TO>
+__global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
+  __shared__ float red[8][MB][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.B) + min(n0 + l16, p.N - 1) * p.ldb + 8 * lg;
+  const bf16_t* A[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    A[mb] = reinterpret_cast<const bf16_t*>(p.A) + min((int64_t)mb * 16 + l16, p.M - 1) * p.lda + 8 * lg;
+  f32x4_t acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nkb = (int)(p.K / 64);
+#pragma unroll 2
+  for (int kb = wave; kb < nkb; kb += 8) {
+    const int k0 = kb * 64;
+    u32x4n_t wv[2];
+    uint4 av[MB][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wv[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4n_t*>(W + k0 + 32 * j));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) av[mb][j] = *reinterpret_cast<const uint4*>(A[mb] + k0 + 32 * j);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[j]),
+                                                          __builtin_bit_cast(bf16x8_t, av[mb][j]), acc[mb], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    *reinterpret_cast<float4*>(red[wave][mb][lane]) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
+  __syncthreads();
+  if (wave >= MB) return;
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const float4 v = *reinterpret_cast<const float4*>(red[w][wave][lane]);
+    a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
+  }
+  const int64_t m = (int64_t)wave * 16 + l16, n = n0 + 4 * lg;
+  if (m >= p.M || n >= p.N) return;
+  const int n_ok = (int)min((int64_t)4, p.N - n);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+  if (bias) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
+  epilogue4<bf16_t, TO>(p, reinterpret_cast<TO*>(p.C), reinterpret_cast<TO*>(p.aux), reinterpret_cast<const bf16_t*>(p.R),
+                        reinterpret_cast<const bf16_t*>(p.G), bv, m, n, n_ok, a4);
+}
+
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -734,6 +792,10 @@ int get_split_ws(hipStream_t st, SplitWs* out) {
   return DXA_OK;
 }
 
+inline bool skinny_off_g() {
+  static const bool off = getenv("DXA_GEMM_NO_SKINNY") != nullptr;
+  return off;
+}
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 inline bool strides_mult(const int64_t s[3], int64_t m) { return s[0] % m == 0 && s[1] % m == 0 && s[2] % m == 0; }
 
@@ -823,9 +885,23 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
+  // ---- skinny bf16 path: M <= 64 (KV-cached decode, few-row products): a stream over the weights
+  if (!skinny_off_g() && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->M <= 64 && d->K >= 64 &&
+      d->K % 64 == 0 && p.vecA && p.vecB) {
+    dim3 sgrid((unsigned)dxa_cdiv(d->N, 16));
+    const int mb = dxa_cdiv(d->M, 16);
+#define LAUNCH_SK(MB_)                                                                                              \
+  do {                                                                                                              \
+    if (d->out_dtype == DXA_BF16) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MB_, bf16_t>), sgrid, dim3(512), 0, st, p); \
+    else hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MB_, float>), sgrid, dim3(512), 0, st, p);                   \
+  } while (0)
+    if (mb == 1) LAUNCH_SK(1); else if (mb == 2) LAUNCH_SK(2); else if (mb == 3) LAUNCH_SK(3); else LAUNCH_SK(4);
+#undef LAUNCH_SK
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   // ---- skinny fp32 path: M <= 64 (DiT head at inference), weights streamed by N/16 workgroups of 8 K-splitting waves
-  static const bool skinny_off = getenv("DXA_GEMM_NO_SKINNY") != nullptr;
-  if (!skinny_off && d->layout == DXA_NT && d->in_dtype == DXA_F32 && d->out_dtype == DXA_F32 && nbatch == 1 &&
+  if (!skinny_off_g() && d->layout == DXA_NT && d->in_dtype == DXA_F32 && d->out_dtype == DXA_F32 && nbatch == 1 &&
       d->M <= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB) {
     dim3 sgrid((unsigned)dxa_cdiv(d->N, 16));
     switch (dxa_cdiv(d->M, 16)) {

@@ -142,6 +142,23 @@ def test_gemm_skinny_f32(shape):
     assert_close(acc, a.double() @ w.double().t() + 0.25, rtol, atol, "skinny accumulate")
 
 
+@pytest.mark.parametrize("shape", [(1, 768, 64), (17, 100, 768), (36, 3072, 768), (63, 2304, 1024), (2, 1000, 3584)])
+def test_gemm_skinny_bf16(shape):
+    """bf16 NT with M < 64 (KV-cached decode): weight stream, 16-column workgroups, 8-way K split"""
+    M, N, Kd = shape
+    a = rnd(M, Kd, dtype=torch.bfloat16, seed=23)
+    w = rnd(N, Kd, dtype=torch.bfloat16, seed=24, scale=0.1)
+    bias, res = rnd(N, dtype=torch.bfloat16, seed=25), rnd(M, N, dtype=torch.bfloat16, seed=26)
+    ref = a.double() @ w.double().t()
+    rtol, atol = tol_for(torch.bfloat16, Kd)
+    assert_close(K.mm_nt(a, w), ref, rtol, atol, f"skinny bf16 plain {shape}")
+    out = K.mm_nt(a, w, bias=bias, act=4, residual=res)
+    assert_close(out, ACTS[4](ref + bias.double()) + res.double(), 2 * rtol, 2 * atol, f"skinny bf16 epilogue {shape}")
+    acc = torch.full((M, N), 0.25, device=DEV, dtype=torch.float32)
+    K.mm_nt(a, w, out=acc, accumulate=True)
+    assert_close(acc, ref + 0.25, 2e-5, 2e-3 * math.sqrt(Kd / 320), "skinny bf16 f32-out accumulate")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_batched_gqa(dtype):
     B, Hkv, G, S, D = 2, 2, 3, 70, 64
