@@ -30,6 +30,8 @@ struct AttnP {
   float* lse;
   const int32_t* kv_start;
   const int32_t* kv_end;
+  const int32_t* q_limit;      // [B,Sq] or NULL: query i sees keys j < q_limit[b,i] (block-prefix masks, pi0)
+  const uint8_t* key_valid;    // [B,Sk] or NULL: key j takes part at all (padding / missing camera)
 };
 
 // ------------------------------------------------------------------------------------ generic forward
@@ -54,6 +56,8 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_k(const AttnP p) {
   int j0 = p.kv_start ? p.kv_start[b] : 0;
   int j1 = p.kv_end ? p.kv_end[b] : p.Sk;
   if (p.causal) j1 = min(j1, i + (p.Sk - p.Sq) + 1);
+  if (p.q_limit) j1 = min(j1, p.q_limit[(int64_t)b * p.Sq + i]);
+  const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
   j0 = max(j0, 0);
   j1 = min(j1, p.Sk);
   // wave-private LDS: same-wave write->read needs only the LDS counter, __syncthreads not required,
@@ -70,19 +74,19 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_k(const AttnP p) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) acc += qs[d + e] * kv[e];
     }
-    acc *= p.scale;
+    acc = (kvld && !kvld[j]) ? -INFINITY : acc * p.scale;
     ps[j] = acc;
     mx = fmaxf(mx, acc);
   }
   mx = wave_max(mx);
   float sum = 0.f;
   for (int j = j0 + lane; j < j1; j += 64) {
-    const float e = expf(ps[j] - mx);
+    const float e = mx == -INFINITY ? 0.f : expf(ps[j] - mx);
     ps[j] = e;
     sum += e;
   }
   sum = wave_sum(sum);
-  const bool any = j1 > j0;
+  const bool any = sum > 0.f;
   const float inv = any ? 1.f / sum : 0.f;
   for (int j = j0 + lane; j < j1; j += 64) ps[j] = rnd<T>(ps[j] * inv);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -280,7 +284,8 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
 template <typename T>
 __global__ __launch_bounds__(256) void attn_probs_k(const float* __restrict__ S, const float* __restrict__ lse,
                                                     T* __restrict__ P, int B, int H, int Sq, int Sk, float scale, int causal,
-                                                    const int32_t* __restrict__ kv_start, const int32_t* __restrict__ kv_end) {
+                                                    const int32_t* __restrict__ kv_start, const int32_t* __restrict__ kv_end,
+                                                    const int32_t* __restrict__ q_limit, const uint8_t* __restrict__ key_valid) {
   const int64_t total = (int64_t)B * H * Sq * Sk;
   for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
     const int j = (int)(it % Sk);
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(256) void attn_probs_k(const float* __restrict__ S,
     const int b = (int)(row / ((int64_t)Sq * H));
     int j0 = kv_start ? kv_start[b] : 0, j1 = kv_end ? kv_end[b] : Sk;
     if (causal) j1 = min(j1, i + (Sk - Sq) + 1);
-    const bool vis = j >= j0 && j < j1;
+    if (q_limit) j1 = min(j1, q_limit[(int64_t)b * Sq + i]);
+    const bool vis = j >= j0 && j < j1 && (!key_valid || key_valid[(int64_t)b * Sk + j]);
     stf<T>(P + it, vis ? expf(S[it] * scale - lse[row]) : 0.f);
   }
 }
@@ -655,6 +661,7 @@ AttnP make_params(const dxa_attn_desc* d) {
   p.v = (const char*)d->v; p.v_sb = d->v_sb; p.v_sh = d->v_sh; p.v_ss = d->v_ss;
   p.o = (char*)d->o; p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_ss = d->o_ss;
   p.lse = d->lse; p.kv_start = d->kv_start; p.kv_end = d->kv_end;
+  p.q_limit = d->q_limit; p.key_valid = d->key_valid;
   return p;
 }
 
@@ -679,7 +686,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
   const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
                         d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
                         d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
-  const bool flash_ok = !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && strides8 &&
+  const bool flash_ok = !d->force_generic && !d->q_limit && !d->key_valid && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && strides8 &&
                         al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
   if (flash_ok) {
     dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
@@ -712,7 +719,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
 static bool bwd_flash_ok(const dxa_attn_desc* d) {
   auto s8 = [](int64_t a, int64_t b, int64_t c) { return a % 8 == 0 && b % 8 == 0 && c % 8 == 0; };
   auto s4 = [](int64_t a, int64_t b, int64_t c) { return a % 4 == 0 && b % 4 == 0 && c % 4 == 0; };
-  return !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && d->B <= 65535 && d->Hq <= 65535 &&
+  return !d->force_generic && !d->q_limit && !d->key_valid && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && d->B <= 65535 && d->Hq <= 65535 &&
          s8(d->q_sb, d->q_sh, d->q_ss) && s8(d->k_sb, d->k_sh, d->k_ss) && s8(d->v_sb, d->v_sh, d->v_ss) &&
          s8(d->do_sb, d->do_sh, d->do_ss) && s4(d->o_sb, d->o_sh, d->o_ss) && s4(d->dq_sb, d->dq_sh, d->dq_ss) &&
          s4(d->dk_sb, d->dk_sh, d->dk_ss) && s4(d->dv_sb, d->dv_sh, d->dv_ss) && al(d->q, 16) && al(d->k, 16) &&
@@ -789,9 +796,9 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
   {
     dim3 grid(dxa_grid1d((int64_t)n, 256));
     if (d->dtype == DXA_BF16)
-      hipLaunchKernelGGL((attn_probs_k<bf16_t>), grid, dim3(256), 0, st, Sf, d->lse, (bf16_t*)P, d->B, d->Hq, d->Sq, d->Sk, d->scale, d->causal, d->kv_start, d->kv_end);
+      hipLaunchKernelGGL((attn_probs_k<bf16_t>), grid, dim3(256), 0, st, Sf, d->lse, (bf16_t*)P, d->B, d->Hq, d->Sq, d->Sk, d->scale, d->causal, d->kv_start, d->kv_end, d->q_limit, d->key_valid);
     else
-      hipLaunchKernelGGL((attn_probs_k<float>), grid, dim3(256), 0, st, Sf, d->lse, (float*)P, d->B, d->Hq, d->Sq, d->Sk, d->scale, d->causal, d->kv_start, d->kv_end);
+      hipLaunchKernelGGL((attn_probs_k<float>), grid, dim3(256), 0, st, Sf, d->lse, (float*)P, d->B, d->Hq, d->Sq, d->Sk, d->scale, d->causal, d->kv_start, d->kv_end, d->q_limit, d->key_valid);
   }
   // 3. delta = rowsum(dO * O)
   {

@@ -153,6 +153,11 @@ typedef struct dxa_attn_desc {
   void* dk; int64_t dk_sb, dk_sh, dk_ss;
   void* dv; int64_t dv_sb, dv_sh, dv_ss;
   int32_t force_generic;    /* testing: bypass the MFMA kernel */
+  /* block-prefix masks of the pi0 mixture-of-transformers attention (dexbotic/model/pi0/pi0_arch.py:22-33):
+   * cumsum(ar_mask) is non-decreasing, so "cumsum[j] <= cumsum[i]" is a per-query key count; input_mask is a
+   * per-key validity.  Either may be NULL.  With one of them set the generic kernels run. */
+  const int32_t* q_limit;   /* [B,Sq]: query i attends keys j < q_limit[b,i] */
+  const uint8_t* key_valid; /* [B,Sk]: 0 = key j is padding / a missing camera */
 } dxa_attn_desc;
 int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream);
 size_t dxa_attn_bwd_workspace(const dxa_attn_desc* d);

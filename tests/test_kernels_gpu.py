@@ -352,6 +352,42 @@ def test_attention_left_padding_and_flash_vs_generic():
         assert_close(a, b, 1.0 / 32, 6e-2, f"flash bwd vs generic {name}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_block_prefix_mask_hd256(dtype):
+    """pi0's mixture-of-transformers attention: MQA, head_dim 256, per-query key limits (block prefix) and
+    per-key validity; forward and backward against an explicit additive-mask reference"""
+    B, Hq, Hkv, Sq, Sk, D = 2, 4, 1, 23, 23, 256
+    q, k, v = rnd(B, Hq, Sq, D, dtype=dtype, seed=140), rnd(B, Hkv, Sk, D, dtype=dtype, seed=141), rnd(B, Hkv, Sk, D, dtype=dtype, seed=142)
+    do = rnd(B, Hq, Sq, D, dtype=dtype, seed=143)
+    valid = torch.ones(B, Sk, dtype=torch.bool, device=DEV)
+    valid[0, 5:9] = False
+    valid[1, 14] = False
+    ar = torch.zeros(Sk, dtype=torch.long, device=DEV)
+    ar[16] = 1
+    ar[17] = 1                                                      # blocks: [0,16) | {16} | [17,23)
+    cum = torch.cumsum(ar, 0)
+    lim = (cum[None, :] <= cum[:, None]).sum(1).to(torch.int32)     # keys with cumsum <= the query's
+    q_limit = lim[None].expand(B, Sq).contiguous()
+    mask = (cum[None, :] <= cum[:, None])[None] & valid[:, None, :]                     # [B,Sq,Sk]
+    scale = D ** -0.5
+    o = torch.empty_like(q)
+    lse = K.attn_fwd(q, k, v, o, causal=False, scale=scale, q_limit=q_limit, key_valid=valid.to(torch.uint8))
+    qr, kr, vr = (t.double().detach().clone().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bhid,bhjd->bhij", qr, kr.repeat_interleave(Hq // Hkv, 1)) * scale
+    s = s.masked_fill(~mask[:, None], float("-inf"))
+    ref = torch.softmax(s, -1) @ vr.repeat_interleave(Hq // Hkv, 1)
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (1.0 / 64, 2e-2)
+    assert_close(o, ref, rtol, atol, "masked attn o")
+    ref.backward(do.double())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=False, scale=scale, q_limit=q_limit, key_valid=valid.to(torch.uint8))
+    rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (1.0 / 32, 8e-2)
+    assert_close(dq, qr.grad, rt, at, "masked attn dq")
+    assert_close(dk, kr.grad, rt, at * 2, "masked attn dk")
+    assert_close(dv, vr.grad, rt, at * 2, "masked attn dv")
+    assert torch.all(dk[0, :, 5:9] == 0) and torch.all(dv[1, :, 14] == 0)
+
+
 # ----------------------------------------------------------------------------------------- elementwise
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_swiglu_and_acts(dtype):
