@@ -18,8 +18,10 @@ def model_registry():
     reference (dexbotic_arch.py:18, cogact_arch.py:14)."""
     from .model.cogact.cogact_arch import CogActConfig, CogACTForCausalLM
     from .model.dexbotic_arch import DexboticConfig, DexboticForCausalLM
+    from .model.pi0.pi0_arch import Pi0Config, Pi0ForCausalLM
     return {"dexbotic": (DexboticConfig, DexboticForCausalLM),
-            "dexbotic_cogact": (CogActConfig, CogACTForCausalLM)}
+            "dexbotic_cogact": (CogActConfig, CogACTForCausalLM),
+            "dexbotic_pi0": (Pi0Config, Pi0ForCausalLM)}
 
 
 def discrete_vla():

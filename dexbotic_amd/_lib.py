@@ -88,6 +88,8 @@ SIGNATURES = {
     "dxa_attn_bwd": (_int, [C.POINTER(AttnDesc), _vp, _sz, _vp]),
     "dxa_swiglu_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "dxa_swiglu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_glu_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "dxa_glu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_act_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp]),
     "dxa_act_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
     "dxa_add": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),

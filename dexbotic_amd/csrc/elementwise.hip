@@ -103,6 +103,41 @@ __global__ __launch_bounds__(TPB) void swiglu_bwd_k(const T* __restrict__ gu, co
   }
 }
 
+// gated MLP with any gate activation: out = act(gate) * up (Gemma's GeGLU = gelu_pytorch_tanh, HF gemma/modeling_gemma.py
+// GemmaMLP as used by pi0_arch.py:205-208); same [gate ; up] packing as SwiGLU
+template <typename T, int VEC>
+__global__ __launch_bounds__(TPB) void glu_fwd_k(const T* __restrict__ gu, T* __restrict__ out, int64_t rows, int64_t F, int act) {
+  const int64_t per = F / VEC, total = rows * per;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TPB) {
+    const int64_t r = it / per, c = (it % per) * VEC;
+    float g[VEC], u[VEC], o[VEC];
+    Vec<T, VEC>::ld(g, gu + r * 2 * F + c);
+    Vec<T, VEC>::ld(u, gu + r * 2 * F + F + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = rnd<T>(act_fwd(act, g[i])) * u[i];
+    Vec<T, VEC>::st(out + r * F + c, o);
+  }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(TPB) void glu_bwd_k(const T* __restrict__ gu, const T* __restrict__ dout, T* __restrict__ dgu,
+                                                 int64_t rows, int64_t F, int act) {
+  const int64_t per = F / VEC, total = rows * per;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TPB) {
+    const int64_t r = it / per, c = (it % per) * VEC;
+    float g[VEC], u[VEC], d[VEC], dg[VEC], du[VEC];
+    Vec<T, VEC>::ld(g, gu + r * 2 * F + c);
+    Vec<T, VEC>::ld(u, gu + r * 2 * F + F + c);
+    Vec<T, VEC>::ld(d, dout + r * F + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      du[i] = d[i] * rnd<T>(act_fwd(act, g[i]));
+      dg[i] = d[i] * u[i] * act_grad(act, g[i]);
+    }
+    Vec<T, VEC>::st(dgu + r * 2 * F + c, dg);
+    Vec<T, VEC>::st(dgu + r * 2 * F + F + c, du);
+  }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(TPB) void act_fwd_k(const T* __restrict__ x, T* __restrict__ y, int64_t n, int act) {
   const int64_t total = n / VEC;
@@ -421,6 +456,35 @@ extern "C" int dxa_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64
   } else {
     if (vec) hipLaunchKernelGGL((swiglu_bwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (const float*)dout, (float*)dgu, rows, F);
     else hipLaunchKernelGGL((swiglu_bwd_k<float, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const float*)gu, (const float*)dout, (float*)dgu, rows, F);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+extern "C" int dxa_glu_fwd(const void* gu, void* out, int64_t rows, int64_t F, int act, int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(gu && out && rows >= 0 && F > 0 && ok_dtype(dtype), "dxa_glu_fwd: bad args");
+  if (rows == 0) return DXA_OK;
+  const bool vec = F % 4 == 0 && al(gu, 16) && al(out, 16);
+  if (dtype == DXA_BF16) {
+    if (vec) hipLaunchKernelGGL((glu_fwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F, act);
+    else hipLaunchKernelGGL((glu_fwd_k<bf16_t, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F, act);
+  } else {
+    if (vec) hipLaunchKernelGGL((glu_fwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (float*)out, rows, F, act);
+    else hipLaunchKernelGGL((glu_fwd_k<float, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const float*)gu, (float*)out, rows, F, act);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+extern "C" int dxa_glu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, int act, int dtype,
+                           dxa_stream_t stream) {
+  DXA_CHECK_ARG(gu && dout && dgu && rows >= 0 && F > 0 && ok_dtype(dtype), "dxa_glu_bwd: bad args");
+  if (rows == 0) return DXA_OK;
+  const bool vec = F % 4 == 0 && al(gu, 16) && al(dout, 16) && al(dgu, 16);
+  if (dtype == DXA_BF16) {
+    if (vec) hipLaunchKernelGGL((glu_bwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F, act);
+    else hipLaunchKernelGGL((glu_bwd_k<bf16_t, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F, act);
+  } else {
+    if (vec) hipLaunchKernelGGL((glu_bwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (const float*)dout, (float*)dgu, rows, F, act);
+    else hipLaunchKernelGGL((glu_bwd_k<float, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const float*)gu, (const float*)dout, (float*)dgu, rows, F, act);
   }
   DXA_CHECK_LAUNCH();
   return DXA_OK;

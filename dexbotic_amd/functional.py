@@ -564,3 +564,25 @@ class LmHeadLossFn(Function):
             dh = K.mm_nt(dz, K.transpose(W, KPAD)) if half else K.mm_nn(dz, W)
             dh = dh.view(ctx.hshape)
         return dh, None, None, None, None, None
+
+
+class AddPosFn(Function):
+    """x[N,T,C] + pos[T,C] (learned position embedding of the SigLIP tower, HF siglip/modeling_siglip.py
+    SiglipVisionEmbeddings); d_pos = sum over N of dy."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, pos_name: str):
+        N, T, C_ = x.shape
+        pos = st.w(pos_name).unsqueeze(0).expand(N, T, C_).contiguous()
+        ctx.st, ctx.pos_name, ctx.shape = st, pos_name, (N, T, C_)
+        return K.add(x.contiguous(), pos)
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, (N, T, C_) = ctx.st, ctx.shape
+        dy = dy.contiguous()
+        if st.trainable(ctx.pos_name):
+            # rows of [N, T*C]: the column sums are the per-position gradient
+            K.colsum(dy.view(N, T * C_), out=st.g(ctx.pos_name).view(-1), accumulate=st.accum_flag(ctx.pos_name))
+            st.mark_written(ctx.pos_name)
+        return dy, None, None, None

@@ -325,6 +325,23 @@ def swiglu_bwd(gu: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     return dgu
 
 
+def glu_fwd(gu: torch.Tensor, act: int) -> torch.Tensor:
+    """act(gate) * up for [rows, 2F] = [gate ; up] (GeGLU with act = ACT_GELU_TANH)"""
+    rows, F2 = gu.shape
+    assert gu.is_contiguous() and F2 % 2 == 0
+    out = torch.empty((rows, F2 // 2), device=gu.device, dtype=gu.dtype)
+    L.check(lib.dxa_glu_fwd(_ptr(gu), _ptr(out), rows, F2 // 2, act, dt(gu), _stream()), "dxa_glu_fwd")
+    return out
+
+
+def glu_bwd(gu: torch.Tensor, dout: torch.Tensor, act: int) -> torch.Tensor:
+    rows, F2 = gu.shape
+    assert gu.is_contiguous() and dout.is_contiguous()
+    dgu = torch.empty_like(gu)
+    L.check(lib.dxa_glu_bwd(_ptr(gu), _ptr(dout), _ptr(dgu), rows, F2 // 2, act, dt(gu), _stream()), "dxa_glu_bwd")
+    return dgu
+
+
 def act_fwd(x: torch.Tensor, act: int) -> torch.Tensor:
     assert x.is_contiguous()
     y = torch.empty_like(x)

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 from ....engine import ParamStore
 from .clip.clip_encoder import CLIPVisionConfig, CLIPVisionTower
+from .siglip.siglip_encoder import SiglipVisionConfig, SiglipVisionTower
 
 
 def build_vision_tower(mm_vision_tower, store: ParamStore, prefix: str = "model.mm_vision_tower.", **kwargs):
@@ -11,12 +12,16 @@ def build_vision_tower(mm_vision_tower, store: ParamStore, prefix: str = "model.
     vt = mm_vision_tower
     if isinstance(vt, CLIPVisionConfig):
         return CLIPVisionTower(vt, store, prefix, **kwargs)
+    if isinstance(vt, SiglipVisionConfig):
+        return SiglipVisionTower(vt, store, prefix, **kwargs)
     if isinstance(vt, dict):
+        if "siglip" in str(vt.get("model_type", "")):
+            return SiglipVisionTower(SiglipVisionConfig.from_any(vt), store, prefix, **kwargs)
         return CLIPVisionTower(CLIPVisionConfig.from_any(vt), store, prefix, **kwargs)
     if isinstance(vt, str):
         low = vt.lower()
         if "sig" in low:
-            raise NotImplementedError("SiglipVisionTower (pi0 path, SURVEY.md §8f rank 1) is not built yet")
+            return SiglipVisionTower(vt, store, prefix, **kwargs)
         if "clip" in low:
             return CLIPVisionTower(vt, store, prefix, **kwargs)
         if "pe" in low:

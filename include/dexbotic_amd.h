@@ -170,6 +170,11 @@ int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t workspace_bytes
 int dxa_swiglu_fwd(const void* gu, void* out, int64_t rows, int64_t F, int dtype, dxa_stream_t stream);
 int dxa_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, int dtype,
                    dxa_stream_t stream);
+/* gated MLP with any gate activation: out = act(gate) * up — Gemma's GeGLU (act = DXA_ACT_GELU_TANH), HF gemma/
+ * modeling_gemma.py GemmaMLP as called from dexbotic/model/pi0/pi0_arch.py:205-208.  Same packing as SwiGLU. */
+int dxa_glu_fwd(const void* gu, void* out, int64_t rows, int64_t F, int act, int dtype, dxa_stream_t stream);
+int dxa_glu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, int act, int dtype,
+                dxa_stream_t stream);
 int dxa_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dxa_stream_t stream);
 int dxa_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int act, int dtype, dxa_stream_t stream);
 /* out = a + b (same dtype) */

@@ -401,6 +401,12 @@ def test_swiglu_and_acts(dtype):
     assert_close(out, ref, rtol, atol, "swiglu fwd")
     ref.backward(dout.double())
     assert_close(K.swiglu_bwd(gu, dout), gr.grad, rtol, atol, "swiglu bwd")
+    for act in (2, 4):                                       # GeGLU (Gemma) and SiLU through the generic GLU kernels
+        g2 = gu.double().detach().requires_grad_(True)
+        ref2 = ACTS[act](g2[:, :Fd]) * g2[:, Fd:]
+        assert_close(K.glu_fwd(gu, act), ref2, rtol, atol, f"glu fwd {act}")
+        ref2.backward(dout.double())
+        assert_close(K.glu_bwd(gu, dout, act), g2.grad, rtol, atol, f"glu bwd {act}")
     for act in (1, 2, 3, 4, 5):
         x = rnd(rows, Fd, dtype=dtype, seed=62)
         xr = x.double().requires_grad_(True)
