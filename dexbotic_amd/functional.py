@@ -363,6 +363,9 @@ class NormFn(Function):
         if kind == "rms":
             y, rstd = K.rmsnorm_fwd(x.contiguous(), st.w(wn), eps)
             mean = rstd.new_empty(0)
+        elif kind == "rms1p":                       # GemmaRMSNorm: scale by (1 + weight) in fp32
+            y, rstd = K.rmsnorm_fwd(x.contiguous(), st.w(wn).float() + 1.0, eps)
+            mean = rstd.new_empty(0)
         else:
             y, mean, rstd = K.layernorm_fwd(x.contiguous(), st.w(wn) if wn else None, st.w(bn) if bn else None, eps)
         ctx.st, ctx.kind, ctx.wn, ctx.bn = st, kind, wn, bn
@@ -374,9 +377,10 @@ class NormFn(Function):
         st = ctx.st
         x, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.kind == "rms":
+        if ctx.kind in ("rms", "rms1p"):
             tr = st.trainable(ctx.wn)
-            dx, _ = K.rmsnorm_bwd(dy, x.contiguous(), st.w(ctx.wn), rstd, dw_out=st.g(ctx.wn) if tr else None,
+            w = st.w(ctx.wn) if ctx.kind == "rms" else st.w(ctx.wn).float() + 1.0      # d(1+w) = dw
+            dx, _ = K.rmsnorm_bwd(dy, x.contiguous(), w, rstd, dw_out=st.g(ctx.wn) if tr else None,
                                   accumulate=st.accum_flag(ctx.wn), want_dw=tr)
             if tr:
                 st.mark_written(ctx.wn)
@@ -586,3 +590,138 @@ class AddPosFn(Function):
             K.colsum(dy.view(N, T * C_), out=st.g(ctx.pos_name).view(-1), accumulate=st.accum_flag(ctx.pos_name))
             st.mark_written(ctx.pos_name)
         return dy, None, None, None
+
+
+class ScaleFn(Function):
+    """y = x * s in the tensor's dtype (token embeddings * sqrt(hidden), pi0_arch.py:247-250)"""
+
+    @staticmethod
+    def forward(ctx, x, s: float):
+        ctx.s = s
+        return ScaleFn._mul(x, s)
+
+    @staticmethod
+    def _mul(x, s):
+        x = x.contiguous()
+        if x.dtype == torch.float32:
+            return K.scale_(x.clone(), s)
+        return K.cast(K.scale_(K.cast(x, torch.float32), s), x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ScaleFn._mul(dy, ctx.s), None
+
+
+@dataclass
+class GemmaLayerSpec:
+    """parameter names + shapes of one Gemma decoder layer of one expert (model/llm/gemma.py)"""
+    ln1: str
+    qkv: Tuple[str, ...]
+    o: str
+    ln2: str
+    gu: Tuple[str, ...]
+    down: str
+    d: int
+    F: int
+    eps: float
+
+
+class Pi0MotLayerFn(Function):
+    """One layer of the pi0 mixture of transformers (pi0_arch.py:130-216) for its two experts at once: per expert
+    GemmaRMSNorm -> fused q/k/v -> RoPE; ONE attention over the concatenated tokens with the block-prefix mask; per
+    expert o_proj + residual -> GemmaRMSNorm -> GeGLU -> residual.  Inputs/outputs are the experts' [B*S_e, d_e]
+    activations.  ``skip_post0``: the last layer's llm half after attention feeds only prefix_out, which the loss
+    never reads — it is not computed (the reference computes it and its parameters get no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, anchor, st: ParamStore, sp0: GemmaLayerSpec, sp1: GemmaLayerSpec, geom, cos_t, sin_t,
+                pos0, pos1, q_limit, key_valid, skip_post0: bool):
+        B, S0, S1, Hq, Hkv, D = geom
+        nq = (Hq + 2 * Hkv) * D
+        xs, sps, Ss, poss = (x0, x1), (sp0, sp1), (S0, S1), (pos0, pos1)
+        h1, rstd1, qs, ks, vs = [], [], [], [], []
+        for x, sp, S, pos in zip(xs, sps, Ss, poss):
+            h, r = K.rmsnorm_fwd(x, st.w(sp.ln1).float() + 1.0, sp.eps)
+            q, k, v = K.rope_split(K.mm_nt(h, st.w(*sp.qkv, shape=(nq, sp.d))), cos_t, sin_t, pos, B, S, Hq, Hkv, D)
+            h1.append(h); rstd1.append(r); qs.append(q); ks.append(k); vs.append(v)
+        q, k, v = torch.cat(qs, 2), torch.cat(ks, 2), torch.cat(vs, 2)
+        o = torch.empty((B, S0 + S1, Hq, D), device=x0.device, dtype=x0.dtype)
+        lse = K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=False, scale=D ** -0.5, q_limit=q_limit, key_valid=key_valid)
+        ys, saved = [], []
+        off = 0
+        for i, (x, sp, S) in enumerate(zip(xs, sps, Ss)):
+            a = o[:, off:off + S].reshape(B * S, Hq * D).contiguous()
+            off += S
+            if i == 0 and skip_post0:
+                ys.append(x.new_zeros((0,)))                   # placeholder, never read downstream
+                saved += [a, a.new_empty(0), a.new_empty(0), a.new_empty(0), a.new_empty(0), a.new_empty(0)]
+                continue
+            r = K.mm_nt(a, st.w(sp.o), residual=x)
+            h2, rs2 = K.rmsnorm_fwd(r, st.w(sp.ln2).float() + 1.0, sp.eps)
+            gu = K.mm_nt(h2, st.w(*sp.gu, shape=(2 * sp.F, sp.d)))
+            act = K.glu_fwd(gu, L.ACT_GELU_TANH)
+            ys.append(K.mm_nt(act, st.w(sp.down), residual=r))
+            saved += [a, r, rs2, h2, gu, act]
+        ctx.st, ctx.sps, ctx.geom, ctx.skip_post0 = st, sps, geom, skip_post0
+        ctx.aux = (cos_t, sin_t, pos0, pos1, q_limit, key_valid)
+        ctx.save_for_backward(x0, x1, h1[0], h1[1], rstd1[0], rstd1[1], q, k, v, o, lse, *saved)
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        st, sps, skip_post0 = ctx.st, ctx.sps, ctx.skip_post0
+        B, S0, S1, Hq, Hkv, D = ctx.geom
+        cos_t, sin_t, pos0, pos1, q_limit, key_valid = ctx.aux
+        sv = ctx.saved_tensors
+        xs, h1, rstd1 = sv[0:2], sv[2:4], sv[4:6]
+        q, k, v, o, lse = sv[6:11]
+        per = [sv[11:17], sv[17:23]]
+        nq = (Hq + 2 * Hkv) * D
+        Ss, poss, dys = (S0, S1), (pos0, pos1), (dy0, dy1)
+        S = S0 + S1
+        do = torch.zeros((B, S, Hq, D), device=q.device, dtype=q.dtype)
+        drs = []
+        off = 0
+        for i, (sp, Sn, dy) in enumerate(zip(sps, Ss, dys)):
+            a, r, rs2, h2, gu, act = per[i]
+            if i == 0 and skip_post0:
+                drs.append(None)
+                off += Sn
+                continue
+            dy = dy.contiguous()
+            dact = _dx(st, sp.down, (sp.d, sp.F), dy)
+            _wgrad(st, sp.down, dy, act, (sp.d, sp.F))
+            dgu = K.glu_bwd(gu, dact, L.ACT_GELU_TANH)
+            dh2 = _dx(st, sp.gu, (2 * sp.F, sp.d), dgu)
+            _wgrad(st, sp.gu, dgu, h2, (2 * sp.F, sp.d))
+            tr = st.trainable(sp.ln2)
+            drn, _ = K.rmsnorm_bwd(dh2, r, st.w(sp.ln2).float() + 1.0, rs2, dw_out=st.g(sp.ln2) if tr else None,
+                                   accumulate=st.accum_flag(sp.ln2), want_dw=tr)
+            if tr:
+                st.mark_written(sp.ln2)
+            dr = K.add(dy, drn)
+            da = _dx(st, sp.o, (sp.d, Hq * D), dr)
+            _wgrad(st, sp.o, dr, a, (sp.d, Hq * D))
+            do[:, off:off + Sn].copy_(da.view(B, Sn, Hq, D))
+            off += Sn
+            drs.append(dr)
+        do_h = K.permute_bshd(do, B, S, Hq, D, True)                       # head-major dO for the GQA fold
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do_h, dq, dk, dv, causal=False, scale=D ** -0.5,
+                   q_limit=q_limit, key_valid=key_valid)
+        dxs = []
+        off = 0
+        for i, (sp, Sn, pos) in enumerate(zip(sps, Ss, poss)):
+            sl = slice(off, off + Sn)
+            off += Sn
+            dqkv = K.rope_merge(dq[:, :, sl].contiguous(), dk[:, :, sl].contiguous(), dv[:, :, sl].contiguous(),
+                                cos_t, sin_t, pos, B, Sn, Hq, Hkv, D)
+            dh = _dx(st, sp.qkv, (nq, sp.d), dqkv)
+            _wgrad(st, sp.qkv, dqkv, h1[i], (nq, sp.d))
+            tr = st.trainable(sp.ln1)
+            dxn, _ = K.rmsnorm_bwd(dh, xs[i], st.w(sp.ln1).float() + 1.0, rstd1[i], dw_out=st.g(sp.ln1) if tr else None,
+                                   accumulate=st.accum_flag(sp.ln1), want_dw=tr)
+            if tr:
+                st.mark_written(sp.ln1)
+            dxs.append(dxn if drs[i] is None else K.add(drs[i], dxn))
+        return (dxs[0], dxs[1]) + (None,) * 12

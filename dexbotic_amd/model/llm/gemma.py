@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from ... import functional as Fn
 from ... import kernels as K
 from ...engine import ParamStore
 
@@ -61,6 +62,7 @@ class GemmaExpert(nn.Module):
         store.new_bucket()
         store.register([(prefix + "embed_tokens.weight", (c.vocab_size, d))])
         self.layer_names = []
+        self.layer_specs = []
         for i in range(c.num_hidden_layers):
             lp = f"{prefix}layers.{i}."
             store.new_bucket()
@@ -74,6 +76,7 @@ class GemmaExpert(nn.Module):
             store.register([(lp + "mlp.down_proj.weight", (d, f))])
             self.layer_names.append(dict(ln1=lp + "input_layernorm.weight", qkv=qkv, o=lp + "self_attn.o_proj.weight",
                                     ln2=lp + "post_attention_layernorm.weight", gu=gu, down=lp + "mlp.down_proj.weight"))
+            self.layer_specs.append(Fn.GemmaLayerSpec(d=d, F=f, eps=c.rms_norm_eps, **self.layer_names[-1]))
         store.new_bucket()
         store.register([(prefix + "norm.weight", (d,))])
         self._rope: Dict = {}
@@ -111,12 +114,15 @@ class GemmaExpert(nn.Module):
         return self._rope[key]
 
     def embed(self, input_ids: torch.Tensor) -> torch.Tensor:
-        """embed_tokens(ids) * sqrt(hidden) (pi0_arch.py:247-250; the 4.51 GemmaModel embedding is unscaled)"""
-        W = self.store.w(self.embed_name)
-        rows = W[input_ids.reshape(-1)]                               # gather of B*L rows (data movement)
-        out = K.cast(rows.contiguous(), torch.float32)
-        K.scale_(out, float(self.config.hidden_size) ** 0.5)
-        return K.cast(out, W.dtype).view(*input_ids.shape, -1)
+        """embed_tokens(ids) * sqrt(hidden) (pi0_arch.py:247-250; the 4.51 GemmaModel embedding is unscaled).
+        Differentiable: the gather is the splice kernel with a tokens-only plan (its backward adds rows into the
+        fp32 embedding gradient), the scale is applied in the tensor's dtype."""
+        st = self.store
+        d = self.config.hidden_size
+        dummy = torch.zeros((1, d), device=st.device, dtype=st.compute_dtype)
+        rows = Fn.SpliceFn.apply(dummy, st.params[self.embed_name], st, self.embed_name,
+                                 input_ids.reshape(-1).to(device=st.device, dtype=torch.int64).contiguous())
+        return Fn.ScaleFn.apply(rows, float(d) ** 0.5).view(*input_ids.shape, d)
 
     def pre_attention(self, x2d: torch.Tensor, li: int) -> torch.Tensor:
         """[M, d] -> fused qkv [M, (Hq + 2 Hkv) * hd] of layer li (input_layernorm + q/k/v projections)"""

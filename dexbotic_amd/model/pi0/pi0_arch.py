@@ -8,8 +8,8 @@ it).  What differs is underneath: parameters live in the flat arenas of engine.P
 halves per expert around ONE attention call over both experts' tokens, with the reference's block mask expressed as
 per-query key counts + per-key validity (cumsum(ar_mask) is non-decreasing, so "cumsum[j] <= cumsum[i]" is a prefix).
 
-Built so far: inference (``inference_action``) and the no-grad forward; the training step (loss + backward through the
-mixture) is the next increment and raises NotImplementedError.
+Training: ``forward`` builds the flow-matching loss through ``functional.Pi0MotLayerFn`` (one autograd node per
+layer over both experts, gradients written straight into the arena); inference: ``inference_action``.
 """
 from __future__ import annotations
 
@@ -230,15 +230,33 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
                 outs.append(e.final_norm(h).view(B, n, -1))
         return outs, cache
 
+    def _mot_train(self, ptok, stok, positions, q_limit, key_valid) -> torch.Tensor:
+        """the mixture with autograd: one Pi0MotLayerFn per layer over both experts; only the action expert's final
+        norm is evaluated (prefix_out is never read by the loss, pi0_arch.py:372-388)"""
+        llm, exp, st = self.model.llm, self.model.action_expert, self.store
+        c = self.config.llm_config
+        B, P, Sx = ptok.shape[0], ptok.shape[1], stok.shape[1]
+        geom = (B, P, Sx, c.num_attention_heads, c.num_key_value_heads, c.head_dim)
+        dev = st.device
+        cos_t, sin_t = llm.rope_tables(int(positions.max()) + 1, dev)
+        pos0 = torch.from_numpy(np.ascontiguousarray(positions[:, :P].astype(np.int32))).to(dev).reshape(-1)
+        pos1 = torch.from_numpy(np.ascontiguousarray(positions[:, P:].astype(np.int32))).to(dev).reshape(-1)
+        x0 = ptok.reshape(B * P, -1).contiguous()
+        x1 = stok.reshape(B * Sx, -1).contiguous()
+        n = c.num_hidden_layers
+        for li in range(n):
+            sp0, sp1 = llm.layer_specs[li], exp.layer_specs[li]
+            x0, x1 = Fn.Pi0MotLayerFn.apply(x0, x1, st.params[sp1.down], st, sp0, sp1, geom, cos_t, sin_t, pos0, pos1,
+                                            q_limit, key_valid, li == n - 1)
+        y = Fn.NormFn.apply(x1, st.params[exp.p + "norm.weight"], st, "rms1p", exp.p + "norm.weight", None,
+                            exp.config.rms_norm_eps)
+        return y.view(B, Sx, -1)
+
     # ------------------------------------------------------------------------------------- training
     def forward(self, input_ids=None, attention_mask=None, actions=None, states=None, images=None, image_masks=None,
                 **kwargs) -> CausalLMOutputDexbotic:
         """flow-matching step (pi0_arch.py:317-400).  kwargs ``noise`` [B,chunk,A] and ``time`` [B] inject the draws
-        (reference: N(0,1) and Beta(1.5,1)*0.999+0.001).  Without grad this evaluates v_t and the loss; the
-        backward through the mixture is not built yet."""
-        if torch.is_grad_enabled():
-            raise NotImplementedError("pi0 training backward (SURVEY.md §8f rank 1) is the next increment; "
-                                      "call under torch.no_grad() for the forward / loss evaluation")
+        (reference: N(0,1) and Beta(1.5,1)*0.999+0.001)."""
         c, dev = self.config, self.store.device
         B = actions.shape[0]
         acts = actions.to(dev).float().reshape(B, c.chunk_size, c.action_dim)
@@ -256,8 +274,11 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         cum = np.broadcast_to(np.cumsum(np.concatenate([par, sar]).astype(np.int64)), input_mask.shape)
         q_limit, key_valid = self._mask_tensors(cum, input_mask, cum, input_mask, dev)
         positions = np.cumsum(input_mask, axis=1) - 1
-        (_, suf), _ = self._mot_forward([ptok, stok], positions, q_limit, key_valid)
         st = self.store
+        if torch.is_grad_enabled():
+            suf = self._mot_train(ptok, stok, positions, q_limit, key_valid)
+        else:
+            (_, suf), _ = self._mot_forward([ptok, stok], positions, q_limit, key_valid)
         v_t = Fn.LinearFn.apply(suf[:, -c.chunk_size:].reshape(B * c.chunk_size, -1).contiguous(),
                                 st.params["model.action_out_proj.weight"], st, "model.action_out_proj.weight",
                                 "model.action_out_proj.bias", L.ACT_NONE, None).view(B, c.chunk_size, -1).float()

@@ -21,7 +21,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a)).to(DEV)
 
 
-def build(golden_dir, dtype):
+def build(golden_dir, dtype, train=False):
     from dexbotic_amd.model.pi0.pi0_arch import Pi0Config, Pi0ForCausalLM
     g = np.load(os.path.join(golden_dir, "pi0_t1.npz"), allow_pickle=False)
     c = P.Pi0OracleConfig()
@@ -37,7 +37,7 @@ def build(golden_dir, dtype):
                layer_norm_eps=c.v_eps)
     cfg = Pi0Config(vision_config=vis, action_config=act, llm_config=gem, mm_projector_type="linear",
                     action_dim=c.action_dim, chunk_size=c.chunk_size, compute_dtype=dtype)
-    m = Pi0ForCausalLM(cfg, device=DEV, train=False)
+    m = Pi0ForCausalLM(cfg, device=DEV, train=train)
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in w.items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
     m.eval()
@@ -61,9 +61,29 @@ def test_fp32_pi0_forward_loss_matches_reference(golden_dir):
                 time=g["time"])
     assert rel_err(out.logits.cpu().numpy(), g["v_t"]) < FP32_TOL
     assert abs(out.loss.item() - float(g["loss"])) < FP32_TOL * abs(float(g["loss"]))
-    with pytest.raises(NotImplementedError):
-        m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]),
-          image_masks=T(g["image_masks"]), states=T(g["states"]), actions=T(g["actions"]))
+
+
+def test_fp32_pi0_training_step_grads_match_reference(golden_dir):
+    g, m = build(golden_dir, "float32", train=True)
+    m.train()
+    st = m.store
+    st.set_expected(m.unused_parameter_names())
+    st.begin_step()
+    out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]),
+            image_masks=T(g["image_masks"]), states=T(g["states"]), actions=T(g["actions"]), noise=T(g["noise"]),
+            time=g["time"])
+    assert abs(out.loss.item() - float(g["loss"])) < FP32_TOL * abs(float(g["loss"]))
+    out.loss.backward()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel_err(st.g(key[5:]).cpu().numpy(), g[key]) < FP32_TOL, key
+        elif key.startswith("gradN/"):
+            gn = float(g[key])
+            assert st.grad_written[key[6:]], key
+            assert abs(st.g(key[6:]).double().norm().item() - gn) < FP32_TOL * gn + 1e-6 * float(g["grad_norm"]), key
+    # parameters the reference leaves without a gradient are exactly the ones reported unused
+    have = {k[6:] for k in g.files if k.startswith("gradN/")}
+    assert set(m.unused_parameter_names()) == set(st.slots) - have
 
 
 def test_bf16_pi0_inference_tracks_reference(golden_dir):
