@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
   const int coff = p.Sk - p.Sq;
   int blk_hi = j_hi;  // exclusive key bound for the whole workgroup
   if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
-  const int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;  // exclusive bound for this lane's query
+  int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;  // exclusive bound for this lane's query
+  if (p.q_limit) my_hi = min(my_hi, qi < p.Sq ? p.q_limit[(int64_t)b * p.Sq + qi] : 0);   // block-prefix mask (pi0)
+  const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
   const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
 
   for (int kt = t_lo; kt < t_hi; ++kt) {
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
         *reinterpret_cast<uint4*>(Ks + r * KROW + ((c ^ (r & (NCH - 1))) << 4)) = val;
       }
     }
-    // ---- stage V^T tile: thread (kc = key chunk of 8, dg = group of 4 d) transposes 8x4 -> 4x8
-    if (tid < 8 * (D / 4)) {
-      const int kc = tid & 7, dg = tid >> 3;
+    // ---- stage V^T tile: work item (kc = key chunk of 8, dg = group of 4 d) transposes 8x4 -> 4x8
+    for (int wi = tid; wi < 8 * (D / 4); wi += 256) {
+      const int kc = wi & 7, dg = wi >> 3;
       uint2 vv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + 16 * n + 4 * lg + r;
-        const bool vis = key >= j_lo && key < my_hi;
+        const bool vis = key >= j_lo && key < my_hi && (!kvld || kvld[key]);     // key < my_hi <= Sk: in bounds
         const float s = vis ? sacc[n][r] * sc2 : -INFINITY;          // scores in log2 units
         sacc[n][r] = s;
         tmax = fmaxf(tmax, s);
@@ -686,11 +688,12 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
   const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
                         d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
                         d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
-  const bool flash_ok = !d->force_generic && !d->q_limit && !d->key_valid && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && strides8 &&
+  const bool flash_ok = !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && strides8 &&
                         al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
   if (flash_ok) {
     dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
-    if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128>), grid, dim3(256), 0, st, p);
+    if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256>), grid, dim3(256), 0, st, p);
+    else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_fwd_flash_k<64>), grid, dim3(256), 0, st, p);
     DXA_CHECK_LAUNCH();
     return DXA_OK;

@@ -289,6 +289,8 @@ ATTN_CASES = [
     (3, 2, 2, 17, 64, False, False, False),    # DiT-like
     (1, 7, 1, 287, 128, True, False, True),    # 7:1 GQA
     (2, 2, 1, 64, 128, True, True, True),
+    (2, 8, 1, 200, 256, False, True, True),    # Gemma-like MQA, head_dim 256 (pi0)
+    (1, 4, 1, 70, 256, True, False, True),
 ]
 
 
