@@ -206,6 +206,13 @@ class VitBlockSpec:
     I: int = 0      # mlp width
 
 
+def _padded_head_dim(D: int, dtype) -> int:
+    """head width the MFMA attention kernels run at for a model head_dim D (bf16 only; fp32 uses the generic kernels)"""
+    if dtype != torch.bfloat16 or D in (64, 128, 256) or D > 256 or D % 8 != 0:
+        return D
+    return 64 if D < 64 else (128 if D < 128 else 256)
+
+
 class VitBlockFn(Function):
     """Pre-LN block: x + out(attn(qkv(LN(x)))) ; + fc2(act(fc1(LN(.)))).
     CLIP encoder layer (HF:clip/modeling_clip.py:259-384; affine LN eps 1e-5, quick_gelu) and DiTBlock
@@ -220,11 +227,17 @@ class VitBlockFn(Function):
         x = x.reshape(M, C_)
         h1, mean1, rstd1 = K.layernorm_fwd(x, w(sp.ln1_w), w(sp.ln1_b), sp.eps)
         qkv = K.mm_nt(h1, st.w(*sp.qkv_w, shape=(3 * C_, C_)), bias=st.w(*sp.qkv_b, shape=(3 * C_,)))
-        q5 = qkv.view(N, T, 3, H, D)
+        Dp = _padded_head_dim(D, x.dtype)
+        if Dp != D:
+            # head_dim the MFMA attention kernels do not take (SigLIP-So400m: 72): run them at the next supported
+            # width on zero-padded heads — q.k is unchanged by zero columns, the padded output columns are dropped
+            qkv = K.copy2d(qkv.view(M * 3 * H, D), torch.empty((M * 3 * H, Dp), device=x.device, dtype=x.dtype), D, Dp)
+        q5 = qkv.view(N, T, 3, H, Dp)
         q, k, v = (q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        o = torch.empty((N, T, H, D), device=x.device, dtype=x.dtype)
+        o = torch.empty((N, T, H, Dp), device=x.device, dtype=x.dtype)
         lse = K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=False, scale=D ** -0.5)
-        x2 = K.mm_nt(o.view(M, C_), st.w(sp.out_w), bias=st.w(sp.out_b), residual=x)
+        o_in = o if Dp == D else K.copy2d(o.view(M * H, Dp), torch.empty((M * H, D), device=x.device, dtype=x.dtype), D, D)
+        x2 = K.mm_nt(o_in.view(M, C_), st.w(sp.out_w), bias=st.w(sp.out_b), residual=x)
         h2, mean2, rstd2 = K.layernorm_fwd(x2, w(sp.ln2_w), w(sp.ln2_b), sp.eps)
         pre = torch.empty((M, I), device=x.device, dtype=x.dtype)
         a = K.mm_nt(h2, st.w(sp.fc1_w), bias=st.w(sp.fc1_b), act=sp.act, aux_out=pre)
@@ -254,14 +267,21 @@ class VitBlockFn(Function):
         del dh2
         # ---- attention
         do = _dx(st, sp.out_w, (C_, C_), dx2)                   # [M, C] token-major
-        _wgrad(st, sp.out_w, dx2, o.view(M, C_), (C_, C_))
+        Dp = o.shape[-1]                                          # padded head width of the forward (== D normally)
+        o_in = o if Dp == D else K.copy2d(o.view(M * H, Dp), torch.empty((M * H, D), device=o.device, dtype=o.dtype), D, D)
+        _wgrad(st, sp.out_w, dx2, o_in.view(M, C_), (C_, C_))
         _bgrad(st, sp.out_b, dx2)
+        if Dp != D:
+            do = K.copy2d(do.view(M * H, D), torch.empty((M * H, Dp), device=o.device, dtype=o.dtype), D, Dp)
         dqkv = torch.empty_like(qkv)
-        q5, d5 = qkv.view(N, T, 3, H, D), dqkv.view(N, T, 3, H, D)
+        q5, d5 = qkv.view(N, T, 3, H, Dp), dqkv.view(N, T, 3, H, Dp)
         q, k, v = (q5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         dq, dk, dv = (d5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.view(N, T, H, D).permute(0, 2, 1, 3), dq, dk, dv,
+        K.attn_bwd(q, k, v, o.permute(0, 2, 1, 3), lse, do.view(N, T, H, Dp).permute(0, 2, 1, 3), dq, dk, dv,
                    causal=False, scale=D ** -0.5)
+        if Dp != D:
+            dqkv = K.copy2d(dqkv.view(M * 3 * H, Dp), torch.empty((M * 3 * H, D), device=o.device, dtype=o.dtype), D, D)
+            dqkv = dqkv.view(M, 3 * C_)
         dh1 = _dx(st, sp.qkv_w, (3 * C_, C_), dqkv)
         _wgrad(st, sp.qkv_w, dqkv, h1, (3 * C_, C_))
         _bgrad(st, sp.qkv_b, dqkv)

@@ -95,3 +95,36 @@ def test_bf16_pi0_inference_tracks_reference(golden_dir):
     # random-weight tiny model amplify rounding, so this is a sanity bound on the relative L2 error, not a parity claim
     a, r = acts.cpu().numpy().astype(np.float64), g["infer_actions"].astype(np.float64)
     assert np.linalg.norm(a - r) / np.linalg.norm(r) < 0.15
+
+
+def test_bf16_siglip_tower_head_dim_72_padded_attention():
+    """SigLIP-So400m has head_dim 72: the bf16 tower runs the MFMA attention kernels at 128 on zero-padded heads.
+    Forward features and the gradient of a scalar against the fp32 CPU restatement."""
+    from dexbotic_amd.engine import ParamStore, attach_parameters
+    from dexbotic_amd.model.modules.mm_vision.siglip.siglip_encoder import SiglipVisionConfig, SiglipVisionTower
+    c = P.Pi0OracleConfig(v_hidden=144, v_inter=192, v_layers=2, v_heads=2, v_image=56, v_patch=14)
+    shapes = {k: v for k, v in P.pi0_shapes(c).items() if k.startswith("model.mm_vision_tower.")}
+    w = make_weights(shapes, 99)
+    st = ParamStore(DEV, torch.bfloat16)
+    tower = SiglipVisionTower(SiglipVisionConfig(hidden_size=144, intermediate_size=192, num_hidden_layers=2,
+                                                 num_attention_heads=2, image_size=56, patch_size=14), st)
+    st.finalize(train=True)
+    attach_parameters(tower, st)
+    for k, v in w.items():
+        st.w32(k).copy_(torch.from_numpy(v).to(DEV))
+    st.sync_shadow()
+    st.set_expected(tower.unused_parameter_names())
+    st.begin_step()
+    imgs = torch.from_numpy(np.clip(np.random.RandomState(3).standard_normal((3, 3, 56, 56)), -2.5, 2.5).astype(np.float32))
+    out = tower(imgs.to(DEV))
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    ref = P.siglip_features(sd, c, imgs)
+    assert rel_err(out.float().detach().cpu().numpy(), ref.detach().numpy()) < 4e-2
+    probe = torch.from_numpy(np.random.RandomState(4).standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * probe).sum().backward()
+    (out.float() * probe.to(DEV)).sum().backward()
+    for n in ("model.mm_vision_tower.vision_tower.encoder.layers.0.self_attn.q_proj.weight",
+              "model.mm_vision_tower.vision_tower.encoder.layers.1.self_attn.v_proj.weight",
+              "model.mm_vision_tower.vision_tower.embeddings.position_embedding.weight"):
+        gr = sd[n].grad.double()
+        assert (st.g(n).double().cpu() - gr).norm() / gr.norm() < 5e-2, n
