@@ -24,6 +24,12 @@ def model_registry():
             "dexbotic_pi0": (Pi0Config, Pi0ForCausalLM)}
 
 
+def hybrid_cogact():
+    """HybridCogACTForCausalLM shares model_type "dexbotic_cogact" with CogACT (hybrid_cogact_arch.py:18-22)"""
+    from .model.cogact.hybrid_cogact_arch import HybridCogACTForCausalLM
+    return HybridCogACTForCausalLM
+
+
 def discrete_vla():
     """DiscreteVLAForCausalLM shares model_type "dexbotic" with the base class in the reference
     (discrete_vla_arch.py:12-13); exps pick it by class, so it is exported by name here."""

@@ -111,6 +111,7 @@ SIGNATURES = {
     "dxa_token_drop": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "dxa_token_drop_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "dxa_mse_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
+    "dxa_mse_loss_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "dxa_ddim_step": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _f32, _f32, _f32, _vp]),
     "dxa_adamw": (_int, [C.POINTER(AdamWDesc), _vp]),
     "dxa_sumsq": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),

@@ -374,6 +374,25 @@ __global__ __launch_bounds__(1024) void mse_loss_k(const float* __restrict__ pre
   const float tot = block_sum(s, red);
   if (threadIdx.x == 0) loss[0] = tot / (float)n;
 }
+// sample-weighted eps-MSE of HybridCogACT (hybrid_cogact_arch.py:168-173): loss = sum_r w_r mean_c(d_rc^2) / (sum_r w_r + 1e-6)
+__global__ __launch_bounds__(1024) void mse_loss_rows_k(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const float* __restrict__ row_w, float* __restrict__ loss,
+                                                        float* __restrict__ dpred, int64_t rows, int64_t cols, float gscale) {
+  __shared__ float red[16];
+  float ws = 0.f;
+  for (int64_t r = threadIdx.x; r < rows; r += 1024) ws += row_w[r];
+  const float wsum = block_sum(ws, red) + 1e-6f;
+  __syncthreads();
+  const int64_t n = rows * cols;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float w = row_w[i / cols], d = pred[i] - target[i];
+    s += w * d * d;
+    if (dpred) dpred[i] = 2.f * w * d / ((float)cols * wsum) * gscale;
+  }
+  const float tot = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = tot / ((float)cols * wsum);
+}
 __global__ __launch_bounds__(TPB) void ddim_step_k(float* __restrict__ x, const float* __restrict__ mo, int64_t B, int64_t per,
                                                    int use_cfg, float cfg_scale, float c_recip, float c_recipm1, float ab_prev) {
   const int64_t total = B * per;
@@ -720,6 +739,13 @@ extern "C" int dxa_mse_loss(const float* pred, const float* target, float* loss,
                             dxa_stream_t stream) {
   DXA_CHECK_ARG(pred && target && loss && n > 0, "dxa_mse_loss: bad args");
   hipLaunchKernelGGL(mse_loss_k, dim3(1), dim3(1024), 0, ST, pred, target, loss, dpred, n, gscale);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+extern "C" int dxa_mse_loss_rows(const float* pred, const float* target, const float* row_w, float* loss, float* dpred,
+                                 int64_t rows, int64_t cols, float gscale, dxa_stream_t stream) {
+  DXA_CHECK_ARG(pred && target && row_w && loss && rows > 0 && cols > 0, "dxa_mse_loss_rows: bad args");
+  hipLaunchKernelGGL(mse_loss_rows_k, dim3(1), dim3(1024), 0, ST, pred, target, row_w, loss, dpred, rows, cols, gscale);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

@@ -612,6 +612,21 @@ class AddPosFn(Function):
         return dy, None, None, None
 
 
+class MseLossRowsFn(Function):
+    """sample-weighted eps-MSE (hybrid_cogact_arch.py:168-173): sum_r w_r mean(d_r^2) / (sum_r w_r + 1e-6)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, row_w):
+        loss, dpred = K.mse_loss_rows(pred.contiguous(), target.contiguous(), row_w.float().contiguous(), 1.0, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return K.scale_dev_(dpred.clone(), g.reshape(1).float().contiguous()), None, None
+
+
 class ScaleFn(Function):
     """y = x * s in the tensor's dtype (token embeddings * sqrt(hidden), pi0_arch.py:247-250)"""
 

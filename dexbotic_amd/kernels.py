@@ -516,6 +516,18 @@ def mse_loss(pred, target, gscale: float = 1.0, want_grad: bool = True):
     return loss, dpred
 
 
+def mse_loss_rows(pred, target, row_w, gscale: float = 1.0, want_grad: bool = True):
+    """sum_r w_r mean_c(d^2) / (sum w + 1e-6) over pred/target [rows, ...]; row_w [rows] fp32"""
+    assert pred.is_contiguous() and target.is_contiguous() and pred.dtype == torch.float32
+    rows = pred.shape[0]
+    assert row_w.dtype == torch.float32 and row_w.is_contiguous() and row_w.numel() == rows
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred) if want_grad else None
+    L.check(lib.dxa_mse_loss_rows(_ptr(pred), _ptr(target), _ptr(row_w), _ptr(loss), _ptr(dpred), rows,
+                                  pred.numel() // rows, gscale, _stream()), "dxa_mse_loss_rows")
+    return loss, dpred
+
+
 def ddim_step(x, model_out, B, use_cfg, cfg_scale, c_recip, c_recipm1, ab_prev):
     per = x.numel() // x.shape[0]
     L.check(lib.dxa_ddim_step(_ptr(x), _ptr(model_out), B, per, int(use_cfg), cfg_scale, c_recip, c_recipm1, ab_prev,

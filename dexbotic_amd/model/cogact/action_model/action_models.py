@@ -47,11 +47,15 @@ class ActionModel(nn.Module):
                                           past_action_window_size=past_action_window_size)
 
     def loss(self, x: torch.Tensor, z: torch.Tensor, reduction: str = "mean", *, noise: Optional[torch.Tensor] = None,
-             timestep: Optional[torch.Tensor] = None, drop_ids: Optional[torch.Tensor] = None):
+             timestep: Optional[torch.Tensor] = None, drop_ids: Optional[torch.Tensor] = None,
+             sample_weight: Optional[torch.Tensor] = None):
         """x (N,T,A) ground-truth chunk, z (N,1,token) condition.  The three random draws of the reference
         (action_models.py:106-109 noise/timestep, dit.py:85-87 CFG drop) can be injected for parity tests;
         otherwise they come from torch's device RNG exactly where the reference draws them."""
-        assert reduction == "mean", "the CogACT path uses the mean reduction (cogact_arch.py:134)"
+        # reduction="mean": CogACT (cogact_arch.py:134).  HybridCogACT asks for "none" and then takes the
+        # has_action-weighted mean of the per-sample means (hybrid_cogact_arch.py:165-173): pass that weight as
+        # `sample_weight` [N] and the weighted scalar comes back (the [N,T,A] tensor itself is never needed).
+        assert reduction == "mean" or sample_weight is not None, "reduction='none' needs sample_weight"
         x = x.float()
         if noise is None:
             noise = torch.randn_like(x)
@@ -62,6 +66,8 @@ class ActionModel(nn.Module):
         x_t = self.diffusion.q_sample(x, timestep, noise)
         noise_pred = self.net(x_t, timestep, z, drop_ids=drop_ids)
         assert noise_pred.shape == noise.shape == x.shape
+        if sample_weight is not None:
+            return Fn.MseLossRowsFn.apply(noise_pred, noise.float(), sample_weight)
         return Fn.MseLossFn.apply(noise_pred, noise.float())
 
     def create_ddim(self, ddim_step: int = 10):

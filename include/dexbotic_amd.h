@@ -240,6 +240,10 @@ int dxa_token_drop_bwd(const float* dout, const uint8_t* drop, float* dz, float*
 /* loss = mean((pred-target)^2) (action_models.py:119-121); dpred = 2 (pred-target) / n * gscale */
 int dxa_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int64_t n,
                  float gscale, dxa_stream_t stream);
+/* sample-weighted variant (HybridCogACT co-training, dexbotic/model/cogact/hybrid_cogact_arch.py:168-173):
+ * loss = sum_r w[r] * mean_c((pred-target)[r,c]^2) / (sum_r w[r] + 1e-6); dpred = d loss / d pred * gscale */
+int dxa_mse_loss_rows(const float* pred, const float* target, const float* row_w, float* loss, float* dpred,
+                      int64_t rows, int64_t cols, float gscale, dxa_stream_t stream);
 /* One DDIM(eta=0) update with classifier-free guidance (dit.py:294-311, diffusion.py:626-673):
  * eps = eu + s (ec - eu) with ec = model_out[0:B], eu = model_out[B:2B] (cfg) or eps = model_out;
  * x0 = c_recip x - c_recipm1 eps ; eps' = (c_recip x - x0)/c_recipm1 ; x <- sqrt(ab_prev) x0 +

@@ -664,3 +664,30 @@ def greedy_decode(sd: SD, cfg: OracleConfig, input_ids: torch.Tensor, images: to
         if eos_token_id is not None and nxt == eos_token_id:
             break
     return np.array(new, dtype=np.int64), torch.stack(rows)
+
+
+def hybrid_forward(sd: SD, cfg: OracleConfig, input_ids, attention_mask, labels, images, actions, has_action, has_text,
+                   noise, timesteps, drop_ids, repeated_diffusion_steps: int = 4) -> dict:
+    """HybridCogACTForCausalLM.forward (hybrid_cogact_arch.py:59-207): one VLM prefill; text_loss = causal-LM CE
+    (labels of the no-text case all ignored, then * has_text.any()); action_loss = has_action-weighted mean of the
+    per-sample eps-MSE means over the R repeats, denominator sum(w) + 1e-6; loss = text_loss + action_loss."""
+    feats = extract_vision_features(sd, cfg, images)
+    am = attention_mask.numpy()
+    src, new_mask, _ = splice_plan(input_ids.numpy(), am, feats.shape[1], cfg.tokenizer_model_max_length,
+                                   cfg.tokenizer_padding_side)
+    embeds = splice_embeds(sd, src, feats)
+    mask_t = torch.from_numpy(new_mask)
+    hidden = qwen2_forward(sd, cfg, embeds, mask_t)
+    logits = hidden @ sd["lm_head.weight"].t()
+    new_labels = torch.from_numpy(splice_labels(input_ids.numpy(), am, labels.numpy(), feats.shape[1],
+                                                cfg.tokenizer_model_max_length, cfg.tokenizer_padding_side))
+    ht = has_text.bool().view(-1)
+    if not bool(ht.any()):
+        new_labels[~ht] = IGNORE_INDEX
+    text_loss = causal_lm_loss(logits, new_labels) * ht.any().float()
+    cog = cognition_features(hidden, mask_t)
+    _, x_t, eps_hat = action_loss(sd, cfg, actions.float(), cog, noise, timesteps, drop_ids, repeated_diffusion_steps)
+    w = has_action.reshape(-1).float().repeat(repeated_diffusion_steps)
+    per = ((eps_hat - noise) ** 2).mean(dim=[1, 2])
+    a_loss = (per * w).sum() / (w.sum() + 1e-6)
+    return dict(loss=text_loss + a_loss, text_loss=text_loss, action_loss=a_loss, hidden=hidden)

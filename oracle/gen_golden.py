@@ -393,6 +393,61 @@ def gen_lm(tag: str, cfg, seed: int, B: int, L: int, lengths, n_new: int):
           f"min margin {res['decode_margin'].min():.4g}")
 
 
+def gen_hybrid(tag: str, cfg, seed: int, B: int, L: int, lengths):
+    """HybridCogACTForCausalLM.forward (hybrid_cogact_arch.py:59-207): text CE on the has_text samples + has_action-
+    weighted diffusion loss, one backward.  Same tiny configuration / weights as cogact_<tag>."""
+    from oracle.weights import cogact_shapes, make_weights, weights_crc
+    from dexbotic.model.cogact import hybrid_cogact_arch as H
+    w = make_weights(cogact_shapes(cfg), seed)
+    base = build_reference(cfg, w)                      # CogACTForCausalLM: same config object and key map
+    m = H.HybridCogACTForCausalLM(base.config)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    for p_ in m.parameters():
+        p_.requires_grad = True
+    m.train()
+    rs = np.random.RandomState(seed + 11)
+    ids = rs.randint(10, cfg.vocab_size - 10, size=(B, L)).astype(np.int64)
+    ids[:, 1] = -200
+    mask = np.zeros((B, L), dtype=bool)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = True
+    has_text = np.array([1, 0, 1][:B], dtype=np.int64)
+    has_action = np.array([[1], [1], [0]][:B], dtype=np.int64)
+    labels = ids.copy()
+    labels[:, :5] = -100
+    labels[~mask] = -100
+    labels[has_text == 0] = -100                         # the data pipeline leaves no text targets on action-only samples
+    images = np.clip(rs.standard_normal((B, 3, cfg.v_image, cfg.v_image)), -2.5, 2.5).astype(np.float32)
+    actions = rs.uniform(-1, 1, size=(B, cfg.chunk_size * cfg.action_dim)).astype(np.float32)
+    R = 4
+    noise = rs.standard_normal((R * B, cfg.chunk_size, cfg.action_dim)).astype(np.float32)
+    timesteps = rs.randint(0, cfg.diffusion_steps, size=(R * B,)).astype(np.int64)
+    drop_u = rs.uniform(0, 1, size=(R * B,)).astype(np.float32)
+    drop_u[2] = 0.01
+    t = torch.from_numpy
+    with inject_rng(noise=t(noise), timesteps=t(timesteps), drop_u=t(drop_u)):
+        out = m(input_ids=t(ids), attention_mask=t(mask), labels=t(labels), images=t(images), actions=t(actions),
+                has_action=t(has_action), has_text=t(has_text))
+    out.loss.backward()
+    sd = dict(m.named_parameters())
+    res = dict(weights_crc=np.uint32(weights_crc(w)), seed=np.int64(seed), input_ids=ids, attention_mask=mask, labels=labels,
+               images=images, actions=actions, has_action=has_action, has_text=has_text, noise=noise, timesteps=timesteps,
+               drop_u=drop_u, loss=np.float32(out.loss.item()), text_loss=np.float32(out.text_loss.item()),
+               action_loss=np.float32(out.action_loss.item()))
+    gsq = 0.0
+    for n, p_ in sd.items():
+        if p_.grad is not None:
+            gsq += float(p_.grad.double().pow(2).sum())
+            res["gradN/" + n] = np.float64(p_.grad.double().norm().item())
+    res["grad_norm"] = np.float64(gsq ** 0.5)
+    for n in ("lm_head.weight", "model.action_head.net.final_layer.linear.weight", "model.llm.layers.0.self_attn.q_proj.weight",
+              "model.mm_projector.2.weight"):
+        res["grad/" + n] = sd[n].grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, f"hybrid_{tag}.npz"), **res)
+    print(f"[gen_golden] hybrid_{tag}: loss {res['loss']:.5f} = text {res['text_loss']:.5f} + action {res['action_loss']:.5f}"
+          f" |g| {res['grad_norm']:.4f}")
+
+
 def gen_action_bins():
     """Integer rows (A9): run the reference transform + _denorm + discrete decode."""
     from dexbotic.data.dataset.transform.action import ActionNormAnd2String
@@ -458,6 +513,7 @@ def main():
                         v_layers=4, v_heads=3, dit_hidden=192, dit_depth=3, dit_heads=3)
     gen_cogact("t2", cfg2, seed=4321, B=2, L=16, lengths=[16, 13], views=2)
     gen_lm("t1", OracleConfig(), seed=1234, B=3, L=12, lengths=[12, 9, 11], n_new=6)
+    gen_hybrid("t1", OracleConfig(), seed=1234, B=3, L=12, lengths=[12, 9, 11])
 
 
 if __name__ == "__main__":

@@ -108,3 +108,33 @@ def test_discrete_vla_inference_action(golden_dir):
     text = tok.decode(new).strip("</s>")
     want = O.denorm(O.discrete_action_to_continuous(text, 255), norms)
     assert np.array_equal(np.asarray(acts), want)
+
+
+def test_fp32_hybrid_cogact_step_matches_reference(golden_dir):
+    """HybridCogACTForCausalLM: text CE + has_action-weighted diffusion loss, one backward (golden hybrid_t1)"""
+    import os
+    from dexbotic_amd.model.cogact.hybrid_cogact_arch import HybridCogACTForCausalLM
+    from oracle.weights import cogact_shapes, make_weights, weights_crc
+    from .helpers import CFGS, product_config
+    g = np.load(os.path.join(golden_dir, "hybrid_t1.npz"), allow_pickle=False)
+    cfg = CFGS["t1"]
+    w = make_weights(cogact_shapes(cfg), int(g["seed"]))
+    assert weights_crc(w) == int(g["weights_crc"])
+    m = HybridCogACTForCausalLM(product_config(cfg, "float32"), device=DEV, train=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    m.train()
+    st = m.store
+    st.set_expected(m.unused_parameter_names())
+    st.begin_step()
+    out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), labels=T(g["labels"]), images=T(g["images"]),
+            actions=T(g["actions"]), has_action=T(g["has_action"]), has_text=T(g["has_text"]), noise=T(g["noise"]),
+            timesteps=T(g["timesteps"]), drop_ids=T(g["drop_u"]) < 0.1)
+    for k in ("loss", "text_loss", "action_loss"):
+        assert abs(getattr(out, k).item() - float(g[k])) < FP32_TOL * abs(float(g[k])), k
+    out.loss.backward()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel_err(st.g(key[5:]).cpu().numpy(), g[key]) < FP32_TOL, key
+        elif key.startswith("gradN/") and st.grad_written.get(key[6:], False):
+            gn = float(g[key])
+            assert abs(st.g(key[6:]).double().norm().item() - gn) < FP32_TOL * gn + 1e-6 * float(g["grad_norm"]), key

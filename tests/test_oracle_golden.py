@@ -175,3 +175,24 @@ def test_lm_loss_grads_and_greedy_ids_match_reference(golden_dir):
         ids, rows = O.greedy_decode(sd0, cfg, t(g["decode_prompt"]), t(g["images"][:1]), len(g["decode_new_ids"]))
     assert np.array_equal(ids, g["decode_new_ids"])
     assert rel(rows.numpy(), g["decode_logits"]) < 2e-5
+
+
+def test_hybrid_cogact_losses_and_grads_match_reference(golden_dir):
+    """HybridCogACT co-training step (text CE + has_action-weighted diffusion loss) against the reference"""
+    g = np.load(os.path.join(golden_dir, "hybrid_t1.npz"), allow_pickle=False)
+    cfg = CFGS["t1"]
+    w = make_weights(cogact_shapes(cfg), int(g["seed"]))
+    assert weights_crc(w) == int(g["weights_crc"])
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    t = torch.from_numpy
+    out = O.hybrid_forward(sd, cfg, t(g["input_ids"]), t(g["attention_mask"]), t(g["labels"]), t(g["images"]),
+                           t(g["actions"]), t(g["has_action"]), t(g["has_text"]), t(g["noise"]), t(g["timesteps"]),
+                           t(g["drop_u"]) < 0.1)
+    for k in ("loss", "text_loss", "action_loss"):
+        assert abs(float(out[k]) - float(g[k])) < 1e-5 * abs(float(g[k])), k
+    out["loss"].backward()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel(sd[key[5:]].grad.numpy(), g[key]) < 5e-5, key
+    gsq = sum(float(v.grad.double().pow(2).sum()) for v in sd.values() if v.grad is not None)
+    assert abs(gsq ** 0.5 - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
