@@ -379,7 +379,7 @@ def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 1000
 
 def dit_forward(sd: SD, cfg: OracleConfig, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor,
                 drop_ids: Optional[torch.Tensor] = None,
-                prefix: str = "model.action_head.net.") -> torch.Tensor:
+                prefix: str = "model.action_head.net.", per_token: Optional[torch.Tensor] = None) -> torch.Tensor:
     """DiT.forward (dit.py:273-292).  drop_ids [N] bool: LabelEmbedder.token_drop replaces z by
     `uncondition` where True (dit.py:80-96; train-mode CFG dropout, injected instead of drawn).
     Blocks: dit.py:137-162 with timm Attention(qkv_bias=True)/Mlp(GELU tanh) (un-vendored, unpinned
@@ -400,6 +400,9 @@ def dit_forward(sd: SD, cfg: OracleConfig, x: torch.Tensor, t: torch.Tensor, z: 
     c = te[:, None, :] + ze
     h = torch.cat([c, xe], dim=1) + sd[p + "positional_embedding"]
     T1 = h.shape[1]
+    pe = None
+    if per_token is not None:      # MemVLA: perceptual tokens embedded once (memvla/action_model/dit.py:315-316)
+        pe = F.linear(per_token, sd[p + "per_token_embedder.linear.weight"], sd[p + "per_token_embedder.linear.bias"])
     for k in range(cfg.dit_depth):
         bp = f"{p}blocks.{k}."
         y = F.layer_norm(h, (hD,), None, None, 1e-6)
@@ -409,6 +412,18 @@ def dit_forward(sd: SD, cfg: OracleConfig, x: torch.Tensor, t: torch.Tensor, z: 
         att = torch.softmax((q @ kk.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
         o = (att @ v).transpose(1, 2).reshape(N, T1, hD)
         h = h + F.linear(o, sd[bp + "attn.proj.weight"], sd[bp + "attn.proj.bias"])
+        if pe is not None:
+            # memvla/action_model/dit.py:175-185: x + MultiheadAttention(norm3(x), per, per) — nn.MultiheadAttention
+            # (batch_first, bias): packed in_proj rows [q; k; v], scaled dot product, out_proj
+            y = F.layer_norm(h, (hD,), sd[bp + "norm3.weight"], sd[bp + "norm3.bias"], 1e-6)
+            Wi, bi = sd[bp + "per_attn.in_proj_weight"], sd[bp + "per_attn.in_proj_bias"]
+            P_ = pe.shape[1]
+            q = F.linear(y, Wi[:hD], bi[:hD]).reshape(N, T1, Hh, hd).transpose(1, 2)
+            kk = F.linear(pe, Wi[hD:2 * hD], bi[hD:2 * hD]).reshape(N, P_, Hh, hd).transpose(1, 2)
+            v = F.linear(pe, Wi[2 * hD:], bi[2 * hD:]).reshape(N, P_, Hh, hd).transpose(1, 2)
+            att = torch.softmax((q @ kk.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+            o = (att @ v).transpose(1, 2).reshape(N, T1, hD)
+            h = h + F.linear(o, sd[bp + "per_attn.out_proj.weight"], sd[bp + "per_attn.out_proj.bias"])
         y = F.layer_norm(h, (hD,), None, None, 1e-6)
         y = F.linear(y, sd[bp + "mlp.fc1.weight"], sd[bp + "mlp.fc1.bias"])
         y = F.gelu(y, approximate="tanh")
@@ -419,10 +434,10 @@ def dit_forward(sd: SD, cfg: OracleConfig, x: torch.Tensor, t: torch.Tensor, z: 
 
 
 def dit_forward_with_cfg(sd: SD, cfg: OracleConfig, x: torch.Tensor, t: torch.Tensor,
-                         z: torch.Tensor, cfg_scale: float) -> torch.Tensor:
+                         z: torch.Tensor, cfg_scale: float, per_token: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dit.py:294-311: both halves run on the FIRST half of x; eps = u + s (c - u)."""
     half = x[: len(x) // 2]
-    out = dit_forward(sd, cfg, torch.cat([half, half], 0), t, z)
+    out = dit_forward(sd, cfg, torch.cat([half, half], 0), t, z, per_token=per_token)
     c_eps, u_eps = torch.split(out, len(out) // 2, dim=0)
     e = u_eps + cfg_scale * (c_eps - u_eps)
     return torch.cat([e, e], dim=0)
@@ -446,7 +461,8 @@ def action_loss(sd: SD, cfg: OracleConfig, actions: torch.Tensor, cognition: tor
 
 
 def ddim_sample(sd: SD, cfg: OracleConfig, cognition: torch.Tensor, noise: torch.Tensor,
-                cfg_scale: float = 1.5, num_ddim_steps: int = 10, return_traj: bool = False):
+                cfg_scale: float = 1.5, num_ddim_steps: int = 10, return_traj: bool = False,
+                per_token: Optional[torch.Tensor] = None):
     """inference_action's sampler (cogact_arch.py:163-192): CFG batch [x;x], z=[cog;uncond];
     ddim_sample_loop (diffusion.py:714-794) over ddim_sample (:626-673) with eta=0,
     clip_denoised=False, FIXED_SMALL/EPSILON p_mean_variance (:351-441).  Arithmetic between
@@ -465,9 +481,9 @@ def ddim_sample(sd: SD, cfg: OracleConfig, cognition: torch.Tensor, noise: torch
     for i in reversed(range(tab.num_timesteps)):
         t = torch.full((x.shape[0],), tab.timestep_map[i], dtype=torch.long)   # _WrappedModel :1106-1111
         if use_cfg:
-            eps = dit_forward_with_cfg(sd, cfg, x, t, z, cfg_scale)
+            eps = dit_forward_with_cfg(sd, cfg, x, t, z, cfg_scale, per_token=per_token)
         else:
-            eps = dit_forward(sd, cfg, x, t, z)
+            eps = dit_forward(sd, cfg, x, t, z, per_token=per_token)
         # _predict_xstart_from_eps (:443-448)
         x0 = f32(tab.sqrt_recip_alphas_cumprod, i) * x - f32(tab.sqrt_recipm1_alphas_cumprod, i) * eps
         # _predict_eps_from_xstart (:450-454) re-derivation
