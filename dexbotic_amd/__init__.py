@@ -18,10 +18,12 @@ def model_registry():
     reference (dexbotic_arch.py:18, cogact_arch.py:14)."""
     from .model.cogact.cogact_arch import CogActConfig, CogACTForCausalLM
     from .model.dexbotic_arch import DexboticConfig, DexboticForCausalLM
+    from .model.memvla.memvla_arch import MemVLAConfig, MemVLAForCausalLM
     from .model.pi0.pi0_arch import Pi0Config, Pi0ForCausalLM
     return {"dexbotic": (DexboticConfig, DexboticForCausalLM),
             "dexbotic_cogact": (CogActConfig, CogACTForCausalLM),
-            "dexbotic_pi0": (Pi0Config, Pi0ForCausalLM)}
+            "dexbotic_pi0": (Pi0Config, Pi0ForCausalLM),
+            "dexbotic_memvla": (MemVLAConfig, MemVLAForCausalLM)}
 
 
 def hybrid_cogact():

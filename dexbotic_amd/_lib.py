@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DXA_LIB") or os.path.join(_HERE, "libdexbotic_amd.so")   # DXA_LIB: kernel-tuning builds
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5, 6
 NT, NN, TN = 0, 1, 2
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
@@ -88,6 +88,9 @@ SIGNATURES = {
     "dxa_attn_bwd": (_int, [C.POINTER(AttnDesc), _vp, _sz, _vp]),
     "dxa_swiglu_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "dxa_swiglu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_axpby": (_int, [_vp, _vp, _vp, _i64, _f32, _f32, _int, _vp]),
+    "dxa_mul": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "dxa_mul_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "dxa_glu_fwd": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_glu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_act_fwd": (_int, [_vp, _vp, _i64, _int, _int, _vp]),

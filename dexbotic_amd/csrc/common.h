@@ -96,6 +96,7 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
     case DXA_ACT_QUICK_GELU: return x / (1.f + expf(-1.702f * x));
     case DXA_ACT_SILU: return x / (1.f + expf(-x));
     case DXA_ACT_RELU: return x > 0.f ? x : 0.f;
+    case DXA_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
     default: return x;
   }
 }
@@ -122,6 +123,10 @@ __device__ __forceinline__ float act_grad(int act, float x) {
       return s * (1.f + x * (1.f - s));
     }
     case DXA_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case DXA_ACT_SIGMOID: {
+      const float s = 1.f / (1.f + expf(-x));
+      return s * (1.f - s);
+    }
     default: return 1.f;
   }
 }

@@ -550,6 +550,61 @@ extern "C" int dxa_add(const void* a, const void* b, void* out, int64_t n, int d
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
+namespace {
+template <typename T, int VEC, int OP>   // OP 0: alpha*a + beta*b ; 1: a*b
+__global__ __launch_bounds__(TPB) void binary_k(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n,
+                                                float alpha, float beta) {
+  const int64_t total = n / VEC;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TPB) {
+    float x[VEC], y[VEC];
+    Vec<T, VEC>::ld(x, a + it * VEC);
+    Vec<T, VEC>::ld(y, b + it * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) x[i] = OP == 0 ? alpha * x[i] + beta * y[i] : x[i] * y[i];
+    Vec<T, VEC>::st(o + it * VEC, x);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void mul_rows_k(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ o,
+                                                  int64_t R, int64_t Nn, int64_t C) {
+  const int64_t total = R * Nn * C;
+  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TPB) {
+    const int64_t c = it % C, r = it / (Nn * C);
+    stf<T>(o + it, ldf<T>(x + it) * ldf<T>(g + r * C + c));
+  }
+}
+template <int OP>
+int launch_binary(const void* a, const void* b, void* out, int64_t n, float alpha, float beta, int dtype, dxa_stream_t stream) {
+  const bool vec = n % 4 == 0 && al(a, 16) && al(b, 16) && al(out, 16);
+  if (dtype == DXA_BF16) {
+    if (vec) hipLaunchKernelGGL((binary_k<bf16_t, 4, OP>), dim3(dxa_grid1d(n / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, alpha, beta);
+    else hipLaunchKernelGGL((binary_k<bf16_t, 1, OP>), dim3(dxa_grid1d(n, TPB)), dim3(TPB), 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, alpha, beta);
+  } else {
+    if (vec) hipLaunchKernelGGL((binary_k<float, 4, OP>), dim3(dxa_grid1d(n / 4, TPB)), dim3(TPB), 0, ST, (const float*)a, (const float*)b, (float*)out, n, alpha, beta);
+    else hipLaunchKernelGGL((binary_k<float, 1, OP>), dim3(dxa_grid1d(n, TPB)), dim3(TPB), 0, ST, (const float*)a, (const float*)b, (float*)out, n, alpha, beta);
+  }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+}  // namespace
+extern "C" int dxa_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta, int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(a && b && out && n >= 0 && ok_dtype(dtype), "dxa_axpby: bad args");
+  if (n == 0) return DXA_OK;
+  return launch_binary<0>(a, b, out, n, alpha, beta, dtype, stream);
+}
+extern "C" int dxa_mul(const void* a, const void* b, void* out, int64_t n, int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(a && b && out && n >= 0 && ok_dtype(dtype), "dxa_mul: bad args");
+  if (n == 0) return DXA_OK;
+  return launch_binary<1>(a, b, out, n, 1.f, 1.f, dtype, stream);
+}
+extern "C" int dxa_mul_rows(const void* x, const void* g, void* out, int64_t R, int64_t Nn, int64_t C, int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && g && out && R >= 0 && Nn >= 0 && C > 0 && ok_dtype(dtype), "dxa_mul_rows: bad args");
+  if (R * Nn == 0) return DXA_OK;
+  if (dtype == DXA_BF16) hipLaunchKernelGGL((mul_rows_k<bf16_t>), dim3(dxa_grid1d(R * Nn * C, TPB)), dim3(TPB), 0, ST, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)out, R, Nn, C);
+  else hipLaunchKernelGGL((mul_rows_k<float>), dim3(dxa_grid1d(R * Nn * C, TPB)), dim3(TPB), 0, ST, (const float*)x, (const float*)g, (float*)out, R, Nn, C);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
 extern "C" int dxa_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, dxa_stream_t stream) {
   DXA_CHECK_ARG(src && dst && n >= 0 && ok_dtype(src_dtype) && ok_dtype(dst_dtype), "dxa_cast: bad args");
   if (n == 0) return DXA_OK;

@@ -760,3 +760,102 @@ class Pi0MotLayerFn(Function):
                 st.mark_written(sp.ln1)
             dxs.append(dxn if drs[i] is None else K.add(drs[i], dxn))
         return (dxs[0], dxs[1]) + (None,) * 12
+
+
+# ------------------------------------------------------------------ small differentiable pieces (MemVLA memory modules)
+class AddFn(Function):
+    """a + b (same shape): residual connections outside the fused blocks"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class AttnFn(Function):
+    """softmax(q k^T / sqrt(D)) v for [B,S,H,D] VIEWS (any strides with D contiguous) -> [B,Sq,H*D]: the cross
+    attention of CrossTransformerBlock (memvla_arch.py:84-127) and of the DiT per-attention (nn.MultiheadAttention,
+    memvla/action_model/dit.py:158-185)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        B, Sq, H, D = q.shape
+        o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
+        lse = K.attn_fwd(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), o.permute(0, 2, 1, 3),
+                         causal=False, scale=D ** -0.5)
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o.view(B, Sq, H * D)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, Sq, H, D = q.shape
+        do = do.contiguous().view(B, Sq, H, D)
+        dq, dk, dv = torch.empty(q.shape, device=q.device, dtype=q.dtype), torch.empty(k.shape, device=q.device, dtype=q.dtype), \
+            torch.empty(v.shape, device=q.device, dtype=q.dtype)
+        P = lambda t: t.permute(0, 2, 1, 3)
+        K.attn_bwd(P(q), P(k), P(v), P(o), lse, P(do), P(dq), P(dk), P(dv), causal=False, scale=D ** -0.5)
+        return dq, dk, dv
+
+
+class GateFuseFn(Function):
+    """scale * x1 + (1 - scale) * x2 (GateFusion, memvla_arch.py:170-187; scale = sigmoid(proj(cat)) comes in)"""
+
+    @staticmethod
+    def forward(ctx, scale, x1, x2):
+        scale, x1, x2 = scale.contiguous(), x1.contiguous(), x2.contiguous()
+        d = K.axpby(x1, x2, 1.0, -1.0)
+        ctx.save_for_backward(scale, d)
+        return K.add(K.mul(scale, d), x2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, d = ctx.saved_tensors
+        dy = dy.contiguous()
+        dd = K.mul(dy, scale)
+        return K.mul(dy, d), dd, K.axpby(dy, dd, 1.0, -1.0)
+
+
+class TokenMeanFn(Function):
+    """mean over the token axis: [B,N,C] -> [B,C] (AdaptiveAvgPool2d(1) of BottleneckSE, memvla_arch.py:139-141)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, N, C_ = x.shape
+        ctx.shape = (B, N, C_)
+        x = x.contiguous()
+        out = torch.empty((B, C_), device=x.device, dtype=torch.float32)
+        for b in range(B):
+            K.colsum(x[b], out=out[b])
+        return K.cast(K.scale_(out, 1.0 / N), x.dtype)
+
+    @staticmethod
+    def backward(ctx, dm):
+        B, N, C_ = ctx.shape
+        ones = torch.ones((B, N, C_), device=dm.device, dtype=dm.dtype)     # broadcast of dm / N over the tokens
+        g = K.cast(K.scale_(K.cast(dm.contiguous(), torch.float32), 1.0 / N), dm.dtype)
+        return K.mul_rows(ones, g)
+
+
+class RowGateFn(Function):
+    """x[B,N,C] * g[B,C] (SE channel gate, memvla_arch.py:160-161)"""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x, g = x.contiguous(), g.contiguous()
+        ctx.save_for_backward(x, g)
+        return K.mul_rows(x, g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        B = x.shape[0]
+        prod = K.mul(dy, x)
+        dg = torch.empty((B, x.shape[2]), device=x.device, dtype=torch.float32)
+        for b in range(B):
+            K.colsum(prod[b], out=dg[b])
+        return K.mul_rows(dy, g), K.cast(dg, x.dtype)

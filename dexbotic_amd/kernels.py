@@ -325,6 +325,29 @@ def swiglu_bwd(gu: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     return dgu
 
 
+def axpby(a: torch.Tensor, b: torch.Tensor, alpha: float, beta: float) -> torch.Tensor:
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty_like(a)
+    L.check(lib.dxa_axpby(_ptr(a), _ptr(b), _ptr(out), a.numel(), alpha, beta, dt(a), _stream()), "dxa_axpby")
+    return out
+
+
+def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    out = torch.empty_like(a)
+    L.check(lib.dxa_mul(_ptr(a), _ptr(b), _ptr(out), a.numel(), dt(a), _stream()), "dxa_mul")
+    return out
+
+
+def mul_rows(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """x [R, N, C] * g [R, C] (broadcast over N)"""
+    R, Nn, C_ = x.shape
+    assert x.is_contiguous() and g.is_contiguous() and g.shape == (R, C_) and g.dtype == x.dtype
+    out = torch.empty_like(x)
+    L.check(lib.dxa_mul_rows(_ptr(x), _ptr(g), _ptr(out), R, Nn, C_, dt(x), _stream()), "dxa_mul_rows")
+    return out
+
+
 def glu_fwd(gu: torch.Tensor, act: int) -> torch.Tensor:
     """act(gate) * up for [rows, 2F] = [gate ; up] (GeGLU with act = ACT_GELU_TANH)"""
     rows, F2 = gu.shape

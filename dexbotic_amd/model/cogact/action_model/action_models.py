@@ -31,7 +31,8 @@ DiT_models = {"DiT-S": DiT_S, "DiT-B": DiT_B, "DiT-L": DiT_L}
 class ActionModel(nn.Module):
     def __init__(self, store: ParamStore, prefix: str, token_size: int, model_type: str, in_channels: int,
                  future_action_window_size: int, past_action_window_size: int, diffusion_steps: int = 100,
-                 noise_schedule: str = "squaredcos_cap_v2"):
+                 noise_schedule: str = "squaredcos_cap_v2", use_per_attn: bool = False,
+                 per_token_size: Optional[int] = None):
         super().__init__()
         self.in_channels = in_channels
         self.noise_schedule = noise_schedule
@@ -44,11 +45,13 @@ class ActionModel(nn.Module):
         self.net = DiT_models[model_type](store=store, prefix=prefix + "net.", token_size=token_size,
                                           in_channels=in_channels, class_dropout_prob=0.1, learn_sigma=False,
                                           future_action_window_size=future_action_window_size,
-                                          past_action_window_size=past_action_window_size)
+                                          past_action_window_size=past_action_window_size,
+                                          use_per_attn=use_per_attn, per_token_size=per_token_size)
+        self.model_type = model_type
 
     def loss(self, x: torch.Tensor, z: torch.Tensor, reduction: str = "mean", *, noise: Optional[torch.Tensor] = None,
              timestep: Optional[torch.Tensor] = None, drop_ids: Optional[torch.Tensor] = None,
-             sample_weight: Optional[torch.Tensor] = None):
+             sample_weight: Optional[torch.Tensor] = None, per_token: Optional[torch.Tensor] = None):
         """x (N,T,A) ground-truth chunk, z (N,1,token) condition.  The three random draws of the reference
         (action_models.py:106-109 noise/timestep, dit.py:85-87 CFG drop) can be injected for parity tests;
         otherwise they come from torch's device RNG exactly where the reference draws them."""
@@ -64,7 +67,7 @@ class ActionModel(nn.Module):
         if drop_ids is None and self.training and self.net.class_dropout_prob > 0:
             drop_ids = torch.rand(x.shape[0], device=x.device) < self.net.class_dropout_prob
         x_t = self.diffusion.q_sample(x, timestep, noise)
-        noise_pred = self.net(x_t, timestep, z, drop_ids=drop_ids)
+        noise_pred = self.net(x_t, timestep, z, drop_ids=drop_ids, per_token=per_token)   # per_token: MemVLA
         assert noise_pred.shape == noise.shape == x.shape
         if sample_weight is not None:
             return Fn.MseLossRowsFn.apply(noise_pred, noise.float(), sample_weight)

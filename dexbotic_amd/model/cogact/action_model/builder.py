@@ -13,9 +13,11 @@ def build_action_model(config, store: ParamStore, prefix: str = "model.action_he
         raise ValueError(f"Missing required config keys: {missing}")
     model_type = config.action_model_type
     if "DiT" in model_type:
+        # memvla/action_model/builder.py:14-20: a config that carries per_token_size builds the per-attention DiT
+        pts = getattr(config, "per_token_size", None)
         return ActionModel(store=store, prefix=prefix, model_type=model_type, token_size=config.hidden_size,
                            in_channels=config.action_dim, future_action_window_size=config.chunk_size - 1,
-                           past_action_window_size=0)
+                           past_action_window_size=0, use_per_attn=pts is not None, per_token_size=pts)
     if "Linear" in model_type:
         raise NotImplementedError("LinearModel head (action_models.py:15-45) is not on the DB-CogACT path")
     raise ValueError(f"Unknown action model type: {model_type}")

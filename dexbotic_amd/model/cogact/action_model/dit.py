@@ -22,8 +22,12 @@ class DiT(nn.Module):
     def __init__(self, store: ParamStore, prefix: str, in_channels: int = 7, hidden_size: int = 1152,
                  depth: int = 28, num_heads: int = 16, mlp_ratio: float = 4.0, class_dropout_prob: float = 0.1,
                  token_size: int = 4096, future_action_window_size: int = 1, past_action_window_size: int = 0,
-                 learn_sigma: bool = False):
+                 learn_sigma: bool = False, use_per_attn: bool = False, per_token_size: Optional[int] = None):
+        """``use_per_attn``: the MemVLA variant (memvla/action_model/dit.py:136-185, 240-249) — every block also
+        cross-attends to the perceptual tokens (nn.MultiheadAttention + affine norm3), a PerTokenEmbedder replaces
+        the unused HistoryEmbedder."""
         super().__init__()
+        self.use_per_attn, self.per_token_size = use_per_attn, per_token_size
         assert past_action_window_size == 0, "Error: action_history is not used now"
         assert not learn_sigma
         self.store, self.p = store, prefix
@@ -38,7 +42,12 @@ class DiT(nn.Module):
         h, A, p = hidden_size, in_channels, prefix
         store.new_bucket()
         store.register([(p + "positional_embedding", (self.T + 1, h))])
-        store.register([(p + "history_embedder.linear.weight", (h, A)), (p + "history_embedder.linear.bias", (h,))])
+        if use_per_attn:
+            assert per_token_size is not None
+            store.register([(p + "per_token_embedder.linear.weight", (h, per_token_size)),
+                            (p + "per_token_embedder.linear.bias", (h,))])
+        else:
+            store.register([(p + "history_embedder.linear.weight", (h, A)), (p + "history_embedder.linear.bias", (h,))])
         store.register([(p + "x_embedder.linear.weight", (h, A)), (p + "x_embedder.linear.bias", (h,))])
         store.register([(p + "t_embedder.mlp.0.weight", (h, 256)), (p + "t_embedder.mlp.0.bias", (h,))])
         store.register([(p + "t_embedder.mlp.2.weight", (h, h)), (p + "t_embedder.mlp.2.bias", (h,))])
@@ -52,6 +61,10 @@ class DiT(nn.Module):
             store.register([(b + "attn.proj.weight", (h, h)), (b + "attn.proj.bias", (h,))])
             store.register([(b + "mlp.fc1.weight", (self.mlp_hidden, h)), (b + "mlp.fc1.bias", (self.mlp_hidden,))])
             store.register([(b + "mlp.fc2.weight", (h, self.mlp_hidden)), (b + "mlp.fc2.bias", (h,))])
+            if use_per_attn:
+                store.register([(b + "per_attn.in_proj_weight", (3 * h, h)), (b + "per_attn.in_proj_bias", (3 * h,))])
+                store.register([(b + "per_attn.out_proj.weight", (h, h)), (b + "per_attn.out_proj.bias", (h,))])
+                store.register([(b + "norm3.weight", (h,)), (b + "norm3.bias", (h,))])
             self.block_specs.append(Fn.VitBlockSpec(
                 ln1_w=None, ln1_b=None, qkv_w=(b + "attn.qkv.weight",), qkv_b=(b + "attn.qkv.bias",),
                 out_w=b + "attn.proj.weight", out_b=b + "attn.proj.bias", ln2_w=None, ln2_b=None,
@@ -77,9 +90,17 @@ class DiT(nn.Module):
                     nn.init.xavier_uniform_(t)
         h = self.hidden_size
         st.w32(p + "positional_embedding").copy_(h ** -0.5 * torch.randn(self.T + 1, h))
-        for n in ("x_embedder.linear.weight", "history_embedder.linear.weight", "z_embedder.uncondition",
+        emb = "per_token_embedder.linear.weight" if self.use_per_attn else "history_embedder.linear.weight"
+        for n in ("x_embedder.linear.weight", emb, "z_embedder.uncondition",
                   "z_embedder.linear.weight", "t_embedder.mlp.0.weight", "t_embedder.mlp.2.weight"):
             nn.init.normal_(st.w32(p + n), std=0.02)
+        if self.use_per_attn:                       # zero-initialised cross attention (memvla dit.py:167-171)
+            for k in range(self.depth):
+                b = f"{p}blocks.{k}."
+                for n in ("per_attn.in_proj_weight", "per_attn.in_proj_bias", "per_attn.out_proj.weight",
+                          "per_attn.out_proj.bias", "norm3.bias"):
+                    st.w32(b + n).zero_()
+                st.w32(b + "norm3.weight").fill_(1.0)
         st.w32(p + "final_layer.linear.weight").zero_()
         st.w32(p + "final_layer.linear.bias").zero_()
 
@@ -96,8 +117,30 @@ class DiT(nn.Module):
             self._freqs[key] = f.to(device)
         return self._freqs[key]
 
+    def _block_with_per_attn(self, st, k: int, hcur: torch.Tensor, pe: torch.Tensor, N: int, T1: int) -> torch.Tensor:
+        """memvla DiTBlock (memvla/action_model/dit.py:175-187): x + attn(norm1 x); x + MHA(norm3 x, per, per);
+        x + mlp(norm2 x) — composed from the small autograd pieces (the fused VitBlockFn has no slot for the middle
+        term).  nn.MultiheadAttention's packed in_proj is applied whole to both inputs and sliced [q | k | v]."""
+        b, h, H = f"{self.p}blocks.{k}.", self.hidden_size, self.num_heads
+        D, anchor = h // H, self._anchor()
+        lin = lambda x, wn, bn: Fn.LinearFn.apply(x, anchor, st, wn, bn, L.ACT_NONE, None)
+        y = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
+        qkv = lin(y, b + "attn.qkv.weight", b + "attn.qkv.bias").view(N, T1, 3, H, D)
+        o = Fn.AttnFn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).reshape(N * T1, h)
+        hcur = Fn.AddFn.apply(hcur, lin(o, b + "attn.proj.weight", b + "attn.proj.bias"))
+        y3 = Fn.NormFn.apply(hcur, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
+        P_ = pe.shape[1]
+        qf = lin(y3, b + "per_attn.in_proj_weight", b + "per_attn.in_proj_bias").view(N, T1, 3, H, D)
+        kvf = lin(pe.reshape(N * P_, h), b + "per_attn.in_proj_weight", b + "per_attn.in_proj_bias").view(N, P_, 3, H, D)
+        o2 = Fn.AttnFn.apply(qf[:, :, 0], kvf[:, :, 1], kvf[:, :, 2]).reshape(N * T1, h)
+        hcur = Fn.AddFn.apply(hcur, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
+        y2 = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
+        m = Fn.MlpFn.apply(y2, anchor, st, b + "mlp.fc1.weight", b + "mlp.fc1.bias", b + "mlp.fc2.weight",
+                           b + "mlp.fc2.bias", L.ACT_GELU_TANH)
+        return Fn.AddFn.apply(hcur, m)
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor, drop_ids: Optional[torch.Tensor] = None,
-                train: Optional[bool] = None):
+                train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None):
         """x (N,T,A) noisy actions, t (N,) timesteps, z (N,1,token) conditions -> eps_hat (N,T,A).
         ``drop_ids`` (N,) bool/uint8: classifier-free-guidance token drop (drawn by the caller in train mode)."""
         from .... import kernels as K
@@ -118,17 +161,25 @@ class DiT(nn.Module):
         ze = Fn.LinearFn.apply(z2, anchor, st, p + "z_embedder.linear.weight", p + "z_embedder.linear.bias",
                                L.ACT_NONE, None)                                        # (N,h)
         hcur = Fn.DitAssembleFn.apply(xe, te, ze, anchor, st, p + "positional_embedding")   # (N,T+1,h)
-        for sp in self.block_specs:
-            sp.N, sp.T = N, T + 1
-            hcur = Fn.VitBlockFn.apply(hcur, anchor, st, sp)
+        if self.use_per_attn:
+            assert per_token is not None
+            pe = Fn.LinearFn.apply(per_token.float().contiguous(), anchor, st, p + "per_token_embedder.linear.weight",
+                                   p + "per_token_embedder.linear.bias", L.ACT_NONE, None)      # (N,P,h)
+            hcur = hcur.reshape(N * (T + 1), h)
+            for k in range(self.depth):
+                hcur = self._block_with_per_attn(st, k, hcur, pe, N, T + 1)
+        else:
+            for sp in self.block_specs:
+                sp.N, sp.T = N, T + 1
+                hcur = Fn.VitBlockFn.apply(hcur, anchor, st, sp)
         hcur = Fn.NormFn.apply(hcur.reshape(N * (T + 1), h), anchor, st, "ln", None, None, 1e-6)
         out = Fn.LinearFn.apply(hcur, anchor, st, p + "final_layer.linear.weight", p + "final_layer.linear.bias",
                                 L.ACT_NONE, None)
         return out.view(N, T + 1, A)[:, 1:, :]
 
-    def forward_with_cfg(self, x, t, z, cfg_scale=None):
+    def forward_with_cfg(self, x, t, z, cfg_scale=None, per_token=None):
         """dit.py:294-311: both halves of the batch are the FIRST half of x; returns the RAW network output
         for [cond; uncond] — the guidance mix eps = u + s (c - u) is fused into dxa_ddim_step
         (diffusion.SpacedDiffusion.ddim_sample_loop receives cfg_scale)."""
         half = x[: len(x) // 2]
-        return self.forward(torch.cat([half, half], dim=0), t, z)
+        return self.forward(torch.cat([half, half], dim=0), t, z, per_token=per_token)

@@ -1,0 +1,350 @@
+"""MemVLA policy: host-side mirror of dexbotic/model/memvla/memvla_arch.py on libdexbotic_amd kernels
+(SURVEY.md §8a row A12).
+
+= the CogACT path (vision tower, projector, splice, Qwen2 decoder, cognition token, DiT diffusion head) plus
+``BottleneckSE`` perceptual compression (:129-167), ``PerCogMemBank`` (:190-409: per-episode banks of perceptual and
+cognitive tokens, two ``CrossTransformerBlock`` retrieval layers over [bank ; timestep PE], ``GateFusion``, append +
+token-merge consolidation) and a DiT whose blocks also cross-attend to the perceptual tokens.  The bank is STATEFUL and
+order dependent exactly like the reference: the samples of a batch are walked in order, each retrieving from what the
+earlier frames of its episode left behind (detached).  That loop is host logic; every tensor op in it is a kernel.
+
+Deviation (also pinned in the goldens, oracle/memvla_oracle.py): the reference's retrieval blocks pass dropout 0.1 to
+F.scaled_dot_product_attention unconditionally — random even in eval.  Here the retrieval attention is deterministic
+(``retrieval_dropout`` = 0; a non-zero value raises).
+"""
+from __future__ import annotations
+
+import math
+from contextlib import contextmanager
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _lib as L
+from ... import functional as Fn
+from ... import kernels as K
+from ...engine import Fp32View, ParamStore
+from ..cogact.cogact_arch import CogActConfig, CogActModel, CogACTForCausalLM
+from ..dexbotic_arch import CausalLMOutputDexbotic
+
+BANK = "model.per_cog_mem_bank."
+
+
+class MemVLAConfig(CogActConfig):
+    model_type = "dexbotic_memvla"
+
+    def __init__(self, per_token_size: Optional[int] = None, dataloader_type: Optional[str] = None,
+                 group_size: Optional[int] = None, mem_length: Optional[int] = None, retrieval_layers: Optional[int] = None,
+                 use_timestep_pe: Optional[bool] = None, fusion_type: Optional[str] = None,
+                 consolidate_type: Optional[str] = None, update_fused: bool = True, retrieval_dropout: float = 0.0,
+                 **kwargs):
+        super().__init__(**kwargs)
+        self.per_token_size, self.dataloader_type, self.group_size = per_token_size, dataloader_type, group_size
+        self.mem_length, self.retrieval_layers, self.use_timestep_pe = mem_length, retrieval_layers, use_timestep_pe
+        self.fusion_type, self.consolidate_type, self.update_fused = fusion_type, consolidate_type, update_fused
+        self.retrieval_dropout = retrieval_dropout
+        if retrieval_dropout:
+            raise NotImplementedError("attention / FFN dropout inside the retrieval blocks is not reproduced")
+
+
+def _lin(st, x, wn, bn, act=L.ACT_NONE, wshape=None):
+    return Fn.LinearFn.apply(x, st.params[wn], st, wn, bn, act, wshape)
+
+
+class BottleneckSE(nn.Module):
+    """memvla_arch.py:129-167.  The 1x1 convolutions are token-wise linears ([out, in, 1, 1] weights used as [out, in])."""
+
+    def __init__(self, store: ParamStore, prefix: str, C_in: int, C_out: int, reduction: int = 16, hidden_ratio: float = 0.5):
+        super().__init__()
+        self.store, self.p, self.C_in, self.C_out = store, prefix, C_in, C_out
+        self.se, self.hm = max(1, C_in // reduction), max(1, int(C_in * hidden_ratio))
+        store.new_bucket()
+        store.register([(prefix + "excite.1.weight", (self.se, C_in, 1, 1)), (prefix + "excite.1.bias", (self.se,))])
+        store.register([(prefix + "excite.3.weight", (C_in, self.se, 1, 1)), (prefix + "excite.3.bias", (C_in,))])
+        store.register([(prefix + "reduce.0.weight", (self.hm, C_in, 1, 1)), (prefix + "reduce.0.bias", (self.hm,))])
+        store.register([(prefix + "reduce.2.weight", (C_out, self.hm, 1, 1)), (prefix + "reduce.2.bias", (C_out,))])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        st, p = self.store, self.p
+        B, N, C_ = x.shape
+        assert int(math.sqrt(N)) ** 2 == N, "Input feature has no spatial structure"
+        m = Fn.TokenMeanFn.apply(x)                                                              # [B,C]
+        g = _lin(st, m, p + "excite.1.weight", p + "excite.1.bias", L.ACT_RELU, (self.se, C_))
+        g = _lin(st, g, p + "excite.3.weight", p + "excite.3.bias", L.ACT_SIGMOID, (C_, self.se))
+        y = Fn.RowGateFn.apply(x, g).reshape(B * N, C_)
+        y = _lin(st, y, p + "reduce.0.weight", p + "reduce.0.bias", L.ACT_RELU, (self.hm, C_))
+        return _lin(st, y, p + "reduce.2.weight", p + "reduce.2.bias", L.ACT_NONE, (self.C_out, self.hm)).view(B, N, self.C_out)
+
+
+class CrossTransformerBlock(nn.Module):
+    """memvla_arch.py:84-127 (dropout 0): post-LN cross attention, 4 heads, GELU(erf) FFN"""
+
+    def __init__(self, store: ParamStore, prefix: str, feature_dim: int, num_heads: int = 4):
+        super().__init__()
+        assert feature_dim % num_heads == 0, "feature_dim % num_heads must be 0"
+        self.store, self.p, self.D, self.H = store, prefix, feature_dim, num_heads
+        D = feature_dim
+        for n in ("q_proj", "k_proj", "v_proj"):
+            store.register([(prefix + n + ".weight", (D, D)), (prefix + n + ".bias", (D,))])
+        store.register([(prefix + "attn_norm.weight", (D,)), (prefix + "attn_norm.bias", (D,))])
+        store.register([(prefix + "ffn.0.weight", (4 * D, D)), (prefix + "ffn.0.bias", (4 * D,))])
+        store.register([(prefix + "ffn.3.weight", (D, 4 * D)), (prefix + "ffn.3.bias", (D,))])
+        store.register([(prefix + "ffn_norm.weight", (D,)), (prefix + "ffn_norm.bias", (D,))])
+
+    def forward(self, query: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        st, p, D, H = self.store, self.p, self.D, self.H
+        B, N, _ = query.shape
+        M = k.shape[1]
+        hd = D // H
+        q2 = query.reshape(B * N, D)
+        qp = _lin(st, q2, p + "q_proj.weight", p + "q_proj.bias").view(B, N, H, hd)
+        kp = _lin(st, k.reshape(B * M, D), p + "k_proj.weight", p + "k_proj.bias").view(B, M, H, hd)
+        vp = _lin(st, v.reshape(B * M, D), p + "v_proj.weight", p + "v_proj.bias").view(B, M, H, hd)
+        o = Fn.AttnFn.apply(qp, kp, vp).reshape(B * N, D)
+        anchor = st.params[p + "attn_norm.weight"]
+        x = Fn.NormFn.apply(Fn.AddFn.apply(q2, o), anchor, st, "ln", p + "attn_norm.weight", p + "attn_norm.bias", 1e-5)
+        f = Fn.MlpFn.apply(x, anchor, st, p + "ffn.0.weight", p + "ffn.0.bias", p + "ffn.3.weight", p + "ffn.3.bias",
+                           L.ACT_GELU_ERF)
+        y = Fn.NormFn.apply(Fn.AddFn.apply(x, f), anchor, st, "ln", p + "ffn_norm.weight", p + "ffn_norm.bias", 1e-5)
+        return y.view(B, N, D)
+
+
+class PerCogMemBank(nn.Module):
+    """memvla_arch.py:190-444.  'group' training batches (banks cleared per batch, :330-333) and the single-episode
+    eval path; 'gate' fusion; 'tome' (token merge) or 'fifo' consolidation; timestep PE."""
+
+    def __init__(self, store: ParamStore, dataloader_type: str, group_size: int, per_token_size: int, cog_token_size: int,
+                 mem_length: int = 16, retrieval_layers: int = 2, use_timestep_pe: bool = True, fusion_type: str = "gate",
+                 consolidate_type: str = "tome", update_fused: bool = True):
+        super().__init__()
+        assert dataloader_type in ("stream", "group", "parallel_stream")
+        assert fusion_type in ("gate", "add") and consolidate_type in ("fifo", "tome")
+        if dataloader_type != "group":
+            raise NotImplementedError("native PerCogMemBank: the 'group' dataloader mode (the reference trainer's sampler)")
+        if not use_timestep_pe or fusion_type != "gate":
+            raise NotImplementedError("native PerCogMemBank: timestep PE + gate fusion (the reference defaults)")
+        self.store = store
+        self.roles = ("per", "cog")
+        self.dataloader_type, self.group_size, self.mem_length = dataloader_type, group_size, mem_length
+        self.retrieval_layers, self.consolidate_type, self.update_fused = retrieval_layers, consolidate_type, update_fused
+        self.token_dim = {"per": per_token_size, "cog": cog_token_size}
+        store.new_bucket()
+        self.blocks = {r: [CrossTransformerBlock(store, f"{BANK}retrieval_blocks.{r}.{i}.", self.token_dim[r])
+                           for i in range(retrieval_layers)] for r in self.roles}
+        for r in self.roles:
+            D = self.token_dim[r]
+            store.register([(f"{BANK}gate_fusion_blocks.{r}.proj.weight", (D, 2 * D)),
+                            (f"{BANK}gate_fusion_blocks.{r}.proj.bias", (D,))])
+        for r in self.roles:
+            D = self.token_dim[r]
+            store.register([(f"{BANK}timestep_embedders.{r}.mlp.0.weight", (D, 256)),
+                            (f"{BANK}timestep_embedders.{r}.mlp.0.bias", (D,))])
+            store.register([(f"{BANK}timestep_embedders.{r}.mlp.2.weight", (D, D)),
+                            (f"{BANK}timestep_embedders.{r}.mlp.2.bias", (D,))])
+        self._freqs = {}
+        self.reset()
+
+    def reset(self):
+        self.banks: Dict[str, Dict[tuple, List[Tuple[torch.Tensor, torch.Tensor]]]] = {r: {} for r in self.roles}
+
+    # ---- pieces -------------------------------------------------------------------------------------------
+    def _encode_time(self, role: str, t: torch.Tensor, dtype) -> torch.Tensor:
+        """TimestepEmbedder (:36-81): sinusoid(256) -> Linear -> SiLU -> Linear, in the compute dtype"""
+        st = self.store
+        key = str(t.device)
+        if key not in self._freqs:
+            self._freqs[key] = torch.exp(-math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128).to(t.device)
+        p = f"{BANK}timestep_embedders.{role}."
+        e = K.timestep_embedding(t.float().contiguous(), self._freqs[key]).to(dtype)
+        return Fn.MlpFn.apply(e, st.params[p + "mlp.0.weight"], st, p + "mlp.0.weight", p + "mlp.0.bias",
+                              p + "mlp.2.weight", p + "mlp.2.bias", L.ACT_SILU)
+
+    @torch.no_grad()
+    def _consolidate(self, role: str, eid, feat: torch.Tensor, timestep: torch.Tensor) -> None:
+        bank = self.banks[role].setdefault(eid, [])
+        bank.append((timestep, feat.detach().clone()))
+        while len(bank) > self.mem_length:
+            if self.consolidate_type == "fifo":
+                del bank[:-self.mem_length]
+                break
+            # token merge (:263-287): fuse the most similar pair of neighbouring entries.  Bookkeeping on detached
+            # features; the similarity decision needs a host value, as in the reference (.item()).
+            sims = []
+            for i in range(len(bank) - 1):
+                f1, f2 = bank[i][1].float(), bank[i + 1][1].float()
+                f1 = f1.flatten(1) if f1.dim() > 1 else f1.unsqueeze(0)
+                f2 = f2.flatten(1) if f2.dim() > 1 else f2.unsqueeze(0)
+                sims.append(F.cosine_similarity(f1, f2, dim=1).mean().item())
+            j = int(np.argmax(np.array(sims)))
+            (ti, fi), (tj, fj) = bank[j], bank[j + 1]
+            bank[j] = (0.5 * (ti + tj), K.axpby(fi.contiguous(), fj.contiguous(), 0.5, 0.5))
+            bank.pop(j + 1)
+
+    def _process_batch(self, role: str, tokens: torch.Tensor, episode_ids, timesteps) -> torch.Tensor:
+        st = self.store
+        B, N, D = tokens.shape
+        if self.training:
+            self.banks[role].clear()                                   # 'group' (:330-333)
+        else:
+            episode_ids = [(0, 0) for _ in range(B)]
+        gp = f"{BANK}gate_fusion_blocks.{role}."
+        outs = []
+        for i in range(B):
+            eid = tuple(episode_ids[i])
+            working = tokens[i:i + 1].contiguous()                      # (1,N,D)
+            hist = self.banks[role].get(eid, [])
+            if hist:
+                mem = torch.stack([f for _, f in hist], 0).reshape(1, -1, D)
+                ht = torch.stack([t.float() for t, _ in hist], 0).to(tokens.device)
+                pe = self._encode_time(role, ht, tokens.dtype)          # (T,D)
+                pe = pe.unsqueeze(1).expand(-1, N, -1).reshape(1, -1, D)
+            else:
+                mem = working
+                pe = self._encode_time(role, timesteps[i].reshape(1).to(tokens.device), tokens.dtype)
+                pe = pe.unsqueeze(1).expand(-1, N, -1).reshape(1, -1, D)
+            key = Fn.AddFn.apply(mem.contiguous(), pe.contiguous())
+            q = working
+            for blk in self.blocks[role]:
+                q = blk(q, key, mem)
+            w2, q2 = working.reshape(N, D), q.reshape(N, D)
+            scale = _lin(st, torch.cat([w2, q2], dim=-1), gp + "proj.weight", gp + "proj.bias", L.ACT_SIGMOID)
+            fused = Fn.GateFuseFn.apply(scale, w2, q2).view(1, N, D)
+            outs.append(fused)
+            self._consolidate(role, eid, fused[0] if self.update_fused else tokens[i], timesteps[i])
+        return torch.cat(outs, dim=0)
+
+    def process_batch_per(self, per_tokens, episode_ids, timesteps):
+        return self._process_batch("per", per_tokens, episode_ids, timesteps)
+
+    def process_batch_cog(self, cog_tokens, episode_ids, timesteps):
+        return self._process_batch("cog", cog_tokens, episode_ids, timesteps)
+
+
+class MemVLAModel(CogActModel):
+    def __init__(self, config: MemVLAConfig, store: ParamStore):
+        # same registration order as the forward: tower, projector, decoder (CogActModel) then the memory modules;
+        # the action head is built last by CogActModel.__init__ through build_action_model(config with per_token_size)
+        action_type = config.action_model_type
+        config.action_model_type = None
+        CogActModel.__init__(self, config, store)
+        config.action_model_type = action_type
+        self.per_compr = None
+        self.per_cog_mem_bank = None
+        if getattr(config, "per_token_size", None) is not None:
+            self.per_compr = BottleneckSE(store, "model.per_compr.", config.hidden_size, config.per_token_size)
+        need = ["dataloader_type", "group_size", "mem_length", "retrieval_layers", "use_timestep_pe", "fusion_type",
+                "consolidate_type", "per_token_size"]
+        if all(getattr(config, k, None) is not None for k in need):
+            self.per_cog_mem_bank = PerCogMemBank(
+                store, config.dataloader_type, config.group_size, config.per_token_size, config.hidden_size,
+                config.mem_length, config.retrieval_layers, config.use_timestep_pe, config.fusion_type,
+                config.consolidate_type, getattr(config, "update_fused", True))
+        if action_type is not None:
+            self.action_head = self._build_action_head_module(config)
+
+
+class MemVLAForCausalLM(CogACTForCausalLM):
+    config_class = MemVLAConfig
+
+    def _real_init(self, config: MemVLAConfig):
+        self.model = MemVLAModel(config, self.store)
+        self.store.new_bucket()
+        self.store.register([("lm_head.weight", (config.vocab_size, config.hidden_size))])
+        self.cur_timestep = 0          # inference
+
+    def unused_parameter_names(self) -> List[str]:
+        names = ["lm_head.weight"] + self.model.mm_vision_tower.unused_parameter_names()
+        return names
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        if self.model.per_cog_mem_bank is not None:
+            self.model.per_cog_mem_bank.train(mode)
+        return self
+
+    def _vlm(self, input_ids, attention_mask, images):
+        """prefill -> (last hidden state [B,S,d], projector output = vision_proj_feats [B, V*N_v, d])"""
+        feats = {}
+
+        def hook(_, __, out):
+            feats["vision_proj"] = out
+        h = self.model.mm_projector.register_forward_hook(hook)
+        try:
+            (_, _, attention_mask, _, inputs_embeds, _, _) = self.model._prepare_inputs_labels_for_multimodal(
+                input_ids, None, attention_mask, None, None, None, images)
+        finally:
+            h.remove()
+        return self.model.run_llm(inputs_embeds, attention_mask), feats["vision_proj"], attention_mask
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                return_dict=None, cache_position=None, actions=None, states=None, repeated_diffusion_steps: int = 4,
+                indexes=None, **kwargs) -> CausalLMOutputDexbotic:
+        """memvla_arch.py:546-664.  kwargs ``noise`` / ``timesteps`` / ``drop_ids`` inject the diffusion draws."""
+        hidden, vision_proj, attention_mask = self._vlm(input_ids, attention_mask, images)
+        B, S, d = hidden.shape
+        loss = None
+        if attention_mask is not None and actions is not None:
+            plan = self.model._last_plan
+            idx = torch.from_numpy(np.arange(B, dtype=np.int64) * S + plan.last_index).to(hidden.device)
+            cog = Fn.GatherRowsFn.apply(hidden.reshape(B * S, d), idx).to(hidden.dtype).view(B, 1, d)
+            per = self.model.per_compr(vision_proj.reshape(B, -1, d))
+            eids = [tuple(int(v) for v in item[:2]) for item in indexes]
+            ts = [torch.tensor(float(item[2]), device=hidden.device) for item in indexes]
+            bank = self.model.per_cog_mem_bank
+            cog = bank.process_batch_cog(cog, eids, ts)
+            per = bank.process_batch_per(per, eids, ts)
+            A, T = self.config.action_dim, self.config.chunk_size
+            acts = actions.reshape(actions.size(0), -1, A).float()[:, :T, :]
+            R = repeated_diffusion_steps
+            loss = self.model.action_head_module.loss(
+                acts.repeat(R, 1, 1), cog.float().repeat(R, 1, 1), per_token=per.float().repeat(R, 1, 1),
+                noise=kwargs.get("noise"), timestep=kwargs.get("timesteps"), drop_ids=kwargs.get("drop_ids"))
+        return CausalLMOutputDexbotic(loss=loss, logits=hidden, hidden_states=(hidden,))
+
+    @torch.no_grad()
+    def inference_action(self, input_ids, image_tensor, episode_first_frame, inference_args={}, **kwargs):
+        """memvla_arch.py:666-746: one frame of a running episode ('True' on the first frame resets the memory)"""
+        cfg_scale = inference_args.get("cfg_scale", 1.5)
+        num_ddim_steps = inference_args.get("num_ddim_steps", 10)
+        action_norms = inference_args.get("action_norms")
+        assert episode_first_frame in ("True", "False"), "episode_first_frame must be 'True' or 'False'"
+        bank = self.model.per_cog_mem_bank
+        if episode_first_frame == "True":
+            bank.reset()
+            self.cur_timestep = 0
+        dev = self.store.device
+        hidden, vision_proj, _ = self._vlm(input_ids, None, image_tensor.to(device=dev, dtype=self.store.compute_dtype))
+        B, d = hidden.shape[0], hidden.shape[-1]
+        cog = hidden[:, -1, :].unsqueeze(1).contiguous()
+        per = self.model.per_compr(vision_proj.reshape(B, -1, d))
+        ts = [torch.tensor(float(self.cur_timestep), device=dev)]
+        self.cur_timestep += 1
+        cog = bank.process_batch_cog(cog, [(0, 0)], ts)
+        per = bank.process_batch_per(per, [(0, 0)], ts)
+        head = self.model.action_head
+        noise = kwargs.get("noise")
+        if noise is None:
+            noise = torch.randn(B, self.config.chunk_size, self.config.action_dim, device=dev, dtype=torch.float32)
+        noise = noise.to(device=dev, dtype=torch.float32)
+        if head.ddim_diffusion is None or head.ddim_diffusion.num_timesteps != num_ddim_steps:
+            head.create_ddim(ddim_step=num_ddim_steps)
+        cogf = cog.float()
+        if cfg_scale > 1.0:
+            noise = torch.cat([noise, noise], 0)
+            unc = self.store.w32("model.action_head.net.z_embedder.uncondition")
+            z = torch.cat([cogf, unc.unsqueeze(0).expand(B, 1, -1)], 0)
+            model_kwargs = dict(z=z, cfg_scale=cfg_scale)
+            sample_fn = head.net.forward_with_cfg
+        else:
+            model_kwargs = dict(z=cogf)
+            sample_fn = head.net.forward
+        model_kwargs["per_token"] = per.float().repeat(2, 1, 1)
+        samples = head.ddim_diffusion.ddim_sample_loop(sample_fn, noise.shape, noise, clip_denoised=False,
+                                                       model_kwargs=model_kwargs, eta=0.0, device=dev)
+        if cfg_scale > 1.0:
+            samples = samples[:B]
+        return self._denorm(samples[0].cpu().numpy(), action_norms).tolist()

@@ -37,7 +37,8 @@ enum dxa_act {
   DXA_ACT_GELU_TANH = 2,  /* nn.GELU("tanh")      — cogact/action_model/dit.py:151         */
   DXA_ACT_QUICK_GELU = 3, /* x*sigmoid(1.702x)    — HF:clip/modeling_clip.py (CLIPMLP)     */
   DXA_ACT_SILU = 4,       /* x*sigmoid(x)         — HF:qwen2/modeling_qwen2.py:35-48, dit.py:30 */
-  DXA_ACT_RELU = 5
+  DXA_ACT_RELU = 5,       /* nn.ReLU              — memvla_arch.py:139-155 (BottleneckSE)            */
+  DXA_ACT_SIGMOID = 6     /* torch.sigmoid        — memvla_arch.py:143,178 (SE gate, GateFusion)     */
 };
 /* operand layouts of dxa_gemm: which operand has the contraction index contiguous in memory */
 enum dxa_layout {
@@ -175,6 +176,11 @@ int dxa_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, in
 int dxa_glu_fwd(const void* gu, void* out, int64_t rows, int64_t F, int act, int dtype, dxa_stream_t stream);
 int dxa_glu_bwd(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, int act, int dtype,
                 dxa_stream_t stream);
+/* out = alpha*a + beta*b, out = a*b, out[r, n, :] = x[r, n, :] * g[r, :] — the residual / gating arithmetic of the
+ * MemVLA memory modules (memvla_arch.py:160-187: SE channel gate, GateFusion lerp) */
+int dxa_axpby(const void* a, const void* b, void* out, int64_t n, float alpha, float beta, int dtype, dxa_stream_t stream);
+int dxa_mul(const void* a, const void* b, void* out, int64_t n, int dtype, dxa_stream_t stream);
+int dxa_mul_rows(const void* x, const void* g, void* out, int64_t R, int64_t Nn, int64_t C, int dtype, dxa_stream_t stream);
 int dxa_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, dxa_stream_t stream);
 int dxa_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int act, int dtype, dxa_stream_t stream);
 /* out = a + b (same dtype) */

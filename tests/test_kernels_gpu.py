@@ -40,7 +40,7 @@ def tol_for(dtype, K_=1):
     return 2e-5, 6e-6 * math.sqrt(max(K_, 1))
 
 
-ACTS = {0: lambda x: x, 1: lambda x: F.gelu(x), 2: lambda x: F.gelu(x, approximate="tanh"),
+ACTS = {6: lambda x: torch.sigmoid(x), 0: lambda x: x, 1: lambda x: F.gelu(x), 2: lambda x: F.gelu(x, approximate="tanh"),
         3: lambda x: x * torch.sigmoid(1.702 * x), 4: F.silu, 5: F.relu}
 
 
@@ -409,7 +409,7 @@ def test_swiglu_and_acts(dtype):
         assert_close(K.glu_fwd(gu, act), ref2, rtol, atol, f"glu fwd {act}")
         ref2.backward(dout.double())
         assert_close(K.glu_bwd(gu, dout, act), g2.grad, rtol, atol, f"glu bwd {act}")
-    for act in (1, 2, 3, 4, 5):
+    for act in (1, 2, 3, 4, 5, 6):
         x = rnd(rows, Fd, dtype=dtype, seed=62)
         xr = x.double().requires_grad_(True)
         yr = ACTS[act](xr)
@@ -418,6 +418,10 @@ def test_swiglu_and_acts(dtype):
         assert_close(K.act_bwd(x, dout, act), xr.grad, rtol, atol, f"act bwd {act}")
     a, b = rnd(5, 70, dtype=dtype, seed=63), rnd(5, 70, dtype=dtype, seed=64)
     assert_close(K.add(a, b), a.double() + b.double(), rtol, atol, "add")
+    assert_close(K.axpby(a, b, 0.5, -2.0), 0.5 * a.double() - 2.0 * b.double(), rtol, atol, "axpby")
+    assert_close(K.mul(a, b), a.double() * b.double(), rtol, atol, "mul")
+    x3, g2 = rnd(3, 11, 70, dtype=dtype, seed=66), rnd(3, 70, dtype=dtype, seed=67)
+    assert_close(K.mul_rows(x3, g2), x3.double() * g2.double()[:, None, :], rtol, atol, "mul_rows")
     c = K.cast(rnd(33, 12, seed=65), torch.bfloat16)
     assert torch.equal(c, rnd(33, 12, seed=65).to(torch.bfloat16))
 

@@ -1,0 +1,81 @@
+"""Row A12 on the GPU: the native MemVLA policy (CogACT path + BottleneckSE + stateful perceptual/cognitive memory bank
++ per-attention DiT) against golden vectors from the reference MemVLAForCausalLM (tests/golden/memvla_t1.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cogact_oracle as O
+from oracle import memvla_oracle as M
+from oracle.weights import make_weights, weights_crc
+
+from .helpers import product_config, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP32_TOL = 1e-3
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+def build(golden_dir, dtype, train):
+    from dexbotic_amd.model.memvla.memvla_arch import MemVLAConfig, MemVLAForCausalLM
+    g = np.load(os.path.join(golden_dir, "memvla_t1.npz"), allow_pickle=False)
+    cfg = O.OracleConfig()
+    w = make_weights(M.memvla_shapes(cfg, int(g["per_token_size"])), int(g["seed"]))
+    assert weights_crc(w) == int(g["weights_crc"])
+    base = product_config(cfg, dtype)
+    mc = MemVLAConfig(llm_config=base.llm_config, mm_vision_tower=base.mm_vision_tower, mm_projector_type="mlp2x_gelu",
+                      action_model_type="DiT-T", action_dim=cfg.action_dim, chunk_size=cfg.chunk_size,
+                      compute_dtype=dtype, per_token_size=int(g["per_token_size"]), dataloader_type="group", group_size=3,
+                      mem_length=int(g["mem_length"]), retrieval_layers=2, use_timestep_pe=True, fusion_type="gate",
+                      consolidate_type="tome")
+    m = MemVLAForCausalLM(mc, device=DEV, train=train)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in w.items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return g, cfg, m
+
+
+def test_fp32_memvla_training_step_matches_reference(golden_dir):
+    g, cfg, m = build(golden_dir, "float32", True)
+    m.train()
+    st = m.store
+    st.set_expected(m.unused_parameter_names())
+    st.begin_step()
+    out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]), actions=T(g["actions"]),
+            indexes=[list(map(int, r)) for r in g["indexes"]], noise=T(g["noise"]), timesteps=T(g["timesteps"]),
+            drop_ids=T(g["drop_u"]) < 0.1)
+    assert abs(out.loss.item() - float(g["loss"])) < FP32_TOL * abs(float(g["loss"]))
+    out.loss.backward()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel_err(st.g(key[5:]).cpu().numpy(), g[key]) < FP32_TOL, key
+        elif key.startswith("gradN/"):
+            gn = float(g[key])
+            assert st.grad_written[key[6:]], key
+            assert abs(st.g(key[6:]).double().norm().item() - gn) < FP32_TOL * gn + 1e-6 * float(g["grad_norm"]), key
+
+
+def test_fp32_memvla_inference_episode_matches_reference(golden_dir):
+    g, cfg, m = build(golden_dir, "float32", False)
+    m.eval()
+    norms = {"min": [-1.0] * cfg.action_dim, "max": [1.0] * cfg.action_dim}
+    for f in range(g["infer_frames"].shape[0]):
+        acts = m.inference_action(T(g["infer_prompt"]), T(g["infer_frames"][f:f + 1]), "True" if f == 0 else "False",
+                                  {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms}, noise=T(g["infer_inits"][f]))
+        assert rel_err(np.array(acts), g["infer_actions"][f]) < FP32_TOL, f
+
+
+def test_bf16_memvla_step_runs_and_tracks(golden_dir):
+    g, cfg, m = build(golden_dir, "bfloat16", True)
+    m.train()
+    m.store.set_expected(m.unused_parameter_names())
+    m.store.begin_step()
+    out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]), actions=T(g["actions"]),
+            indexes=[list(map(int, r)) for r in g["indexes"]], noise=T(g["noise"]), timesteps=T(g["timesteps"]),
+            drop_ids=T(g["drop_u"]) < 0.1)
+    assert abs(out.loss.item() - float(g["loss"])) < 5e-2 * abs(float(g["loss"]))
+    out.loss.backward()
