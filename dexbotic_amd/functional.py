@@ -38,13 +38,22 @@ def _use_nt(st: ParamStore, names) -> bool:
     return bool(getattr(st, "has_wt", False)) and _names(names) in st.wt_index
 
 
+def _f32_nt(dy2d: torch.Tensor) -> bool:
+    """fp32 products of the action head (>= 128 rows): the tiled kernel's k-contiguous (NT) staging is ~1.5-2.5x faster
+    than its k-strided NN / TN staging (scripts/gemm_f32_bench.py), so transposing a small operand first pays"""
+    return dy2d.dtype == torch.float32 and dy2d.shape[0] >= 128 and dy2d.shape[1] >= 128
+
+
 def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor:
     """dX = dY W for W = fused view over `names` of shape wshape = (out, in)"""
     names = _names(names)
     if _use_nt(st, names):
         st.wait_transposed()
         return K.mm_nt(dy2d, st.wt(*names, shape=(wshape[1], wshape[0])), **kw)
-    return K.mm_nn(dy2d, st.w(*names, shape=tuple(wshape)), **kw)
+    W = st.w(*names, shape=tuple(wshape))
+    if _f32_nt(dy2d):
+        return K.mm_nt(dy2d, K.transpose(W, 1), **kw)
+    return K.mm_nn(dy2d, W, **kw)
 
 
 def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) -> None:
@@ -57,6 +66,8 @@ def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) 
     out = st.g(*names, shape=shape)
     if _use_nt(st, names) and dy2d.dtype == torch.bfloat16:
         K.mm_nt(K.transpose(dy2d, KPAD), K.transpose(x2d, KPAD), out=out, accumulate=st.accum_flag(*names))
+    elif _f32_nt(dy2d) and x2d.dtype == torch.float32:
+        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names))
     else:
         K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names))
     st.mark_written(*names)
