@@ -349,6 +349,7 @@ template <int D> struct FlashTile {
   static constexpr int NCH = D / 8;             // 16-byte chunks per row
   static constexpr int ROW = D * 2;             // bytes per row
   static constexpr int RM_BYTES = 64 * ROW;
+  static constexpr int SWZ = (NCH < 16 ? NCH : 16) - 1;   // chunk ^= row & SWZ (16 rows x 16-byte chunks span the 64 banks)
   static constexpr int RPI = 256 / NCH;         // rows covered by one pass of the 256 threads
   static constexpr int NPASS = 64 / RPI;        // 16-byte loads per thread per tile
 };
@@ -377,7 +378,7 @@ __device__ __forceinline__ void tile_sstore(char* dst, const tile_reg_t (&reg)[F
 #pragma unroll
   for (int i = 0; i < FT::NPASS; ++i) {
     const int r = r0 + FT::RPI * i;
-    *reinterpret_cast<tile_reg_t*>(d0 + FT::RPI * i * FT::ROW + ((c ^ (r & (FT::NCH - 1))) << 4)) = reg[i];
+    *reinterpret_cast<tile_reg_t*>(d0 + FT::RPI * i * FT::ROW + ((c ^ (r & FT::SWZ)) << 4)) = reg[i];
   }
 }
 // Per-lane byte offsets into a swizzled row-major tile, split so that everything that varies inside the MFMA
@@ -388,10 +389,10 @@ template <int D> struct FragAddr {
   using FT = FlashTile<D>;
   uint32_t row[D / 32], col[D / 16];
   __device__ __forceinline__ FragAddr(int l16, int lg) {
-    const int xr = l16 & (FT::NCH - 1);
+    const int xr = l16 & FT::SWZ;
 #pragma unroll
     for (int ds = 0; ds < D / 32; ++ds) row[ds] = l16 * FT::ROW + ((((ds ^ (xr >> 2)) << 2) | (lg ^ (xr & 3))) << 4);
-    const int rl = 4 * lg + (l16 >> 2), xc = rl & (FT::NCH - 1), b = (l16 & 3) >> 1;
+    const int rl = 4 * lg + (l16 >> 2), xc = rl & FT::SWZ, b = (l16 & 3) >> 1;
 #pragma unroll
     for (int di = 0; di < D / 16; ++di)
       col[di] = rl * FT::ROW + ((((di ^ (xc >> 1)) << 1) | (b ^ (xc & 1))) << 4) + (l16 & 1) * 8;
@@ -468,7 +469,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
   const int coff = p.Sk - p.Sq;
   int blk_hi = j_hi;
   if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
-  const int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;
+  int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;
+  if (p.q_limit) my_hi = min(my_hi, qi < p.Sq ? p.q_limit[(int64_t)b * p.Sq + qi] : 0);   // block-prefix mask (pi0)
+  const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
   const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
   tile_reg_t rk[FT::NPASS], rv[FT::NPASS];
   if (t_lo < t_hi) {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int key = key0 + 16 * n + 4 * lg + rr;
-        const bool vis = key >= j_lo && key < my_hi;
+        const bool vis = key >= j_lo && key < my_hi && (!kvld || kvld[key]);
         const float pr = vis ? __builtin_amdgcn_exp2f(s[rr] * sc2 - lse2) : 0.f;
         dsv[rr] = pr * (dp[rr] - dlt) * p.scale;
       }
@@ -533,10 +536,10 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
   using FT = FlashTile<D>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES];
-  __shared__ __attribute__((aligned(16))) float stat[2][64];      // lse and delta of the staged queries
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 tiles + 3 x 64 floats (65 KiB at D = 256)
   char* Qs = smem;
   char* Os = smem + FT::RM_BYTES;
+  float (*stat)[64] = reinterpret_cast<float (*)[64]>(smem + 2 * FT::RM_BYTES);   // lse*log2e, delta, per-query key limit
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
   const FragAddr<D> fa(l16, lg);
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
   j_lo = max(j_lo, 0);
   j_hi = min(j_hi, p.Sk);
   const int coff = p.Sk - p.Sq;
-  const bool key_ok = key >= j_lo && key < j_hi;
+  const bool key_ok = key >= j_lo && key < j_hi && (!p.key_valid || (key < p.Sk && p.key_valid[(int64_t)b * p.Sk + key]));
   const float sc2 = p.scale * LOG2E;
   // queries that can see any key of this workgroup: q >= key0 - coff (causal)
   const int qt_lo = p.causal ? max(0, key0 - coff) / 64 : 0;
@@ -584,17 +587,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
       const float* src = (tid < 64 ? p.lse : bp.delta) + ((int64_t)b * p.Hq + h) * p.Sq;
       rs = q < p.Sq ? src[q] : 0.f;
       if (tid < 64) rs *= LOG2E;
+    } else if (tid < 192) {                // keys j < limit are visible to query q (INT_MAX without the mask)
+      const int q = q0 + (tid & 63);
+      rs = (p.q_limit && q < p.Sq) ? (float)p.q_limit[(int64_t)b * p.Sq + q] : 3.0e9f;
     }
   };
-  if (total > 0) gload(0);
+  constexpr bool PREFETCH = D <= 128;     // at D = 256 the accumulators leave no room for a second tile in registers
+  if (PREFETCH && total > 0) gload(0);
   for (int it = 0; it < total; ++it) {
     const int q0 = (qt_lo + it % nqt) * 64;
     __syncthreads();                       // previous tile fully consumed
+    if (!PREFETCH) gload(it);
     tile_sstore<D>(Qs, rq, tid);
     tile_sstore<D>(Os, ro, tid);
-    if (tid < 128) stat[tid >> 6][tid & 63] = rs;
+    if (tid < 192) stat[tid >> 6][tid & 63] = rs;
     __syncthreads();
-    if (it + 1 < total) gload(it + 1);     // next tile's loads fly during this tile's MFMAs
+    if (PREFETCH && it + 1 < total) gload(it + 1);     // next tile's loads fly during this tile's MFMAs
     uint32_t pp[8], dsp[8];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -610,12 +618,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
       const int ql = 16 * n + 4 * lg;
       const float4 lse4 = *reinterpret_cast<const float4*>(&stat[0][ql]);
       const float4 dl4 = *reinterpret_cast<const float4*>(&stat[1][ql]);
+      const float4 lm4 = *reinterpret_cast<const float4*>(&stat[2][ql]);
       const float lse[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+      const float lim[4] = {lm4.x, lm4.y, lm4.z, lm4.w};
       float pv[4], dsv[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int q = q0 + ql + rr;
-        const bool vis = key_ok && q < p.Sq && (!p.causal || key <= q + coff);
+        const bool vis = key_ok && q < p.Sq && (!p.causal || key <= q + coff) && (float)key < lim[rr];
         pv[rr] = vis ? __builtin_amdgcn_exp2f(s[rr] * sc2 - lse[rr]) : 0.f;      // stat[0] holds lse * log2(e)
         dsv[rr] = pv[rr] * (dp[rr] - dl[rr]) * p.scale;
       }
@@ -722,7 +732,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
 static bool bwd_flash_ok(const dxa_attn_desc* d) {
   auto s8 = [](int64_t a, int64_t b, int64_t c) { return a % 8 == 0 && b % 8 == 0 && c % 8 == 0; };
   auto s4 = [](int64_t a, int64_t b, int64_t c) { return a % 4 == 0 && b % 4 == 0 && c % 4 == 0; };
-  return !d->force_generic && !d->q_limit && !d->key_valid && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128) && d->B <= 65535 && d->Hq <= 65535 &&
+  return !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && d->B <= 65535 && d->Hq <= 65535 &&
          s8(d->q_sb, d->q_sh, d->q_ss) && s8(d->k_sb, d->k_sh, d->k_ss) && s8(d->v_sb, d->v_sh, d->v_ss) &&
          s8(d->do_sb, d->do_sh, d->do_ss) && s4(d->o_sb, d->o_sh, d->o_ss) && s4(d->dq_sb, d->dq_sh, d->dq_ss) &&
          s4(d->dk_sb, d->dk_sh, d->dk_ss) && s4(d->dv_sb, d->dv_sh, d->dv_ss) && al(d->q, 16) && al(d->k, 16) &&
@@ -754,13 +764,20 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
     dim3 gq((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
     dim3 gk((unsigned)((d->Sk + 63) / 64), (unsigned)d->Hkv, (unsigned)d->B);
-    if (d->D == 128) {
-      hipLaunchKernelGGL((attn_bwd_dq_k<128>), gq, dim3(256), 0, st, bp);
-      hipLaunchKernelGGL((attn_bwd_dkv_k<128>), gk, dim3(256), 0, st, bp);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_k<64>), gq, dim3(256), 0, st, bp);
-      hipLaunchKernelGGL((attn_bwd_dkv_k<64>), gk, dim3(256), 0, st, bp);
-    }
+#define LAUNCH_BWD(D_)                                                                                           \
+  do {                                                                                                            \
+    constexpr int lds_ = 2 * FlashTile<D_>::RM_BYTES + 3 * 64 * (int)sizeof(float);                               \
+    static bool attr_ = false;                                                                                    \
+    if (!attr_ && lds_ > 48 * 1024) {                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k<D_>),                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                \
+      attr_ = true;                                                                                               \
+    }                                                                                                             \
+    hipLaunchKernelGGL((attn_bwd_dq_k<D_>), gq, dim3(256), 0, st, bp);                                            \
+    hipLaunchKernelGGL((attn_bwd_dkv_k<D_>), gk, dim3(256), lds_, st, bp);                                        \
+  } while (0)
+    if (d->D == 256) LAUNCH_BWD(256); else if (d->D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(64);
+#undef LAUNCH_BWD
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
