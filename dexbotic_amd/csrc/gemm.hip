@@ -47,6 +47,7 @@ struct GemmP {
   int vecA, vecB, vecC, vecR, vecG, vecBias;
   // ring kernel, split-K tail: tiles [0, full) run whole; the last tail_r tiles are cut into split_s K-ranges
   int full, tail_r, split_s;
+  int group_m;  // ring kernel: row-tiles per group of the tile order
   float* ws;    // fp32 partial accumulators, tail_r * (split_s - 1) slots of 256x256
   int* flags;   // per tail tile arrival counter (self-resetting)
 };
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     split_s = p.split_s;
     bid = p.full + tail_i;
   }
-  constexpr int GROUP_M = 4;
+  const int GROUP_M = p.group_m;
   const int width = GROUP_M * p.tn;
   const int group = bid / width;
   const int first_pm = group * GROUP_M;
@@ -856,6 +857,8 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     p.tn = dxa_cdiv(d->N, 256);
     const int nt = p.tm * p.tn, nk_tot = (int)(d->K / 32);
     p.full = nt; p.tail_r = 0; p.split_s = 1;
+    static const int group_m = getenv("DXA_GEMM_GROUP_M") ? atoi(getenv("DXA_GEMM_GROUP_M")) : 4;
+    p.group_m = group_m;
     static const bool split_off = getenv("DXA_GEMM_NO_SPLIT") != nullptr;
     const int tail = nt % NUM_CU;
     if (!split_off && tail > 0) {
