@@ -339,14 +339,18 @@ class FusedAdamW:
         wds = [c.weight_decay if dec else 0.0 for _, dec in self.group_keys]
         return lrs, wds
 
-    def step(self, lr_scale: float = 1.0) -> None:
+    def step(self, lr_scale: float = 1.0, sumsq: Optional[torch.Tensor] = None) -> None:
+        """``sumsq``: device scalar holding sum(g^2) over the arena if someone already accumulated it (GradNormTracker
+        does, bucket by bucket under the backward); otherwise one pass over the gradient arena computes it here."""
         from . import kernels as K
         st, c = self.store, self.cfg
         self.step_count += 1
         clip = None
         if c.max_grad_norm is not None:
-            K.sumsq(st.grad, self.sumsq, self.scratch)
-            K.clip_coef(self.sumsq, float(c.max_grad_norm), self.norm, self.coef)
+            if sumsq is None:
+                K.sumsq(st.grad, self.sumsq, self.scratch)
+                sumsq = self.sumsq
+            K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef)
             clip = self.coef
         lrs, wds = self._lrs_wds(lr_scale)
         K.adamw(st.master, st.grad, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
@@ -360,6 +364,75 @@ def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float
         return step / max(1, warmup_steps)
     prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+# --------------------------------------------------------------------------- overlapped gradient norm
+class GradNormTracker:
+    """sum(g^2) for the global-norm clip, accumulated bucket by bucket on a side HIP stream while the backward is
+    still running (the pass is HBM-bound, the backward MFMA-bound), instead of one 32 GB sweep in front of AdamW.
+    Buckets are folded in as they become final: straight from ``ParamStore.on_bucket_ready`` on one GPU, after the
+    bucket's all-reduce on the communication stream under data parallelism (``GradReducer.after_reduce``).  The
+    accumulation order is the (deterministic) bucket order; slots no kernel writes hold zeros and add nothing."""
+
+    def __init__(self, store: ParamStore, min_bytes: int = 256 << 20):
+        self.store = store
+        self.min_bytes = min_bytes
+        dev = store.device
+        self.acc = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.scratch = torch.empty(4096, device=dev, dtype=torch.float64)
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._lo: Optional[int] = None
+        self._hi: Optional[int] = None
+
+    def begin(self) -> None:
+        self.acc.zero_()                       # on the compute stream; every fold waits for that stream first
+        self._lo = self._hi = None
+
+    def fold(self, lo: int, hi: int, stream=None) -> None:
+        """acc += sum(grad[lo:hi]^2) on ``stream`` (default: the tracker's own side stream)"""
+        from . import kernels as K
+        if hi <= lo:
+            return
+        stream = stream or self.stream
+        if stream is None:
+            K.sumsq(self.store.grad[lo:hi], self.acc, self.scratch, accumulate=True)
+            return
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            K.sumsq(self.store.grad[lo:hi], self.acc, self.scratch, accumulate=True)
+
+    def bucket_ready(self, b: int) -> None:
+        lo, hi = self.store.bucket_ranges[b]
+        if hi <= lo:
+            return
+        if self._lo is None:
+            self._lo, self._hi = lo, hi
+        elif hi == self._lo or abs(self._lo - hi) < ALIGN:
+            self._lo = lo
+        elif lo == self._hi or abs(lo - self._hi) < ALIGN:
+            self._hi = hi
+        else:
+            self.fold(self._lo, self._hi)
+            self._lo, self._hi = lo, hi
+        if (self._hi - self._lo) * 4 >= self.min_bytes:
+            self.fold(self._lo, self._hi)
+            self._lo = self._hi = None
+
+    def finish(self, fire_unfired: bool = True) -> torch.Tensor:
+        """fold what is pending (and, on one GPU, the buckets an unused slot kept from firing), then make the compute
+        stream wait for the side stream; returns the device scalar"""
+        st = self.store
+        if fire_unfired:
+            for b in reversed(range(len(st.bucket_ranges))):
+                if not st._bucket_fired[b] and st._bucket_pending[b] < st._bucket_total[b]:
+                    st._bucket_fired[b] = True
+                    self.bucket_ready(b)
+        if self._lo is not None:
+            self.fold(self._lo, self._hi)
+            self._lo = self._hi = None
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return self.acc
 
 
 # ---------------------------------------------------------------------------------------- DP reducer
@@ -393,6 +466,7 @@ class GradReducer:
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
         self._handles: List = []
+        self.after_reduce = None    # callable(lo, hi, stream): runs on the communication stream once a slice is averaged
         self.bytes_reduced = 0
         skip = set(skip)
         # buckets whose every slot is skipped (never gets a gradient) are not communicated
@@ -423,6 +497,8 @@ class GradReducer:
                     K.cast(stage, torch.float32, out=buf)
                 else:
                     self.dist.all_reduce(buf, op=self.dist.ReduceOp.AVG, group=self.group)
+            if self.after_reduce is not None:
+                self.after_reduce(lo, hi, self.comm_stream)
         else:  # CPU / gloo: no AVG op
             if half:
                 stage = buf.to(torch.bfloat16)
@@ -431,6 +507,8 @@ class GradReducer:
             else:
                 self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
                 buf.div_(self.world)
+            if self.after_reduce is not None:
+                self.after_reduce(lo, hi, None)
 
     def bucket_ready(self, b: int) -> None:
         if b in self.skip_buckets:

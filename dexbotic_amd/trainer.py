@@ -13,7 +13,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .engine import FusedAdamW, GradReducer, OptimConfig, cosine_lr_scale
+from .engine import FusedAdamW, GradNormTracker, GradReducer, OptimConfig, cosine_lr_scale
 
 
 class NativeTrainer:
@@ -35,6 +35,12 @@ class NativeTrainer:
         if use_dist and (dist.get_world_size() > 1 or force_reducer):
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
                                        comm_dtype=grad_comm_dtype)
+        # global-norm clip: sum(g^2) is folded in bucket by bucket under the backward (after the all-reduce under DP)
+        self.norm_tracker = None
+        if self.cfg.max_grad_norm is not None and self.store.device.type == "cuda":
+            self.norm_tracker = GradNormTracker(self.store, min_bytes=min_bucket_bytes)
+            if self.reducer is not None:
+                self.reducer.after_reduce = lambda lo, hi, stream: self.norm_tracker.fold(lo, hi, stream)
         self.store.attach_grads()
         self._zeroed_unused = False
 
@@ -52,7 +58,15 @@ class NativeTrainer:
         else:
             self.store.begin_micro()
         # with accumulation, communication happens on the last micro-batch only (like DDP.no_sync)
-        self.store.on_bucket_ready = self.reducer.bucket_ready if (self.reducer is not None and last) else None
+        hook = None
+        if last:
+            if self.reducer is not None and (self.reducer.world > 1 or self.reducer.force):
+                hook = self.reducer.bucket_ready
+            elif self.norm_tracker is not None:
+                hook = self.norm_tracker.bucket_ready
+            if self.norm_tracker is not None:
+                self.norm_tracker.begin()
+        self.store.on_bucket_ready = hook
         out = self.model(**batch)
         loss = out.loss
         (loss / self.grad_accum if self.grad_accum > 1 else loss).backward()
@@ -63,8 +77,12 @@ class NativeTrainer:
                 for nm in self.store.never_written():
                     self.store.g(nm).zero_()
                 self._zeroed_unused = True
+            reducing = self.reducer is not None and (self.reducer.world > 1 or self.reducer.force)
             if self.reducer is not None:
                 self.reducer.finish()
-            self.opt.step(self.lr_scale())
+            sumsq = None
+            if self.norm_tracker is not None:
+                sumsq = self.norm_tracker.finish(fire_unfired=not reducing)
+            self.opt.step(self.lr_scale(), sumsq=sumsq)
             self.global_step += 1
         return loss.detach()
