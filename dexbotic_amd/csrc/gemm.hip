@@ -519,11 +519,14 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 //     32-row fragments (4 tile rows per 256-B bank row).
 // Requirements: K % 32 == 0, 16-byte aligned A/B rows, no batching, operands < 2 GiB.
 // =====================================================================================================
-template <typename TO>
+// AI = 32-row A blocks per wave: 4 -> 256-row tiles, 3 -> 192-row tiles (few-row products such as the B=1 prefill,
+// M = 543: 3 x 192 wastes 6% of the MFMA work, 3 x 256 wastes 29%).
+template <typename TO, int AI>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_ST = 256 * 64, STAGE = 2 * A_ST;   // 16 KiB + 16 KiB per slab
+  constexpr int BMR = AI * 64;                       // tile rows; A has BMR / 16 DMA pieces per slab
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -551,7 +554,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   const int gsz = min(p.tm - first_pm, GROUP_M);
   const int pm = first_pm + (bid % width) % gsz;
   const int pn = (bid % width) / gsz;
-  const int64_t m0 = (int64_t)pm * 256, n0 = (int64_t)pn * 256;
+  const int64_t m0 = (int64_t)pm * BMR, n0 = (int64_t)pn * 256;
+  const bool has_a = AI == 4 || wave < 6;              // 192-row tiles: waves 6,7 carry B pieces only
 
   const uint32_t bytesA = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2);
   const uint32_t bytesB = (uint32_t)(((p.N - 1) * p.ldb + p.K) * 2);
@@ -572,11 +576,12 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   const int nk = (int)((int64_t)(split_j + 1) * nk_tot / split_s) - k_lo;   // slabs of this workgroup
 #define DMA_A(slab, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + ((slab) & 3) * STAGE + (wave * 2 + (j)) * 1024), 16, offA[j], (k_lo + (slab)) * 64, 0, 0)
 #define DMA_B(slab, j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + ((slab) & 3) * STAGE + A_ST + (wave * 2 + (j)) * 1024), 16, offB[j], (k_lo + (slab)) * 64, 0, 0)
-#define DMA_SLAB(slab) do { DMA_A(slab, 0); DMA_A(slab, 1); DMA_B(slab, 0); DMA_B(slab, 1); } while (0)
+#define DMA_SLAB(slab) do { if (has_a) { DMA_A(slab, 0); DMA_A(slab, 1); } DMA_B(slab, 0); DMA_B(slab, 1); } while (0)
+#define WAIT_PREV_SLAB() do { if (has_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } while (0)
 
-  f32x16_t acc[4][2];
+  f32x16_t acc[AI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   if (nk > 1) DMA_SLAB(1);
   if (nk > 2) {
     DMA_SLAB(2);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    WAIT_PREV_SLAB();
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -595,11 +600,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   __builtin_amdgcn_sched_barrier(0);
 
   // fragment registers: R0 = k-step 0 of the current slab, R1 = k-step 1
-  u32x4_t a0[4], b0[2], a1[4], b1[2];
+  u32x4_t a0[AI], b0[2], a1[AI], b1[2];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int sw = (l32 >> 2) & 3;
-  const uint32_t abase0 = lds0 + (wm * 128 + l32) * 64 + (((0 + lh) ^ sw) << 4);
-  const uint32_t abase1 = lds0 + (wm * 128 + l32) * 64 + (((2 + lh) ^ sw) << 4);
+  const uint32_t abase0 = lds0 + (wm * (BMR / 2) + l32) * 64 + (((0 + lh) ^ sw) << 4);
+  const uint32_t abase1 = lds0 + (wm * (BMR / 2) + l32) * 64 + (((2 + lh) ^ sw) << 4);
   const uint32_t bbase0 = lds0 + A_ST + (wn * 64 + l32) * 64 + (((0 + lh) ^ sw) << 4);
   const uint32_t bbase1 = lds0 + A_ST + (wn * 64 + l32) * 64 + (((2 + lh) ^ sw) << 4);
 #if defined(DXA_ABL) && DXA_ABL == 3
@@ -610,7 +615,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #define RD_SET(A_, B_, abase, bbase, soff)                                                      \
   do {                                                                                          \
     const uint32_t ax_ = (abase) + (soff), bx_ = (bbase) + (soff);                              \
-    DS_READ(A_[0], ax_, 0); DS_READ(A_[1], ax_, 2048); DS_READ(A_[2], ax_, 4096); DS_READ(A_[3], ax_, 6144); \
+    DS_READ(A_[0], ax_, 0); DS_READ(A_[1], ax_, 2048); DS_READ(A_[2], ax_, 4096);          \
+    if constexpr (AI > 3) DS_READ(A_[3], ax_, 6144);                                            \
     DS_READ(B_[0], bx_, 0); DS_READ(B_[1], bx_, 2048);                                          \
   } while (0)
 #if defined(DXA_ABL) && DXA_ABL == 4
@@ -636,13 +642,13 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     SB();
     MFMA1(a0, b0, 1, 0); MFMA1(a0, b0, 1, 1);
     SB();
-    if (dma) { DMA_A(t + 3, 0); DMA_A(t + 3, 1); }
+    if (dma && has_a) { DMA_A(t + 3, 0); DMA_A(t + 3, 1); }
     SB();
     MFMA1(a0, b0, 2, 0); MFMA1(a0, b0, 2, 1);
     SB();
     if (dma) { DMA_B(t + 3, 0); DMA_B(t + 3, 1); }
     SB();
-    MFMA1(a0, b0, 3, 0); MFMA1(a0, b0, 3, 1);
+    if constexpr (AI > 3) { MFMA1(a0, b0, 3, 0); MFMA1(a0, b0, 3, 1); }
     SB();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SB();
@@ -652,9 +658,9 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     SB();
     MFMA1(a1, b1, 1, 0); MFMA1(a1, b1, 1, 1);
     MFMA1(a1, b1, 2, 0); MFMA1(a1, b1, 2, 1);
-    MFMA1(a1, b1, 3, 0); MFMA1(a1, b1, 3, 1);
+    if constexpr (AI > 3) { MFMA1(a1, b1, 3, 0); MFMA1(a1, b1, 3, 1); }
     SB();
-    if (dma) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my pieces of slab t+2 have landed
+    if (dma) WAIT_PREV_SLAB();                                   // my pieces of slab t+2 have landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if !(defined(DXA_ABL) && DXA_ABL == 2)
     __builtin_amdgcn_s_barrier();
@@ -664,6 +670,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #undef DMA_A
 #undef DMA_B
 #undef DMA_SLAB
+#undef WAIT_PREV_SLAB
 #undef DS_READ
 #undef RD_SET
 #undef MFMA1
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
       // agent-scope relaxed atomics write through the XCD-private L2, so no cache-wide write-back is needed
       float* dst = reinterpret_cast<float*>(slot0 + (size_t)split_j * 16384) + tid;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -697,7 +704,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     for (int sj = 0; sj < split_s - 1; ++sj) {
       const float* src = reinterpret_cast<const float*>(slot0 + (size_t)sj * 16384) + tid;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -734,15 +741,16 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int i = 2 * pass + ii;
+            if (i >= AI) continue;
             float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             *reinterpret_cast<float4*>(slab + (ii * 32 + l32) * ROWP + (j * 32 + 8 * q + 4 * lh) * 4) = v;
           }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
+      for (int it = 0; it < (AI == 3 && pass == 1 ? 8 : 16); ++it) {
         const int row = cr + 4 * it;
-        const int64_t m = m0 + wm * 128 + pass * 64 + row;
+        const int64_t m = m0 + wm * (BMR / 2) + pass * 64 + row;
         const float4 v = *reinterpret_cast<const float4*>(slab + row * ROWP + cc * 4);
         if (m < p.M && n_ok > 0) {
           const float a4[4] = {v.x, v.y, v.z, v.w};
@@ -755,8 +763,10 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
-template __global__ void gemm_nt_ring_kernel<bf16_t>(const GemmP);
-template __global__ void gemm_nt_ring_kernel<float>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<bf16_t, 4>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<float, 4>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<bf16_t, 3>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<float, 3>(const GemmP);
 
 template <typename TI, typename TO, int TM>
 int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
@@ -853,7 +863,11 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
   if (!fast_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->K >= 32 && d->K % 32 == 0 &&
       p.vecA && p.vecB && d->M >= 64 && d->N >= 64 && (int64_t)d->M * d->N >= 128 * 128 &&
       bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
-    p.tm = dxa_cdiv(d->M, 256);
+    // 192-row tiles when they trim the padded row count by more than 8% (they run ~6% below the 256-row tile's rate)
+    static const int force_ai = getenv("DXA_GEMM_RING_AI") ? atoi(getenv("DXA_GEMM_RING_AI")) : 0;
+    const int64_t pad256 = (int64_t)dxa_cdiv(d->M, 256) * 256, pad192 = (int64_t)dxa_cdiv(d->M, 192) * 192;
+    const int ai = force_ai ? force_ai : (pad192 * 27 < pad256 * 25 ? 3 : 4);
+    p.tm = dxa_cdiv(d->M, ai * 64);
     p.tn = dxa_cdiv(d->N, 256);
     const int nt = p.tm * p.tn, nk_tot = (int)(d->K / 32);
     p.full = nt; p.tail_r = 0; p.split_s = 1;
@@ -873,17 +887,18 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     }
     dim3 fgrid((unsigned)(p.full + p.tail_r * p.split_s));
     constexpr int RING_LDS = 139264;   // max(4 x 32 KiB ring, 8 waves x 64 x 272 B epilogue slabs)
-#define LAUNCH_RING(TO_)                                                                                        \
+#define LAUNCH_RING(TO_, AI_)                                                                                   \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<TO_>),                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<TO_, AI_>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_>), fgrid, dim3(512), RING_LDS, st, p);                          \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_, AI_>), fgrid, dim3(512), RING_LDS, st, p);                     \
   } while (0)
-    if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t); else LAUNCH_RING(float);
+    if (ai == 3) { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 3); else LAUNCH_RING(float, 3); }
+    else { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 4); else LAUNCH_RING(float, 4); }
 #undef LAUNCH_RING
     DXA_CHECK_LAUNCH();
     return DXA_OK;

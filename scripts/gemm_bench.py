@@ -21,6 +21,8 @@ SHAPES = [  # (name, layout, M, N, K)
     ("gate_up dW ", "tn", 37888, 3584, M), ("down    dW ", "tn", 3584, 18944, M),
     ("square 4096", "nt", 4096, 4096, 4096), ("square 8192", "nt", 8192, 8192, 8192),
     ("epi K=64   ", "nt", M, 37888, 64), ("epi K=512  ", "nt", M, 37888, 512), ("epi K=1024 ", "nt", M, 37888, 1024),
+    ("pre qkv    ", "nt", 543, 4608, 3584), ("pre o_proj ", "nt", 543, 3584, 3584), ("pre gate_up", "nt", 543, 37888, 3584),
+    ("pre down   ", "nt", 543, 3584, 18944), ("pre vit fc1", "nt", 514, 4096, 1024), ("pre vit fc2", "nt", 514, 1024, 4096),
     ("dWgu as nt ", "nt", 37888, 3584, 4608), ("dWdown  nt ", "nt", 3584, 18944, 4608), ("da as nt   ", "nt", M, 18944, 3584),
 ]
 

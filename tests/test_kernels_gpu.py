@@ -124,6 +124,28 @@ def test_gemm_ring_split_tail(shape, f32out):
             assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"split tail bf16 rep {rep}")
 
 
+@pytest.mark.parametrize("shape", [(543, 4608, 3584), (543, 3584, 18944), (514, 1024, 4096), (130, 300, 64), (330, 260, 96),
+                                   (192, 256, 32), (1050, 777, 2048)])
+@pytest.mark.parametrize("f32out", [False, True])
+def test_gemm_ring_192_row_tiles(shape, f32out):
+    """bf16 NT ring kernel, 192-row tile variant (chosen when it trims the row padding: the B=1 prefill shapes);
+    with and without the split-K tail, ragged M and N edges"""
+    M, N, Kd = shape
+    assert -(-M // 192) * 192 * 27 < -(-M // 256) * 256 * 25          # dispatch takes the 192-row variant
+    a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=25), rnd(N, Kd, dtype=torch.bfloat16, seed=26, scale=0.1)
+    ref = a.double() @ w.double().t()
+    for rep in range(2):
+        if f32out:
+            out = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+            K.mm_nt(a, w, out=out, accumulate=True)
+            assert_close(out, ref + 0.5, 2e-5, 2e-3 * math.sqrt(Kd / 320), f"192-row f32 accumulate rep {rep}")
+        else:
+            bias, res = rnd(N, dtype=torch.bfloat16, seed=27), rnd(M, N, dtype=torch.bfloat16, seed=28)
+            out = K.mm_nt(a, w, bias=bias, residual=res)
+            rtol, atol = tol_for(torch.bfloat16, Kd)
+            assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"192-row bf16 rep {rep}")
+
+
 @pytest.mark.parametrize("shape", [(1, 768, 64), (17, 100, 768), (36, 3072, 768), (36, 768, 3072), (64, 2304, 768)])
 def test_gemm_skinny_f32(shape):
     """fp32 NT with M <= 64 (DiT head at inference): 16-column workgroups, 8-way K split inside the workgroup"""
