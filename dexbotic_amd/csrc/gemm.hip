@@ -497,6 +497,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
                         reinterpret_cast<const bf16_t*>(p.G), bv, m, n, n_ok, a4);
 }
 
+constexpr int NUM_CU_D = 256;   // split-K scratch slots (one per CU)
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -676,19 +677,25 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #undef MFMA1
 #undef SB
 
-  // ---- split-K tail: partial accumulators travel through a lane-linear fp32 slot (1 KiB per wave store).
+  // ---- split-K tail: partial accumulators travel through a lane-linear fp32 slot (8 KiB per wave store).
+  // sc1 (agent scope) stores write through the XCD-private L2 and sc1 loads miss in it, so no cache-wide
+  // write-back / invalidate is needed; 16-byte accesses keep the gatherer off the instruction-issue limit.
   if (split_s > 1) {
-    float4* slot0 = reinterpret_cast<float4*>(p.ws) + (size_t)tail_i * (split_s - 1) * 16384;
+    constexpr int SC1 = 16;                                   // buffer-instruction cache policy bit (gfx94x/95x)
+    constexpr uint32_t SLOT = 256 * 256 * 4;                  // bytes per partial
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(NUM_CU_D * SLOT), 0x00020000);
+    const uint32_t slot0 = (uint32_t)tail_i * (uint32_t)(split_s - 1) * SLOT + (uint32_t)tid * 16u;
     if (split_j < split_s - 1) {
-      // agent-scope relaxed atomics write through the XCD-private L2, so no cache-wide write-back is needed
-      float* dst = reinterpret_cast<float*>(slot0 + (size_t)split_j * 16384) + tid;
+      const uint32_t dst = slot0 + (uint32_t)split_j * SLOT;
 #pragma unroll
       for (int i = 0; i < AI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            __hip_atomic_store(dst + ((i * 2 + j) * 16 + r) * 512, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int q = 0; q < 4; ++q) {
+            const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rW, dst + ((i * 2 + j) * 4 + q) * 8192, 0, SC1);
+          }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(p.flags + tail_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -702,14 +709,19 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     }
     __syncthreads();
     for (int sj = 0; sj < split_s - 1; ++sj) {
-      const float* src = reinterpret_cast<const float*>(slot0 + (size_t)sj * 16384) + tid;
+      const uint32_t src = slot0 + (uint32_t)sj * SLOT;
 #pragma unroll
-      for (int i = 0; i < AI; ++i)
+      for (int i = 0; i < AI; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += __hip_atomic_load(src + ((i * 2 + j) * 16 + r) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int q = 0; q < 4; ++q) {
+            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, src + ((i * 2 + j) * 4 + q) * 8192, 0, SC1));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[c];
+          }
+        if (AI == 4 && i == 1) __builtin_amdgcn_sched_barrier(0);   // at most 16 loads (64 VGPRs) in flight
+      }
     }
   }
 
@@ -783,6 +795,7 @@ int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
 // Split-K scratch of the ring kernel: < 256 slots of 256 KiB + 256 counters per (device, stream), allocated on
 // first use (so the first dxa_gemm on a stream must not run under stream capture) and kept for the process.
 constexpr int NUM_CU = 256;
+static_assert(NUM_CU == NUM_CU_D, "split-K scratch sizing");
 struct SplitWs { float* ws; int* flags; };
 int get_split_ws(hipStream_t st, SplitWs* out) {
   static std::mutex mu;
@@ -878,7 +891,10 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     if (!split_off && tail > 0) {
       // the last round would leave NUM_CU - tail CUs idle: cut its tiles along K (>= 16 slabs per piece)
       // (measured: each fp32 partial slot costs ~0.25 us of write-through traffic, so short K does not pay)
-      const int s = nk_tot >= 64 ? std::min(std::min(NUM_CU / tail, 8), nk_tot / 16) : 1;
+      static const int min_nk = getenv("DXA_SPLIT_MIN_NK") ? atoi(getenv("DXA_SPLIT_MIN_NK")) : 64;
+      static const int min_piece = getenv("DXA_SPLIT_MIN_PIECE") ? atoi(getenv("DXA_SPLIT_MIN_PIECE")) : 16;
+      static const int max_split = getenv("DXA_SPLIT_MAX") ? atoi(getenv("DXA_SPLIT_MAX")) : 8;
+      const int s = nk_tot >= min_nk ? std::min(std::min(NUM_CU / tail, max_split), nk_tot / min_piece) : 1;
       if (s >= 2) {
         SplitWs w;
         if (int rc = get_split_ws(st, &w)) return rc;
