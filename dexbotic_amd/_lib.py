@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("DXA_LIB") or os.path.join(_HERE, "libdexbotic_amd.so"
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5, 6
 NT, NN, TN = 0, 1, 2
+FILTER_BICUBIC = 3
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _int = C.c_int
@@ -67,6 +68,16 @@ class AdamWDesc(C.Structure):
         ("lr", _f32 * 8), ("wd", _f32 * 8),
         ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("bc1", _f32), ("bc2", _f32),
         ("clip_coef", _vp),
+    ]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [
+        ("src", _vp), ("n", _i32), ("h", _i32), ("w", _i32), ("pad", _i32), ("bg", C.c_ubyte * 4),
+        ("res_h", _i32), ("res_w", _i32), ("crop_top", _i32), ("crop_left", _i32), ("out_h", _i32), ("out_w", _i32),
+        ("row0", _i32), ("rows", _i32), ("hb", _vp), ("hk", _vp), ("hks", _i32), ("vb", _vp), ("vk", _vp), ("vks", _i32),
+        ("tmp", _vp), ("out", _vp), ("out_dtype", _i32), ("out_u8", _vp), ("rescale", C.c_double),
+        ("mean", _f32 * 3), ("std", _f32 * 3),
     ]
 
 
@@ -121,6 +132,9 @@ SIGNATURES = {
     "dxa_cross_entropy_fwd": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "dxa_cross_entropy_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dxa_argmax_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),
+    "dxa_resample_ksize": (_int, [_int, _int]),
+    "dxa_resample_coeffs": (_int, [_int, _int, _int, _vp, _vp]),
+    "dxa_image_preprocess": (_int, [C.POINTER(ImageDesc), _vp]),
     "dxa_clip_coef": (_int, [_vp, _f32, _vp, _vp, _vp]),
     "dxa_scale": (_int, [_vp, _i64, _f32, _vp]),
     "dxa_scale_dev": (_int, [_vp, _i64, _vp, _vp]),

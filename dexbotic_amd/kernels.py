@@ -629,3 +629,74 @@ def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(rows, device=x.device, dtype=torch.int64)
     L.check(lib.dxa_argmax_rows(_ptr(x), x.stride(0), _ptr(out), rows, cols, dt(x), _stream()), "dxa_argmax_rows")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ image preprocessing
+_RESAMPLE_TABLES: dict = {}
+
+
+def resample_tables(in_size: int, out_size: int, device) -> Tuple[int, "torch.Tensor", "torch.Tensor", "torch.Tensor"]:
+    """Pillow bicubic tap tables of one axis: (ksize, bounds host int32 [out,2], bounds device, taps device [out,ksize]);
+    built once per (in_size, out_size, device) by the library's host routine and kept on the device"""
+    key = (int(in_size), int(out_size), str(device))
+    hit = _RESAMPLE_TABLES.get(key)
+    if hit is None:
+        ks = lib.dxa_resample_ksize(int(in_size), int(out_size))
+        bounds = torch.empty(out_size, 2, dtype=torch.int32)
+        taps = torch.empty(out_size, ks, dtype=torch.int32)
+        L.check(lib.dxa_resample_coeffs(int(in_size), int(out_size), L.FILTER_BICUBIC, bounds.data_ptr(), taps.data_ptr()),
+                "dxa_resample_coeffs")
+        hit = (ks, bounds, bounds.to(device), taps.to(device))
+        _RESAMPLE_TABLES[key] = hit
+    return hit
+
+
+def resize_output_size(h: int, w: int, shortest_edge: int) -> Tuple[int, int]:
+    """(out_h, out_w) of the processor's shortest-edge resize: long side = int(shortest_edge * long / short)"""
+    if w <= h:
+        return int(shortest_edge * h / w), shortest_edge
+    return shortest_edge, int(shortest_edge * w / h)
+
+
+def image_preprocess(frames: torch.Tensor, *, pad: bool, bg: Sequence[int], size: int, crop: Tuple[int, int],
+                     mean: Sequence[float], std: Sequence[float], rescale: float = 1 / 255,
+                     out_dtype: torch.dtype = torch.float32, want_u8: bool = False):
+    """uint8 RGB frames [n, h, w, 3] on the device -> [n, 3, crop_h, crop_w] (expand2square, Pillow-exact bicubic
+    shortest-edge resize, center crop, rescale, normalise).  With want_u8 also returns the uint8 resized frame."""
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or not frames.is_contiguous():
+        raise L.DxaError(f"image_preprocess: expected contiguous uint8 [n,h,w,3], got {frames.dtype} {tuple(frames.shape)}")
+    n, h, w, _ = frames.shape
+    ph, pw = (max(h, w), max(h, w)) if pad else (h, w)
+    res_h, res_w = resize_output_size(ph, pw, size)
+    ch, cw = crop
+    if ch > res_h or cw > res_w:
+        raise L.DxaError(f"image_preprocess: crop {crop} larger than the resized frame {(res_h, res_w)}")
+    top, left = (res_h - ch) // 2, (res_w - cw) // 2
+    dev = frames.device
+    d = L.ImageDesc()
+    d.src, d.n, d.h, d.w, d.pad = _ptr(frames), n, h, w, int(bool(pad))
+    for i in range(3):
+        d.bg[i] = int(bg[i])
+        d.mean[i] = float(mean[i])
+        d.std[i] = float(std[i])
+    d.res_h, d.res_w, d.crop_top, d.crop_left, d.out_h, d.out_w = res_h, res_w, top, left, ch, cw
+    keep = []
+    if res_w != pw:
+        d.hks, _, hb, hk = resample_tables(pw, res_w, dev)
+        d.hb, d.hk = _ptr(hb), _ptr(hk)
+        keep += [hb, hk]
+    row0, rows = top, ch
+    if res_h != ph:
+        d.vks, vb_host, vb, vk = resample_tables(ph, res_h, dev)
+        d.vb, d.vk = _ptr(vb), _ptr(vk)
+        keep += [vb, vk]
+        win = vb_host[top:top + ch]
+        row0 = int(win[:, 0].min())
+        rows = int((win[:, 0] + win[:, 1]).max()) - row0
+    d.row0, d.rows = row0, rows
+    tmp = torch.empty(n * rows * cw * 3, device=dev, dtype=torch.uint8)
+    out = torch.empty(n, 3, ch, cw, device=dev, dtype=out_dtype)
+    u8 = torch.empty(n, ch, cw, 3, device=dev, dtype=torch.uint8) if want_u8 else None
+    d.tmp, d.out, d.out_dtype, d.out_u8, d.rescale = _ptr(tmp), _ptr(out), dt(out), _ptr(u8), float(rescale)
+    L.check(lib.dxa_image_preprocess(C.byref(d), _stream()), "dxa_image_preprocess")
+    return (out, u8) if want_u8 else out

@@ -373,15 +373,18 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         return seq
 
     def process_images(self, images):
-        """expand-to-square with the mean colour + CLIP preprocessing (host side; dexbotic_arch.py:498-529)."""
+        """dexbotic_arch.py:498-529 on the device: the uint8 frames are uploaded as they are and libdexbotic_amd pads,
+        resizes (Pillow-exact bicubic), crops and normalises them (data/dataset/rgb_preprocess.py).  Frames of equal
+        size share one launch; the result is stacked when all outputs have one shape, as in the reference."""
+        from ..data.dataset.rgb_preprocess import PreprocessRGB, to_uint8_hwc
         proc = self.model.mm_vision_module.image_processor
-        if getattr(self.config, "image_aspect_ratio", "pad") != "pad":
-            return proc(images, return_tensors="pt")["pixel_values"]
-        out = []
-        for im in images:
-            im = self.expand2square(im, tuple(int(x * 255) for x in proc.image_mean))
-            out.append(proc.preprocess(im, return_tensors="pt")["pixel_values"][0])
-        if all(x.shape == out[0].shape for x in out):
+        aspect = getattr(self.config, "image_aspect_ratio", "pad")
+        pre = PreprocessRGB(proc, image_aspect_ratio="pad" if aspect == "pad" else None, device=self.device)
+        frames = [to_uint8_hwc(im) for im in images]
+        if frames and all(f.shape == frames[0].shape for f in frames):
+            return pre.batch(torch.stack(frames))
+        out = [pre.batch(f[None])[0] for f in frames]
+        if out and all(x.shape == out[0].shape for x in out):
             out = torch.stack(out, dim=0)
         return out
 

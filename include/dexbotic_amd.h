@@ -302,6 +302,51 @@ int dxa_cross_entropy_bwd(const void* logits, int64_t ld, const int64_t* labels,
 int dxa_argmax_rows(const void* x, int64_t ld, int64_t* out, int64_t rows, int64_t cols, int dtype,
                     dxa_stream_t stream);
 
+/* ---- device-side image preprocessing ------------------------------------------------
+ * Replaces, for uint8 RGB frames already on the device, what the reference does per frame on the host with
+ * Pillow + the CLIP image processor:
+ *   dexbotic/data/dataset/rgb_preprocess.py:13-28   PreprocessRGB.__call__   (training data path)
+ *   dexbotic/data/dataset/rgb_preprocess.py:30-44   expand2square
+ *   dexbotic/model/dexbotic_arch.py:498-529         process_images           (inference server path)
+ * i.e. [expand to square with a constant colour] -> Image.resize(BICUBIC) -> center crop -> x * rescale ->
+ * (x - mean) / std -> CHW.  The resize is Pillow's 8-bit two-pass resampler (Pillow 12.2.0
+ * src/libImaging/Resample.c; 22-bit fixed-point taps, uint8 image between the passes); the uint8 result
+ * (out_u8) is bit-exact with Pillow's, the float result equals the processor's float32 arithmetic.
+ *
+ * dxa_resample_ksize / dxa_resample_coeffs: HOST functions, the tap tables of one axis (precompute_coeffs +
+ *   normalize_coeffs_8bpc): bounds[out_size][2] = (first source index, tap count), kk[out_size][ksize].
+ *   The caller copies them to the device once per (in_size, out_size) and passes the device copies below.
+ * dxa_image_preprocess: n frames of identical h x w.  `pad` != 0 centres the frame in a max(h,w) square of colour
+ *   bg.  res_h x res_w is the size after the resize of that (padded) frame; a pass that does not change the size
+ *   has NULL tables (Pillow skips it too).  The crop window [crop_top, +out_h) x [crop_left, +out_w) of the
+ *   resized frame is what is produced.  tmp is a uint8 scratch of n * rows * out_w * 3 bytes, where
+ *   [row0, row0 + rows) are the (padded) source rows the vertical taps of the cropped output rows touch
+ *   (row0 = 0, rows = padded height is always valid).
+ * ---------------------------------------------------------------------------------------------- */
+#define DXA_FILTER_BICUBIC 3 /* PIL.Image.BICUBIC */
+typedef struct dxa_image_desc {
+  const void* src;        /* uint8 [n, h, w, 3] RGB */
+  int n, h, w;
+  int pad;                /* expand2square */
+  unsigned char bg[4];    /* r, g, b, unused */
+  int res_h, res_w;
+  int crop_top, crop_left, out_h, out_w;
+  int row0, rows;
+  const int32_t *hb, *hk; /* horizontal bounds / taps (device) or NULL */
+  int hks;
+  const int32_t *vb, *vk; /* vertical */
+  int vks;
+  void* tmp;              /* uint8 scratch */
+  void* out;              /* [n, 3, out_h, out_w] of out_dtype (DXA_F32 or DXA_BF16) */
+  int out_dtype;
+  void* out_u8;           /* optional uint8 [n, out_h, out_w, 3]: the resized + cropped frame */
+  double rescale;         /* 1/255 */
+  float mean[3], std[3];
+} dxa_image_desc;
+int dxa_resample_ksize(int in_size, int out_size);
+int dxa_resample_coeffs(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk);
+int dxa_image_preprocess(const dxa_image_desc* d, dxa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
