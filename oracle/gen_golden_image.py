@@ -102,6 +102,20 @@ def main():
         out[f"collate_{tag}/input_ids"] = b["input_ids"].numpy()
         out[f"collate_{tag}/labels"] = b["labels"].numpy()
         out[f"collate_{tag}/attention_mask"] = b["attention_mask"].numpy()
+    conv_mod = load(os.path.join(REF, "dexbotic/tokenization/conversation.py"), "ref_conversation")
+    conv_prompts = []
+    for name in ("dexbotic", "step", "llama_3"):
+        for stub in (" ", None):
+            conv = conv_mod.conv_templates[name].copy()
+            conv.append_message(conv.roles[0], "<image>\n" + "pick up the red block")
+            conv.append_message(conv.roles[1], stub)
+            conv_prompts.append(conv.get_prompt())
+        conv = conv_mod.conv_templates[name].copy()
+        conv.append_message(conv.roles[0], ("what is <image> this", None, "Pad"))
+        conv.append_message(conv.roles[1], "a cube")
+        conv.append_message(conv.roles[0], "and now?")
+        conv_prompts.append(conv.get_prompt())
+    out["conv_prompts"] = np.array(conv_prompts)
     path = os.path.join(ROOT, "tests", "golden", "image_t1.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -96,3 +96,43 @@ def test_bad_arguments_fail_loudly():
         pre.batch(torch.zeros(1, 8, 8, 3))                              # not uint8
     with pytest.raises(L.DxaError):
         pre.batch(torch.zeros(1, 8, 8, 4, dtype=torch.uint8))           # not RGB
+
+
+def test_process_frame_end_to_end(golden_dir):
+    """PNG over the wire -> device preprocessing -> prompt -> CogACT action sampling -> JSON, against the same pieces
+    called directly (oracle preprocessing, tokenizer_image_token, inference_action with the same noise draw)"""
+    import io
+    import types
+    from dexbotic_amd.serve import InferenceServer, encode_png
+    from dexbotic_amd.tokenization.tokenization import tokenizer_image_token
+    from oracle import image_oracle as IO
+    from .helpers import build_product, load_golden
+    _, cfg, w = load_golden(golden_dir, "t1")
+    m = build_product(cfg, w, "float32", DEV, train=False)
+    m.eval()
+
+    class Tok:
+        bos_token_id = None
+
+        def __call__(self, text):
+            return types.SimpleNamespace(input_ids=[3 + (sum(map(ord, wd)) % (cfg.vocab_size - 3)) for wd in text.split()])
+
+    norms = {"min": [-1.0, -2.0, -3.0, -1.0, -1.0, -1.0, 0.0], "max": [1.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0]}
+    srv = InferenceServer(m, Tok(), norm_stats=norms)
+    client = srv.create_app().test_client()
+    frames = [IO.synthetic_image(90, 120, 70), IO.synthetic_image(90, 120, 71)]
+    s = cfg.v_image
+    for views in (1, 2):
+        torch.manual_seed(11)
+        r = client.post("/process_frame", content_type="multipart/form-data",
+                        data={"text": "pick up the red block",
+                              "image": [(io.BytesIO(encode_png(f)), f"{i}.png") for i, f in enumerate(frames[:views])]})
+        assert r.status_code == 200
+        got = np.asarray(r.get_json()["response"])
+        assert got.shape == (cfg.chunk_size, cfg.action_dim)
+        pix = torch.from_numpy(np.stack([IO.normalize(IO.preprocess_u8(f, size=s, crop=s)) for f in frames[:views]])).to(DEV)
+        pix = pix if views == 1 else pix[None]
+        ids = tokenizer_image_token(srv.build_prompt("pick up the red block"), Tok(), return_tensors="pt")[None].to(DEV)
+        torch.manual_seed(11)
+        want = np.asarray(m.inference_action(ids, pix, {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms}))
+        assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)), views

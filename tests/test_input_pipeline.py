@@ -65,3 +65,61 @@ def test_resample_tables_match_oracle():
         assert np.array_equal(b, bounds) and np.array_equal(k, kk), (n_in, n_out)
     assert L.lib.dxa_resample_coeffs(0, 224, L.FILTER_BICUBIC, None, None) != 0
     assert "positive" in L.last_error()
+
+
+def test_conversation_templates_match_reference(g):
+    from dexbotic_amd.tokenization import conversation as Cv
+    want = [str(x) for x in g["conv_prompts"]]
+    i = 0
+    for name in ("dexbotic", "step", "llama_3"):
+        for stub in (" ", None):
+            c = Cv.conv_templates[name].copy()
+            c.append_message(c.roles[0], "<image>\n" + "pick up the red block")
+            c.append_message(c.roles[1], stub)
+            assert c.get_prompt() == want[i], (name, stub)
+            i += 1
+        c = Cv.conv_templates[name].copy()
+        c.append_message(c.roles[0], ("what is <image> this", None, "Pad"))
+        c.append_message(c.roles[1], "a cube")
+        c.append_message(c.roles[0], "and now?")
+        assert c.get_prompt() == want[i], name
+        i += 1
+    assert Cv.conv_templates["dexbotic"].messages == []            # copies do not leak into the registry
+
+
+class _StubModel:
+    """stands in for the device model: records what the server hands over"""
+    device, dtype = torch.device("cpu"), torch.float32
+    config = types.SimpleNamespace(chat_template="dexbotic")
+
+    def process_images(self, frames):
+        self.sizes = [f.size for f in frames]
+        return torch.zeros(len(frames), 3, 4, 4)
+
+    def inference_action(self, ids, pix, args):
+        self.ids, self.pix_shape, self.args = ids, tuple(pix.shape), args
+        return [[0.5] * 7, [0.25] * 7]
+
+
+def test_process_frame_wire_format(g):
+    """POST /process_frame (multipart: text + PNG files) -> {"response": [[7 floats] ...]}, base_exp.py:638-653"""
+    import io
+    from dexbotic_amd.serve import InferenceServer, encode_png
+    from dexbotic_amd.tokenization.tokenization import tokenizer_image_token
+    model = _StubModel()
+    srv = InferenceServer(model, Tok(), norm_stats={"min": [-1] * 7, "max": [1] * 7})
+    client = srv.create_app().test_client()
+    frame = np.zeros((12, 20, 3), np.uint8)
+    frame[..., 0] = 200
+    r = client.post("/process_frame", data={"text": "pick up the red block", "image": (io.BytesIO(encode_png(frame)), "0.png")},
+                    content_type="multipart/form-data")
+    assert r.status_code == 200 and r.get_json() == {"response": [[0.5] * 7, [0.25] * 7]}
+    assert model.sizes == [(20, 12)] and model.pix_shape == (1, 3, 4, 4)
+    assert model.args == {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": {"min": [-1] * 7, "max": [1] * 7}}
+    want = tokenizer_image_token(str(g["conv_prompts"][0]), Tok())                 # the reference's own prompt string
+    assert model.ids.tolist() == [want] and want.count(-200) == 1
+    # two views: [1, views, 3, H, W]
+    r = client.post("/process_frame", data={"text": "x", "image": [(io.BytesIO(encode_png(frame)), "0.png"),
+                                                                    (io.BytesIO(encode_png(frame)), "1.png")]},
+                    content_type="multipart/form-data")
+    assert r.status_code == 200 and model.pix_shape == (1, 2, 3, 4, 4)
