@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("bias", _vp), ("residual", _vp), ("ldr", _i64), ("aux_out", _vp), ("mulgrad", _vp), ("ldg", _i64),
         ("alpha", _f32), ("accumulate", _i32), ("nb", _i32 * 3),
         ("sA", _i64 * 3), ("sB", _i64 * 3), ("sC", _i64 * 3), ("sR", _i64 * 3), ("sG", _i64 * 3),
+        ("epi_f32", _i32),
     ]
 
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "dxa_last_error": (C.c_char_p, []),
     "dxa_version": (_int, []),
     "dxa_gemm": (_int, [C.POINTER(GemmDesc), _vp]),
+    "dxa_split3": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),
     "dxa_rmsnorm_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
     "dxa_rmsnorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),

@@ -522,7 +522,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // =====================================================================================================
 // AI = 32-row A blocks per wave: 4 -> 256-row tiles, 3 -> 192-row tiles (few-row products such as the B=1 prefill,
 // M = 543: 3 x 192 wastes 6% of the MFMA work, 3 x 256 wastes 29%).
-template <typename TO, int AI>
+template <typename TO, int AI, typename TE>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -736,14 +736,14 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
     char* slab = smem + wave * (64 * ROWP);
     TO* C = reinterpret_cast<TO*>(p.C);
     TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
-    const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
-    const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
-    const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+    const TE* R = reinterpret_cast<const TE*>(p.R);
+    const TE* G = reinterpret_cast<const TE*>(p.G);
+    const TE* bias = reinterpret_cast<const TE*>(p.bias);
     const int cr = lane >> 4, cc = (lane & 15) * 4;
     const int64_t n = n0 + wn * 64 + cc;
     const int n_ok = (int)max((int64_t)0, min((int64_t)4, p.N - n));
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias && n_ok > 0) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
+    if (bias && n_ok > 0) load4<TE>(bv, bias + n, p.vecBias, n_ok);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
         const float4 v = *reinterpret_cast<const float4*>(slab + row * ROWP + cc * 4);
         if (m < p.M && n_ok > 0) {
           const float a4[4] = {v.x, v.y, v.z, v.w};
-          epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+          epilogue4<TE, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -775,10 +775,33 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
-template __global__ void gemm_nt_ring_kernel<bf16_t, 4>(const GemmP);
-template __global__ void gemm_nt_ring_kernel<float, 4>(const GemmP);
-template __global__ void gemm_nt_ring_kernel<bf16_t, 3>(const GemmP);
-template __global__ void gemm_nt_ring_kernel<float, 3>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<bf16_t, 4, bf16_t>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<float, 4, bf16_t>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<bf16_t, 3, bf16_t>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<float, 3, bf16_t>(const GemmP);
+template __global__ void gemm_nt_ring_kernel<float, 4, float>(const GemmP);   // fp32 epilogue operands (bf16x3 products)
+template __global__ void gemm_nt_ring_kernel<float, 3, float>(const GemmP);
+
+// x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
+__global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
+                                                int64_t rows, int64_t cols, int side) {
+  const int64_t c4 = cols >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * c4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4, c = (i - r * c4) * 4;
+    float x[4];
+    Vec<float, 4>::ld(x, src + r * ld + c);
+    float hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = bf2f(f2bf(x[e]));
+      lo[e] = x[e] - hi[e];
+    }
+    bf16_t* d = dst + r * 3 * cols + c;
+    Vec<bf16_t, 4>::st(d, hi);
+    Vec<bf16_t, 4>::st(d + cols, side == 0 ? hi : lo);
+    Vec<bf16_t, 4>::st(d + 2 * cols, side == 0 ? lo : hi);
+  }
+}
 
 template <typename TI, typename TO, int TM>
 int launch(const GemmP& p, int layout, dim3 grid, hipStream_t st) {
@@ -865,9 +888,11 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
                 : (aligned_to(d->B, 16) && d->ldb % epc == 0 && strides_mult(d->sB, epc));
   p.vecC = aligned_to(d->C, 4 * os) && d->ldc % 4 == 0 && strides_mult(d->sC, 4) &&
            (!d->aux_out || aligned_to(d->aux_out, 4 * os));
-  p.vecR = d->residual && aligned_to(d->residual, 4 * es) && d->ldr % 4 == 0 && strides_mult(d->sR, 4);
-  p.vecG = d->mulgrad && aligned_to(d->mulgrad, 4 * es) && d->ldg % 4 == 0 && strides_mult(d->sG, 4);
-  p.vecBias = d->bias && aligned_to(d->bias, 4 * es);
+  const size_t ees = d->epi_f32 ? 4 : es;   // element size of bias / residual / mulgrad
+  DXA_CHECK_ARG(!d->epi_f32 || (d->in_dtype == DXA_BF16 && d->out_dtype == DXA_F32), "dxa_gemm: epi_f32 needs bf16 in, fp32 out");
+  p.vecR = d->residual && aligned_to(d->residual, 4 * ees) && d->ldr % 4 == 0 && strides_mult(d->sR, 4);
+  p.vecG = d->mulgrad && aligned_to(d->mulgrad, 4 * ees) && d->ldg % 4 == 0 && strides_mult(d->sG, 4);
+  p.vecBias = d->bias && aligned_to(d->bias, 4 * ees);
 
   hipStream_t st = (hipStream_t)stream;
   // ---- fast path (ring kernel): bf16 NT, K % 32 == 0, 16-byte aligned rows, no batching, operands < 2 GiB
@@ -903,22 +928,25 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     }
     dim3 fgrid((unsigned)(p.full + p.tail_r * p.split_s));
     constexpr int RING_LDS = 139264;   // max(4 x 32 KiB ring, 8 waves x 64 x 272 B epilogue slabs)
-#define LAUNCH_RING(TO_, AI_)                                                                                   \
+#define LAUNCH_RING(TO_, AI_, TE_)                                                                              \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<TO_, AI_>),                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<TO_, AI_, TE_>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_, AI_>), fgrid, dim3(512), RING_LDS, st, p);                     \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_, AI_, TE_>), fgrid, dim3(512), RING_LDS, st, p);                \
   } while (0)
-    if (ai == 3) { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 3); else LAUNCH_RING(float, 3); }
-    else { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 4); else LAUNCH_RING(float, 4); }
+    if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }
+    else if (ai == 3) { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 3, bf16_t); else LAUNCH_RING(float, 3, bf16_t); }
+    else { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 4, bf16_t); else LAUNCH_RING(float, 4, bf16_t); }
 #undef LAUNCH_RING
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
+  DXA_CHECK_ARG(!d->epi_f32, "dxa_gemm: epi_f32 is only implemented on the bf16 NT fast path (K %% 32 == 0, M, N >= 64, "
+                              "16-byte aligned rows, no batching)");
   // ---- skinny bf16 path: M <= 64 (KV-cached decode, few-row products): a stream over the weights
   if (!skinny_off_g() && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->M <= 64 && d->K >= 64 &&
       d->K % 64 == 0 && p.vecA && p.vecB) {
@@ -962,6 +990,19 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     rc = small ? launch<float, float, 2>(p, d->layout, grid, st) : launch<float, float, 4>(p, d->layout, grid, st);
   }
   if (rc != DXA_OK) return rc;
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t cols, int side, dxa_stream_t stream) {
+  DXA_CHECK_ARG(rows >= 0 && cols >= 0 && (side == 0 || side == 1), "dxa_split3: bad arguments");
+  if (rows == 0 || cols == 0) return DXA_OK;
+  DXA_CHECK_ARG(src && dst, "dxa_split3: null buffer");
+  DXA_CHECK_ARG(cols % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(src) % 16) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dst) % 8) == 0,
+                "dxa_split3: cols and ld must be multiples of 4 and the buffers 16-byte aligned");
+  hipLaunchKernelGGL(split3_k, dim3(dxa_grid1d(rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, ld,
+                     (bf16_t*)dst, rows, cols, side);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

@@ -6,6 +6,7 @@ allocator (PyTorch = device memory and streams only).  Nothing here computes wit
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional, Sequence, Tuple
 
@@ -50,19 +51,57 @@ def _row_major(t: torch.Tensor, name: str) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+# How fp32 x fp32 NT products of >= 128 rows are computed: "exact" = fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TF/s peak);
+# "bf16x3" = three-term split-bf16 product on the bf16 ring kernel (16 mantissa bits per operand, ~1e-5 relative; the
+# reference's trainer runs the same fp32 head matmuls as TF32, base_exp.py:254).  Set by NativeTrainer.step /
+# inference_action from the model config; parity tests in fp32 mode leave it at "exact".
+F32_GEMM_MODE = "exact"
+
+
+@contextlib.contextmanager
+def f32_gemm_mode(mode: str):
+    global F32_GEMM_MODE
+    if mode not in ("exact", "bf16x3"):
+        raise L.DxaError(f"unknown fp32 GEMM mode {mode!r}")
+    prev, F32_GEMM_MODE = F32_GEMM_MODE, mode
+    try:
+        yield
+    finally:
+        F32_GEMM_MODE = prev
+
+
+def split3(x: torch.Tensor, rows: int, cols: int, ld: int, side: int) -> torch.Tensor:
+    """fp32 [rows, cols] -> bf16 [rows, 3*cols] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), x = hi + lo"""
+    out = torch.empty((rows, 3 * cols), device=x.device, dtype=torch.bfloat16)
+    L.check(lib.dxa_split3(_ptr(x), ld, _ptr(out), rows, cols, side, _stream()), "dxa_split3")
+    return out
+
+
+def _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb) -> bool:
+    return (F32_GEMM_MODE == "bf16x3" and layout == L.NT and a.dtype == torch.float32 and b.dtype == torch.float32
+            and out.dtype == torch.float32 and tuple(nb) == (1, 1, 1) and M >= 128 and N >= 128 and K >= 64 and K % 32 == 0
+            and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and 6 * max(M, N) * K < (1 << 31))
+
+
 def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int,
          out: torch.Tensor, ldc: int, *, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = L.ACT_NONE,
          aux_out: Optional[torch.Tensor] = None, mulgrad: Optional[torch.Tensor] = None, ldg: int = 0,
          alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = (1, 1, 1),
          sA: Sequence[int] = (0, 0, 0), sB: Sequence[int] = (0, 0, 0), sC: Sequence[int] = (0, 0, 0),
-         sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0)) -> torch.Tensor:
+         sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0), epi_f32: bool = False) -> torch.Tensor:
+    if not epi_f32 and _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb):
+        a3, b3 = split3(a, M, K, lda, 0), split3(b, N, K, ldb, 1)
+        return gemm(L.NT, a3, b3, M, N, 3 * K, 3 * K, 3 * K, out, ldc, bias=bias, residual=residual, ldr=ldr, act=act,
+                    aux_out=aux_out, mulgrad=mulgrad, ldg=ldg, alpha=alpha, accumulate=accumulate, epi_f32=True)
     d = L.GemmDesc()
     d.layout, d.in_dtype, d.out_dtype, d.act = layout, dt(a), dt(out), act
+    d.epi_f32 = int(epi_f32)
     if dt(b) != d.in_dtype:
         raise L.DxaError("gemm: A and B dtypes differ")
     for t, n in ((bias, "bias"), (residual, "residual"), (mulgrad, "mulgrad")):
-        if t is not None and dt(t) != d.in_dtype:
+        if t is not None and dt(t) != (F32 if epi_f32 else d.in_dtype):
             raise L.DxaError(f"gemm: {n} dtype must equal the input dtype")
     if aux_out is not None and dt(aux_out) != d.out_dtype:
         raise L.DxaError("gemm: aux_out dtype must equal the output dtype")

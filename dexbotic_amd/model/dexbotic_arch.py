@@ -55,6 +55,9 @@ class DexboticConfig:
         self.tokenizer_padding_side = kwargs.pop("tokenizer_padding_side", "right")
         self.image_aspect_ratio = kwargs.pop("image_aspect_ratio", "pad")
         self.use_cache = kwargs.pop("use_cache", True)
+        # fp32 x fp32 products of the fp32 action head: "bf16x3" (split-bf16 on the MFMA ring kernel, the counterpart of
+        # the reference's tf32=True, base_exp.py:254) in bf16 compute mode, exact fp32 MFMA in fp32 (parity) mode
+        self.fp32_matmul = kwargs.pop("fp32_matmul", None) or ("bf16x3" if "bfloat16" in self.compute_dtype else "exact")
         for k, v in self.llm_config.to_dict().items():          # _merge_llm: only add missing keys
             if not hasattr(self, k):
                 setattr(self, k, v)

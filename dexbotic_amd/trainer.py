@@ -13,6 +13,8 @@ from typing import Dict, Optional
 
 import torch
 
+from . import kernels as K
+
 from .engine import FusedAdamW, GradNormTracker, GradReducer, OptimConfig, cosine_lr_scale
 
 
@@ -67,9 +69,10 @@ class NativeTrainer:
             if self.norm_tracker is not None:
                 self.norm_tracker.begin()
         self.store.on_bucket_ready = hook
-        out = self.model(**batch)
-        loss = out.loss
-        (loss / self.grad_accum if self.grad_accum > 1 else loss).backward()
+        with K.f32_gemm_mode(getattr(self.model.config, "fp32_matmul", "exact")):
+            out = self.model(**batch)
+            loss = out.loss
+            (loss / self.grad_accum if self.grad_accum > 1 else loss).backward()
         self.micro += 1
         if last:
             if not self._zeroed_unused:

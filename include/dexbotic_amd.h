@@ -85,8 +85,18 @@ typedef struct dxa_gemm_desc {
   int32_t accumulate; /* C += result */
   int32_t nb[3];      /* batch extents (>=1) */
   int64_t sA[3], sB[3], sC[3], sR[3], sG[3]; /* batch strides in elements */
+  int32_t epi_f32;    /* 1: bias / residual / mulgrad are fp32 although A, B are bf16 (needs out_dtype fp32 and the
+                         shapes of the bf16 NT fast path) — the epilogue of a split-bf16 fp32 product, see dxa_split3 */
 } dxa_gemm_desc;
 int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream);
+
+/* fp32 product on the bf16 MFMA path ("bf16x3", the counterpart of the TF32 matmuls the reference's trainer enables
+ * with tf32=True, dexbotic/exp/base_exp.py:254, for the fp32 action head under autocast(float32),
+ * dexbotic/model/cogact/cogact_arch.py:133): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits), and
+ *   A B^T ~= A_hi B_hi^T + A_hi B_lo^T + A_lo B_hi^T = [A_hi | A_hi | A_lo] [B_hi | B_lo | B_hi]^T,
+ * i.e. ONE bf16 NT product with K' = 3K accumulated in fp32 inside the MFMA.  dxa_split3 writes that operand:
+ * dst[r, 0:K | K:2K | 2K:3K] = (hi, hi, lo) for side 0 (A) and (hi, lo, hi) for side 1 (B); dst is bf16 [rows, 3*cols]. */
+int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t cols, int side, dxa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.  w/b are [cols] in w_dtype (NULL = no affine).

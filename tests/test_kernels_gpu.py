@@ -146,6 +146,36 @@ def test_gemm_ring_192_row_tiles(shape, f32out):
             assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"192-row bf16 rep {rep}")
 
 
+@pytest.mark.parametrize("shape", [(576, 2304, 768), (1088, 3072, 1024), (130, 140, 64), (2176, 1024, 4096)])
+def test_gemm_f32_bf16x3(shape):
+    """fp32 NT product as ONE bf16 ring-kernel product over [hi|hi|lo] x [hi|lo|hi] (dxa_split3 + epi_f32): 16 mantissa
+    bits per operand, so ~1e-5 of the result scale (TF32, what the reference's tf32=True gives, is ~5e-4); the fp32
+    epilogue (bias, activation, residual, aux_out, accumulate) is the exact kernel's"""
+    M, N, Kd = shape
+    a, w = rnd(M, Kd, seed=31), rnd(N, Kd, seed=32, scale=0.1)
+    bias, res = rnd(N, seed=33), rnd(M, N, seed=34)
+    pre = a.double() @ w.double().t() + bias.double()
+    ref = F.gelu(pre, approximate="tanh") + res.double()
+    exact = K.mm_nt(a, w, bias=bias, act=2, residual=res)
+    aux = torch.empty(M, N, device=DEV)
+    with K.f32_gemm_mode("bf16x3"):
+        out = K.mm_nt(a, w, bias=bias, act=2, residual=res, aux_out=aux)
+        acc = torch.full((M, N), 0.25, device=DEV)
+        K.mm_nt(a, w, out=acc, accumulate=True)
+        small = K.mm_nt(a[:64], w)                        # below 128 rows: stays on the exact kernels
+    assert K.F32_GEMM_MODE == "exact"
+    scale = float((a.double() @ w.double().t()).pow(2).mean().sqrt())
+    assert float((aux.double() - pre).abs().max()) < 1e-4 * scale
+    assert float((out.double() - ref).abs().max()) < 1e-4 * scale
+    assert float((acc.double() - 0.25 - (pre - bias.double())).abs().max()) < 1e-4 * scale
+    assert float((exact.double() - ref).abs().max()) < 2e-5 * scale
+    assert torch.equal(small, K.mm_nt(a[:64], w))
+    # the split itself: hi + lo reproduces x to 2^-17 relative
+    s3 = K.split3(a, M, Kd, Kd, 0).float()
+    assert torch.equal(s3[:, :Kd], s3[:, Kd:2 * Kd])
+    assert float(((s3[:, :Kd] + s3[:, 2 * Kd:]) - a).abs().max()) <= float(a.abs().max()) * 2.0 ** -16
+
+
 @pytest.mark.parametrize("shape", [(1, 768, 64), (17, 100, 768), (36, 3072, 768), (36, 768, 3072), (64, 2304, 768)])
 def test_gemm_skinny_f32(shape):
     """fp32 NT with M <= 64 (DiT head at inference): 16-column workgroups, 8-way K split inside the workgroup"""
