@@ -20,7 +20,7 @@ DexboticTrainer.create_optimizer / _link_exp_config (exp/trainer.py:25-36,88-124
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch

@@ -14,7 +14,7 @@ gradient checkpointing (base_exp.py:243) exists to fit 80 GB parts and costs a 4
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Sequence, Tuple
+from typing import Optional, Tuple
 
 import torch
 from torch.autograd import Function

@@ -21,13 +21,12 @@ import torch.nn as nn
 
 from .. import functional as Fn
 from .. import kernels as K
-from ..constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+from ..constants import IGNORE_INDEX
 from ..engine import ParamStore, attach_parameters
 from ..splice import SplicePlan, build_splice_plan
 from .llm.qwen2 import Qwen2Backbone, Qwen2Config
 from .modules.mm_projector.builder import build_vision_projector
 from .modules.mm_vision.builder import build_vision_tower
-from .modules.mm_vision.clip.clip_encoder import CLIPVisionConfig
 
 _DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, torch.float32: torch.float32,
            torch.bfloat16: torch.bfloat16}

@@ -10,7 +10,7 @@ residual); the attention itself runs once over BOTH experts' tokens (pi0_arch.py
 from __future__ import annotations
 
 from dataclasses import asdict, dataclass
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.nn as nn

@@ -15,7 +15,6 @@ F.scaled_dot_product_attention unconditionally — random even in eval.  Here th
 from __future__ import annotations
 
 import math
-from contextlib import contextmanager
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -26,7 +25,7 @@ import torch.nn.functional as F
 from ... import _lib as L
 from ... import functional as Fn
 from ... import kernels as K
-from ...engine import Fp32View, ParamStore
+from ...engine import ParamStore
 from ..cogact.cogact_arch import CogActConfig, CogActModel, CogACTForCausalLM
 from ..dexbotic_arch import CausalLMOutputDexbotic
 

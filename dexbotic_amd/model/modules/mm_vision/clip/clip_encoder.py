@@ -11,7 +11,6 @@ from __future__ import annotations
 import json
 import os
 from dataclasses import asdict, dataclass
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -13,7 +13,7 @@ layer over both experts, gradients written straight into the arena); inference: 
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import numpy as np
 import torch
@@ -22,7 +22,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ... import functional as Fn
 from ... import kernels as K
-from ...engine import ParamStore, attach_parameters
+from ...engine import ParamStore
 from ..dexbotic_arch import ActionOutputForCausalLM, CausalLMOutputDexbotic, NativePreTrainedMixin, _DTYPES
 from ..llm.gemma import GemmaConfig, GemmaExpert
 from ..modules.mm_projector.builder import build_vision_projector

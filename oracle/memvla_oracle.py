@@ -12,10 +12,8 @@ with that dropout set to 0, the only setting a deterministic comparison can pin.
 """
 from __future__ import annotations
 
-import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Tuple
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -8,7 +8,6 @@ micro-batch only."""
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -104,7 +104,7 @@ def test_denorm_bit_exact(golden_dir):
 
 
 def test_optimizer_groups_and_schedule(golden_dir):
-    from dexbotic_amd.engine import FusedAdamW, OptimConfig, cosine_lr_scale, no_decay_name
+    from dexbotic_amd.engine import cosine_lr_scale, no_decay_name
     from oracle.gen_golden import no_decay_name as ref_rule
     g, cfg, w = load_golden(golden_dir, "t1")
     for name in w:

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import cogact_oracle as O
-from tests.helpers import CFGS, build_product, load_golden, rel_err
+from tests.helpers import build_product, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
