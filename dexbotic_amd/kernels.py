@@ -739,3 +739,24 @@ def image_preprocess(frames: torch.Tensor, *, pad: bool, bg: Sequence[int], size
     d.tmp, d.out, d.out_dtype, d.out_u8, d.rescale = _ptr(tmp), _ptr(out), dt(out), _ptr(u8), float(rescale)
     L.check(lib.dxa_image_preprocess(C.byref(d), _stream()), "dxa_image_preprocess")
     return (out, u8) if want_u8 else out
+
+
+# ------------------------------------------------------------------------------------------------ fused DiT blocks
+DIT_FUSED_MAX_ROWS, DIT_FUSED_MAX_TOKENS = 48, 32
+
+
+def dit_blocks_supported(N: int, T1: int, H: int, heads: int, I: int) -> bool:
+    return (N * T1 <= DIT_FUSED_MAX_ROWS and T1 <= DIT_FUSED_MAX_TOKENS and H == heads * 64 and H <= 1024 and I % 64 == 0)
+
+
+def dit_blocks_fwd(h: torch.Tensor, weight_table: torch.Tensor, depth: int, N: int, T1: int, H: int, heads: int, I: int,
+                   eps: float) -> torch.Tensor:
+    """all DiT blocks of one denoising call in one launch; h [N*T1, H] fp32 is updated in place.  ``weight_table`` is an
+    int64 device tensor of depth*8 raw fp32 pointers (qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b per block)"""
+    assert h.dtype == torch.float32 and h.is_contiguous() and h.shape == (N * T1, H)
+    assert weight_table.dtype == torch.int64 and weight_table.numel() == depth * 8 and weight_table.is_cuda
+    nbytes = lib.dxa_dit_blocks_workspace(N * T1, H, I)
+    ws = torch.empty(nbytes, device=h.device, dtype=torch.uint8)
+    L.check(lib.dxa_dit_blocks_fwd(_ptr(h), _ptr(weight_table), depth, N, T1, H, heads, I, float(eps), _ptr(ws), nbytes,
+                                   _stream()), "dxa_dit_blocks_fwd")
+    return h

@@ -8,6 +8,7 @@ forward_with_cfg (:294-311).  Parameter names = the reference's (``net.blocks.{k
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -139,6 +140,28 @@ class DiT(nn.Module):
                            b + "mlp.fc2.bias", L.ACT_GELU_TANH)
         return Fn.AddFn.apply(hcur, m)
 
+    def _use_fused_blocks(self, N: int, T1: int) -> bool:
+        from .... import kernels as K
+        # opt-in: measured on MI355X the persistent kernel is correct but not yet faster than the block-by-block launches
+        # (1.13 ms vs ~1.0 ms per 12-block forward) — every workgroup re-reads the whole activation matrix
+        return (not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "0") != "0" and
+                self.store.device.type == "cuda" and
+                K.dit_blocks_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden))
+
+    def _weight_table(self, st) -> torch.Tensor:
+        """device array of the raw fp32 master pointers of every block (the arena never moves)"""
+        if getattr(self, "_wtab", None) is None:
+            ptrs = []
+            for k in range(self.depth):
+                b = f"{self.p}blocks.{k}."
+                for n in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight",
+                          "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"):
+                    w = st.w(b + n)
+                    assert w.dtype == torch.float32 and w.is_contiguous()
+                    ptrs.append(w.data_ptr())
+            self._wtab = torch.tensor(ptrs, dtype=torch.int64).to(self.store.device)
+        return self._wtab
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor, drop_ids: Optional[torch.Tensor] = None,
                 train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None):
         """x (N,T,A) noisy actions, t (N,) timesteps, z (N,1,token) conditions -> eps_hat (N,T,A).
@@ -168,6 +191,10 @@ class DiT(nn.Module):
             hcur = hcur.reshape(N * (T + 1), h)
             for k in range(self.depth):
                 hcur = self._block_with_per_attn(st, k, hcur, pe, N, T + 1)
+        elif self._use_fused_blocks(N, T + 1):
+            # inference, one request: every block in ONE persistent launch (csrc/dit_fused.hip)
+            hcur = K.dit_blocks_fwd(hcur.reshape(N * (T + 1), h).contiguous(), self._weight_table(st), self.depth, N, T + 1, h,
+                                    self.num_heads, self.mlp_hidden, 1e-6)
         else:
             for sp in self.block_specs:
                 sp.N, sp.T = N, T + 1

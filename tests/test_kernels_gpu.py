@@ -678,3 +678,36 @@ def test_cross_entropy_and_argmax(dtype, rows, V):
     y[2] = 0                                               # all equal: index 0
     assert torch.equal(K.argmax_rows(y), torch.argmax(y.float(), dim=1))
     assert int(K.argmax_rows(y)[0]) == 7 and int(K.argmax_rows(y)[2]) == 0
+
+
+# ------------------------------------------------------------------------------------------------ fused DiT blocks
+@pytest.mark.parametrize("cfg", [(2, 17, 768, 12, 3072, 3), (2, 17, 128, 2, 512, 2), (1, 17, 192, 3, 768, 4), (2, 24, 256, 4, 1024, 1)])
+def test_dit_blocks_fused(cfg):
+    """the persistent DiT-block kernel (one launch, device-wide barriers) against the block arithmetic in fp64"""
+    N, T1, H, heads, I, depth = cfg
+    M = N * T1
+    h0 = rnd(M, H, seed=41)
+    ws, ptrs = [], []
+    for k in range(depth):
+        blk = [rnd(3 * H, H, seed=50 + 10 * k, scale=H ** -0.5), rnd(3 * H, seed=51 + 10 * k, scale=0.1),
+               rnd(H, H, seed=52 + 10 * k, scale=H ** -0.5), rnd(H, seed=53 + 10 * k, scale=0.1),
+               rnd(I, H, seed=54 + 10 * k, scale=H ** -0.5), rnd(I, seed=55 + 10 * k, scale=0.1),
+               rnd(H, I, seed=56 + 10 * k, scale=I ** -0.5), rnd(H, seed=57 + 10 * k, scale=0.1)]
+        ws.append(blk)
+        ptrs += [w.data_ptr() for w in blk]
+    assert K.dit_blocks_supported(N, T1, H, heads, I)
+    table = torch.tensor(ptrs, dtype=torch.int64).to(DEV)
+    ref = h0.double()
+    for qw, qb, pw, pb, w1, b1, w2, b2 in ws:
+        y = F.layer_norm(ref, (H,), eps=1e-6)
+        qkv = (y @ qw.double().t() + qb.double()).view(N, T1, 3, heads, 64)
+        q, k_, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        att = torch.softmax(q @ k_.transpose(-1, -2) / 8.0, dim=-1) @ v
+        ref = ref + att.permute(0, 2, 1, 3).reshape(M, H) @ pw.double().t() + pb.double()
+        y = F.layer_norm(ref, (H,), eps=1e-6)
+        ref = ref + F.gelu(y @ w1.double().t() + b1.double(), approximate="tanh") @ w2.double().t() + b2.double()
+    for rep in range(3):                                           # the barrier counter is reset by every call
+        out = K.dit_blocks_fwd(h0.clone(), table, depth, N, T1, H, heads, I, 1e-6)
+        assert_close(out, ref, 2e-4, 2e-4 * float(ref.abs().max()), f"fused DiT blocks {cfg} rep {rep}")
+    with pytest.raises(L.DxaError):
+        K.dit_blocks_fwd(torch.zeros(64, H, device=DEV), table, depth, 4, 16, H, heads, I, 1e-6)
