@@ -23,19 +23,23 @@ constexpr int MB = 3;        // 16-row blocks
 constexpr int MAXT = 32;     // tokens per sample
 constexpr int HD = 64;       // head width
 
+constexpr int SMAX = 8;      // K slices of the narrow products (proj, fc2)
+
 struct DitP {
-  float *h, *qkv, *o, *a;
-  const float* const* w;     // [depth][8]: qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b
-  unsigned* bar;
+  float *h, *qkv, *o, *a, *part;   // part [SMAX][M][H]: partial sums of the K-sliced products
+  const float* const* w;           // [depth][8]: qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b
+  unsigned *bar, *cnt_proj, *cnt_fc2;
   int M, N, T1, H, heads, I, depth;
+  int s_proj, s_fc2;
   float eps, scale;
   int dbg;   // tuning aid: 1 = barriers only, 2 = work only (wrong results)
 };
 
 struct Smem {
   float red[8][MB][64][4];
-  float mu[MAXM], rs[MAXM];
+  float sx[8][MAXM], sxx[8][MAXM], wsum[16];   // LayerNorm: per-wave row sums / sums of squares, sum_k W[n,k]
   float q[MAXT][HD], k[MAXT][HD + 1], v[MAXT][HD], p[MAXT][MAXT + 1];
+  int last;
 };
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -48,16 +52,20 @@ struct Act {
   __amdgpu_buffer_rsrc_t r;
   __device__ __forceinline__ Act(float* p, size_t floats)
       : r(__builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(floats * sizeof(float)), 0x00020000)) {}
+  // coherent load: data written by other workgroups since the last device-wide barrier (partials, residual)
   __device__ __forceinline__ float4 ld4(size_t idx) const {
-#if defined(DXA_DIT_SC1_LOADS)
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, SC1);
-#else
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, 0);   // cached; the barrier invalidates
-#endif
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
   }
-  __device__ __forceinline__ float ld1(size_t idx) const {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(idx * 4), 0, SC1));
+  // cached load: data complete before the last device-wide barrier (whose acquire dropped stale lines); the 20+
+  // workgroups of an XCD then share one copy in its L2 instead of each pulling the matrix from the memory side
+  __device__ __forceinline__ float4 ld4c(size_t idx) const {
+#if !defined(DXA_DIT_CACHED_LOADS)
+    return ld4(idx);     // measured: the cached variant (+ acquire at every barrier) is 8 % slower end to end
+#else
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+#endif
   }
   __device__ __forceinline__ void st4(size_t idx, const float4& v) const {
     const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
@@ -68,7 +76,7 @@ struct Act {
   }
 };
 
-__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch) {
+__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch, bool sleep) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -76,88 +84,59 @@ __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned
     const unsigned target = epoch * nblk;
     const unsigned arrived = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (arrived != target)
-      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-#if !defined(DXA_DIT_SC1_LOADS)
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (sleep) __builtin_amdgcn_s_sleep(1);
+      }
+#if defined(DXA_DIT_CACHED_LOADS)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale activation lines from this CU's L1 / this XCD's L2
 #endif
   }
   __syncthreads();
 }
 
-// per-row mean / rstd of h: a wave owns rows wave, wave+8, ...; the row is read ONCE into registers (H <= 1024)
-__device__ __forceinline__ void row_stats(const DitP& p, Smem& s, const Act& h) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int MAXR = 6;                                   // rows per wave (48 / 8)
-  constexpr int MAXV = 4;                                   // float4 per lane per row (H <= 1024)
-  float4 x[MAXR][MAXV];
-  const int nv = (p.H + 255) / 256;
-#pragma unroll
-  for (int r = 0; r < MAXR; ++r) {
-    const int m = wave + 8 * r;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      x[r][i] = (m < p.M && i < nv && c < p.H) ? h.ld4((size_t)m * p.H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < MAXR; ++r) {
-    const int m = wave + 8 * r;
-    if (m >= p.M) break;
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) sum += x[r][i].x + x[r][i].y + x[r][i].z + x[r][i].w;
-    const float mean = wave_sum(sum) / (float)p.H;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (i < nv && c < p.H) {
-        const float d0 = x[r][i].x - mean, d1 = x[r][i].y - mean, d2 = x[r][i].z - mean, d3 = x[r][i].w - mean;
-        ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-      }
-    }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)p.H + p.eps);
-    if (lane == 0) { s.mu[m] = mean; s.rs[m] = rstd; }
-  }
-  __syncthreads();
-}
-
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESADD = 2 };
 
-// C[M, Nout] = epi(pro(A)[M, K] W[Nout, K]^T + bias); LN: pro(a) = (a - mu[m]) * rs[m]; RESADD: C += (in place).
-// A and C are activations (sc1 accesses), W and bias are weights (ordinary cached loads).
+// C[M, Nout] = epi(pro(A)[M, K] W[Nout, K]^T + bias).  A, C are activations (sc1 accesses), W, bias weights (cached).
+//  * LN: pro(a) = (a - mu[m]) * rs[m] is applied in the EPILOGUE, rs[m] * (acc[m,n] - mu[m] * wsum[n]), with
+//    wsum[n] = sum_k W[n,k] picked up by the product itself from an all-ones row appended to A (row M < 48) and the
+//    row statistics accumulated from the very A fragments the waves load for the product (each row is covered
+//    exactly once by the 8 waves): no separate pass over h, nothing waits for the statistics.
+//  * S > 1 (narrow products): the work items are (16 columns) x (K slice); a slice's partial tile goes to `part`
+//    through write-through stores and the LAST workgroup to arrive at the tile's counter (split-K protocol of the ring
+//    GEMM) adds the S partials in slice order, the bias and the residual: deterministic, no extra device-wide barrier.
 template <bool LN, int EPI>
 __device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A, int lda, const float* __restrict__ W,
-                                           const float* __restrict__ bias, const Act& C, int ldc, int Nout, int K) {
+                                           const float* __restrict__ bias, const Act& C, int ldc, int Nout, int K, int S,
+                                           unsigned* cnt, unsigned cnt_target, const Act& part) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
   size_t arow[MB];
-  float mu[MB], rs[MB];
+  int akind[MB];            // 0: real row, 1: the ones row (m == M, LN only), 2: padding
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = min(mb * 16 + l16, p.M - 1);
-    arow[mb] = (size_t)m * lda + 4 * lg;
-    mu[mb] = LN ? s.mu[m] : 0.f;
-    rs[mb] = LN ? s.rs[m] : 1.f;
+    const int m = mb * 16 + l16;
+    arow[mb] = (size_t)min(m, p.M - 1) * lda + 4 * lg;
+    akind[mb] = m < p.M ? 0 : ((LN && m == p.M) ? 1 : 2);
   }
-  const int nkb = K / 64;
-  for (int cb = blockIdx.x; cb * 16 < Nout; cb += gridDim.x) {
-    const int n0 = cb * 16;
+  const int ncb = Nout / 16, nkb = K / 64, per = nkb / S;
+  for (int item = blockIdx.x; item < ncb * S; item += gridDim.x) {
+    const int cb = item % ncb, ks = item / ncb, n0 = cb * 16;
+    const int kb_lo = ks * per, kb_hi = kb_lo + per;
     const float* Wp = W + (size_t)(n0 + l16) * K + 4 * lg;
-    // epilogue operands of the folding waves are requested first: they are back long before the K loop ends
+    // epilogue operands of the folding waves are requested early
     const int em = wave * 16 + l16, en = n0 + 4 * lg;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave < MB && em < p.M) {
       b4 = *reinterpret_cast<const float4*>(bias + en);
-      if (EPI == EPI_RESADD) c4 = C.ld4((size_t)em * ldc + en);
+      if (EPI == EPI_RESADD && S == 1) c4 = C.ld4((size_t)em * ldc + en);
     }
     f32x4_t acc[MB];
+    float sx[MB], sxx[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    // two 64-deep K blocks per trip: 32 independent 16-byte loads per lane in flight
-    for (int kb = wave; kb < nkb; kb += 16) {
-      const bool two = kb + 8 < nkb;
+    for (int mb = 0; mb < MB; ++mb) { acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sx[mb] = 0.f; sxx[mb] = 0.f; }
+    // two 64-deep K blocks per trip: up to 32 independent 16-byte loads per lane in flight
+    for (int kb = kb_lo + wave; kb < kb_hi; kb += 16) {
+      const bool two = kb + 8 < kb_hi;
       float4 wv[2][4], av[2][MB][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -168,7 +147,10 @@ __device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A,
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) av[u][mb][j] = A.ld4(arow[mb] + k0 + 16 * j);
+            for (int j = 0; j < 4; ++j) {
+              if (akind[mb] == 0) av[u][mb][j] = A.ld4c(arow[mb] + k0 + 16 * j);
+              else av[u][mb][j] = akind[mb] == 1 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
       }
 #pragma unroll
@@ -178,31 +160,54 @@ __device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A,
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
-            float4 t = av[u][mb][j];
-            if (LN) {
-              t.x = (t.x - mu[mb]) * rs[mb]; t.y = (t.y - mu[mb]) * rs[mb];
-              t.z = (t.z - mu[mb]) * rs[mb]; t.w = (t.w - mu[mb]) * rs[mb];
+            if (LN && akind[mb] == 0) {
+              const float4 t = av[u][mb][j];
+              sx[mb] += (t.x + t.y) + (t.z + t.w);
+              sxx[mb] += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
             }
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].x, t.x, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].y, t.y, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].z, t.z, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].w, t.w, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].x, av[u][mb][j].x, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].y, av[u][mb][j].y, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].z, av[u][mb][j].z, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].w, av[u][mb][j].w, acc[mb], 0, 0, 0);
           }
+      }
+    }
+    if (LN) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {       // the 4 lanes l16 + 16 lg hold disjoint columns of row mb*16 + l16
+        float a = sx[mb], b = sxx[mb];
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        if (lg == 0) { s.sx[wave][mb * 16 + l16] = a; s.sxx[wave][mb * 16 + l16] = b; }
       }
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
       *reinterpret_cast<float4*>(s.red[wave][mb][lane]) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
     __syncthreads();
+    // wave mb folds the 8 partials of row block mb: lane holds out[m = 16 mb + l16][n0 + 4 lg + {0..3}]
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave < MB) {
-      // wave mb folds the 8 partials of row block mb: lane holds out[m = 16 mb + l16][n0 + 4 lg + {0..3}]
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) {
         const float4 v = *reinterpret_cast<const float4*>(s.red[w8][wave][lane]);
         r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
       }
-      if (em < p.M) {
+      if (LN && em == p.M) *reinterpret_cast<float4*>(&s.wsum[4 * lg]) = r;     // the ones row: sum_k W[n, k]
+    }
+    if (LN) __syncthreads();
+    if (S == 1) {
+      if (wave < MB && em < p.M) {
+        if (LN) {
+          const float4 ws = *reinterpret_cast<const float4*>(&s.wsum[4 * lg]);
+          float tx = 0.f, txx = 0.f;
+#pragma unroll
+          for (int w8 = 0; w8 < 8; ++w8) { tx += s.sx[w8][em]; txx += s.sxx[w8][em]; }
+          const float mu = tx / (float)K;
+          const float rs = rsqrtf(fmaxf(txx / (float)K - mu * mu, 0.f) + p.eps);
+          r.x = rs * (r.x - mu * ws.x); r.y = rs * (r.y - mu * ws.y);
+          r.z = rs * (r.z - mu * ws.z); r.w = rs * (r.w - mu * ws.w);
+        }
         r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
         if (EPI == EPI_GELU) {
           r.x = act_fwd(DXA_ACT_GELU_TANH, r.x); r.y = act_fwd(DXA_ACT_GELU_TANH, r.y);
@@ -211,6 +216,30 @@ __device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A,
           r.x += c4.x; r.y += c4.y; r.z += c4.z; r.w += c4.w;
         }
         C.st4((size_t)em * ldc + en, r);
+      }
+    } else {
+      // K-sliced (never LN): publish the partial tile, the last arrival gathers
+      if (wave < MB && em < p.M) part.st4(((size_t)ks * p.M + em) * Nout + en, r);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned arrived = __hip_atomic_fetch_add(cnt + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s.last = arrived == cnt_target;
+      }
+      __syncthreads();
+      if (s.last && wave < MB && em < p.M) {
+        float4 t = b4;
+        if (EPI == EPI_RESADD) {
+          const float4 c0 = C.ld4((size_t)em * ldc + en);
+          t.x += c0.x; t.y += c0.y; t.z += c0.z; t.w += c0.w;
+        }
+        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < S; ++q) {
+          const float4 v = part.ld4(((size_t)q * p.M + em) * Nout + en);
+          acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+        }
+        t.x += acc4.x; t.y += acc4.y; t.z += acc4.z; t.w += acc4.w;
+        C.st4((size_t)em * ldc + en, t);
       }
     }
     __syncthreads();
@@ -226,7 +255,7 @@ __device__ __forceinline__ void attention_phase(const DitP& p, Smem& s, const Ac
     for (int e = tid; e < T1 * (HD / 4); e += 512) {
       const int i = e / (HD / 4), d = (e - i * (HD / 4)) * 4;
       const size_t r = base + (size_t)i * ld + d;
-      const float4 q4 = qkv.ld4(r), k4 = qkv.ld4(r + p.H), v4 = qkv.ld4(r + 2 * p.H);
+      const float4 q4 = qkv.ld4c(r), k4 = qkv.ld4c(r + p.H), v4 = qkv.ld4c(r + 2 * p.H);
       *reinterpret_cast<float4*>(&s.q[i][d]) = q4;
       s.k[i][d] = k4.x; s.k[i][d + 1] = k4.y; s.k[i][d + 2] = k4.z; s.k[i][d + 3] = k4.w;
       *reinterpret_cast<float4*>(&s.v[i][d]) = v4;
@@ -264,31 +293,42 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
   __shared__ Smem s;
   unsigned epoch = 0;
   const unsigned nblk = gridDim.x;
-  const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I);
+  const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I),
+      part(p.part, (size_t)SMAX * p.M * p.H);
   const bool work = p.dbg != 1, sync = p.dbg != 2;
   for (int blk = 0; blk < p.depth; ++blk) {
     const float* const* w = p.w + blk * 8;
-    if (work) row_stats(p, s, h);
-    if (work) gemm_phase<true, EPI_BIAS>(p, s, h, p.H, w[0], w[1], qkv, 3 * p.H, 3 * p.H, p.H);
-    if (sync) grid_sync(p.bar, nblk, epoch);
-    if (work) attention_phase(p, s, qkv, o);
-    if (sync) grid_sync(p.bar, nblk, epoch);
-    if (work) gemm_phase<false, EPI_RESADD>(p, s, o, p.H, w[2], w[3], h, p.H, p.H, p.H);
-    if (sync) grid_sync(p.bar, nblk, epoch);
-    if (work) row_stats(p, s, h);
-    if (work) gemm_phase<true, EPI_GELU>(p, s, h, p.H, w[4], w[5], a, p.I, p.I, p.H);
-    if (sync) grid_sync(p.bar, nblk, epoch);
-    if (work) gemm_phase<false, EPI_RESADD>(p, s, a, p.I, w[6], w[7], h, p.H, p.H, p.I);
-    if (sync) grid_sync(p.bar, nblk, epoch);
+    if (work) gemm_phase<true, EPI_BIAS>(p, s, h, p.H, w[0], w[1], qkv, 3 * p.H, 3 * p.H, p.H, 1, nullptr, 0, part);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    if (work && p.dbg != 3) attention_phase(p, s, qkv, o);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    if (work) gemm_phase<false, EPI_RESADD>(p, s, o, p.H, w[2], w[3], h, p.H, p.H, p.H, p.s_proj, p.cnt_proj,
+                                            (unsigned)(blk + 1) * p.s_proj, part);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    if (work) gemm_phase<true, EPI_GELU>(p, s, h, p.H, w[4], w[5], a, p.I, p.I, p.H, 1, nullptr, 0, part);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    if (work) gemm_phase<false, EPI_RESADD>(p, s, a, p.I, w[6], w[7], h, p.H, p.H, p.I, p.s_fc2, p.cnt_fc2,
+                                            (unsigned)(blk + 1) * p.s_fc2, part);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
   }
+}
+
+constexpr size_t TAIL_BYTES = 1024;   // barrier counter + two per-tile counter arrays (H / 16 <= 64 entries each)
+size_t act_bytes_for(int M, int H, int I) {
+  return ((size_t)M * ((4 + SMAX) * (size_t)H + I) * sizeof(float) + 255) / 256 * 256;
+}
+int pick_slices(int ncb, int nkb, int grid) {
+  for (int sl = SMAX; sl > 1; --sl)
+    if (nkb % sl == 0 && ncb * sl <= grid) return sl;
+  return 1;
 }
 
 }  // namespace
 
 extern "C" size_t dxa_dit_blocks_workspace(int M, int H, int I) {
-  // qkv [M,3H] + o [M,H] + a [M,I] floats + the barrier counter (kept 256-byte aligned)
+  // qkv [M,3H] + o [M,H] + a [M,I] + K-slice partials [8][M,H] floats + the counters
   if (M <= 0 || H <= 0 || I <= 0) return 0;
-  return ((size_t)M * (4 * (size_t)H + I) * sizeof(float) + 255) / 256 * 256 + 256;
+  return act_bytes_for(M, H, I) + TAIL_BYTES;
 }
 
 extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I,
@@ -296,9 +336,10 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   DXA_CHECK_ARG(h && weights && workspace, "dxa_dit_blocks_fwd: null buffer");
   DXA_CHECK_ARG(depth >= 1 && N >= 1 && T1 >= 1 && heads >= 1, "dxa_dit_blocks_fwd: bad sizes");
   const int M = N * T1;
-  DXA_CHECK_ARG(M <= MAXM && T1 <= MAXT, "dxa_dit_blocks_fwd: at most %d rows / %d tokens per sample (got %d / %d)", MAXM,
+  DXA_CHECK_ARG(M < MAXM && T1 <= MAXT, "dxa_dit_blocks_fwd: at most %d rows / %d tokens per sample (got %d / %d)", MAXM - 1,
                 MAXT, M, T1);
-  DXA_CHECK_ARG(H % 64 == 0 && I % 64 == 0 && H == heads * HD && H <= 1024, "dxa_dit_blocks_fwd: needs head width 64 and H, I %% 64 == 0");
+  DXA_CHECK_ARG(H % 64 == 0 && I % 64 == 0 && H == heads * HD && H <= 1024,
+                "dxa_dit_blocks_fwd: needs head width 64, H <= 1024 and H, I %% 64 == 0");
   DXA_CHECK_ARG(workspace_bytes >= dxa_dit_blocks_workspace(M, H, I), "dxa_dit_blocks_fwd: workspace too small");
   DXA_CHECK_ARG((reinterpret_cast<uintptr_t>(h) % 16) == 0 && (reinterpret_cast<uintptr_t>(workspace) % 16) == 0,
                 "dxa_dit_blocks_fwd: buffers must be 16-byte aligned");
@@ -307,8 +348,11 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   p.qkv = reinterpret_cast<float*>(workspace);
   p.o = p.qkv + (size_t)M * 3 * H;
   p.a = p.o + (size_t)M * H;
-  const size_t act_bytes = ((size_t)M * (4 * (size_t)H + I) * sizeof(float) + 255) / 256 * 256;
-  p.bar = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + act_bytes);
+  p.part = p.a + (size_t)M * I;
+  unsigned* tail = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + act_bytes_for(M, H, I));
+  p.bar = tail;
+  p.cnt_proj = tail + 64;
+  p.cnt_fc2 = tail + 128;
   p.w = weights;
   p.M = M; p.N = N; p.T1 = T1; p.H = H; p.heads = heads; p.I = I; p.depth = depth;
   p.eps = eps;
@@ -316,14 +360,28 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   static const int dbg = getenv("DXA_DIT_DBG") ? atoi(getenv("DXA_DIT_DBG")) : 0;
   p.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
-  DXA_CHECK_HIP(hipMemsetAsync(p.bar, 0, sizeof(unsigned), st));
+  DXA_CHECK_HIP(hipMemsetAsync(tail, 0, TAIL_BYTES, st));
   // every workgroup must be resident at once (device-wide barrier): one per 16 columns of the widest product,
   // never more than the 256 CUs can hold
   int grid = I / 16;
   if (3 * H / 16 > grid) grid = 3 * H / 16;
-  if (grid > 240) grid = 240;
+  // ... and never more than fit on the device at once (registers allow one 512-thread workgroup per CU)
+  static int resident = 0;
+  if (resident == 0) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    DXA_CHECK_HIP(hipGetDevice(&dev));
+    DXA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    DXA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dit_blocks_fused_k, 512, 0));
+    resident = per_cu * prop.multiProcessorCount;
+    DXA_CHECK_ARG(resident >= 1, "dxa_dit_blocks_fwd: the kernel does not fit on this device");
+  }
+  if (grid > resident) grid = resident;
   static const int grid_cap = getenv("DXA_DIT_GRID") ? atoi(getenv("DXA_DIT_GRID")) : 0;   // tuning aid
   if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+  static const int no_slice = getenv("DXA_DIT_NO_SLICE") ? 1 : 0;
+  p.s_proj = no_slice ? 1 : pick_slices(H / 16, H / 64, grid);
+  p.s_fc2 = no_slice ? 1 : pick_slices(H / 16, I / 64, grid);
   hipLaunchKernelGGL(dit_blocks_fused_k, dim3(grid), dim3(512), 0, st, p);
   DXA_CHECK_LAUNCH();
   return DXA_OK;

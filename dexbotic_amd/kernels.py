@@ -742,7 +742,7 @@ def image_preprocess(frames: torch.Tensor, *, pad: bool, bg: Sequence[int], size
 
 
 # ------------------------------------------------------------------------------------------------ fused DiT blocks
-DIT_FUSED_MAX_ROWS, DIT_FUSED_MAX_TOKENS = 48, 32
+DIT_FUSED_MAX_ROWS, DIT_FUSED_MAX_TOKENS = 47, 32
 
 
 def dit_blocks_supported(N: int, T1: int, H: int, heads: int, I: int) -> bool:

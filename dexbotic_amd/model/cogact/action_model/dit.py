@@ -142,9 +142,8 @@ class DiT(nn.Module):
 
     def _use_fused_blocks(self, N: int, T1: int) -> bool:
         from .... import kernels as K
-        # opt-in: measured on MI355X the persistent kernel is correct but not yet faster than the block-by-block launches
-        # (1.13 ms vs ~1.0 ms per 12-block forward) — every workgroup re-reads the whole activation matrix
-        return (not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "0") != "0" and
+        # one persistent launch for all blocks of a denoising call (DXA_DIT_FUSED=0 restores the block-by-block kernels)
+        return (not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "1") != "0" and
                 self.store.device.type == "cuda" and
                 K.dit_blocks_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden))
 

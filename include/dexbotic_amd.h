@@ -362,7 +362,7 @@ int dxa_image_preprocess(const dxa_image_desc* d, dxa_stream_t stream);
  * :281-293 inside every DDIM step of cogact_arch.py:186-197) in ONE launch: h [N*T1, H] (fp32, in place) goes through
  *   h += proj(attn(qkv(LN(h)))) ; h += fc2(gelu_tanh(fc1(LN(h))))      (LayerNorm without affine, eps; head width 64)
  * `weights` is a DEVICE array of depth*8 fp32 pointers: qkv_w [3H,H], qkv_b, proj_w [H,H], proj_b, fc1_w [I,H], fc1_b,
- * fc2_w [H,I], fc2_b per block.  Limits: N*T1 <= 48 rows, T1 <= 32, H = heads*64 <= 1024, I a multiple of 64 (the CFG
+ * fc2_w [H,I], fc2_b per block.  Limits: N*T1 <= 47 rows, T1 <= 32, H = heads*64 <= 1024, I a multiple of 64 (the CFG
  * batch of one request: 2 x 17 rows); anything else runs block by block on the ordinary kernels.  The workspace holds
  * the qkv / attention / MLP activations and the device-wide barrier counter. */
 size_t dxa_dit_blocks_workspace(int M, int H, int I);
