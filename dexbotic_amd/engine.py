@@ -388,17 +388,18 @@ class GradNormTracker:
         self.acc.zero_()                       # on the compute stream; every fold waits for that stream first
         self._lo = self._hi = None
 
-    def fold(self, lo: int, hi: int, stream=None) -> None:
-        """acc += sum(grad[lo:hi]^2) on ``stream`` (default: the tracker's own side stream)"""
+    def fold(self, lo: int, hi: int, after=None) -> None:
+        """acc += sum(grad[lo:hi]^2) on the tracker's side stream, ordered after everything enqueued so far on ``after``
+        (default: the compute stream; the communication stream when the slice has just been all-reduced there — the
+        collectives that follow on that stream are not held up by the reduction)"""
         from . import kernels as K
         if hi <= lo:
             return
-        stream = stream or self.stream
-        if stream is None:
+        if self.stream is None:
             K.sumsq(self.store.grad[lo:hi], self.acc, self.scratch, accumulate=True)
             return
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
+        self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             K.sumsq(self.store.grad[lo:hi], self.acc, self.scratch, accumulate=True)
 
     def bucket_ready(self, b: int) -> None:
@@ -466,7 +467,7 @@ class GradReducer:
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
         self._handles: List = []
-        self.after_reduce = None    # callable(lo, hi, stream): runs on the communication stream once a slice is averaged
+        self.after_reduce = None    # callable(lo, hi, comm_stream): called once a slice's collective (and cast back) is enqueued
         self.bytes_reduced = 0
         skip = set(skip)
         # buckets whose every slot is skipped (never gets a gradient) are not communicated
