@@ -136,3 +136,20 @@ def test_process_frame_end_to_end(golden_dir):
         torch.manual_seed(11)
         want = np.asarray(m.inference_action(ids, pix, {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms}))
         assert np.max(np.abs(got - want)) <= 1e-5 * np.max(np.abs(want)), views
+
+
+def test_random_and_extreme_frame_sizes():
+    """sizes the goldens do not hold: extreme aspect ratios, up-scaling in one axis and down-scaling in the other,
+    1-pixel sides — device result against the oracle (itself pinned to Pillow), uint8 stage exact"""
+    from oracle import image_oracle as IO
+    rs = np.random.RandomState(9)
+    sizes = [(int(rs.randint(3, 700)), int(rs.randint(3, 900))) for _ in range(6)] + [(1, 50), (50, 1), (224, 3), (2000, 37), (37, 2000)]
+    for h, w in sizes:
+        frame = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        for aspect in ("pad", None):
+            pre = make(aspect, "mean")
+            out, u8 = pre.batch(torch.from_numpy(frame)[None], want_u8=True)
+            want = IO.preprocess_u8(frame, aspect=aspect)
+            assert np.array_equal(u8[0].cpu().numpy(), want), (h, w, aspect)
+            ref = IO.normalize(want)
+            assert np.max(np.abs(out[0].cpu().numpy() - ref)) <= 1e-6 * np.max(np.abs(ref)), (h, w, aspect)

@@ -66,3 +66,19 @@ def test_collate(g):
         assert np.array_equal(ids, g[f"collate_{tag}/input_ids"]), tag
         assert np.array_equal(lab, g[f"collate_{tag}/labels"]), tag
         assert np.array_equal(mask, g[f"collate_{tag}/attention_mask"]), tag
+
+
+def test_oracle_against_live_pillow_on_random_sizes():
+    """beyond the committed goldens: the restatement against whatever Pillow is installed (same package the reference
+    resizes with), random frame sizes incl. extreme aspect ratios and up-scaling; skipped where Pillow is absent"""
+    Image = pytest.importorskip("PIL.Image")
+    rs = np.random.RandomState(5)
+    sizes = [(rs.randint(3, 700), rs.randint(3, 900)) for _ in range(12)] + [(1, 50), (50, 1), (224, 3), (2000, 37)]
+    for n, (h, w) in enumerate(sizes):
+        frame = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        for aspect in ("pad", None):
+            img = IO.expand2square(frame, IO.pad_color("mean")) if aspect == "pad" else frame
+            oh, ow = IO.resize_output_size(img.shape[0], img.shape[1], 224)
+            want = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
+            got = IO.pil_resize_bicubic(img, oh, ow)
+            assert np.array_equal(got, want), (n, h, w, aspect)
