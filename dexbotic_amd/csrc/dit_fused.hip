@@ -14,6 +14,10 @@
 // fp32 throughout, same arithmetic as the unfused kernels (held to them by tests/test_kernels_gpu.py).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -83,9 +87,10 @@ __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned
     epoch += 1;
     const unsigned target = epoch * nblk;
     const unsigned arrived = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-#if defined(DXA_DIT_FLAG_BARRIER)
-    // tuning variant: the last arrival publishes the epoch in a flag on another cache line and the
-    // others poll that flag; ~1.2 us cheaper per barrier and it keeps the pollers off the atomic unit
+#if !defined(DXA_DIT_COUNTER_POLL)
+    // the last arrival publishes the epoch in a flag on another cache line and the others poll that flag: 3.5 us per
+    // barrier against 4.7 us when everybody polls the counter (scripts/probes/grid_barrier_probe.hip), and the pollers
+    // stay off the memory-side atomic unit the arrivals need (0.68 vs 0.86 ms per 12-block forward)
     unsigned* flag = bar + 32;
     if (arrived == target) {
       __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -324,9 +329,45 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
                                             (unsigned)(blk + 1) * p.s_fc2, part);
     if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
   }
+  // Leave the counters zeroed for the next launch on this stream (like the split-K flags of the ring GEMM): every
+  // workgroup has passed the last barrier when it gets here, so the LAST one out may clear them.  Agent-scope atomic
+  // stores, not a host-side memset: under HIP-graph replay a memset node's zeros were not reliably what the next
+  // kernel's atomics saw (the sampler hung), atomics are performed at the memory side and always are.
+  if (threadIdx.x == 0) {
+    unsigned* exit_cnt = p.bar + 48;
+    const unsigned out = __hip_atomic_fetch_add(exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (out == nblk) {
+      for (int i = 0; i < 64; ++i) {
+        __hip_atomic_store(p.cnt_proj + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.cnt_fc2 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(p.bar + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
-constexpr size_t TAIL_BYTES = 1024;   // barrier counter + two per-tile counter arrays (H / 16 <= 64 entries each)
+// Barrier counter, flag, exit counter and the two per-tile counter arrays (H / 16 <= 64 entries each): one 1 KiB block
+// per (device, stream), zeroed when it is created and left zeroed by every launch.
+constexpr size_t SYNC_BYTES = 1024;
+int get_sync_block(hipStream_t st, unsigned** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, unsigned*> tab;
+  int dev = 0;
+  DXA_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tab.find({dev, st});
+  if (it == tab.end()) {
+    unsigned* p = nullptr;
+    DXA_CHECK_HIP(hipMalloc((void**)&p, SYNC_BYTES));
+    DXA_CHECK_HIP(hipMemset(p, 0, SYNC_BYTES));
+    DXA_CHECK_HIP(hipDeviceSynchronize());
+    it = tab.emplace(std::make_pair(dev, st), p).first;
+  }
+  *out = it->second;
+  return DXA_OK;
+}
 size_t act_bytes_for(int M, int H, int I) {
   return ((size_t)M * ((4 + SMAX) * (size_t)H + I) * sizeof(float) + 255) / 256 * 256;
 }
@@ -339,9 +380,9 @@ int pick_slices(int ncb, int nkb, int grid) {
 }  // namespace
 
 extern "C" size_t dxa_dit_blocks_workspace(int M, int H, int I) {
-  // qkv [M,3H] + o [M,H] + a [M,I] + K-slice partials [8][M,H] floats + the counters
+  // qkv [M,3H] + o [M,H] + a [M,I] + K-slice partials [8][M,H] floats
   if (M <= 0 || H <= 0 || I <= 0) return 0;
-  return act_bytes_for(M, H, I) + TAIL_BYTES;
+  return act_bytes_for(M, H, I);
 }
 
 extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I,
@@ -362,7 +403,9 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   p.o = p.qkv + (size_t)M * 3 * H;
   p.a = p.o + (size_t)M * H;
   p.part = p.a + (size_t)M * I;
-  unsigned* tail = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + act_bytes_for(M, H, I));
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* tail = nullptr;          // first use on a stream allocates: must not happen under stream capture
+  if (int rc = get_sync_block(st, &tail)) return rc;
   p.bar = tail;
   p.cnt_proj = tail + 64;
   p.cnt_fc2 = tail + 128;
@@ -372,8 +415,6 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   p.scale = 1.f / sqrtf((float)HD);
   static const int dbg = getenv("DXA_DIT_DBG") ? atoi(getenv("DXA_DIT_DBG")) : 0;
   p.dbg = dbg;
-  hipStream_t st = (hipStream_t)stream;
-  DXA_CHECK_HIP(hipMemsetAsync(tail, 0, TAIL_BYTES, st));
   // every workgroup must be resident at once (device-wide barrier): one per 16 columns of the widest product,
   // never more than the 256 CUs can hold
   int grid = I / 16;

@@ -142,10 +142,9 @@ class DiT(nn.Module):
 
     def _use_fused_blocks(self, N: int, T1: int) -> bool:
         from .... import kernels as K
-        # DXA_DIT_FUSED=1: one persistent launch for all blocks of a denoising call (csrc/dit_fused.hip).  Opt-in: it is
-        # ~0.7 ms per request faster (p50 29.4 vs 30.0 ms) but relies on a spin-wait device-wide barrier, and a variant of
-        # that barrier hung a GPU box once during tuning — the default stays on the launch-per-kernel path
-        return (not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "0") != "0" and
+        # one persistent launch for all blocks of a single-request denoising call (csrc/dit_fused.hip);
+        # DXA_DIT_FUSED=0 restores the block-by-block kernels
+        return (not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "1") != "0" and
                 self.store.device.type == "cuda" and
                 K.dit_blocks_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden))
 

@@ -364,7 +364,8 @@ int dxa_image_preprocess(const dxa_image_desc* d, dxa_stream_t stream);
  * `weights` is a DEVICE array of depth*8 fp32 pointers: qkv_w [3H,H], qkv_b, proj_w [H,H], proj_b, fc1_w [I,H], fc1_b,
  * fc2_w [H,I], fc2_b per block.  Limits: N*T1 <= 47 rows, T1 <= 32, H = heads*64 <= 1024, I a multiple of 64 (the CFG
  * batch of one request: 2 x 17 rows); anything else runs block by block on the ordinary kernels.  The workspace holds
- * the qkv / attention / MLP activations and the device-wide barrier counter. */
+ * the qkv / attention / MLP activations and the K-slice partials; the barrier counters live in a library-owned block per
+ * (device, stream) that every launch leaves zeroed (first use on a stream allocates it: not under stream capture). */
 size_t dxa_dit_blocks_workspace(int M, int H, int I);
 int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I, float eps,
                        void* workspace, size_t workspace_bytes, dxa_stream_t stream);
