@@ -68,7 +68,7 @@ class AdamWDesc(C.Structure):
         ("chunk_start", _vp), ("chunk_len", _vp), ("chunk_grp", _vp), ("n_chunks", _i32),
         ("lr", _f32 * 8), ("wd", _f32 * 8),
         ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("bc1", _f32), ("bc2", _f32),
-        ("clip_coef", _vp),
+        ("clip_coef", _vp), ("g_dtype", _i32),
     ]
 
 
@@ -115,6 +115,7 @@ SIGNATURES = {
     "dxa_permute_bshd": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "dxa_splice_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "dxa_splice_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_zero_rows": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "dxa_gather_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_scatter_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "dxa_im2col": (_int, [_vp, _vp, _int, _int, _int, _int, _i64, _int, _int, _vp]),
@@ -130,7 +131,7 @@ SIGNATURES = {
     "dxa_mse_loss_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "dxa_ddim_step": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _f32, _f32, _f32, _vp]),
     "dxa_adamw": (_int, [C.POINTER(AdamWDesc), _vp]),
-    "dxa_sumsq": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
+    "dxa_sumsq": (_int, [_vp, _i64, _int, _vp, _vp, _int, _vp]),
     "dxa_cross_entropy_fwd": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "dxa_cross_entropy_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dxa_argmax_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),

@@ -210,25 +210,74 @@ __global__ __launch_bounds__(TPB) void splice_fwd_k(const int64_t* __restrict__ 
     Vec<T, VEC>::st(out + r * d + c, v);
   }
 }
+// Backward of the splice.  One workgroup per (output row r, 256*VEC-column chunk).  Image rows are used once: plain store.
+// Token rows add into the dense fp32 embedding gradient WITHOUT atomics: the workgroup of the FIRST row carrying a token
+// id sums, in ascending row order, every row with that id (ballot over 256-row windows of the plan) and adds the total
+// to the gradient row; workgroups of later duplicates exit.  The plan (n_rows int64, L2 resident) is re-scanned per
+// workgroup: a few us in total, and the result is bitwise reproducible whatever the dispatch order.
 template <typename T, int VEC>
-__global__ __launch_bounds__(TPB) void splice_bwd_k(const int64_t* __restrict__ plan, const T* __restrict__ dout,
+__global__ __launch_bounds__(256) void splice_bwd_k(const int64_t* __restrict__ plan, const T* __restrict__ dout,
                                                     float* __restrict__ d_embed, T* __restrict__ d_img, int64_t n_rows, int64_t d) {
-  const int64_t per = d / VEC, total = n_rows * per;
-  for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TPB) {
-    const int64_t r = it / per, c = (it % per) * VEC;
-    const int64_t p = plan[r];
-    if (p == PLAN_PAD) continue;
-    float v[VEC];
-    Vec<T, VEC>::ld(v, dout + r * d + c);
-    if (p >= 0) {
-      if (d_embed) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) atomicAdd(d_embed + p * d + c + i, v[i]);
-      }
-    } else if (d_img) {
+  __shared__ unsigned long long s_mask[4];
+  __shared__ int s_dup;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int64_t r = blockIdx.x;
+  const int64_t c = ((int64_t)blockIdx.y * 256 + tid) * VEC;
+  const bool col_ok = c < d;
+  const int64_t p = plan[r];
+  if (p == PLAN_PAD) return;
+  if (p < 0) {
+    if (d_img && col_ok) {
+      float v[VEC];
+      Vec<T, VEC>::ld(v, dout + r * d + c);
       Vec<T, VEC>::st(d_img + (-1 - p) * d + c, v);
     }
+    return;
   }
+  if (!d_embed) return;
+  if (tid == 0) s_dup = 0;
+  __syncthreads();
+  for (int64_t i = tid; i < r; i += 256)
+    if (plan[i] == p) s_dup = 1;
+  __syncthreads();
+  if (s_dup) return;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int64_t base = r - (r & 255); base < n_rows; base += 256) {
+    const int64_t i = base + tid;
+    const bool m = i >= r && i < n_rows && plan[i] == p;
+    const unsigned long long bal = __ballot(m);
+    if ((tid & 63) == 0) s_mask[wave] = bal;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned long long mm = s_mask[w];
+      while (mm) {
+        const int b = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        if (col_ok) {
+          float v[VEC];
+          Vec<T, VEC>::ld(v, dout + (base + w * 64 + b) * d + c);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (col_ok) {
+    float* g = d_embed + p * d + c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] += acc[e];
+  }
+}
+// zero the embedding-gradient rows a previous plan touched (sparse re-zero instead of a 2 GB memset per step)
+__global__ __launch_bounds__(256) void zero_rows_k(const int64_t* __restrict__ plan, float* __restrict__ g, int64_t n_rows, int64_t d) {
+  const int64_t r = blockIdx.x;
+  const int64_t p = plan[r];
+  if (p < 0) return;
+  for (int64_t c = threadIdx.x; c < d; c += 256) g[p * d + c] = 0.f;
 }
 template <typename TS, typename TD>
 __global__ __launch_bounds__(TPB) void gather_rows_k(const TS* __restrict__ x, const int64_t* __restrict__ idx,
@@ -657,15 +706,24 @@ extern "C" int dxa_splice_fwd(const int64_t* plan, const void* embed, const void
 extern "C" int dxa_splice_bwd(const int64_t* plan, const void* dout, float* d_embed, void* d_img, int64_t n_rows,
                               int64_t d, int dtype, dxa_stream_t stream) {
   DXA_CHECK_ARG(plan && dout && n_rows >= 0 && d > 0 && ok_dtype(dtype), "dxa_splice_bwd: bad args");
+  DXA_CHECK_ARG(n_rows < (1ll << 31), "dxa_splice_bwd: too many rows");
   if (n_rows == 0) return DXA_OK;
   const bool vec = d % 4 == 0 && al(dout, 16) && (!d_img || al(d_img, 16));
+  const dim3 g4((unsigned)n_rows, (unsigned)dxa_cdiv(d, 1024)), g1((unsigned)n_rows, (unsigned)dxa_cdiv(d, 256));
   if (dtype == DXA_BF16) {
-    if (vec) hipLaunchKernelGGL((splice_bwd_k<bf16_t, 4>), dim3(dxa_grid1d(n_rows * d / 4, TPB)), dim3(TPB), 0, ST, plan, (const bf16_t*)dout, d_embed, (bf16_t*)d_img, n_rows, d);
-    else hipLaunchKernelGGL((splice_bwd_k<bf16_t, 1>), dim3(dxa_grid1d(n_rows * d, TPB)), dim3(TPB), 0, ST, plan, (const bf16_t*)dout, d_embed, (bf16_t*)d_img, n_rows, d);
+    if (vec) hipLaunchKernelGGL((splice_bwd_k<bf16_t, 4>), g4, dim3(256), 0, ST, plan, (const bf16_t*)dout, d_embed, (bf16_t*)d_img, n_rows, d);
+    else hipLaunchKernelGGL((splice_bwd_k<bf16_t, 1>), g1, dim3(256), 0, ST, plan, (const bf16_t*)dout, d_embed, (bf16_t*)d_img, n_rows, d);
   } else {
-    if (vec) hipLaunchKernelGGL((splice_bwd_k<float, 4>), dim3(dxa_grid1d(n_rows * d / 4, TPB)), dim3(TPB), 0, ST, plan, (const float*)dout, d_embed, (float*)d_img, n_rows, d);
-    else hipLaunchKernelGGL((splice_bwd_k<float, 1>), dim3(dxa_grid1d(n_rows * d, TPB)), dim3(TPB), 0, ST, plan, (const float*)dout, d_embed, (float*)d_img, n_rows, d);
+    if (vec) hipLaunchKernelGGL((splice_bwd_k<float, 4>), g4, dim3(256), 0, ST, plan, (const float*)dout, d_embed, (float*)d_img, n_rows, d);
+    else hipLaunchKernelGGL((splice_bwd_k<float, 1>), g1, dim3(256), 0, ST, plan, (const float*)dout, d_embed, (float*)d_img, n_rows, d);
   }
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+extern "C" int dxa_zero_rows(const int64_t* plan, float* g, int64_t n_rows, int64_t d, dxa_stream_t stream) {
+  DXA_CHECK_ARG(plan && g && n_rows >= 0 && d > 0 && n_rows < (1ll << 31), "dxa_zero_rows: bad args");
+  if (n_rows == 0) return DXA_OK;
+  hipLaunchKernelGGL(zero_rows_k, dim3((unsigned)n_rows), dim3(256), 0, ST, plan, g, n_rows, d);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

@@ -12,7 +12,7 @@
 namespace {
 
 struct AdamP {
-  float* p; const float* g; float* m; float* v; bf16_t* shadow;
+  float* p; const void* g; float* m; float* v; bf16_t* shadow;
   const int64_t* cs; const int32_t* cl; const int32_t* cg;
   float lr[8], wd[8];
   float b1, b2, eps, bc1, bc2;
@@ -29,6 +29,25 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
   p -= step_size * (m / denom);
 }
 
+// 4 consecutive gradients as fp32: fp32 arena (16-byte load) or the bf16 communication copy of it (8-byte load)
+template <typename TG> struct GradLd;
+template <> struct GradLd<float> {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f4 nt4(const float* g, int64_t i) { return __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i); }
+  static __device__ __forceinline__ f4 ld4(const float* g, int64_t i) { return reinterpret_cast<const f4*>(g)[i]; }
+};
+template <> struct GradLd<bf16_t> {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ f4 cvt(u2 v) {
+    return (f4){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                __uint_as_float(v.y & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ f4 nt4(const bf16_t* g, int64_t i) { return cvt(__builtin_nontemporal_load(reinterpret_cast<const u2*>(g) + i)); }
+  static __device__ __forceinline__ f4 ld4(const bf16_t* g, int64_t i) { return cvt(reinterpret_cast<const u2*>(g)[i]); }
+};
+
+template <typename TG>
 __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   const int c = blockIdx.x;
   const int64_t start = a.cs[c];
@@ -39,7 +58,7 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   const float step_size = lr / a.bc1;
   const float inv_sqrt_bc2 = sqrtf(a.bc2);  // (name kept: it is the divisor sqrt(1-beta2^t))
   float* p = a.p + start;
-  const float* g = a.g + start;
+  const TG* g = reinterpret_cast<const TG*>(a.g) + start;
   float* m = a.m + start;
   float* v = a.v + start;
   bf16_t* sh = a.shadow ? a.shadow + start : nullptr;
@@ -72,8 +91,8 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   for (; i + 256 < n4; i += 512) {
     f4 p0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + i);
     f4 p1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p) + i + 256);
-    const f4 g0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i);
-    const f4 g1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i + 256);
+    const f4 g0 = GradLd<TG>::nt4(g, i);
+    const f4 g1 = GradLd<TG>::nt4(g, i + 256);
     f4 m0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i);
     f4 m1 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i + 256);
     f4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i);
@@ -85,7 +104,7 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   }
   for (; i < n4; i += 256) {
     f4 p0 = reinterpret_cast<const f4*>(p)[i];
-    const f4 g0 = reinterpret_cast<const f4*>(g)[i];
+    const f4 g0 = GradLd<TG>::ld4(g, i);
     f4 m0 = reinterpret_cast<const f4*>(m)[i];
     f4 v0 = reinterpret_cast<const f4*>(v)[i];
     upd(p0, g0, m0, v0);
@@ -93,40 +112,41 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   }
   for (int i = (n4 << 2) + threadIdx.x; i < len; i += 256) {
     float pv = p[i], mv = m[i], vv = v[i];
-    adam1(pv, g[i] * clip, mv, vv, lr, wd, a, step_size, inv_sqrt_bc2);
+    adam1(pv, ldf<TG>(g + i) * clip, mv, vv, lr, wd, a, step_size, inv_sqrt_bc2);
     p[i] = pv; m[i] = mv; v[i] = vv;
     if (sh) sh[i] = f2bf(pv);
   }
 }
 
 // stage 1: up to 4096 blocks, each writes one double partial; stage 2: one block folds them
-__global__ __launch_bounds__(256) void sumsq_stage1_k(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+template <typename TG>
+__global__ __launch_bounds__(256) void sumsq_stage1_k(const TG* __restrict__ x, int64_t n, double* __restrict__ part) {
   __shared__ float red[16];
   float s = 0.f;
   const int64_t n4 = n >> 2;
-  const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const bool vec = (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(TG) - 1)) == 0;
   if (vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4* x4 = reinterpret_cast<const f4*>(x);
+    const TG* x4 = x;   // indexed in groups of 4 elements through GradLd
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (; i + 3 * stride < n4; i += 4 * stride) {     // four independent 16-B loads in flight per thread
-      const f4 a = __builtin_nontemporal_load(x4 + i), b = __builtin_nontemporal_load(x4 + i + stride);
-      const f4 c = __builtin_nontemporal_load(x4 + i + 2 * stride), d = __builtin_nontemporal_load(x4 + i + 3 * stride);
+      const f4 a = GradLd<TG>::nt4(x4, i), b = GradLd<TG>::nt4(x4, i + stride);
+      const f4 c = GradLd<TG>::nt4(x4, i + 2 * stride), d = GradLd<TG>::nt4(x4, i + 3 * stride);
       s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
       s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
       s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
       s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
     }
     for (; i < n4; i += stride) {
-      const f4 a = x4[i];
+      const f4 a = GradLd<TG>::ld4(x4, i);
       s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
     }
     s += s1 + s2 + s3;
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float t = ldf<TG>(x + i); s += t * t; }
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const float t = ldf<TG>(x + i); s += t * t; }
   }
   const float t = block_sum(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = (double)t;
@@ -170,20 +190,23 @@ extern "C" int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream) {
   DXA_CHECK_ARG(d->n_chunks >= 0, "dxa_adamw: negative chunk count");
   if (d->n_chunks == 0) return DXA_OK;
   AdamP a;
+  DXA_CHECK_ARG(d->g_dtype == DXA_F32 || d->g_dtype == DXA_BF16, "dxa_adamw: bad gradient dtype %d", d->g_dtype);
   a.p = d->p; a.g = d->g; a.m = d->m; a.v = d->v; a.shadow = (bf16_t*)d->shadow;
   a.cs = d->chunk_start; a.cl = d->chunk_len; a.cg = d->chunk_grp;
   for (int i = 0; i < 8; ++i) { a.lr[i] = d->lr[i]; a.wd[i] = d->wd[i]; }
   a.b1 = d->beta1; a.b2 = d->beta2; a.eps = d->eps; a.bc1 = d->bc1; a.bc2 = d->bc2;
   a.clip = d->clip_coef;
-  hipLaunchKernelGGL(adamw_k, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->g_dtype == DXA_BF16) hipLaunchKernelGGL(adamw_k<bf16_t>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(adamw_k<float>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
 
-extern "C" int dxa_sumsq(const float* x, int64_t n, double* scratch, float* out, int accumulate, dxa_stream_t stream) {
-  DXA_CHECK_ARG(x && scratch && out && n >= 0, "dxa_sumsq: bad args");
+extern "C" int dxa_sumsq(const void* x, int64_t n, int dtype, double* scratch, float* out, int accumulate, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && scratch && out && n >= 0 && (dtype == DXA_F32 || dtype == DXA_BF16), "dxa_sumsq: bad args");
   int nb = dxa_grid1d((n + 3) / 4, 256, 4096);
-  hipLaunchKernelGGL(sumsq_stage1_k, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+  if (dtype == DXA_BF16) hipLaunchKernelGGL(sumsq_stage1_k<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n, scratch);
+  else hipLaunchKernelGGL(sumsq_stage1_k<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, scratch);
   hipLaunchKernelGGL(sumsq_stage2_k, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, out, accumulate);
   DXA_CHECK_LAUNCH();
   return DXA_OK;

@@ -54,16 +54,22 @@ class ParamStore:
         self.master: Optional[torch.Tensor] = None
         self.shadow: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
+        self.gradc: Optional[torch.Tensor] = None     # bf16 communication copy of the gradient arena (DP, bf16 exchange)
+        self._mirrored: set = set()                   # slots whose copy a kernel epilogue already wrote this micro-batch
         self.params: Dict[str, nn.Parameter] = {}
         self.grad_written: Dict[str, bool] = {}
         self.on_bucket_ready: Optional[Callable[[int], None]] = None
         self._bucket_pending: List[int] = []
         self._micro_written: set = set()
+        self._uses: Dict[str, int] = {}
         self.shadow_t: Optional[torch.Tensor] = None
         self._wt_groups: List[Tuple[Tuple[str, ...], int, int]] = []
         self.wt_index: set = set()
         self._t_stream = None
         self._t_pending = False
+        # embedding-gradient rows written since the slice was last all-zero (sparse re-zero, functional.SpliceFn)
+        self.sparse_embed_zero = False
+        self._embed_dirty: Dict[str, Optional[List[torch.Tensor]]] = {}     # missing / None = unknown -> dense zero
 
     # ---- layout -------------------------------------------------------------------------------------
     def new_bucket(self) -> int:
@@ -127,6 +133,26 @@ class ParamStore:
         assert self.grad is not None, "store was finalized with train=False"
         return self._view(self.grad, names, shape)
 
+    # ---- bf16 communication copy of the gradients (data parallel, comm_dtype=bfloat16) -------------------------------
+    def enable_grad_mirror(self) -> None:
+        """Same layout as the gradient arena, 2 bytes per element (16 GB at 8 B params; the MI355X has 288 GB).  The dW
+        GEMM epilogues write it next to the fp32 gradient, the reducer exchanges it in place and AdamW / the grad-norm read
+        the averaged copy directly: no cast sweep in either direction."""
+        assert self.grad is not None, "store was finalized with train=False"
+        if self.gradc is None:
+            self.gradc = torch.zeros(self.total, device=self.device, dtype=torch.bfloat16)
+
+    def gc(self, *names: str, shape: Optional[Sequence[int]] = None) -> torch.Tensor:
+        assert self.gradc is not None, "enable_grad_mirror() first"
+        return self._view(self.gradc, names, shape)
+
+    def mirror_out(self, *names: str, shape: Optional[Sequence[int]] = None) -> Optional[torch.Tensor]:
+        """where a gradient-writing kernel should put the bf16 copy of what it writes to g(*names), or None"""
+        if self.gradc is None:
+            return None
+        self._mirrored.update(names)
+        return self._view(self.gradc, names, shape)
+
     # ---- gradient bookkeeping -----------------------------------------------------------------------
     def trainable(self, name: str) -> bool:
         return self.params[name].requires_grad and self.grad is not None
@@ -135,18 +161,39 @@ class ParamStore:
         """True if the gradient slot already holds a value this step (=> kernels must accumulate)."""
         return self.grad_written[names[0]]
 
+    def note_use(self, *names: str) -> None:
+        """Forward-side accounting, called by every autograd Function whose backward will write these slots: a
+        parameter applied k times in one forward (MemVLA's retrieval / gate blocks run once per sample,
+        memvla_arch.py:194-216) receives k gradient contributions, and its bucket is final only after the k-th."""
+        for nm in names:
+            self._uses[nm] = self._uses.get(nm, 0) + 1
+
     def mark_written(self, *names: str) -> None:
         """``grad_written`` is sticky for the optimizer step (=> later micro-batches accumulate); the bucket
-        countdown restarts every micro-batch so the reducer can fire on the last one."""
+        countdown restarts every micro-batch so the reducer can fire on the last one.  A slot counts as complete
+        when as many backward writes as forward uses (``note_use``) have been enqueued; slots nobody announced
+        complete on their first write."""
         for nm in names:
             self.grad_written[nm] = True
+            b = self.slots[nm].bucket
+            self._bucket_touched[b] = True
+            left = self._uses.get(nm, 0)
+            if left > 1:
+                self._uses[nm] = left - 1          # more consumers of this slot still owe their backward
+                continue
+            self._uses[nm] = 0
             if nm not in self._micro_written:
                 self._micro_written.add(nm)
-                b = self.slots[nm].bucket
                 self._bucket_pending[b] -= 1
                 if self._bucket_pending[b] == 0 and self.on_bucket_ready is not None and not self._bucket_fired[b]:
                     self._bucket_fired[b] = True
                     self.on_bucket_ready(b)
+
+    def unfired_touched(self) -> List[int]:
+        """buckets (highest first = backward order) that received gradient writes this micro-batch but never
+        completed their countdown: a frozen / unused slot, or a Function whose backward autograd pruned"""
+        return [b for b in reversed(range(len(self.bucket_ranges)))
+                if not self._bucket_fired[b] and self._bucket_touched[b]]
 
     def set_expected(self, exclude: Iterable[str] = ()) -> None:
         """(re)count, per bucket, the slots a backward pass is expected to write: trainable and not in
@@ -160,8 +207,11 @@ class ParamStore:
 
     def begin_micro(self) -> None:
         self._micro_written = set()
+        self._mirrored = set()
+        self._uses = {}
         self._bucket_pending = list(self._bucket_total)
         self._bucket_fired = [False] * len(self._bucket_total)
+        self._bucket_touched = [False] * len(self._bucket_total)
 
     def begin_step(self, zero_names: Iterable[str] = ()) -> None:
         """Reset per-step state.  Gradients are produced with beta=0 writes by the GEMM kernels, so
@@ -171,6 +221,28 @@ class ParamStore:
         self.begin_micro()
         for nm in zero_names:
             self.g(nm).zero_()
+
+    def zero_embed_grad(self, name: str) -> None:
+        """make the dense embedding-gradient slice all-zero before this step's first scatter into it: only the rows
+        written since it was last all-zero when those are known (``sparse_embed_zero``), else the whole slice"""
+        from . import kernels as K
+        g = self.g(name)
+        dirty = self._embed_dirty.get(name)
+        if self.sparse_embed_zero and dirty is not None and g.is_cuda:
+            for plan in dirty:
+                K.zero_rows(plan, g)
+        else:
+            g.zero_()
+        self._embed_dirty[name] = []
+
+    def note_embed_rows(self, name: str, plan: torch.Tensor) -> None:
+        dirty = self._embed_dirty.get(name)
+        if dirty is not None:
+            dirty.append(plan)
+
+    def invalidate_embed_tracking(self) -> None:
+        """someone else (a gradient all-reduce, user code) wrote the embedding-gradient slice: next zeroing is dense"""
+        self._embed_dirty = {}
 
     def never_written(self) -> List[str]:
         return [nm for nm, wtn in self.grad_written.items() if not wtn and self.params[nm].requires_grad]
@@ -339,21 +411,25 @@ class FusedAdamW:
         wds = [c.weight_decay if dec else 0.0 for _, dec in self.group_keys]
         return lrs, wds
 
-    def step(self, lr_scale: float = 1.0, sumsq: Optional[torch.Tensor] = None) -> None:
+    def step(self, lr_scale: float = 1.0, sumsq: Optional[torch.Tensor] = None,
+             grads: Optional[torch.Tensor] = None) -> None:
         """``sumsq``: device scalar holding sum(g^2) over the arena if someone already accumulated it (GradNormTracker
-        does, bucket by bucket under the backward); otherwise one pass over the gradient arena computes it here."""
+        does, bucket by bucket under the backward); otherwise one pass over the gradient arena computes it here.
+        ``grads``: arena to read the gradients from (default the fp32 gradient arena; the averaged bf16 communication
+        copy under bf16 data parallelism)."""
         from . import kernels as K
         st, c = self.store, self.cfg
+        grads = st.grad if grads is None else grads
         self.step_count += 1
         clip = None
         if c.max_grad_norm is not None:
             if sumsq is None:
-                K.sumsq(st.grad, self.sumsq, self.scratch)
+                K.sumsq(grads, self.sumsq, self.scratch)
                 sumsq = self.sumsq
             K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef)
             clip = self.coef
         lrs, wds = self._lrs_wds(lr_scale)
-        K.adamw(st.master, st.grad, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
+        K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
                 lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
         st.sync_transposed(overlap=True)
 
@@ -377,6 +453,7 @@ class GradNormTracker:
     def __init__(self, store: ParamStore, min_bytes: int = 256 << 20):
         self.store = store
         self.min_bytes = min_bytes
+        self.src: Optional[torch.Tensor] = None      # arena the norm is taken over (default: the fp32 gradient arena)
         dev = store.device
         self.acc = torch.zeros(1, device=dev, dtype=torch.float32)
         self.scratch = torch.empty(4096, device=dev, dtype=torch.float64)
@@ -395,12 +472,13 @@ class GradNormTracker:
         from . import kernels as K
         if hi <= lo:
             return
+        src = self.store.grad if self.src is None else self.src
         if self.stream is None:
-            K.sumsq(self.store.grad[lo:hi], self.acc, self.scratch, accumulate=True)
+            K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
             return
         self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            K.sumsq(self.store.grad[lo:hi], self.acc, self.scratch, accumulate=True)
+            K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
 
     def bucket_ready(self, b: int) -> None:
         lo, hi = self.store.bucket_ranges[b]
@@ -424,10 +502,9 @@ class GradNormTracker:
         stream wait for the side stream; returns the device scalar"""
         st = self.store
         if fire_unfired:
-            for b in reversed(range(len(st.bucket_ranges))):
-                if not st._bucket_fired[b] and st._bucket_pending[b] < st._bucket_total[b]:
-                    st._bucket_fired[b] = True
-                    self.bucket_ready(b)
+            for b in st.unfired_touched():
+                st._bucket_fired[b] = True
+                self.bucket_ready(b)
         if self._lo is not None:
             self.fold(self._lo, self._hi)
             self._lo = self._hi = None
@@ -438,37 +515,51 @@ class GradNormTracker:
 
 # ---------------------------------------------------------------------------------------- DP reducer
 class GradReducer:
-    """Data-parallel gradient averaging over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in
-    the CPU tests).  Buckets are contiguous slices of the gradient arena in reverse forward order
-    (DiT head -> LLM layers 27..0 -> projector -> ViT); a bucket is all-reduced in place on a side HIP
-    stream as soon as every slot in it has been written by the backward, so communication of block i
-    overlaps the backward compute of blocks < i.  xGMI is point-to-point (7 links x ~153 GB/s):
-    buckets are merged up to ``min_bucket_bytes`` so each collective is large enough to drive all
-    links, and parameters that never receive a gradient (lm_head, the unused last CLIP layer) are
-    never sent (the reference papers over them with ddp_find_unused_parameters=True, trainer.py:121).
+    """Data-parallel gradient averaging over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+    Buckets are contiguous slices of the gradient arena in reverse forward order (DiT head -> LLM layers 27..0 ->
+    projector -> ViT); a bucket is exchanged in place on a side HIP stream as soon as every slot in it has received its
+    last gradient write, so the communication of block i overlaps the backward compute of blocks < i.  Buckets are merged
+    up to ``min_bucket_bytes`` per collective; parameters that never receive a gradient (lm_head, the unused last CLIP
+    layer) are never sent (the reference papers over them with ddp_find_unused_parameters=True, trainer.py:121).
+
+    ``algo="rs_ag"`` (default): reduce-scatter(AVG) into this rank's 1/world shard of the merged slice, then all-gather
+    of the shards, both in place — the two halves of a ring all-reduce issued separately, so that every rank sources
+    and sinks 1/world of every slice over each of its xGMI links (point-to-point fabric, 7 links per GPU).  Lengths not
+    divisible by the world size: the divisible prefix goes through RS+AG, the < world-element tail through one tiny
+    all-reduce.  ``algo="allreduce"``: one ``all_reduce(AVG)`` per merged slice (RCCL picks the algorithm).
+
+    ``comm_dtype=bfloat16``: what is exchanged is the bf16 communication copy of the gradients (ParamStore.gradc; what
+    the reference's DeepSpeed bf16 run reduces, script/deepspeed/zero2.json): half the xGMI bytes.  The dW GEMM
+    epilogues write that copy next to the fp32 gradient; the few slots written by other kernels (norm weights, biases,
+    embeddings) are cast on the communication stream just before their slice is sent; the optimizer and the grad-norm
+    read the averaged copy directly (``result_arena``), so there is no cast sweep in either direction.
     """
 
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
-                 skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32):
+                 skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32,
+                 algo: str = "rs_ag"):
         import torch.distributed as dist
         self.dist = dist
         self.force = force          # run the collectives even at world size 1 (exercises the RCCL path)
-        # fp32: the arena slice is averaged in place.  bf16: the slice is cast to a bf16 staging buffer on the
-        # communication stream, averaged, and cast back — half the xGMI bytes; this is what the reference's
-        # DeepSpeed ZeRO-2 bf16 run reduces (its gradients are bf16 tensors, script/deepspeed/zero2.json).
         assert comm_dtype in (torch.float32, torch.bfloat16)
-        self.comm_dtype = comm_dtype
+        assert algo in ("rs_ag", "allreduce")
+        self.comm_dtype, self.algo = comm_dtype, algo
         self.store = store
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        init = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if init else 1
+        self.rank = dist.get_rank(group) if init else 0
         self.min_bucket_bytes = min_bucket_bytes
         self.skip_buckets = set()
         self.comm_stream = torch.cuda.Stream(device=store.device) if store.device.type == "cuda" else None
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
-        self._handles: List = []
-        self.after_reduce = None    # callable(lo, hi, comm_stream): called once a slice's collective (and cast back) is enqueued
+        self.after_reduce = None    # callable(lo, hi, comm_stream): called once a slice's exchange is enqueued
         self.bytes_reduced = 0
+        self.collectives = 0
+        if comm_dtype == torch.bfloat16:
+            store.enable_grad_mirror()
         skip = set(skip)
         # buckets whose every slot is skipped (never gets a gradient) are not communicated
         by_bucket: Dict[int, List[str]] = {}
@@ -477,7 +568,76 @@ class GradReducer:
         for b, names in by_bucket.items():
             if all((n in skip) or (not store.params[n].requires_grad) for n in names):
                 self.skip_buckets.add(b)
+        self._slots = sorted(store.slots.values(), key=lambda s: s.offset)
+        self._offsets = [s.offset for s in self._slots]
         store.on_bucket_ready = self.bucket_ready
+
+    @property
+    def result_arena(self) -> torch.Tensor:
+        """the arena that holds the averaged gradients once finish() has returned"""
+        return self.store.gradc if self.comm_dtype == torch.bfloat16 else self.store.grad
+
+    # ---- bf16 copy of the slots no GEMM epilogue mirrored ------------------------------------------------------------
+    def _fill_mirror(self, lo: int, hi: int) -> None:
+        import bisect
+        st = self.store
+        i = max(0, bisect.bisect_right(self._offsets, lo) - 1)
+        run_lo = run_hi = None
+        while i < len(self._slots) and self._slots[i].offset < hi:
+            s = self._slots[i]
+            i += 1
+            if s.offset + s.numel <= lo:
+                continue
+            need = st.grad_written.get(s.name, False) and s.name not in st._mirrored
+            if need and run_hi is not None and s.offset - run_hi < ALIGN:
+                run_hi = s.offset + s.numel                      # alignment gap rides along (zeros on both sides)
+                continue
+            if run_lo is not None:
+                self._cast_run(run_lo, run_hi)
+                run_lo = run_hi = None
+            if need:
+                run_lo, run_hi = s.offset, s.offset + s.numel
+        if run_lo is not None:
+            self._cast_run(run_lo, run_hi)
+
+    def _cast_run(self, lo: int, hi: int) -> None:
+        st = self.store
+        if st.grad.is_cuda:
+            from . import kernels as K
+            K.cast(st.grad[lo:hi], torch.bfloat16, out=st.gradc[lo:hi])
+        else:
+            st.gradc[lo:hi].copy_(st.grad[lo:hi])
+
+    # ---- the exchange ------------------------------------------------------------------------------------------------
+    def _avg(self, t: torch.Tensor, native_avg: bool) -> None:
+        d = self.dist
+        if native_avg:
+            d.all_reduce(t, op=d.ReduceOp.AVG, group=self.group)
+        else:                                                    # gloo has no AVG
+            d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
+            t.copy_((t.float() / self.world).to(t.dtype))
+
+    def _exchange(self, buf: torch.Tensor) -> None:
+        d, w = self.dist, self.world
+        native_avg = buf.is_cuda
+        n = buf.numel()
+        per = n // w
+        if self.algo == "allreduce" or per == 0:
+            self._avg(buf, native_avg)
+            self.collectives += 1
+            return
+        body = per * w
+        shard = buf[self.rank * per:(self.rank + 1) * per]
+        if native_avg:
+            d.reduce_scatter_tensor(shard, buf[:body], op=d.ReduceOp.AVG, group=self.group)
+        else:
+            d.reduce_scatter_tensor(shard, buf[:body], op=d.ReduceOp.SUM, group=self.group)
+            shard.copy_((shard.float() / w).to(shard.dtype))
+        d.all_gather_into_tensor(buf[:body], shard, group=self.group)
+        self.collectives += 2
+        if body < n:
+            self._avg(buf[body:], native_avg)
+            self.collectives += 1
 
     def _flush(self) -> None:
         if self._pending_lo is None or (self.world == 1 and not self.force):
@@ -485,29 +645,21 @@ class GradReducer:
             return
         lo, hi = self._pending_lo, self._pending_hi
         self._pending_lo = self._pending_hi = None
-        buf = self.store.grad[lo:hi]
         half = self.comm_dtype == torch.bfloat16
+        buf = (self.store.gradc if half else self.store.grad)[lo:hi]
         self.bytes_reduced += buf.numel() * (2 if half else 4)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 if half:
-                    from . import kernels as K
-                    stage = K.cast(buf, torch.bfloat16)      # allocated and freed on the communication stream
-                    self.dist.all_reduce(stage, op=self.dist.ReduceOp.AVG, group=self.group)
-                    K.cast(stage, torch.float32, out=buf)
-                else:
-                    self.dist.all_reduce(buf, op=self.dist.ReduceOp.AVG, group=self.group)
+                    self._fill_mirror(lo, hi)
+                self._exchange(buf)
             if self.after_reduce is not None:
                 self.after_reduce(lo, hi, self.comm_stream)
-        else:  # CPU / gloo: no AVG op
+        else:
             if half:
-                stage = buf.to(torch.bfloat16)
-                self.dist.all_reduce(stage, op=self.dist.ReduceOp.SUM, group=self.group)
-                buf.copy_(stage.float() / self.world)
-            else:
-                self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
-                buf.div_(self.world)
+                self._fill_mirror(lo, hi)
+            self._exchange(buf)
             if self.after_reduce is not None:
                 self.after_reduce(lo, hi, None)
 
@@ -532,10 +684,10 @@ class GradReducer:
     def finish(self) -> None:
         """flush the tail bucket and make the compute stream wait for all collectives"""
         st = self.store
-        for b in reversed(range(len(st.bucket_ranges))):   # buckets a frozen/unused slot kept from firing
-            if not st._bucket_fired[b] and st._bucket_pending[b] < st._bucket_total[b]:
-                st._bucket_fired[b] = True
-                self.bucket_ready(b)
+        for b in st.unfired_touched():                     # buckets a frozen/unused slot kept from firing
+            st._bucket_fired[b] = True
+            self.bucket_ready(b)
         self._flush()
+        st.invalidate_embed_tracking()                     # other ranks' token rows are now non-zero here too
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -28,6 +28,29 @@ def _names(x) -> Tuple[str, ...]:
     return (x,) if isinstance(x, str) else tuple(x)
 
 
+_OUTER_GRAD = [True]     # grad mode at the apply() call site (inside Function.forward it always reads False)
+
+
+class _StoreFn(Function):
+    """autograd Function that writes parameter gradients into the ParamStore arenas"""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        _OUTER_GRAD[0] = torch.is_grad_enabled()
+        return super().apply(*args, **kwargs)
+
+
+def _use(ctx, st: ParamStore, *groups) -> None:
+    """forward-side half of the bucket accounting (ParamStore.note_use): this Function's backward will write each of
+    these gradient slots once.  Only when a backward can actually run (grad mode on, some input requires grad)."""
+    if not (_OUTER_GRAD[0] and any(ctx.needs_input_grad)):
+        return
+    for g in groups:
+        if g is None:
+            continue
+        st.note_use(*[n for n in _names(g) if n is not None])
+
+
 KPAD = 64   # the transposed activations pad the token axis (= contraction axis of dW) to the GEMM K slab
 
 
@@ -116,7 +139,7 @@ class Qwen2LayerSpec:
     eps: float = 1e-6
 
 
-class Qwen2LayerFn(Function):
+class Qwen2LayerFn(_StoreFn):
     """HF Qwen2DecoderLayer (HF:qwen2/modeling_qwen2.py:258-300) called from cogact_arch.py:97-106:
     x + o_proj(attn(rope(qkv(rmsnorm(x))))) ; then + down(silu(gate)*up) of rmsnorm."""
 
@@ -137,6 +160,7 @@ class Qwen2LayerFn(Function):
         a = K.swiglu_fwd(gu)
         y = K.mm_nt(a, st.w(sp.down_w), residual=x2)
         ctx.st, ctx.sp = st, sp
+        _use(ctx, st, sp.ln1, sp.qkv_w, sp.qkv_b, sp.o_w, sp.ln2, sp.gu_w, sp.down_w)
         ctx.aux = (cos_t, sin_t, kv_start, kv_end)
         ctx.save_for_backward(x, rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a)
         return y
@@ -224,7 +248,7 @@ def _padded_head_dim(D: int, dtype) -> int:
     return 64 if D < 64 else (128 if D < 128 else 256)
 
 
-class VitBlockFn(Function):
+class VitBlockFn(_StoreFn):
     """Pre-LN block: x + out(attn(qkv(LN(x)))) ; + fc2(act(fc1(LN(.)))).
     CLIP encoder layer (HF:clip/modeling_clip.py:259-384; affine LN eps 1e-5, quick_gelu) and DiTBlock
     (cogact/action_model/dit.py:137-162 with timm Attention/Mlp; LN without affine eps 1e-6, tanh-GELU)."""
@@ -254,6 +278,8 @@ class VitBlockFn(Function):
         a = K.mm_nt(h2, st.w(sp.fc1_w), bias=st.w(sp.fc1_b), act=sp.act, aux_out=pre)
         y = K.mm_nt(a, st.w(sp.fc2_w), bias=st.w(sp.fc2_b), residual=x2)
         ctx.st, ctx.sp = st, sp
+        _use(ctx, st, sp.ln1_w, sp.ln1_b, sp.qkv_w, sp.qkv_b, sp.out_w, sp.out_b, sp.ln2_w, sp.ln2_b, sp.fc1_w, sp.fc1_b,
+             sp.fc2_w, sp.fc2_b)
         ctx.save_for_backward(x, mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a)
         return y.view(N, T, C_)
 
@@ -314,7 +340,7 @@ def _ln_bwd(st: ParamStore, dy, x, wn: Optional[str], bn: Optional[str], mean, r
 
 
 # --------------------------------------------------------------------------------------- generic pieces
-class LinearFn(Function):
+class LinearFn(_StoreFn):
     """y = act(x W^T + b) (+ residual).  nn.Linear call sites of the path that are not inside a block:
     patch embedding (HF:clip/modeling_clip.py:149-155 as a GEMM over im2col rows), DiT embedders and final
     layer (dit.py:22-64,106-135,165-178)."""
@@ -331,6 +357,7 @@ class LinearFn(Function):
         y = K.mm_nt(x2[:, :W.shape[1]] if x2.shape[1] != W.shape[1] else x2, W,
                     bias=st.w(bn) if bn else None, act=act, aux_out=pre)
         ctx.st, ctx.wn, ctx.bn, ctx.act, ctx.wshape, ctx.xshape = st, wn, bn, act, wshape, x.shape
+        _use(ctx, st, wn, bn)
         ctx.save_for_backward(x2, pre if pre is not None else x2.new_empty(0))
         return y.view(*x.shape[:-1], W.shape[0])
 
@@ -355,7 +382,7 @@ class LinearFn(Function):
         return dx, None, None, None, None, None, None
 
 
-class MlpFn(Function):
+class MlpFn(_StoreFn):
     """y = (act(x W1^T + b1)) W2^T + b2 : mm_projector mlp2x_gelu (mm_projector/builder.py:71-79) and the
     TimestepEmbedder MLP (dit.py:27-31)."""
 
@@ -367,6 +394,7 @@ class MlpFn(Function):
         a = K.mm_nt(x2, W1, bias=st.w(b1), act=act, aux_out=pre)
         y = K.mm_nt(a, W2, bias=st.w(b2))
         ctx.st, ctx.names, ctx.act, ctx.xshape = st, (w1, b1, w2, b2), act, x.shape
+        _use(ctx, st, w1, b1, w2, b2)
         ctx.save_for_backward(x2, pre, a)
         return y.view(*x.shape[:-1], W2.shape[0])
 
@@ -386,7 +414,7 @@ class MlpFn(Function):
         return dx, None, None, None, None, None, None, None
 
 
-class NormFn(Function):
+class NormFn(_StoreFn):
     """stand-alone LayerNorm / RMSNorm: CLIP pre_layrnorm, Qwen2 final norm, DiT final LayerNorm."""
 
     @staticmethod
@@ -400,6 +428,7 @@ class NormFn(Function):
         else:
             y, mean, rstd = K.layernorm_fwd(x.contiguous(), st.w(wn) if wn else None, st.w(bn) if bn else None, eps)
         ctx.st, ctx.kind, ctx.wn, ctx.bn = st, kind, wn, bn
+        _use(ctx, st, wn, bn if kind not in ("rms", "rms1p") else None)
         ctx.save_for_backward(x, mean, rstd)
         return y
 
@@ -420,13 +449,14 @@ class NormFn(Function):
         return dx, None, None, None, None, None, None
 
 
-class VitEmbedFn(Function):
+class VitEmbedFn(_StoreFn):
     """CLS + position embeddings (HF:clip/modeling_clip.py:206-217)."""
 
     @staticmethod
     def forward(ctx, patch, anchor, st: ParamStore, cls_n: str, pos_n: str, N: int, np_: int):
         x = K.vit_embed_fwd(patch.contiguous(), st.w(cls_n), st.w(pos_n), N, np_)
         ctx.st, ctx.cls_n, ctx.pos_n, ctx.N, ctx.np_ = st, cls_n, pos_n, N, np_
+        _use(ctx, st, cls_n, pos_n)
         return x
 
     @staticmethod
@@ -459,7 +489,7 @@ class DropClsFn(Function):
         return dx.view(N, T, C_)
 
 
-class SpliceFn(Function):
+class SpliceFn(_StoreFn):
     """_prepare_inputs_labels_for_multimodal (dexbotic_arch.py:182-373): embed_tokens gather + image
     block insertion + zero padding, driven by the integer plan built on the host (splice.py)."""
 
@@ -468,6 +498,7 @@ class SpliceFn(Function):
         d = img_feats.shape[-1]
         out = K.splice_fwd(plan, st.w(embed_n), img_feats.reshape(-1, d).contiguous())
         ctx.st, ctx.embed_n, ctx.ishape = st, embed_n, img_feats.shape
+        _use(ctx, st, embed_n)
         ctx.save_for_backward(plan)
         return out
 
@@ -483,9 +514,15 @@ class SpliceFn(Function):
         if st.trainable(ctx.embed_n):
             d_embed = st.g(ctx.embed_n)
             if not st.accum_flag(ctx.embed_n):
-                d_embed.zero_()                                 # dense nn.Embedding gradient: only B*S_text rows hit
-            st.mark_written(ctx.embed_n)
+                # dense nn.Embedding gradient of which only <= B*S_text rows are ever non-zero: re-zero just the rows
+                # the previous step touched when the store tracks them (single GPU), the whole slice otherwise
+                st.zero_embed_grad(ctx.embed_n)
+            st.note_embed_rows(ctx.embed_n, plan)
         K.splice_bwd(plan, dout, d_embed, d_img)
+        if d_embed is not None:
+            # AFTER the scatter-add is enqueued: embed_tokens is alone in its bucket, so this fires the reducer / the
+            # grad-norm fold, which order themselves after everything enqueued so far on this stream
+            st.mark_written(ctx.embed_n)
         return d_img, None, None, None, None
 
 
@@ -505,12 +542,13 @@ class GatherRowsFn(Function):
         return K.scatter_rows(dout.contiguous(), idx, ctx.R, ctx.dtype), None
 
 
-class TokenDropFn(Function):
+class TokenDropFn(_StoreFn):
     """LabelEmbedder.token_drop (dit.py:80-96)."""
 
     @staticmethod
     def forward(ctx, z, anchor, st: ParamStore, unc_n: str, drop: torch.Tensor):
         ctx.st, ctx.unc_n = st, unc_n
+        _use(ctx, st, unc_n)
         ctx.save_for_backward(drop)
         return K.token_drop(z.contiguous(), st.w32(unc_n).view(-1), drop)
 
@@ -522,12 +560,13 @@ class TokenDropFn(Function):
         return dz, None, None, None, None
 
 
-class DitAssembleFn(Function):
+class DitAssembleFn(_StoreFn):
     """x = cat(t_emb + z_emb, x_emb) + positional_embedding (dit.py:281-286)."""
 
     @staticmethod
     def forward(ctx, xe, te, ze, anchor, st: ParamStore, pos_n: str):
         ctx.st, ctx.pos_n = st, pos_n
+        _use(ctx, st, pos_n)
         return K.dit_assemble_fwd(xe.contiguous(), te.contiguous(), ze.contiguous(), st.w32(pos_n))
 
     @staticmethod
@@ -557,7 +596,7 @@ class MseLossFn(Function):
         return K.scale_dev_(dpred.clone(), g.reshape(1).float().contiguous()), None
 
 
-class LmHeadLossFn(Function):
+class LmHeadLossFn(_StoreFn):
     """logits = lm_head(hidden) and the HF causal-LM cross-entropy over the (already shifted) labels
     (dexbotic_arch.py:483-488; transformers/loss/loss_utils.py ForCausalLMLoss): loss = mean over the non-ignored
     rows of logsumexp(logits) - logits[label], in fp32 on the stored logits.  Returns (loss, logits).  The vocabulary
@@ -576,6 +615,7 @@ class LmHeadLossFn(Function):
         else:
             loss = loss * float("nan")                          # F.cross_entropy(mean) over zero targets
         ctx.st, ctx.wn, ctx.n_valid, ctx.hshape = st, wn, n_valid, hidden.shape
+        _use(ctx, st, wn)
         ctx.save_for_backward(h2, logits, lse, labels_shifted)
         ctx.mark_non_differentiable(logits)
         return loss.view(()), logits.view(*hidden.shape[:-1], W.shape[0])
@@ -601,7 +641,7 @@ class LmHeadLossFn(Function):
         return dh, None, None, None, None, None
 
 
-class AddPosFn(Function):
+class AddPosFn(_StoreFn):
     """x[N,T,C] + pos[T,C] (learned position embedding of the SigLIP tower, HF siglip/modeling_siglip.py
     SiglipVisionEmbeddings); d_pos = sum over N of dy."""
 
@@ -610,6 +650,7 @@ class AddPosFn(Function):
         N, T, C_ = x.shape
         pos = st.w(pos_name).unsqueeze(0).expand(N, T, C_).contiguous()
         ctx.st, ctx.pos_name, ctx.shape = st, pos_name, (N, T, C_)
+        _use(ctx, st, pos_name)
         return K.add(x.contiguous(), pos)
 
     @staticmethod
@@ -672,7 +713,7 @@ class GemmaLayerSpec:
     eps: float
 
 
-class Pi0MotLayerFn(Function):
+class Pi0MotLayerFn(_StoreFn):
     """One layer of the pi0 mixture of transformers (pi0_arch.py:130-216) for its two experts at once: per expert
     GemmaRMSNorm -> fused q/k/v -> RoPE; ONE attention over the concatenated tokens with the block-prefix mask; per
     expert o_proj + residual -> GemmaRMSNorm -> GeGLU -> residual.  Inputs/outputs are the experts' [B*S_e, d_e]
@@ -709,6 +750,10 @@ class Pi0MotLayerFn(Function):
             ys.append(K.mm_nt(act, st.w(sp.down), residual=r))
             saved += [a, r, rs2, h2, gu, act]
         ctx.st, ctx.sps, ctx.geom, ctx.skip_post0 = st, sps, geom, skip_post0
+        for i, sp in enumerate(sps):
+            _use(ctx, st, sp.ln1, sp.qkv)
+            if not (i == 0 and skip_post0):
+                _use(ctx, st, sp.o, sp.ln2, sp.gu, sp.down)
         ctx.aux = (cos_t, sin_t, pos0, pos1, q_limit, key_valid)
         ctx.save_for_backward(x0, x1, h1[0], h1[1], rstd1[0], rstd1[1], q, k, v, o, lse, *saved)
         return ys[0], ys[1]

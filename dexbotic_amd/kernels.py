@@ -475,6 +475,12 @@ def splice_bwd(plan: torch.Tensor, dout: torch.Tensor, d_embed: Optional[torch.T
             "dxa_splice_bwd")
 
 
+def zero_rows(plan: torch.Tensor, g: torch.Tensor) -> None:
+    """g[plan[r], :] = 0 for every token entry (plan[r] >= 0) of the plan; g fp32 [V, d]"""
+    assert plan.dtype == torch.int64 and plan.is_contiguous() and g.dtype == torch.float32 and g.is_contiguous()
+    L.check(lib.dxa_zero_rows(_ptr(plan), _ptr(g), plan.numel(), g.shape[1], _stream()), "dxa_zero_rows")
+
+
 def gather_rows(x: torch.Tensor, idx: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     assert x.is_contiguous() and idx.dtype == torch.int64
     out = torch.empty((idx.numel(), x.shape[1]), device=x.device, dtype=dtype)
@@ -599,8 +605,8 @@ def ddim_step(x, model_out, B, use_cfg, cfg_scale, c_recip, c_recipm1, ab_prev):
 
 # --------------------------------------------------------------------------------------------- optimizer
 def sumsq(x: torch.Tensor, out: torch.Tensor, scratch: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
-    assert x.dtype == torch.float32 and x.is_contiguous() and scratch.dtype == torch.float64 and scratch.numel() >= 4096
-    L.check(lib.dxa_sumsq(_ptr(x), x.numel(), _ptr(scratch), _ptr(out), int(accumulate), _stream()), "dxa_sumsq")
+    assert x.is_contiguous() and scratch.dtype == torch.float64 and scratch.numel() >= 4096
+    L.check(lib.dxa_sumsq(_ptr(x), x.numel(), dt(x), _ptr(scratch), _ptr(out), int(accumulate), _stream()), "dxa_sumsq")
     return out
 
 
@@ -624,6 +630,7 @@ def scale_dev_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
 def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1, beta2, eps, step, clip=None):
     d = L.AdamWDesc()
     d.p, d.g, d.m, d.v, d.shadow = _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow)
+    d.g_dtype = dt(g)
     d.chunk_start, d.chunk_len, d.chunk_grp = _ptr(chunk_start), _ptr(chunk_len), _ptr(chunk_grp)
     d.n_chunks = chunk_start.numel()
     assert len(lrs) <= 8 and len(lrs) == len(wds)

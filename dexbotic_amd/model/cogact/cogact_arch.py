@@ -82,7 +82,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
         loss = None
         if attention_mask is not None and actions is not None:
             plan = self.model._last_plan
-            idx = torch.from_numpy(np.arange(B, dtype=np.int64) * S + plan.last_index).to(last_hidden_state.device)
+            idx = plan.dev(last_hidden_state.device)["last_flat"]
             cognition = Fn.GatherRowsFn.apply(last_hidden_state.reshape(B * S, d), idx)      # [B,d] fp32
             A, T = self.config.action_dim, self.config.chunk_size
             acts = actions.reshape(actions.size(0), -1, A).float()[:, :T, :]
@@ -139,12 +139,10 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             head.create_ddim(ddim_step=num_ddim_steps)
         dev = self.store.device
         images = image_tensor.to(device=dev, dtype=self.store.compute_dtype)
-        if input_ids.shape[1] == 1:
-            raise NotImplementedError("KV-cache decode (discrete VLA, SURVEY.md §8f rank 3) is not built yet")
         n_img_tokens = self.model.num_image_tokens(images)
-        plan = build_splice_plan(input_ids.detach().cpu().numpy(), None, None, n_img_tokens,
-                                 getattr(self.config, "tokenizer_model_max_length", None),
-                                 getattr(self.config, "tokenizer_padding_side", "right"))
+        plan = self.model._plans.get(input_ids, None, None, n_img_tokens,
+                                     getattr(self.config, "tokenizer_model_max_length", None),
+                                     getattr(self.config, "tokenizer_padding_side", "right"))
         B, S = plan.plan.shape
         noise = kwargs.get("noise")
         if noise is None:
@@ -155,7 +153,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             samples = self._graph_sample(images, plan.plan.reshape(-1), B, S, noise, float(cfg_scale), int(num_ddim_steps))
             traj = None
         else:
-            plan_t = torch.from_numpy(plan.plan.reshape(-1)).to(dev)
+            plan_t = plan.dev(dev)["plan"]
             samples, traj = self._sample_actions(images, plan_t, B, S, noise, float(cfg_scale), int(num_ddim_steps),
                                                  return_traj)
         actions = self._denorm(samples[0].cpu().numpy(), action_norms).tolist()

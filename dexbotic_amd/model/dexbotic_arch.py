@@ -23,7 +23,7 @@ from .. import functional as Fn
 from .. import kernels as K
 from ..constants import IGNORE_INDEX
 from ..engine import ParamStore, attach_parameters
-from ..splice import SplicePlan, build_splice_plan
+from ..splice import PlanCache, SplicePlan, build_splice_plan
 from .llm.qwen2 import Qwen2Backbone, Qwen2Config
 from .modules.mm_projector.builder import build_vision_projector
 from .modules.mm_vision.builder import build_vision_tower
@@ -126,6 +126,7 @@ class DexboticVLMModel(nn.Module):
             self.mm_projector = self._build_mm_projector_module(config)
         self.llm = Qwen2Backbone(store, "model.llm.", config.llm_config)
         self._last_plan: Optional[SplicePlan] = None
+        self._plans = PlanCache()
 
     def initialize_model(self, extra_config: dict):
         for key, value in extra_config.items():
@@ -189,26 +190,24 @@ class DexboticVLMModel(nn.Module):
                                               cache_position, images) -> tuple:
         """Same contract as the reference (returns input_ids=None and the spliced inputs_embeds); the plan
         (kv ranges, last-token index) is kept in ``self._last_plan`` for the backbone / cognition gather."""
-        if input_ids.shape[1] == 1:
-            raise NotImplementedError("KV-cache decode (discrete VLA, SURVEY.md §8f rank 3) is not built yet")
         if self.mm_vision_module is None or images is None:
             raise NotImplementedError("text-only forward is outside the VLA path")
-        image_features = self._extract_vision_features(images)                          # [B, V*N_v, d]
-        ids_np = input_ids.detach().cpu().numpy()
-        am_np = None if attention_mask is None else attention_mask.detach().cpu().numpy()
-        lb_np = None if labels is None else labels.detach().cpu().numpy()
-        plan = build_splice_plan(ids_np, am_np, lb_np, image_features.shape[1],
-                                 getattr(self.config, "tokenizer_model_max_length", None),
-                                 getattr(self.config, "tokenizer_padding_side", "right"))
+        # the integer plan first (host arithmetic on a few KB; ids handed over as host tensors — the collator's own
+        # output — or a batch object seen before cost no device sync), THEN the vision tower is enqueued
+        plan = self._plans.get(input_ids, attention_mask, labels, self.num_image_tokens(images),
+                               getattr(self.config, "tokenizer_model_max_length", None),
+                               getattr(self.config, "tokenizer_padding_side", "right"))
         self._last_plan = plan
+        image_features = self._extract_vision_features(images)                          # [B, V*N_v, d]
         dev = image_features.device
-        plan_t = torch.from_numpy(plan.plan.reshape(-1)).to(dev)
+        pd = plan.dev(dev)
         B, S = plan.plan.shape
         embeds = Fn.SpliceFn.apply(image_features, self.store.params[self.llm.embed_name], self.store,
-                                   self.llm.embed_name, plan_t).view(B, S, -1)
-        new_labels = None if labels is None else torch.from_numpy(plan.labels).to(dev)
-        new_mask = None if attention_mask is None else torch.from_numpy(plan.attention_mask).to(
-            device=dev, dtype=attention_mask.dtype)
+                                   self.llm.embed_name, pd["plan"]).view(B, S, -1)
+        new_labels = None if labels is None else pd["labels"]
+        new_mask = None
+        if attention_mask is not None:
+            new_mask = pd["mask"] if attention_mask.dtype == torch.bool else pd["mask"].to(attention_mask.dtype)
         return None, position_ids, new_mask, past_key_values, embeds, new_labels, cache_position
 
     def run_llm(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
@@ -217,8 +216,8 @@ class DexboticVLMModel(nn.Module):
         kv_start = kv_end = None
         plan = self._last_plan
         if attention_mask is not None and plan is not None and not plan.attention_mask.all():
-            kv_start = torch.from_numpy(plan.kv_start).to(inputs_embeds.device)
-            kv_end = torch.from_numpy(plan.kv_end).to(inputs_embeds.device)
+            pd = plan.dev(inputs_embeds.device)
+            kv_start, kv_end = pd["kv_start"], pd["kv_end"]
         return self.llm(inputs_embeds, kv_start, kv_end)
 
 

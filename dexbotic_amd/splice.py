@@ -33,6 +33,22 @@ class SplicePlan:
     kv_end: np.ndarray          # [B] int32 one past the last valid key
     last_index: np.ndarray      # [B] int64 position of the last un-padded token (cognition token)
 
+    def dev(self, device) -> dict:
+        """device copies of the integer arrays the kernels consume, uploaded once per plan (a cached plan re-used by
+        the next step costs no host->device traffic at all)"""
+        import torch
+        cache = self.__dict__.setdefault("_dev", {})
+        key = str(device)
+        ent = cache.get(key)
+        if ent is None:
+            B, S = self.plan.shape
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
+            ent = {"plan": up(self.plan.reshape(-1)), "labels": up(self.labels), "mask": up(self.attention_mask),
+                   "kv_start": up(self.kv_start), "kv_end": up(self.kv_end),
+                   "last_flat": up(np.arange(B, dtype=np.int64) * S + self.last_index)}
+            cache[key] = ent
+        return ent
+
 
 def build_splice_plan(input_ids: np.ndarray, attention_mask: Optional[np.ndarray], labels: Optional[np.ndarray],
                       n_img_rows: int, max_length: Optional[int] = None, padding_side: str = "right") -> SplicePlan:
@@ -82,3 +98,48 @@ def build_splice_plan(input_ids: np.ndarray, attention_mask: Optional[np.ndarray
     cs = new_mask.cumsum(axis=1)
     last = (cs == cs.max(axis=1, keepdims=True)).argmax(axis=1).astype(np.int64) if S else np.zeros(B, np.int64)
     return SplicePlan(plan, new_mask, new_labels, lengths, kv_start, kv_end, last)
+
+
+class PlanCache:
+    """Splice plans keyed by the CONTENT of the integer inputs (ids / mask / labels are a few KB), plus an identity
+    shortcut for device-resident id tensors so that a batch object seen before costs no device->host copy (the
+    reference pays ~10 tiny kernels and several syncs per sample here, dexbotic_arch.py:182-373)."""
+
+    def __init__(self, capacity: int = 32):
+        self.capacity = capacity
+        self._by_content: dict = {}
+        self._by_ident: dict = {}
+
+    @staticmethod
+    def _ident(t):
+        import weakref
+        return (id(t), t._version, tuple(t.shape)), weakref.ref(t)
+
+    def host(self, t):
+        """numpy view of an integer input; device tensors are copied (a stream sync) unless this very tensor object,
+        unmodified, was seen before"""
+        if t is None or isinstance(t, np.ndarray):
+            return t
+        if not t.is_cuda:
+            return t.detach().numpy()
+        key, ref = self._ident(t)
+        hit = self._by_ident.get(key)
+        if hit is not None and hit[0]() is t:
+            return hit[1]
+        arr = t.detach().cpu().numpy()
+        if len(self._by_ident) >= 4 * self.capacity:
+            self._by_ident.clear()
+        self._by_ident[key] = (ref, arr)
+        return arr
+
+    def get(self, ids, mask, labels, n_img_rows: int, max_length, padding_side: str) -> SplicePlan:
+        ids, mask, labels = self.host(ids), self.host(mask), self.host(labels)
+        key = (ids.shape, ids.tobytes(), None if mask is None else mask.tobytes(),
+               None if labels is None else labels.tobytes(), n_img_rows, max_length, padding_side)
+        plan = self._by_content.get(key)
+        if plan is None:
+            plan = build_splice_plan(ids, mask, labels, n_img_rows, max_length, padding_side)
+            if len(self._by_content) >= self.capacity:
+                self._by_content.pop(next(iter(self._by_content)))
+            self._by_content[key] = plan
+        return plan

@@ -21,7 +21,7 @@ from .engine import FusedAdamW, GradNormTracker, GradReducer, OptimConfig, cosin
 class NativeTrainer:
     def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
-                 force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32):
+                 force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag"):
         import torch.distributed as dist
         self.model = model
         self.store = model.store
@@ -36,14 +36,18 @@ class NativeTrainer:
         self.reducer = None
         if use_dist and (dist.get_world_size() > 1 or force_reducer):
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
-                                       comm_dtype=grad_comm_dtype)
+                                       comm_dtype=grad_comm_dtype, algo=grad_sync)
         # global-norm clip: sum(g^2) is folded in bucket by bucket under the backward (after the all-reduce under DP)
         self.norm_tracker = None
         if self.cfg.max_grad_norm is not None and self.store.device.type == "cuda":
             self.norm_tracker = GradNormTracker(self.store, min_bytes=min_bucket_bytes)
             if self.reducer is not None:
                 self.reducer.after_reduce = lambda lo, hi, stream: self.norm_tracker.fold(lo, hi, stream)
+                self.norm_tracker.src = self.reducer.result_arena
         self.store.attach_grads()
+        # single GPU: nobody but the splice backward writes the dense embedding gradient, so it can be re-zeroed row-wise
+        self.store.sparse_embed_zero = self.reducer is None
+        self.store.invalidate_embed_tracking()
         self._zeroed_unused = False
 
     def lr_scale(self) -> float:
@@ -86,6 +90,7 @@ class NativeTrainer:
             sumsq = None
             if self.norm_tracker is not None:
                 sumsq = self.norm_tracker.finish(fire_unfired=not reducing)
-            self.opt.step(self.lr_scale(), sumsq=sumsq)
+            # under bf16 data parallelism the averaged gradients live in the bf16 communication copy
+            self.opt.step(self.lr_scale(), sumsq=sumsq, grads=self.reducer.result_arena if reducing else None)
             self.global_step += 1
         return loss.detach()

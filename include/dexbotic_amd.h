@@ -211,11 +211,15 @@ int dxa_permute_bshd(const void* src, void* dst, int B, int S, int H, int D, int
 /* Token splice (dexbotic_arch.py:182-373).  plan[b*S+s] >= 0: token id; <= -1: image row -1-plan;
  * INT64_MIN: zero padding.  Forward gathers embed_tokens rows / image-feature rows into
  * inputs_embeds [B*S, d].  Backward scatters: image rows plain-stored (each used once, untouched rows
- * must be pre-zeroed), token rows atomically added into the fp32 embedding gradient. */
+ * must be pre-zeroed), token rows added into the fp32 embedding gradient — without atomics: duplicates of a token id
+ * are summed in ascending row order by the workgroup of the first occurrence, so the result is bitwise reproducible.
+ * dxa_zero_rows zeroes the gradient rows of the token entries of a (previous) plan: the sparse re-zero of the dense
+ * nn.Embedding gradient (dexbotic_arch.py:224-228 embeds through nn.Embedding; its .grad is dense). */
 int dxa_splice_fwd(const int64_t* plan, const void* embed, const void* img, void* out, int64_t n_rows,
                    int64_t d, int dtype, dxa_stream_t stream);
 int dxa_splice_bwd(const int64_t* plan, const void* dout, float* d_embed, void* d_img, int64_t n_rows,
                    int64_t d, int dtype, dxa_stream_t stream);
+int dxa_zero_rows(const int64_t* plan, float* g, int64_t n_rows, int64_t d, dxa_stream_t stream);
 /* out[i,:] = x[idx[i],:]   (cognition token, cogact_arch.py:110-120) and its scatter-add backward */
 int dxa_gather_rows(const void* x, const int64_t* idx, void* out, int64_t n, int64_t d, int src_dtype,
                     int dst_dtype, dxa_stream_t stream);
@@ -274,17 +278,20 @@ int dxa_ddim_step(float* x, const float* model_out, int64_t B, int64_t per, int 
  * shadow (optional): bf16 copy of the updated parameters written in the same pass.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dxa_adamw_desc {
-  float* p; const float* g; float* m; float* v;
+  float* p; const void* g; float* m; float* v;
   uint16_t* shadow;            /* or NULL */
   const int64_t* chunk_start; const int32_t* chunk_len; const int32_t* chunk_grp; int32_t n_chunks;
   float lr[8]; float wd[8];
   float beta1, beta2, eps;
   float bc1, bc2;              /* 1-beta1^t, 1-beta2^t */
   const float* clip_coef;      /* device scalar or NULL (=1) */
+  int32_t g_dtype;             /* DXA_F32: g is the fp32 gradient arena; DXA_BF16: g is its bf16 communication copy (the
+                                  data-parallel run averages bf16 gradients like the reference's DeepSpeed bf16 config,
+                                  script/deepspeed/zero2.json, and the optimizer reads the averaged copy directly) */
 } dxa_adamw_desc;
 int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream);
-/* out[0] = sum x^2 over n fp32 elements (deterministic two-stage; scratch >= 4096 doubles) */
-int dxa_sumsq(const float* x, int64_t n, double* scratch, float* out, int accumulate, dxa_stream_t stream);
+/* out[0] = sum x^2 over n fp32 / bf16 elements (deterministic two-stage; scratch >= 4096 doubles) */
+int dxa_sumsq(const void* x, int64_t n, int dtype, double* scratch, float* out, int accumulate, dxa_stream_t stream);
 /* norm = sqrt(sumsq); coef = min(1, max_norm/(norm+1e-6))  (torch.nn.utils.clip_grad_norm_) */
 int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream);
 int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream);

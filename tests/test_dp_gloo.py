@@ -27,7 +27,7 @@ def _build_store():
     names = []
     for b in range(5):                                   # 5 buckets in "forward order"
         st.new_bucket()
-        grp = [(f"blk{b}.w", (7, 5)), (f"blk{b}.b", (5,))]
+        grp = [(f"blk{b}.w", (7, 5)), (f"blk{b}.b", (6,))]     # 41 elements: NOT divisible by the world size
         st.register(grp)
         names += [n for n, _ in grp]
     st.new_bucket()
@@ -44,27 +44,31 @@ def _worker(rank, world, port, tmp):
         from dexbotic_amd.engine import GradReducer
         st, names = _build_store()
         st.set_expected(["unused.w"])
-        red = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"])
         torch.manual_seed(100 + rank)
-        # --- plain step: backward walks the buckets in reverse, marks slots written
-        st.begin_step()
-        st.on_bucket_ready = red.bucket_ready
-        local = {}
-        for n in reversed(names):
-            g = torch.randn(st.slots[n].shape)
-            st.g(n).copy_(g)
-            local[n] = g
-            st.mark_written(n)
-        st.g("unused.w").fill_(float(rank + 1))          # garbage that must NOT be averaged
-        red.finish()
         gathered = [None] * world
-        dist.all_gather_object(gathered, local)
-        for n in names:
-            mean = sum(g[n] for g in gathered) / world
-            assert torch.allclose(st.g(n), mean, atol=1e-6), n
-        assert torch.all(st.g("unused.w") == float(rank + 1))
-        assert red.bytes_reduced == sum(st.slots[n].numel for n in names) * 4 or red.bytes_reduced >= sum(
-            st.slots[n].numel for n in names) * 4          # alignment padding may ride along
+        # --- plain step: backward walks the buckets in reverse, marks slots written.  Both exchange algorithms:
+        #     reduce-scatter + all-gather (odd slice lengths: divisible prefix + all-reduced tail) and one all-reduce
+        for algo, min_bytes in (("rs_ag", 64), ("rs_ag", 1 << 20), ("allreduce", 64)):
+            red = GradReducer(st, min_bucket_bytes=min_bytes, skip=["unused.w"], algo=algo)
+            st.begin_step()
+            st.on_bucket_ready = red.bucket_ready
+            local = {}
+            for n in reversed(names):
+                g = torch.randn(st.slots[n].shape)
+                st.g(n).copy_(g)
+                local[n] = g
+                st.mark_written(n)
+            st.g("unused.w").fill_(float(rank + 1))          # garbage that must NOT be averaged
+            red.finish()
+            dist.all_gather_object(gathered, local)
+            for n in names:
+                mean = sum(g[n] for g in gathered) / world
+                assert torch.allclose(st.g(n), mean, atol=1e-6), (algo, n)
+            assert torch.all(st.g("unused.w") == float(rank + 1))
+            assert red.bytes_reduced >= sum(st.slots[n].numel for n in names) * 4   # alignment padding may ride along
+            if algo == "rs_ag" and min_bytes == 64:
+                assert red.collectives == 3 * 5, red.collectives   # per bucket: RS + AG on 40 elements, AR on the 41st
+        red = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"])
         # --- gradient accumulation: 2 micro-batches, communication only on the last
         st.begin_step()
         red.bytes_reduced = 0
@@ -100,25 +104,61 @@ def _worker(rank, world, port, tmp):
             st.mark_written(n)
         red.finish()
         assert torch.allclose(st.g("blk2.w"), torch.full((7, 5), (world - 1) / 2.0))
-        # --- bf16 gradient communication (what the reference's DeepSpeed bf16 run reduces): half the bytes,
-        #     result = mean of the bf16-rounded local gradients
+        # --- bf16 gradient communication (what the reference's DeepSpeed bf16 run reduces): half the bytes; what is
+        #     exchanged is the bf16 copy of the arena (ParamStore.gradc), the averaged result stays there (AdamW reads it)
+        #     and the local fp32 gradients are left alone.  One slot plays a GEMM epilogue that mirrored its own output.
         st.params["blk2.b"].requires_grad_(True)
         st.set_expected(["unused.w"])
         red16 = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"], comm_dtype=torch.bfloat16)
+        assert red16.result_arena is st.gradc
         st.begin_step()
         st.on_bucket_ready = red16.bucket_ready
-        local = {}
+        local, local32 = {}, {}
         for n in reversed(names):
             g = torch.randn(st.slots[n].shape)
             st.g(n).copy_(g)
+            if n == "blk3.w":
+                st.mirror_out(n).copy_(g)                 # "epilogue" wrote the copy itself: must not be re-cast
+                st.g(n).add_(1000.0)                      # (would show up in the average if it were)
             local[n] = g.to(torch.bfloat16).float()
+            local32[n] = st.g(n).clone()
             st.mark_written(n)
         red16.finish()
         dist.all_gather_object(gathered, local)
         for n in names:
             mean = (sum(g[n] for g in gathered)).to(torch.bfloat16).float() / world
-            assert torch.allclose(st.g(n), mean, rtol=1e-2, atol=1e-6), n
+            assert torch.allclose(st.gc(n).float(), mean, rtol=1e-2, atol=1e-6), n
+            assert torch.equal(st.g(n), local32[n]), n
         assert red16.bytes_reduced >= sum(st.slots[n].numel for n in names) * 2     # 2 bytes per element sent
+        # --- a parameter applied 3x in one forward (MemVLA's per-sample retrieval blocks): its bucket must be
+        #     reduced after the LAST of its three gradient writes, i.e. the result is the mean of the FINAL gradients
+        red3 = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"])
+        st.begin_step()
+        st.on_bucket_ready = red3.bucket_ready
+        for n in names:
+            for _ in range(3 if n.startswith("blk1.") else 1):
+                st.note_use(n)
+        final = {n: torch.zeros(st.slots[n].shape) for n in names}
+        fired_early = []
+        orig = red3.bucket_ready
+        red3_fired = []
+        st.on_bucket_ready = lambda b: (red3_fired.append(b), orig(b))
+        for n in reversed(names):
+            for k in range(3 if n.startswith("blk1.") else 1):
+                g = torch.randn(st.slots[n].shape)
+                if st.accum_flag(n):
+                    st.g(n).add_(g)
+                else:
+                    st.g(n).copy_(g)
+                final[n] += g
+                st.mark_written(n)
+                if n.startswith("blk1.") and k < 2:
+                    assert st.slots[n].bucket not in red3_fired, "bucket fired before the last write"
+        red3.finish()
+        dist.all_gather_object(gathered, final)
+        for n in names:
+            mean = sum(g[n] for g in gathered) / world
+            assert torch.allclose(st.g(n), mean, atol=1e-6), n
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
