@@ -23,6 +23,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2_t_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t_){a, b}, bf16x2_t_));
+}
+
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }

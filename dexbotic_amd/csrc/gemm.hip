@@ -227,8 +227,8 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4], bool vec, int n_ok) {
   if (vec && n_ok == 4) {
     uint2 o;
-    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = o;
   } else {
 #pragma unroll
@@ -502,6 +502,152 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// Everything after the K loop of the 256-column-tile bf16 NT kernels (ring and ping-pong main loops share it): the
+// split-K hand-off of tail tiles and the fused epilogue.  acc[i][j] = 32x32 block (32-row block i of the wave's rows,
+// 32-column block j of its 64 columns) in the v_mfma_f32_32x32x16 accumulator layout with swapped operands.
+// SMALL = false: 17 KiB staging slab per wave at the start of LDS (the K-loop buffers are dead by then).
+// SMALL = true : 4 KiB per wave above the 128 KiB of K-loop buffers (persistent ping-pong kernel: the next tile's
+//                LDS-DMA pieces are already landing in those buffers while this epilogue runs).
+template <typename TO, int AI, typename TE, bool SMALL = false>
+__device__ __forceinline__ void tile_finish(const GemmP& p, f32x16_t (&acc)[AI][2], char* smem, int tid, int lane, int wave,
+                                            int wm, int wn, int l32, int lh, int64_t m0, int64_t n0, int split_j,
+                                            int split_s, int tail_i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BMR = AI * 64;
+  // ---- split-K tail: partial accumulators travel through a lane-linear fp32 slot (8 KiB per wave store).
+  // sc1 (agent scope) stores write through the XCD-private L2 and sc1 loads miss in it, so no cache-wide
+  // write-back / invalidate is needed; 16-byte accesses keep the gatherer off the instruction-issue limit.
+  if (split_s > 1) {
+    constexpr int SC1 = 16;                                   // buffer-instruction cache policy bit (gfx94x/95x)
+    constexpr uint32_t SLOT = 256 * 256 * 4;                  // bytes per partial
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(NUM_CU_D * SLOT), 0x00020000);
+    const uint32_t slot0 = (uint32_t)tail_i * (uint32_t)(split_s - 1) * SLOT + (uint32_t)tid * 16u;
+    if (split_j < split_s - 1) {
+      const uint32_t dst = slot0 + (uint32_t)split_j * SLOT;
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rW, dst + ((i * 2 + j) * 4 + q) * 8192, 0, SC1);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.flags + tail_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // gatherer: it has the highest block ids of its tile, so its partners were dispatched before it
+    if (tid == 0) {
+      while (__hip_atomic_load(p.flags + tail_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_s - 1)
+        __builtin_amdgcn_s_sleep(4);
+      __hip_atomic_store(p.flags + tail_i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int sj = 0; sj < split_s - 1; ++sj) {
+      const uint32_t src = slot0 + (uint32_t)sj * SLOT;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, src + ((i * 2 + j) * 4 + q) * 8192, 0, SC1));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[c];
+          }
+        if (AI == 4 && i == 1) __builtin_amdgcn_sched_barrier(0);   // at most 16 loads (64 VGPRs) in flight
+      }
+    }
+  }
+
+  // ---- epilogue: accumulators -> wave-private LDS slab (fp32, padded rows) -> row-contiguous global stores.
+  // The MFMA layout gives each lane 4 consecutive n of 32 different rows: stored directly that is 8-byte
+  // pieces at a row stride (measured: 0.6 TB/s, 58 us per tile).  Re-read from LDS, 16 lanes cover one
+  // 64-column row segment, so stores (and the residual / mulgrad / accumulate reads) are full 128/256-byte
+  // lines.  Two passes of 64 rows; the slab is private to the wave, so no workgroup barrier is needed (the
+  // loop's last barrier already retired every ring read and LDS-DMA).
+  TO* C = reinterpret_cast<TO*>(p.C);
+  TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
+  const TE* R = reinterpret_cast<const TE*>(p.R);
+  const TE* G = reinterpret_cast<const TE*>(p.G);
+  const TE* bias = reinterpret_cast<const TE*>(p.bias);
+  const int cr = lane >> 4, cc = (lane & 15) * 4;
+  const int64_t n = n0 + wn * 64 + cc;
+  const int n_ok = (int)max((int64_t)0, min((int64_t)4, p.N - n));
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias && n_ok > 0) load4<TE>(bv, bias + n, p.vecBias, n_ok);
+  if constexpr (!SMALL) {
+    constexpr int ROWP = 64 * 4 + 16;
+    char* slab = smem + wave * (64 * ROWP);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = 2 * pass + ii;
+            if (i >= AI) continue;
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            *reinterpret_cast<float4*>(slab + (ii * 32 + l32) * ROWP + (j * 32 + 8 * q + 4 * lh) * 4) = v;
+          }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int it = 0; it < (AI == 3 && pass == 1 ? 8 : 16); ++it) {
+        const int row = cr + 4 * it;
+        const int64_t m = m0 + wm * (BMR / 2) + pass * 64 + row;
+        const float4 v = *reinterpret_cast<const float4*>(slab + row * ROWP + cc * 4);
+        if (m < p.M && n_ok > 0) {
+          const float a4[4] = {v.x, v.y, v.z, v.w};
+          epilogue4<TE, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    // 16 rows x 64 columns of fp32 (4 KiB) per pass; instead of row padding the 16-byte unit u of row r sits at
+    // u ^ r: the 8-lane groups of the ds_write_b128 (8 consecutive rows, one unit) and the 16-lane groups of the
+    // ds_read_b128 (one row, 16 units / two rows, 8 + 8 units) each touch every bank once.
+    char* slab = smem + 131072 + wave * 4096;
+    const int r16 = l32 & 15;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if ((l32 >> 4) == hh) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+              *reinterpret_cast<float4*>(slab + r16 * 256 + (((j * 8 + 2 * q + lh) ^ r16) << 4)) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = cr + 4 * it;
+          const int64_t m = m0 + wm * (BMR / 2) + i * 32 + hh * 16 + row;
+          const float4 v = *reinterpret_cast<const float4*>(slab + row * 256 + (((lane & 15) ^ row) << 4));
+          if (m < p.M && n_ok > 0) {
+            const float a4[4] = {v.x, v.y, v.z, v.w};
+            epilogue4<TE, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);   // passes stay in order: no hoisting of the next pass's loads (register pressure)
+      }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 // =====================================================================================================
 // Fast path: bf16 NT "ring" kernel — 256x256 tile, 512 threads, LDS-DMA ring, ONE barrier per K slab.
 //
@@ -677,102 +823,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const GemmP p) {
 #undef MFMA1
 #undef SB
 
-  // ---- split-K tail: partial accumulators travel through a lane-linear fp32 slot (8 KiB per wave store).
-  // sc1 (agent scope) stores write through the XCD-private L2 and sc1 loads miss in it, so no cache-wide
-  // write-back / invalidate is needed; 16-byte accesses keep the gatherer off the instruction-issue limit.
-  if (split_s > 1) {
-    constexpr int SC1 = 16;                                   // buffer-instruction cache policy bit (gfx94x/95x)
-    constexpr uint32_t SLOT = 256 * 256 * 4;                  // bytes per partial
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(NUM_CU_D * SLOT), 0x00020000);
-    const uint32_t slot0 = (uint32_t)tail_i * (uint32_t)(split_s - 1) * SLOT + (uint32_t)tid * 16u;
-    if (split_j < split_s - 1) {
-      const uint32_t dst = slot0 + (uint32_t)split_j * SLOT;
-#pragma unroll
-      for (int i = 0; i < AI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rW, dst + ((i * 2 + j) * 4 + q) * 8192, 0, SC1);
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(p.flags + tail_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    // gatherer: it has the highest block ids of its tile, so its partners were dispatched before it
-    if (tid == 0) {
-      while (__hip_atomic_load(p.flags + tail_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_s - 1)
-        __builtin_amdgcn_s_sleep(4);
-      __hip_atomic_store(p.flags + tail_i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    for (int sj = 0; sj < split_s - 1; ++sj) {
-      const uint32_t src = slot0 + (uint32_t)sj * SLOT;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, src + ((i * 2 + j) * 4 + q) * 8192, 0, SC1));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[c];
-          }
-        if (AI == 4 && i == 1) __builtin_amdgcn_sched_barrier(0);   // at most 16 loads (64 VGPRs) in flight
-      }
-    }
-  }
-
-  // ---- epilogue: accumulators -> wave-private LDS slab (fp32, padded rows) -> row-contiguous global stores.
-  // The MFMA layout gives each lane 4 consecutive n of 32 different rows: stored directly that is 8-byte
-  // pieces at a row stride (measured: 0.6 TB/s, 58 us per tile).  Re-read from LDS, 16 lanes cover one
-  // 64-column row segment, so stores (and the residual / mulgrad / accumulate reads) are full 128/256-byte
-  // lines.  Two passes of 64 rows; the slab is private to the wave, so no workgroup barrier is needed (the
-  // loop's last barrier already retired every ring read and LDS-DMA).
-  {
-    constexpr int ROWP = 64 * 4 + 16;
-    char* slab = smem + wave * (64 * ROWP);
-    TO* C = reinterpret_cast<TO*>(p.C);
-    TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
-    const TE* R = reinterpret_cast<const TE*>(p.R);
-    const TE* G = reinterpret_cast<const TE*>(p.G);
-    const TE* bias = reinterpret_cast<const TE*>(p.bias);
-    const int cr = lane >> 4, cc = (lane & 15) * 4;
-    const int64_t n = n0 + wn * 64 + cc;
-    const int n_ok = (int)max((int64_t)0, min((int64_t)4, p.N - n));
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias && n_ok > 0) load4<TE>(bv, bias + n, p.vecBias, n_ok);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = 2 * pass + ii;
-            if (i >= AI) continue;
-            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            *reinterpret_cast<float4*>(slab + (ii * 32 + l32) * ROWP + (j * 32 + 8 * q + 4 * lh) * 4) = v;
-          }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-      for (int it = 0; it < (AI == 3 && pass == 1 ? 8 : 16); ++it) {
-        const int row = cr + 4 * it;
-        const int64_t m = m0 + wm * (BMR / 2) + pass * 64 + row;
-        const float4 v = *reinterpret_cast<const float4*>(slab + row * ROWP + cc * 4);
-        if (m < p.M && n_ok > 0) {
-          const float a4[4] = {v.x, v.y, v.z, v.w};
-          epilogue4<TE, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  tile_finish<TO, AI, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 template __global__ void gemm_nt_ring_kernel<bf16_t, 4, bf16_t>(const GemmP);
@@ -781,6 +832,370 @@ template __global__ void gemm_nt_ring_kernel<bf16_t, 3, bf16_t>(const GemmP);
 template __global__ void gemm_nt_ring_kernel<float, 3, bf16_t>(const GemmP);
 template __global__ void gemm_nt_ring_kernel<float, 4, float>(const GemmP);   // fp32 epilogue operands (bf16x3 products)
 template __global__ void gemm_nt_ring_kernel<float, 3, float>(const GemmP);
+
+// =====================================================================================================
+// Fast path 2: bf16 NT "ping-pong" kernel — 256x256 tile, K tile 64 (whole 128-byte lines), 8 waves as
+// 2 (M) x 4 (N), two LDS buffers of 64 KiB.
+//
+// What bounded the ring kernel (PMC + ablations): its L2->LDS feed moved 64-byte row segments and
+// every wave interleaved its own LDS reads / DMA issue with its own MFMAs, so the two waves of a SIMD competed
+// instead of complementing each other (49 % MFMA-busy).  Here the two wave groups (waves 0-3 / 4-7; wave w and
+// w+4 share a SIMD) run ONE barrier interval apart and alternate roles:
+//     group 0:       | M0 | C0 | M1 | C1 | ...          M = memory cluster: ds_read_b128 fragment loads of the
+//     group 1:  | -- | M0 | C0 | M1 | C1 | ...              quadrant computed next + 2 LDS-DMA instructions + counted vmcnt
+//                                                        C = compute cluster: 8 x v_mfma_f32_32x32x16_bf16 (256 clk)
+// so in every interval each SIMD has one wave feeding the matrix pipe and one wave on the LDS / L2 side
+// (measured: the stagger alone is worth 13 %; s_setprio around the clusters nothing).  A K tile is 4 phases = the 4
+// quadrants (64 rows x 32 cols) of the wave's 128 x 64 output:
+//     phase 0: reads A0,B0 -> Q(A0,B0) | 1: reads B1 -> Q(A0,B1) | 2: reads A1 -> Q(A1,B1) | 3: reads B0 -> Q(A1,B0)
+// (A0/A1 = 64-row halves of the wave's rows, B0/B1 = 32-column halves of its columns): 24 ds_read_b128 per wave per
+// K tile for 32 MFMAs.  The next K tile arrives as 4 DMA "pieces" of 16 KiB, one per phase (each piece = that half for
+// ALL waves: 2 x 1 KiB instructions per wave).
+// LDS image: rows of 128 bytes (64 k), 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the 16-lane
+// groups of ds_read_b128 over a 32-row fragment column hit 16 distinct 16-byte slots of the 256-byte bank row.  The DMA
+// writes LDS lane-linearly (8 rows x 128 B per instruction), so the swizzle is applied to the per-lane SOURCE chunk;
+// each row is still fetched as one whole 128-byte line.
+// Ablations on 8192^3 (scripts/ablate_gemm.sh): everything 832 us; without LDS-DMA 574 (1.92 PF/s); without MFMA 607;
+// without ds_read 628; 2 phases per K tile instead of 4 (half the barriers) 819 — the L2->LDS feed (~27 B/clk/CU
+// achieved, 32 needed at the MFMA peak for a 256x256 tile) and its interference with the fragment reads are what is
+// left, not the barriers.
+// Requirements: K % 64 == 0, 16-byte aligned A/B rows, no batching, operands < 2 GiB.
+// =====================================================================================================
+// Tuning builds (scripts/ablate_gemm.sh): -DDXA_PPV=<bits> removes parts of the main loop (results are garbage, timings are
+// not): 1 no LDS-DMA in the loop, 2 no ds_read, 4 no MFMA, 8 s_setprio around the MFMA clusters, 16 no stagger,
+// 32 no epilogue stores.
+#ifndef DXA_PPV
+#define DXA_PPV 0
+#endif
+// origin of tile t of the grouped order (group_m row tiles x all column tiles per group)
+__device__ __forceinline__ void sk_tile_origin(const GemmP& p, int t, int& m0, int& n0) {
+  const int width = p.group_m * p.tn;
+  const int group = t / width;
+  const int first_pm = group * p.group_m;
+  const int gsz = min(p.tm - first_pm, p.group_m);
+  const int rem = t - group * width;
+  const int pn = rem / gsz;
+  m0 = (first_pm + rem - pn * gsz) * 256;
+  n0 = pn * 256;
+}
+template <typename T> struct SkIO;      // 16-byte / 8-byte buffer accesses of CPL consecutive elements
+template <> struct SkIO<float> {
+  template <int CPL>
+  static __device__ __forceinline__ void ld(float (&o)[CPL], __amdgpu_buffer_rsrc_t r, uint32_t off) {
+    static_assert(CPL == 4, "fp32 operands come 4 columns per lane");
+    const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e];
+  }
+  template <int CPL>
+  static __device__ __forceinline__ void st(const float (&v)[CPL], __amdgpu_buffer_rsrc_t r, uint32_t off) {
+    static_assert(CPL == 4, "fp32 outputs go 4 columns per lane");
+    const f32x4_t o = {v[0], v[1], v[2], v[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), r, off, 0, 0);
+  }
+};
+template <> struct SkIO<bf16_t> {
+  template <int CPL>
+  static __device__ __forceinline__ void ld(float (&o)[CPL], __amdgpu_buffer_rsrc_t r, uint32_t off) {
+    if constexpr (CPL == 8) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(v[e] << 16); o[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+    } else {
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { o[2 * e] = __uint_as_float(v[e] << 16); o[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+    }
+  }
+  template <int CPL>
+  static __device__ __forceinline__ void st(const float (&v)[CPL], __amdgpu_buffer_rsrc_t r, uint32_t off) {
+    static_assert(CPL == 8, "bf16 outputs go 8 columns per lane");
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    __builtin_amdgcn_raw_buffer_store_b128(o, r, off, 0, 0);
+  }
+};
+
+// fused epilogue of one 256x256 tile from the accumulators: C = alpha * acc + bias (+ residual) (+ C).  Products with an
+// activation, a mulgrad operand or an aux output (ViT / projector MLPs: ~4 % of the step's FLOPs) stay on the ring kernel,
+// whose epilogue carries the whole menu.
+template <typename TO, typename TE>
+__device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2], char* slab, int lane, int wm, int wn,
+                                            int m0, int n0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CPL = 16 / (int)sizeof(TO);        // columns per lane: 16 bytes of output
+  constexpr int LPR = 64 / CPL;                    // lanes per 64-column row (8 | 16)
+  constexpr int RPI = 64 / LPR;                    // rows per wave instruction (8 | 4)
+  const int l32 = lane & 31, lh = lane >> 5, r16 = l32 & 15;
+  const int lr = lane / LPR, lc = (lane % LPR) * CPL;
+  const int n = n0 + wn * 64 + lc;
+  const int rowb = m0 + wm * 128 + lr;             // + 32 i + 16 hh + RPI it
+  const bool col_ok = n < (int)p.N;
+  const uint32_t Mi = (uint32_t)p.M;
+  const uint32_t esO = sizeof(TO), esE = sizeof(TE);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((p.M - 1) * p.ldc + p.N) * esO), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.R ? p.R : p.A), 0, p.R ? (int)(((p.M - 1) * p.ldr + p.N) * esE) : 0, 0x00020000);
+  const uint32_t ldcB = (uint32_t)p.ldc * esO, ldrB = (uint32_t)p.ldr * esE;
+  const uint32_t offC0 = (uint32_t)rowb * ldcB + (uint32_t)n * esO;
+  const uint32_t offR0 = (uint32_t)rowb * ldrB + (uint32_t)n * esE;
+  float bv[CPL];
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) bv[e] = 0.f;
+  if (p.bias && col_ok) {
+    const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.bias), 0, (int)(p.N * esE), 0x00020000);
+    SkIO<TE>::template ld<CPL>(bv, rBias, (uint32_t)n * esE);
+  }
+  const bool has_R = p.R != nullptr, accum = p.accumulate != 0;
+  const float alpha = p.alpha;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if ((l32 >> 4) == hh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            *reinterpret_cast<float4*>(slab + r16 * 256 + (((j * 8 + 2 * q + lh) ^ r16) << 4)) = v;
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 16 / RPI; ++it) {
+        const int row = lr + RPI * it;                         // row of the 16-row slab
+        const uint32_t rr = (uint32_t)(32 * i + 16 * hh + RPI * it);
+        const bool ok = col_ok && (uint32_t)rowb + rr < Mi;
+        float v[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL / 4; ++u) {
+          const float4 t = *reinterpret_cast<const float4*>(slab + row * 256 + (((lc / 4 + u) ^ row) << 4));
+          v[4 * u] = t.x; v[4 * u + 1] = t.y; v[4 * u + 2] = t.z; v[4 * u + 3] = t.w;
+        }
+        const uint32_t oc = ok ? offC0 + rr * ldcB : 0x80000000u;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] = v[e] * alpha + bv[e];
+        if (has_R) {
+          float r[CPL];
+          SkIO<TE>::template ld<CPL>(r, rR, ok ? offR0 + rr * ldrB : 0x80000000u);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] += r[e];
+        }
+        if (accum) {
+          float c0[CPL];
+          SkIO<TO>::template ld<CPL>(c0, rC, oc);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] += c0[e];
+        }
+#if !(DXA_PPV & 32)
+        SkIO<TO>::template st<CPL>(v, rC, oc);
+#endif
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);   // passes stay in order: no hoisting of the next pass's work (register pressure)
+    }
+#endif
+}
+
+// LEAN = the epilogue is C = alpha * acc + bias (+ residual) (+ C) over whole 16-byte accesses (sk_epilogue); otherwise
+// the generic epilogue of tile_finish (activation / mulgrad / aux / ragged edges).
+template <typename TO, typename TE, bool LEAN>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int REG = 256 * 128;            // one operand of one K tile: 256 rows x 128 B
+  constexpr int BUF = 2 * REG;              // A | B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l32 = lane & 31, lh = lane >> 5;
+
+  // tiles [0, full): one workgroup each, block ids dealt round-robin to the 8 XCDs are remapped so every XCD
+  // walks a contiguous run of tiles.  Tail tiles (the partial last round of the 256 CUs) are cut along K into
+  // split_s workgroups each; the last split gathers the others' fp32 partials and runs the epilogue.
+  int bid = blockIdx.x;
+  int split_j = 0, split_s = 1, tail_i = 0;
+  if (bid < p.full) {
+    const int q = p.full >> 3, r = p.full & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  } else {
+    const int idx = bid - p.full;
+    tail_i = idx % p.tail_r;
+    split_j = idx / p.tail_r;
+    split_s = p.split_s;
+    bid = p.full + tail_i;
+  }
+  int m0i, n0i;
+  sk_tile_origin(p, bid, m0i, n0i);
+  const int64_t m0 = m0i, n0 = n0i;
+
+  const uint32_t bytesA = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t bytesB = (uint32_t)(((p.N - 1) * p.ldb + p.K) * 2);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
+  // DMA instruction (h, j) of a wave covers 8 consecutive tile rows; g = 2*wave + j in 0..15 selects the 8-row group:
+  //   A half h: rows (g & 7) * 8 + (g >> 3) * 128 + 64 h   (the A-h rows of both wave rows wm)
+  //   B half h: rows (g >> 2) * 64 + (g & 3) * 8 + 32 h     (the B-h columns of all four wave columns wn)
+  // lane -> (row = row0 + lane / 8, LDS chunk slot = lane % 8, source chunk = slot ^ ((row >> 1) & 7))
+#define PP_A_ROW0(h, j) ((((wave * 2 + (j)) & 7) * 8) + (((wave * 2 + (j)) >> 3) * 128) + 64 * (h))
+#define PP_B_ROW0(h, j) ((((wave * 2 + (j)) >> 2) * 64) + (((wave * 2 + (j)) & 3) * 8) + 32 * (h))
+  uint32_t voA[2][2], voB[2][2];
+  {
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ra = PP_A_ROW0(h, j) + lrow, rb = PP_B_ROW0(h, j) + lrow;
+        const int ga = m0i + ra, gb = n0i + rb;
+        voA[h][j] = ga < (int)p.M ? (uint32_t)ga * lda2 + (uint32_t)((lslot ^ ((ra >> 1) & 7)) << 4) : 0x80000000u;
+        voB[h][j] = gb < (int)p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+      }
+  }
+  const int nk_tot = (int)(p.K >> 6);
+  const int k_lo = split_j * nk_tot / split_s;
+  const int nk = (split_j + 1) * nk_tot / split_s - k_lo;   // K tiles of this workgroup (>= 1)
+#define PP_DMA(rsrc, vo, ldsoff, buf, tile)                                                                             \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(smem + (buf) * BUF + (ldsoff)), 16, vo,                 \
+                                           (k_lo + (tile)) * 128, 0, 0)
+#if (DXA_PPV & 1)
+#define PP_LOOP(x) do { } while (0)
+#else
+#define PP_LOOP(x) x
+#endif
+#define PP_DMA_A(h, buf, tile) do { PP_DMA(rA, voA[h][0], PP_A_ROW0(h, 0) * 128, buf, tile); PP_DMA(rA, voA[h][1], PP_A_ROW0(h, 1) * 128, buf, tile); } while (0)
+#define PP_DMA_B(h, buf, tile) do { PP_DMA(rB, voB[h][0], REG + PP_B_ROW0(h, 0) * 128, buf, tile); PP_DMA(rB, voB[h][1], REG + PP_B_ROW0(h, 1) * 128, buf, tile); } while (0)
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addresses: A block i (32 rows) of k-step ks: row = wm*128 + 32 i + l32, chunk c = 2 ks + lh at slot
+  // c ^ sw.  2 ks + lh = (ks << 1) ^ lh, the row base has zero bits below 128 and buffer 1 starts at bit 16, so
+  // address = ya ^ (ks << 5) ^ (cur << 16) with ONE per-lane register ya = row base | ((lh ^ sw) << 4) per operand.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int sw = (l32 >> 1) & 7;
+  const uint32_t ya = (lds0 + (wm * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
+  const uint32_t yb = (lds0 + REG + (wn * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
+  u32x4_t af[2][4], bfr[4];
+#if (DXA_PPV & 2)
+#define PP_READ(dst, addr, imm) asm volatile("" : "+v"(dst) : "v"(addr))
+#else
+#define PP_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#endif
+#define PP_RD_A(cur, h)                                                                                     \
+  do {                                                                                                      \
+    const uint32_t a0_ = ya ^ (uint32_t)((cur) * BUF), a1_ = ya ^ (uint32_t)((cur) * BUF + 32),             \
+                   a2_ = ya ^ (uint32_t)((cur) * BUF + 64), a3_ = ya ^ (uint32_t)((cur) * BUF + 96);        \
+    PP_READ(af[0][0], a0_, (2 * (h)) * 4096); PP_READ(af[1][0], a0_, (2 * (h) + 1) * 4096);                \
+    PP_READ(af[0][1], a1_, (2 * (h)) * 4096); PP_READ(af[1][1], a1_, (2 * (h) + 1) * 4096);                \
+    PP_READ(af[0][2], a2_, (2 * (h)) * 4096); PP_READ(af[1][2], a2_, (2 * (h) + 1) * 4096);                \
+    PP_READ(af[0][3], a3_, (2 * (h)) * 4096); PP_READ(af[1][3], a3_, (2 * (h) + 1) * 4096);                \
+  } while (0)
+#define PP_RD_B(cur, j)                                                                                     \
+  do {                                                                                                      \
+    const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF), b1_ = yb ^ (uint32_t)((cur) * BUF + 32),             \
+                   b2_ = yb ^ (uint32_t)((cur) * BUF + 64), b3_ = yb ^ (uint32_t)((cur) * BUF + 96);        \
+    PP_READ(bfr[0], b0_, (j) * 4096); PP_READ(bfr[1], b1_, (j) * 4096);                                     \
+    PP_READ(bfr[2], b2_, (j) * 4096); PP_READ(bfr[3], b3_, (j) * 4096);                                     \
+  } while (0)
+#if (DXA_PPV & 4)
+#define PP_MFMA(ii, ks, i, j) asm volatile("" : "+v"(acc[i][j]) : "v"(bfr[ks]), "v"(af[ii][ks]))
+#else
+#define PP_MFMA(ii, ks, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks]), __builtin_bit_cast(bf16x8_t, af[ii][ks]), acc[i][j], 0, 0, 0)
+#endif
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#define PP_BAR() do { PP_SB(); __builtin_amdgcn_s_barrier(); PP_SB(); } while (0)
+  // compute cluster of quadrant (A half h, B half j): the two accumulators alternate so dependent MFMAs are 2 apart
+#define PP_COMPUTE(h, j)                                                                          \
+  do {                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+    PP_SB();                                                                                      \
+    PP_MFMA(0, 0, 2 * (h), j); PP_MFMA(1, 0, 2 * (h) + 1, j);                                     \
+    PP_MFMA(0, 1, 2 * (h), j); PP_MFMA(1, 1, 2 * (h) + 1, j);                                     \
+    PP_MFMA(0, 2, 2 * (h), j); PP_MFMA(1, 2, 2 * (h) + 1, j);                                     \
+    PP_MFMA(0, 3, 2 * (h), j); PP_MFMA(1, 3, 2 * (h) + 1, j);                                     \
+    PP_SB();                                                                                      \
+  } while (0)
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  // one K tile in buffer `cur`; `more` = another tile follows: its pieces are issued here into the other buffer, one
+  // per phase in the order of their first read (A0, B0, B1, A1).  A piece read in memory cluster M_q is waited for
+  // (vmcnt(4): the two younger pieces stay in flight) at the END of M_{q-1} by every wave; both groups' M_{q-1} end before
+  // the interval in which the first M_q starts, so wait + barrier order the DMA before every read.  A piece of tile
+  // t+1 overwrites bytes last read in tile t-1 (>= 2 barriers earlier).
+#define PP_TILE(cur, t)                                                                                     \
+  do {                                                                                                      \
+    const bool more = (t) + 1 < nk;                                                                         \
+    /* phase 0 */                                                                                           \
+    PP_RD_A(cur, 0); PP_RD_B(cur, 0); PP_SB();                                                              \
+    if (more) { PP_LOOP(PP_DMA_A(0, (cur) ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(4); } else { PP_VMCNT(2); }    \
+    PP_BAR(); PP_COMPUTE(0, 0); PP_BAR();                                                                   \
+    /* phase 1 */                                                                                           \
+    PP_RD_B(cur, 1); PP_SB();                                                                               \
+    if (more) { PP_LOOP(PP_DMA_B(0, (cur) ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(4); } else { PP_VMCNT(0); }    \
+    PP_BAR(); PP_COMPUTE(0, 1); PP_BAR();                                                                   \
+    /* phase 2 */                                                                                           \
+    PP_RD_A(cur, 1); PP_SB();                                                                               \
+    if (more) { PP_LOOP(PP_DMA_B(1, (cur) ^ 1, (t) + 1)); PP_SB(); }                                        \
+    PP_BAR(); PP_COMPUTE(1, 1); PP_BAR();                                                                   \
+    /* phase 3 */                                                                                           \
+    PP_RD_B(cur, 0); PP_SB();                                                                               \
+    if (more) { PP_LOOP(PP_DMA_A(1, (cur) ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(4); }                           \
+    PP_BAR(); PP_COMPUTE(1, 0); PP_BAR();                                                                   \
+  } while (0)
+
+  // ---- prologue: the four pieces of tile 0; A0 and B0 landed for every wave before the first read
+  PP_DMA_A(0, 0, 0); PP_DMA_B(0, 0, 0); PP_DMA_B(1, 0, 0); PP_DMA_A(1, 0, 0);
+  PP_SB();
+  PP_VMCNT(4);
+  PP_BAR();
+  if (!(DXA_PPV & 16) && wm == 1) PP_BAR();    // group 1 runs one barrier interval behind group 0
+  for (int t = 0; t < nk; t += 2) {
+    PP_TILE(0, t);
+    if (t + 1 < nk) PP_TILE(1, t + 1);
+  }
+  if (!(DXA_PPV & 16) && wm == 0) PP_BAR();    // every wave has now passed the same number of barriers
+#undef PP_A_ROW0
+#undef PP_B_ROW0
+#undef PP_DMA
+#undef PP_LOOP
+#undef PP_DMA_A
+#undef PP_DMA_B
+#undef PP_READ
+#undef PP_RD_A
+#undef PP_RD_B
+#undef PP_MFMA
+#undef PP_SB
+#undef PP_BAR
+#undef PP_COMPUTE
+#undef PP_VMCNT
+#undef PP_TILE
+
+  if constexpr (LEAN) {
+    if (split_s == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i);
+      return;
+    }
+  }
+  tile_finish<TO, 4, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+template __global__ void gemm_nt_pp_kernel<bf16_t, bf16_t, true>(const GemmP);
+template __global__ void gemm_nt_pp_kernel<float, bf16_t, true>(const GemmP);
+template __global__ void gemm_nt_pp_kernel<float, float, true>(const GemmP);
+template __global__ void gemm_nt_pp_kernel<bf16_t, bf16_t, false>(const GemmP);
+template __global__ void gemm_nt_pp_kernel<float, bf16_t, false>(const GemmP);
+template __global__ void gemm_nt_pp_kernel<float, float, false>(const GemmP);
 
 // x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
 __global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
@@ -839,6 +1254,19 @@ int get_split_ws(hipStream_t st, SplitWs* out) {
   return DXA_OK;
 }
 
+// persistent kernels launch one workgroup per compute unit
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    else
+      n = NUM_CU;
+  }
+  return n;
+}
 inline bool skinny_off_g() {
   static const bool off = getenv("DXA_GEMM_NO_SKINNY") != nullptr;
   return off;
@@ -938,7 +1366,36 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     }                                                                                                           \
     hipLaunchKernelGGL((gemm_nt_ring_kernel<TO_, AI_, TE_>), fgrid, dim3(512), RING_LDS, st, p);                \
   } while (0)
-    if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }
+    // ---- ping-pong main loop: 256-row tiles, K % 64 == 0; the lean epilogue when it is made of whole 16-byte accesses
+    static const bool pp_off = getenv("DXA_GEMM_NO_PP") != nullptr;
+    const bool pp = !pp_off && ai == 4 && d->K % 64 == 0;
+    const int64_t cpl = 16 / (int64_t)os;
+    const bool lean = pp && d->N % cpl == 0 && d->ldc % cpl == 0 && aligned_to(d->C, 16) &&
+                      ((d->M - 1) * d->ldc + d->N) * (int64_t)os < (1ll << 31) && !d->aux_out && !d->mulgrad &&
+                      d->act == DXA_ACT_NONE && (!d->bias || aligned_to(d->bias, cpl * ees)) &&
+                      (!d->residual || (aligned_to(d->residual, cpl * ees) && d->ldr % cpl == 0 &&
+                                        ((d->M - 1) * d->ldr + d->N) * (int64_t)ees < (1ll << 31)));
+#define LAUNCH_PP(TO_, TE_, LEAN_)                                                                              \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<TO_, TE_, LEAN_>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<TO_, TE_, LEAN_>), fgrid, dim3(512), RING_LDS, st, p);                \
+  } while (0)
+    if (pp && lean) {
+      if (d->epi_f32) LAUNCH_PP(float, float, true);
+      else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, true);
+      else LAUNCH_PP(float, bf16_t, true);
+    } else if (pp) {
+      if (d->epi_f32) LAUNCH_PP(float, float, false);
+      else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, false);
+      else LAUNCH_PP(float, bf16_t, false);
+    }
+#undef LAUNCH_PP
+    else if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }
     else if (ai == 3) { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 3, bf16_t); else LAUNCH_RING(float, 3, bf16_t); }
     else { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 4, bf16_t); else LAUNCH_RING(float, 4, bf16_t); }
 #undef LAUNCH_RING

@@ -31,7 +31,7 @@ def main():
     dev = "cuda"
     only = sys.argv[1] if len(sys.argv) > 1 else None
     for name, lay, m, n, k in SHAPES:
-        if only and only not in lay and only not in name:
+        if only and not any(o == lay or o in name for o in only.split(",")):
             continue
         if lay == "nt":
             a = (torch.rand(m, k, device=dev) * 2 - 1).bfloat16()

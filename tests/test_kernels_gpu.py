@@ -124,6 +124,33 @@ def test_gemm_ring_split_tail(shape, f32out):
             assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"split tail bf16 rep {rep}")
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 520, 128), (1000, 520, 192), (770, 129, 320), (4592, 4608, 3584),
+                                   (2304, 1024, 4608), (512, 2048, 18944), (700, 300, 4096)])
+@pytest.mark.parametrize("f32out", [False, True])
+def test_gemm_pingpong(shape, f32out):
+    """bf16 NT ping-pong kernel (256-row tiles, K % 64 == 0): 1, 2, 3 and many K tiles (odd and even counts: the two LDS
+    buffers alternate), ragged M / N edges, the split-K tail, fused epilogue, fp32 accumulate output; every output element
+    against an fp64 reference, several repetitions (the staggered wave groups must never read a K tile early)"""
+    M, N, Kd = shape
+    assert Kd % 64 == 0 and not (-(-M // 192) * 192 * 27 < -(-M // 256) * 256 * 25)   # dispatch: ping-pong main loop
+    a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=35), rnd(N, Kd, dtype=torch.bfloat16, seed=36, scale=0.1)
+    ref = a.double() @ w.double().t()
+    first = None
+    for rep in range(3):
+        if f32out:
+            out = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+            K.mm_nt(a, w, out=out, accumulate=True)
+            assert_close(out, ref + 0.5, 2e-5, 2e-3 * math.sqrt(Kd / 320), f"ping-pong f32 accumulate rep {rep}")
+        else:
+            bias, res = rnd(N, dtype=torch.bfloat16, seed=37), rnd(M, N, dtype=torch.bfloat16, seed=38)
+            out = K.mm_nt(a, w, bias=bias, residual=res)
+            rtol, atol = tol_for(torch.bfloat16, Kd)
+            assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"ping-pong bf16 rep {rep}")
+        if first is None:
+            first = out.clone()
+        assert torch.equal(out, first), f"ping-pong result changed between repetitions (rep {rep})"
+
+
 @pytest.mark.parametrize("shape", [(543, 4608, 3584), (543, 3584, 18944), (514, 1024, 4096), (130, 300, 64), (330, 260, 96),
                                    (192, 256, 32), (1050, 777, 2048)])
 @pytest.mark.parametrize("f32out", [False, True])
@@ -507,6 +534,13 @@ def test_splice_gather(dtype):
             ri[-1 - p] = dout[r]
     assert_close(d_embed, re, 1e-6, 1e-6, "splice d_embed")
     assert torch.equal(d_img, ri)
+    # duplicates are summed in a fixed order: bitwise reproducible, and the sparse re-zero clears exactly the touched rows
+    for _ in range(3):
+        d2 = torch.zeros(V, d, device=DEV)
+        K.splice_bwd(plan, dout, d2, None)
+        assert torch.equal(d2, d_embed)
+    K.zero_rows(plan, d_embed)
+    assert d_embed.abs().sum().item() == 0.0
     idx = torch.tensor([4, 19, 4], dtype=torch.int64, device=DEV)
     gth = K.gather_rows(out, idx, torch.float32)
     assert torch.equal(gth, out[idx].float())
@@ -627,6 +661,16 @@ def test_adamw_matches_torch():
     x = rnd(1000, seed=112)
     K.scale_(x, 0.25)
     assert_close(x, rnd(1000, seed=112) * 0.25, 0, 0, "scale")
+    # bf16 gradient arena (the data-parallel communication copy): same update as with those values widened to fp32
+    g16 = gs.to(torch.bfloat16)
+    p1, m1, v1 = p.clone(), m.clone(), v.clone()
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    s1, s2 = torch.empty_like(shadow), torch.empty_like(shadow)
+    K.adamw(p1, g16.float(), m1, v1, s1, cs_t, cl_t, cg_t, [1e-3, 5e-4], [0.01, 0.0], 0.9, 0.999, 1e-8, 4, clip=coef)
+    K.adamw(p2, g16, m2, v2, s2, cs_t, cl_t, cg_t, [1e-3, 5e-4], [0.01, 0.0], 0.9, 0.999, 1e-8, 4, clip=coef)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(s1, s2)
+    K.sumsq(g16, ss, scratch)
+    assert abs(ss.item() - g16.double().pow(2).sum().item()) < 1e-5 * ss.item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
