@@ -28,6 +28,36 @@ import torch.nn as nn
 
 ALIGN = 64  # elements; every group starts on a 256-byte boundary
 
+# The reference's factories take ONE argument (build_vision_tower(cfg), build_vision_projector(config),
+# build_action_model(config): mm_vision/builder.py:9-34, mm_projector/builder.py:36-81, cogact/action_model/builder.py:5-27).
+# Native modules additionally need the arena they register their parameters in: the *ForCausalLM constructor opens a
+# build context and the factories pick the store up from it.
+_BUILD_STACK: List["ParamStore"] = []
+
+
+class building:
+    """``with building(store): ...`` — every factory called inside registers into ``store``"""
+
+    def __init__(self, store: "ParamStore"):
+        self.store = store
+
+    def __enter__(self):
+        _BUILD_STACK.append(self.store)
+        return self.store
+
+    def __exit__(self, *exc):
+        _BUILD_STACK.pop()
+        return False
+
+
+def current_store(store: Optional["ParamStore"] = None) -> "ParamStore":
+    if store is not None:
+        return store
+    if not _BUILD_STACK:
+        raise RuntimeError("no ParamStore: native modules are built inside a *ForCausalLM constructor "
+                           "(or `with dexbotic_amd.engine.building(store):`)")
+    return _BUILD_STACK[-1]
+
 
 @dataclass
 class Slot:
@@ -47,6 +77,7 @@ class ParamStore:
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
         self.slots: Dict[str, Slot] = {}
+        self.layernorm_modules: set = set()          # dotted module paths that are nn.LayerNorm in the reference
         self._groups: List[List[str]] = []
         self._cursor = 0
         self._bucket = 0
@@ -76,8 +107,15 @@ class ParamStore:
         self._bucket += 1
         return self._bucket
 
-    def register(self, group: Sequence[Tuple[str, Sequence[int]]]) -> None:
+    def register(self, group: Sequence[Tuple[str, Sequence[int]]], layernorm: bool = False) -> None:
+        """``layernorm``: the group is the weight / bias of an ``nn.LayerNorm`` of the reference: its module container
+        becomes an ``nn.LayerNorm`` instance, so code that selects parameters by module TYPE (the no-weight-decay rule of
+        OptimizerConfig._get_optimizer_grouped_parameters, base_exp.py:101-102: get_parameter_names(model,
+        ALL_LAYERNORM_LAYERS)) treats the native model like the reference's."""
         assert self.master is None, "register() after finalize()"
+        if layernorm:
+            for name, _ in group:
+                self.layernorm_modules.add(name.rsplit(".", 1)[0])
         self._cursor = (self._cursor + ALIGN - 1) // ALIGN * ALIGN
         names = []
         for name, shape in group:
@@ -321,23 +359,35 @@ def attach_parameters(root: nn.Module, store: ParamStore, containers: Optional[D
     for name, p in store.params.items():
         parts = name.split(".")
         mod = root
-        for part in parts[:-1]:
+        for i, part in enumerate(parts[:-1]):
             child = mod._modules.get(part)
             if child is None:
-                child = nn.Module()
+                child = ArenaLayerNorm() if ".".join(parts[:i + 1]) in store.layernorm_modules else nn.Module()
                 mod.add_module(part, child)
             mod = child
         mod.register_parameter(parts[-1], p)
 
 
+class ArenaLayerNorm(nn.LayerNorm):
+    """parameter container with the TYPE of the reference's module (the arithmetic is libdexbotic_amd's layernorm
+    kernels, reached through functional.NormFn / VitBlockFn; calling this object is not part of the native path)"""
+
+    def __init__(self):
+        nn.Module.__init__(self)
+        self.normalized_shape, self.eps, self.elementwise_affine = (), 1e-5, True
+
+    def forward(self, x):  # pragma: no cover - never on the native path
+        raise RuntimeError("ArenaLayerNorm is a parameter container; the native blocks call the layernorm kernels")
+
+
 # ------------------------------------------------------------------------------------------ optimizer
-def no_decay_name(name: str) -> bool:
+def no_decay_name(name: str, store: Optional[ParamStore] = None) -> bool:
     """Parameter-group rule of OptimizerConfig._get_optimizer_grouped_parameters (base_exp.py:95-203)
     under the reference's pinned transformers: no weight decay for parameters of nn.LayerNorm modules
-    and for every name containing "bias" (RMSNorm weights DO decay there)."""
+    (by module type: ``store.layernorm_modules``) and for every name containing "bias" (RMSNorm weights DO decay)."""
     if "bias" in name:
         return True
-    return any(t in name for t in ("layer_norm1.", "layer_norm2.", "pre_layrnorm.", "post_layernorm."))
+    return store is not None and name.rsplit(".", 1)[0] in store.layernorm_modules
 
 
 @dataclass
@@ -372,6 +422,7 @@ class FusedAdamW:
         prefixes = prefixes or {"mm_projector": "mm_projector", "mm_vision": "mm_vision", "action_head": "action_head"}
         # groups: (lr_key, decay?) -> index  (<= 8 groups, as the reference builds them)
         self.group_keys: List[Tuple[str, bool]] = []
+        self.group_of: Dict[str, Tuple[str, bool]] = {}      # parameter name -> (lr key, weight-decayed?)
         cs, cl, cg = [], [], []
         for s in sorted(store.slots.values(), key=lambda s: s.offset):
             if not store.params[s.name].requires_grad or s.name in exclude:
@@ -383,7 +434,8 @@ class FusedAdamW:
                 lr_key = "mm_vision"
             elif cfg.action_head_lr is not None and prefixes["action_head"] in s.name:
                 lr_key = "action_head"
-            key = (lr_key, not no_decay_name(s.name))
+            key = (lr_key, not no_decay_name(s.name, store))
+            self.group_of[s.name] = key
             if key not in self.group_keys:
                 self.group_keys.append(key)
             gi = self.group_keys.index(key)

@@ -1,13 +1,17 @@
 """Action-model factory (mirror of dexbotic/model/cogact/action_model/builder.py:5-27)."""
 from __future__ import annotations
 
-from ....engine import ParamStore
+from typing import Optional
+
+from ....engine import ParamStore, current_store
 from .action_models import ActionModel
 
 REQUIRED = ("action_model_type", "hidden_size", "action_dim", "chunk_size")
 
 
-def build_action_model(config, store: ParamStore, prefix: str = "model.action_head."):
+def build_action_model(config, store: Optional[ParamStore] = None, prefix: str = "model.action_head."):
+    """reference signature ``build_action_model(config)``; the arena comes from the enclosing build context"""
+    store = current_store(store)
     missing = [k for k in REQUIRED if not hasattr(config, k)]
     if missing:                                     # exp/utils.py:43-52 require_config_keys
         raise ValueError(f"Missing required config keys: {missing}")

@@ -65,7 +65,7 @@ class DiT(nn.Module):
             if use_per_attn:
                 store.register([(b + "per_attn.in_proj_weight", (3 * h, h)), (b + "per_attn.in_proj_bias", (3 * h,))])
                 store.register([(b + "per_attn.out_proj.weight", (h, h)), (b + "per_attn.out_proj.bias", (h,))])
-                store.register([(b + "norm3.weight", (h,)), (b + "norm3.bias", (h,))])
+                store.register([(b + "norm3.weight", (h,)), (b + "norm3.bias", (h,))], layernorm=True)
             self.block_specs.append(Fn.VitBlockSpec(
                 ln1_w=None, ln1_b=None, qkv_w=(b + "attn.qkv.weight",), qkv_b=(b + "attn.qkv.bias",),
                 out_w=b + "attn.proj.weight", out_b=b + "attn.proj.bias", ln2_w=None, ln2_b=None,

@@ -14,8 +14,9 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
-from ...splice import build_splice_plan
+from ...engine import building
 from ..dexbotic_arch import (ActionOutputForCausalLM, CausalLMOutputDexbotic, DexboticConfig, DexboticForCausalLM,
+                             register_with_hf,
                              DexboticVLMModel)
 from .action_model.builder import build_action_model
 
@@ -31,6 +32,9 @@ class CogActConfig(DexboticConfig):
         self.chunk_size = chunk_size
 
 
+register_with_hf(CogActConfig)
+
+
 class CogActModel(DexboticVLMModel):
     def __init__(self, config: CogActConfig, store):
         super().__init__(config, store)
@@ -41,7 +45,8 @@ class CogActModel(DexboticVLMModel):
     def _build_action_head_module(self, config: CogActConfig):
         if getattr(self, "action_head", None) is not None:
             return self.action_head
-        self.action_head = build_action_model(config, self.store, "model.action_head.")
+        with building(self.store):
+            self.action_head = build_action_model(config)
         return self.action_head
 
     @property

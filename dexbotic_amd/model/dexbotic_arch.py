@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import functional as Fn
 from .. import kernels as K
 from ..constants import IGNORE_INDEX
-from ..engine import ParamStore, attach_parameters
+from ..engine import ParamStore, attach_parameters, building
 from ..splice import PlanCache, SplicePlan, build_splice_plan
 from .llm.qwen2 import Qwen2Backbone, Qwen2Config
 from .modules.mm_projector.builder import build_vision_projector
@@ -32,10 +32,17 @@ _DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, torch.float32: 
            torch.bfloat16: torch.bfloat16}
 
 
-class DexboticConfig:
-    """Plain-Python mirror of the HF ``PretrainedConfig`` subclass of the reference.  ``llm_config`` may be a
-    Qwen2Config, a dict, an HF config object or a directory with config.json; its keys are merged in
-    (``_merge_llm``, dexbotic_arch.py:79-85) so ``hidden_size`` / ``vocab_size`` are top-level."""
+def _hf_config_base():
+    from transformers import PretrainedConfig
+    return PretrainedConfig
+
+
+class DexboticConfig(_hf_config_base()):
+    """``transformers.PretrainedConfig`` subclass like the reference's (dexbotic_arch.py:17-23), registered with
+    ``AutoConfig`` under the same ``model_type`` string, so ``AutoConfig.from_pretrained(ckpt)`` / ``config.json`` written
+    by either implementation resolve to it.  ``llm_config`` may be a Qwen2Config, a dict, an HF config object or a
+    directory with config.json; its keys are merged in (``_merge_llm``, dexbotic_arch.py:79-85) so ``hidden_size`` /
+    ``vocab_size`` are top-level."""
     model_type = "dexbotic"
 
     def __init__(self, llm_config=None, mm_projector_type: Optional[str] = "mlp2x_gelu", mm_vision_tower=None,
@@ -53,44 +60,64 @@ class DexboticConfig:
         self.tokenizer_model_max_length = kwargs.pop("tokenizer_model_max_length", None)
         self.tokenizer_padding_side = kwargs.pop("tokenizer_padding_side", "right")
         self.image_aspect_ratio = kwargs.pop("image_aspect_ratio", "pad")
-        self.use_cache = kwargs.pop("use_cache", True)
         # fp32 x fp32 products of the fp32 action head: "bf16x3" (split-bf16 on the MFMA ring kernel, the counterpart of
         # the reference's tf32=True, base_exp.py:254) in bf16 compute mode, exact fp32 MFMA in fp32 (parity) mode
         self.fp32_matmul = kwargs.pop("fp32_matmul", None) or ("bf16x3" if "bfloat16" in self.compute_dtype else "exact")
+        kwargs.pop("model_type", None)
+        merged = {k: kwargs.pop(k) for k in list(kwargs) if k in self.llm_config.to_dict() and k != "model_type"}
+        super().__init__(**kwargs)
         for k, v in self.llm_config.to_dict().items():          # _merge_llm: only add missing keys
-            if not hasattr(self, k):
+            if k in ("model_type", "architectures", "transformers_version", "torch_dtype", "dtype"):
+                continue
+            if k in merged:
+                setattr(self, k, merged[k])
+            elif k not in self.__dict__:
                 setattr(self, k, v)
-        for k, v in kwargs.items():
-            setattr(self, k, v)
 
     # ---- (de)serialisation compatible with the reference's config.json ------------------------------
     def to_dict(self) -> Dict[str, Any]:
-        d = {}
-        for k, v in self.__dict__.items():
-            if k.startswith("_"):
-                continue
+        d = super().to_dict()
+        out = {}
+        for k, v in d.items():
             if hasattr(v, "to_dict"):
                 v = v.to_dict()
-            d[k] = v
-        d["model_type"] = self.model_type
-        return d
+            elif isinstance(v, torch.dtype):
+                v = str(v).replace("torch.", "")
+            out[k] = v
+        out["model_type"] = self.model_type
+        return out
+
+    def to_diff_dict(self) -> Dict[str, Any]:
+        return self.to_dict()
 
     @classmethod
-    def from_dict(cls, d: Dict[str, Any]):
-        d = dict(d)
-        d.pop("model_type", None)
-        d.pop("architectures", None)
-        return cls(**d)
-
-    @classmethod
-    def from_pretrained(cls, path: str):
+    def from_pretrained(cls, path: str, **kwargs):
         with open(os.path.join(path, "config.json")) as f:
             return cls.from_dict(json.load(f))
 
-    def save_pretrained(self, path: str) -> None:
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any], **kwargs):
+        d = dict(d)
+        for k in ("model_type", "architectures", "transformers_version"):
+            d.pop(k, None)
+        return cls(**d)
+
+    def save_pretrained(self, path: str, **kwargs) -> None:
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(self.to_dict(), f, indent=2, default=str)
+
+
+def register_with_hf(config_cls) -> None:
+    """AutoConfig.register under the reference's model_type strings (dexbotic_arch.py:18, cogact_arch.py:14, ...)"""
+    from transformers import AutoConfig
+    try:
+        AutoConfig.register(config_cls.model_type, config_cls)
+    except ValueError:
+        pass                                         # already registered (module re-import)
+
+
+register_with_hf(DexboticConfig)
 
 
 @dataclass
@@ -112,7 +139,9 @@ class CausalLMOutputDexbotic:
 
 class DexboticVLMModel(nn.Module):
     """vision tower -> projector -> splice into LLM embeddings -> LLM backbone."""
-    supports_gradient_checkpointing = True
+    # activation recompute is not implemented: every block keeps its activations (25 GB of 288 at the CogACT batch);
+    # gradient_checkpointing_enable() says so instead of silently ignoring the request
+    supports_gradient_checkpointing = False
 
     def __init__(self, config: DexboticConfig, store: ParamStore):
         super().__init__()
@@ -135,13 +164,15 @@ class DexboticVLMModel(nn.Module):
     def _build_mm_projector_module(self, config) -> nn.Module:
         if getattr(self, "mm_projector", None) is not None:
             return self.mm_projector
-        self.mm_projector = build_vision_projector(config, self.store, "model.mm_projector.")
+        with building(self.store):
+            self.mm_projector = build_vision_projector(config)
         return self.mm_projector
 
     def _build_mm_vision_module(self, config) -> nn.Module:
         if getattr(self, "mm_vision_tower", None) is not None:
             return self.mm_vision_tower
-        self.mm_vision_tower = build_vision_tower(config, self.store, "model.mm_vision_tower.")
+        with building(self.store):
+            self.mm_vision_tower = build_vision_tower(config)
         self.config.mm_hidden_size = self.mm_vision_tower.hidden_size
         return self.mm_vision_tower
 
@@ -232,6 +263,16 @@ class NativePreTrainedMixin:
     def post_load(self) -> None:
         self.store.sync_shadow()
 
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None) -> None:
+        """base_exp.py:245 / trainer.py:120 turn this on to fit 80 GB parts (a 4th forward per step).  The native blocks
+        keep their activations — ~0.75 GB per decoder layer at 16 x 287 tokens against 288 GB of HBM — and have no
+        recompute path: refuse loudly rather than pretend."""
+        raise NotImplementedError("dexbotic_amd keeps block activations resident (MI355X: 288 GB HBM); activation "
+                                  "recompute is not implemented — run with gradient_checkpointing=False")
+
+    def gradient_checkpointing_disable(self) -> None:
+        return None
+
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         # checkpoints written under transformers 4.51 carry ".vision_tower.vision_model." (SURVEY.md App. B)
         sd = {k.replace(".vision_tower.vision_model.", ".vision_tower."): v for k, v in state_dict.items()}
@@ -285,7 +326,8 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         config.model_type = self.config_class.model_type
         device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         self.store = ParamStore(device, _DTYPES[config.compute_dtype])
-        self._real_init(config)
+        with building(self.store):                    # the one-argument factories register into this arena
+            self._real_init(config)
         self._finish_init(train)
 
     def _real_init(self, config):

@@ -27,7 +27,7 @@ from ... import functional as Fn
 from ... import kernels as K
 from ...engine import ParamStore
 from ..cogact.cogact_arch import CogActConfig, CogActModel, CogACTForCausalLM
-from ..dexbotic_arch import CausalLMOutputDexbotic
+from ..dexbotic_arch import CausalLMOutputDexbotic, register_with_hf
 
 BANK = "model.per_cog_mem_bank."
 
@@ -47,6 +47,9 @@ class MemVLAConfig(CogActConfig):
         self.retrieval_dropout = retrieval_dropout
         if retrieval_dropout:
             raise NotImplementedError("attention / FFN dropout inside the retrieval blocks is not reproduced")
+
+
+register_with_hf(MemVLAConfig)
 
 
 def _lin(st, x, wn, bn, act=L.ACT_NONE, wshape=None):
@@ -88,10 +91,10 @@ class CrossTransformerBlock(nn.Module):
         D = feature_dim
         for n in ("q_proj", "k_proj", "v_proj"):
             store.register([(prefix + n + ".weight", (D, D)), (prefix + n + ".bias", (D,))])
-        store.register([(prefix + "attn_norm.weight", (D,)), (prefix + "attn_norm.bias", (D,))])
+        store.register([(prefix + "attn_norm.weight", (D,)), (prefix + "attn_norm.bias", (D,))], layernorm=True)
         store.register([(prefix + "ffn.0.weight", (4 * D, D)), (prefix + "ffn.0.bias", (4 * D,))])
         store.register([(prefix + "ffn.3.weight", (D, 4 * D)), (prefix + "ffn.3.bias", (D,))])
-        store.register([(prefix + "ffn_norm.weight", (D,)), (prefix + "ffn_norm.bias", (D,))])
+        store.register([(prefix + "ffn_norm.weight", (D,)), (prefix + "ffn_norm.bias", (D,))], layernorm=True)
 
     def forward(self, query: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         st, p, D, H = self.store, self.p, self.D, self.H

@@ -8,7 +8,9 @@ import torch.nn as nn
 
 from .... import _lib as L
 from .... import functional as Fn
-from ....engine import ParamStore
+from typing import Optional
+
+from ....engine import ParamStore, current_store
 
 REQUIRED = ("mm_projector_type", "mm_hidden_size", "hidden_size")
 
@@ -49,7 +51,9 @@ class LinearProjector(nn.Module):
         return Fn.LinearFn.apply(x, st.params[p + "weight"], st, p + "weight", p + "bias", L.ACT_NONE, None)
 
 
-def build_vision_projector(config, store: ParamStore, prefix: str = "model.mm_projector."):
+def build_vision_projector(config, store: Optional[ParamStore] = None, prefix: str = "model.mm_projector."):
+    """reference signature ``build_vision_projector(config)``; the arena comes from the enclosing build context"""
+    store = current_store(store)
     missing = [k for k in REQUIRED if not hasattr(config, k)]
     if missing:
         raise ValueError(f"Missing required config keys: {missing}")

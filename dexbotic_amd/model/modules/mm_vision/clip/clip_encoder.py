@@ -78,18 +78,18 @@ class CLIPVisionTower(nn.Module):
         store.register([(p + "embeddings.class_embedding", (C_,))])
         store.register([(p + "embeddings.patch_embedding.weight", (C_, 3, P, P))])
         store.register([(p + "embeddings.position_embedding.weight", (self.np_ + 1, C_))])
-        store.register([(p + "pre_layrnorm.weight", (C_,)), (p + "pre_layrnorm.bias", (C_,))])
+        store.register([(p + "pre_layrnorm.weight", (C_,)), (p + "pre_layrnorm.bias", (C_,))], layernorm=True)
         self.layer_specs = []
         for j in range(c.num_hidden_layers):
             lp = f"{p}encoder.layers.{j}."
             store.new_bucket()
             qkv_w = tuple(lp + f"self_attn.{n}_proj.weight" for n in "qkv")
             qkv_b = tuple(lp + f"self_attn.{n}_proj.bias" for n in "qkv")
-            store.register([(lp + "layer_norm1.weight", (C_,)), (lp + "layer_norm1.bias", (C_,))])
+            store.register([(lp + "layer_norm1.weight", (C_,)), (lp + "layer_norm1.bias", (C_,))], layernorm=True)
             store.register([(n, (C_, C_)) for n in qkv_w])
             store.register([(n, (C_,)) for n in qkv_b])
             store.register([(lp + "self_attn.out_proj.weight", (C_, C_)), (lp + "self_attn.out_proj.bias", (C_,))])
-            store.register([(lp + "layer_norm2.weight", (C_,)), (lp + "layer_norm2.bias", (C_,))])
+            store.register([(lp + "layer_norm2.weight", (C_,)), (lp + "layer_norm2.bias", (C_,))], layernorm=True)
             store.register([(lp + "mlp.fc1.weight", (I, C_)), (lp + "mlp.fc1.bias", (I,))])
             store.register([(lp + "mlp.fc2.weight", (C_, I)), (lp + "mlp.fc2.bias", (C_,))])
             store.register_wt(qkv_w, 3 * C_, C_)
@@ -104,7 +104,7 @@ class CLIPVisionTower(nn.Module):
                 fc2_b=lp + "mlp.fc2.bias", act=_ACTS[c.hidden_act], eps=c.layer_norm_eps,
                 H=c.num_attention_heads, D=C_ // c.num_attention_heads, I=I))
         store.new_bucket()
-        store.register([(p + "post_layernorm.weight", (C_,)), (p + "post_layernorm.bias", (C_,))])
+        store.register([(p + "post_layernorm.weight", (C_,)), (p + "post_layernorm.bias", (C_,))], layernorm=True)
 
     # parameters that never receive a gradient on the VLA path (last layer + post_layernorm)
     def unused_parameter_names(self):

@@ -84,11 +84,11 @@ class SiglipVisionTower(nn.Module):
             store.new_bucket()
             qkv_w = tuple(lp + f"self_attn.{n}_proj.weight" for n in "qkv")
             qkv_b = tuple(lp + f"self_attn.{n}_proj.bias" for n in "qkv")
-            store.register([(lp + "layer_norm1.weight", (C_,)), (lp + "layer_norm1.bias", (C_,))])
+            store.register([(lp + "layer_norm1.weight", (C_,)), (lp + "layer_norm1.bias", (C_,))], layernorm=True)
             store.register([(n, (C_, C_)) for n in qkv_w])
             store.register([(n, (C_,)) for n in qkv_b])
             store.register([(lp + "self_attn.out_proj.weight", (C_, C_)), (lp + "self_attn.out_proj.bias", (C_,))])
-            store.register([(lp + "layer_norm2.weight", (C_,)), (lp + "layer_norm2.bias", (C_,))])
+            store.register([(lp + "layer_norm2.weight", (C_,)), (lp + "layer_norm2.bias", (C_,))], layernorm=True)
             store.register([(lp + "mlp.fc1.weight", (I, C_)), (lp + "mlp.fc1.bias", (I,))])
             store.register([(lp + "mlp.fc2.weight", (C_, I)), (lp + "mlp.fc2.bias", (C_,))])
             store.register_wt(qkv_w, 3 * C_, C_)
@@ -103,14 +103,14 @@ class SiglipVisionTower(nn.Module):
                 fc2_b=lp + "mlp.fc2.bias", act=_ACTS[c.hidden_act], eps=c.layer_norm_eps,
                 H=c.num_attention_heads, D=C_ // c.num_attention_heads, I=I))
         store.new_bucket()
-        store.register([(p + "post_layernorm.weight", (C_,)), (p + "post_layernorm.bias", (C_,))])
+        store.register([(p + "post_layernorm.weight", (C_,)), (p + "post_layernorm.bias", (C_,))], layernorm=True)
         # SiglipMultiheadAttentionPoolingHead: checkpoint tensors that the VLA path never touches
         store.new_bucket()
         h = p + "head."
         store.register([(h + "probe", (1, 1, C_))])
         store.register([(h + "attention.in_proj_weight", (3 * C_, C_)), (h + "attention.in_proj_bias", (3 * C_,))])
         store.register([(h + "attention.out_proj.weight", (C_, C_)), (h + "attention.out_proj.bias", (C_,))])
-        store.register([(h + "layernorm.weight", (C_,)), (h + "layernorm.bias", (C_,))])
+        store.register([(h + "layernorm.weight", (C_,)), (h + "layernorm.bias", (C_,))], layernorm=True)
         store.register([(h + "mlp.fc1.weight", (I, C_)), (h + "mlp.fc1.bias", (I,))])
         store.register([(h + "mlp.fc2.weight", (C_, I)), (h + "mlp.fc2.bias", (C_,))])
 

@@ -107,8 +107,16 @@ def test_optimizer_groups_and_schedule(golden_dir):
     from dexbotic_amd.engine import cosine_lr_scale, no_decay_name
     from oracle.gen_golden import no_decay_name as ref_rule
     g, cfg, w = load_golden(golden_dir, "t1")
+    from tests.helpers import build_product
+    m = build_product(cfg, w, "float32", "cpu", train=True)       # arenas + module tree only; no kernel runs on the host
     for name in w:
-        assert no_decay_name(name) == ref_rule(name), name
+        assert no_decay_name(name, m.store) == ref_rule(name), name
+    # ... and by module TYPE, the way the reference selects them (base_exp.py:101-102)
+    import torch.nn as nn
+    from transformers.trainer_pt_utils import get_parameter_names
+    decay = [n for n in get_parameter_names(m, [nn.LayerNorm]) if "bias" not in n]
+    for name in w:
+        assert (name not in decay) == ref_rule(name), name
     assert cosine_lr_scale(0, 100) == 1.0 and abs(cosine_lr_scale(50, 100) - 0.5) < 1e-12
     assert cosine_lr_scale(100, 100) == 0.0 and cosine_lr_scale(5, 100, 10) == 0.5
 
@@ -124,5 +132,44 @@ def test_registry_and_config_roundtrip(tmp_path):
     assert c2.llm_config.to_dict() == c.llm_config.to_dict()
     assert c2.action_model_type == "DiT-T" and c2.chunk_size == 16
     from dexbotic_amd.model.cogact.action_model.builder import build_action_model
-    with pytest.raises(ValueError):
-        build_action_model(object(), None)
+    with pytest.raises(RuntimeError):
+        build_action_model(c)                      # one-argument reference signature: needs an open build context
+    from dexbotic_amd.engine import ParamStore, building
+    with building(ParamStore("cpu")):
+        with pytest.raises(ValueError):
+            build_action_model(object())
+    # HF registry: the reference's model_type strings resolve to the native config classes
+    from transformers import AutoConfig
+    c3 = AutoConfig.from_pretrained(str(tmp_path))
+    assert type(c3) is type(c) and c3.llm_config.to_dict() == c.llm_config.to_dict()
+
+
+def test_action_norm_and_2string_bit_exact(golden_dir):
+    """row A9, encode direction, in the PRODUCT (dexbotic_amd/data/dataset/transform/action.py) against the integer rows the
+    reference's ActionNormAnd2String produced (tests/golden/action_bins.npz): normalised values, bins (round-half-even on
+    exact halves) and strings bit-exact; plus the episode-dict contract of __call__"""
+    import os
+    import numpy as np
+    from dexbotic_amd.data.dataset.transform.action import ActionNormAnd2String
+    g = np.load(os.path.join(golden_dir, "action_bins.npz"))
+    V = int(g["vocab"])
+    tf = ActionNormAnd2String({"default": {"min": g["mn"].tolist(), "max": g["mx"].tolist()}}, vocab_size=V)
+    normed = tf._norm_action(g["action"], g["mn"], g["mx"])
+    assert np.array_equal(normed, g["normed"])
+    bins = tf._action2bin(g["normed_all"], V)
+    assert np.array_equal(bins, g["bins"])
+    assert tf._bin2string(bins, tf.string_format) == g["strings"].tolist()
+    ep = {"action": g["action"].copy(), "prompt": ["pick"], "meta_data": {"dataset": "unseen"}}
+    out = tf(ep)
+    assert np.array_equal(out["action"], g["normed"])
+    assert out["answer"] == tf._bin2string(tf._action2bin(g["normed"], V), " {value}")
+    ep2 = {"action": g["action"].copy(), "prompt": ["pick"], "meta_data": {"dataset": "unseen"}, "answer": ["kept"]}
+    assert tf(ep2)["answer"] == ["kept"]
+    assert tf({"prompt": ["x"]}) == {"prompt": ["x"]}
+    # per-dataset / per-prompt statistics and scalar broadcasting
+    tf2 = ActionNormAnd2String({"default": {"min": -1, "max": 1}, "d1": {"default": {"min": [-2.0], "max": [2.0]},
+                                                                         "open": {"min": [-4] * 7, "max": [4] * 7}}})
+    a = np.full((2, 7), 1.0)
+    assert np.allclose(tf2({"action": a.copy(), "prompt": ["zz"], "meta_data": {"dataset": "d1"}})["action"], 0.5)
+    assert np.allclose(tf2({"action": a.copy(), "prompt": ["open"], "meta_data": {"dataset": "d1"}})["action"], 0.25)
+    assert np.allclose(tf2({"action": a.copy(), "prompt": ["open"], "meta_data": {"dataset": "other"}})["action"], 1.0, atol=1e-7)
