@@ -207,7 +207,7 @@ def splice_embeds(sd: SD, src: np.ndarray, image_features: torch.Tensor) -> torc
     emb = sd["model.llm.embed_tokens.weight"]
     B, S = src.shape
     d = emb.shape[1]
-    flat_img = image_features.reshape(-1, d)
+    flat_img = image_features.reshape(-1, d).to(emb.dtype)    # torch.cat of the reference promotes bf16 (autocast) rows to fp32
     out = torch.zeros(B, S, d, dtype=emb.dtype)
     src_t = torch.from_numpy(src)
     tok = src_t >= 0
