@@ -73,13 +73,24 @@ def synthetic_batch(B, V, s_text, device, seed):
                 images=images.to(device), actions=actions.to(device), labels=ids.to(device))
 
 
-def cpu_baseline(args, cfg_llm, cfg_vis):
-    """The CPU oracle (a port of the reference algorithm, oracle/cogact_oracle.py) timed on the host cores:
-    forward + backward + AdamW of a depth-reduced model at the REAL widths, extrapolated linearly in layer
-    count to the full depth (a 7 B fwd+bwd on a few cores is minutes per step)."""
+def _time_steps(step, warm: int, n_max: int, budget_s: float):
+    """median seconds per call of ``step`` over up to n_max timed calls (at least 2) within ~budget_s, after `warm` calls"""
+    for _ in range(warm):
+        step()
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < 2 or (len(ts) < n_max and time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def _cpu_port_step(cfg_llm, cfg_vis, L_llm, L_vit, L_dit, B, args):
+    """one fine-tune step (fwd + bwd + AdamW) of the CPU oracle (oracle/cogact_oracle.py, a port of the reference
+    algorithm) at the REAL widths with L_llm decoder layers"""
     from oracle import cogact_oracle as O
     from oracle.weights import cogact_shapes
-    L_llm, L_vit, L_dit = 1, 2, 2
     oc = O.OracleConfig(vocab_size=cfg_llm.vocab_size, hidden_size=cfg_llm.hidden_size,
                         intermediate_size=cfg_llm.intermediate_size, num_hidden_layers=L_llm,
                         num_attention_heads=cfg_llm.num_attention_heads,
@@ -91,11 +102,10 @@ def cpu_baseline(args, cfg_llm, cfg_vis):
     shapes.pop("lm_head.weight")
     g = torch.Generator().manual_seed(0)
     sd = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
-    B = 1
     batch = synthetic_batch(B, args.views, args.s_text, "cpu", 1)
     noise = torch.randn(4 * B, 16, 7, generator=g)
     ts = torch.randint(0, 100, (4 * B,), generator=g)
-    params = [p for k, p in sd.items()]
+    params = list(sd.values())
     state = {}
 
     def step():
@@ -111,37 +121,82 @@ def cpu_baseline(args, cfg_llm, cfg_vis):
                          1, 2e-5)
         for p in params:
             p.grad = None
-    step()
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2 or time.perf_counter() - t0 < 8.0:
-        step()
-        n += 1
-    dt_small = (time.perf_counter() - t0) / n
-    # per-layer extrapolation: time(model) ~ fixed + sum(layers); measure the marginal cost with one more LLM layer
-    oc2 = O.OracleConfig(**{**oc.__dict__, "num_hidden_layers": L_llm + 1})
-    sh2 = cogact_shapes(oc2)
-    sh2.pop("lm_head.weight")
-    for k, s in sh2.items():
-        if k not in sd:
-            sd[k] = (torch.randn(s, generator=g) * 0.02).requires_grad_(True)
-    params = [p for k, p in sd.items()]
-    oc = oc2
-    step()
-    t0 = time.perf_counter()
-    n2 = 0
-    while n2 < 2 or time.perf_counter() - t0 < 8.0:
-        step()
-        n2 += 1
-    dt_plus = (time.perf_counter() - t0) / n2
-    per_llm_layer = max(dt_plus - dt_small, 1e-6)
-    # ViT / DiT layers are < 5 % of the FLOPs: scale their measured share by FLOP ratio to the LLM layer
-    est_full = dt_small + per_llm_layer * (cfg_llm.num_hidden_layers - L_llm) * 1.0 \
-        + per_llm_layer * 0.0349 * (23 - L_vit) * args.views + per_llm_layer * 0.002 * (12 - L_dit)
-    return {"value": round(B / est_full, 5), "unit": "episodes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": (f"oracle fwd+bwd+AdamW, B=1, real widths, {L_llm}->{L_llm + 1} LLM layers measured "
-                       f"({dt_small:.2f}s, {dt_plus:.2f}s per step over {n}+{n2} steps), extrapolated linearly to "
-                       f"{cfg_llm.num_hidden_layers} LLM / 23 ViT / 12 DiT layers; fp32")}
+    return step
+
+
+def _cpu_reference_step(cfg_llm, cfg_vis, L_llm, L_vit, L_dit, B, args):
+    """the same step through the REFERENCE's own classes (dexbotic.model.cogact.cogact_arch.CogACTForCausalLM +
+    torch.optim.AdamW), imported from /root/reference with the shims of oracle/gen_golden.py — only where that tree
+    exists (the build container); the GPU box times the port"""
+    from oracle import cogact_oracle as O
+    from oracle import gen_golden as G
+    sys.path.insert(0, G.REF)
+    G.install_timm_shim()
+    oc = O.OracleConfig(vocab_size=cfg_llm.vocab_size, hidden_size=cfg_llm.hidden_size,
+                        intermediate_size=cfg_llm.intermediate_size, num_hidden_layers=L_llm,
+                        num_attention_heads=cfg_llm.num_attention_heads,
+                        num_key_value_heads=cfg_llm.num_key_value_heads, v_hidden=cfg_vis.hidden_size,
+                        v_inter=cfg_vis.intermediate_size, v_layers=L_vit + 1, v_heads=cfg_vis.num_attention_heads,
+                        v_image=cfg_vis.image_size, v_patch=cfg_vis.patch_size, dit_hidden=768, dit_depth=L_dit,
+                        dit_heads=12)
+    m = G.build_reference(oc, None)
+    m.train()
+    opt = torch.optim.AdamW([p for n, p in m.named_parameters() if p.requires_grad and not n.startswith("lm_head")],
+                            lr=2e-5, weight_decay=0.0)
+    batch = synthetic_batch(B, args.views, args.s_text, "cpu", 1)
+
+    def step():
+        out = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"],
+                images=batch["images"], actions=batch["actions"])
+        out.loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    return step
+
+
+def cpu_baseline(args, cfg_llm, cfg_vis):
+    """Reported baseline (never the target): the reference algorithm on the host cores, fp32, fwd + bwd + AdamW at the REAL
+    widths.  A full 28-layer 7 B step on CPU takes minutes, so a bounded sample is timed (BASELINE.md §2 protocol:
+    torch.set_num_threads(all physical cores), 2 warm-ups, median of up to 5 timed steps): depth 1 and 2 decoder layers
+    give the marginal cost of a layer, a 4-layer run is measured beside the linear extrapolation it is checked against, and
+    the full depth is extrapolated linearly in layer count (ViT layers by FLOP ratio to a decoder layer).  kind =
+    "reference" when /root/reference is importable (its own CogACTForCausalLM + torch.optim.AdamW), else "port" (the CPU
+    oracle, oracle/cogact_oracle.py)."""
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count()
+    torch.set_num_threads(int(cores))
+    B, L_vit, L_dit = 4, 2, 12
+    use_ref = os.path.isdir("/root/reference/dexbotic") and not args.cpu_port
+    make = _cpu_reference_step if use_ref else _cpu_port_step
+    budget = args.cpu_budget
+    t1, n1 = _time_steps(make(cfg_llm, cfg_vis, 1, L_vit, L_dit, B, args), 2, 5, budget * 0.25)
+    t2, n2 = _time_steps(make(cfg_llm, cfg_vis, 2, L_vit, L_dit, B, args), 2, 5, budget * 0.35)
+    t4, n4 = _time_steps(make(cfg_llm, cfg_vis, 4, L_vit, L_dit, B, args), 1, 3, budget * 0.4)
+    per_layer = max(t2 - t1, 1e-6)
+    lin4 = t1 + 3 * per_layer
+    # ViT layer / decoder layer forward-FLOP ratio (SURVEY.md section 8d formulas), per view
+    npv = (cfg_vis.image_size // cfg_vis.patch_size) ** 2 + 1
+    C, I = cfg_vis.hidden_size, cfg_vis.intermediate_size
+    d, f = cfg_llm.hidden_size, cfg_llm.intermediate_size
+    hd = d // cfg_llm.num_attention_heads
+    S = args.s_text - 1 + args.views * (npv - 1)
+    vit_layer = 2 * (4 * C * C + 2 * C * I) * npv + 4 * npv * npv * C
+    llm_layer = 2 * (d * (cfg_llm.num_attention_heads + 2 * cfg_llm.num_key_value_heads) * hd + d * d + 3 * d * f) * S \
+        + 4 * S * S * d
+    est_full = t1 + per_layer * (cfg_llm.num_hidden_layers - 1) \
+        + per_layer * (vit_layer / llm_layer) * (cfg_vis.num_hidden_layers - 1 - L_vit) * args.views
+    return {"value": round(B / est_full, 5), "unit": "episodes/s", "cores": int(cores),
+            "kind": "reference" if use_ref else "port",
+            "measured_4_layer_episodes_per_s": round(B / t4, 4), "linear_model_4_layer_episodes_per_s": round(B / lin4, 4),
+            "sample": (f"{'reference CogACTForCausalLM + torch.optim.AdamW' if use_ref else 'CPU oracle (port)'}: fwd+bwd+AdamW, "
+                       f"fp32, B={B} (GPU leg: {args.batch}; per-sample cost on the CPU is flat in B at these sizes), real "
+                       f"widths, {L_vit} of 23 used ViT layers, DiT-B 12 layers, decoder depth 1 / 2 / 4 measured: "
+                       f"{t1:.2f} s ({n1} steps) / {t2:.2f} s ({n2}) / {t4:.2f} s ({n4}) per step, median after warm-up; "
+                       f"full depth (28 decoder + 23 ViT layers) extrapolated linearly from depth 1 -> 2")}
 
 
 def main():
@@ -160,6 +215,10 @@ def main():
     ap.add_argument("--grad-comm", dest="grad_comm", default="bfloat16", choices=["bfloat16", "float32"],
                     help="dtype of the data-parallel gradient all-reduce (the reference's DeepSpeed bf16 run reduces bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", dest="cpu_budget", type=float, default=24.0,
+                    help="seconds of timed CPU work for the cpu_baseline sample (warm-ups come on top)")
+    ap.add_argument("--cpu-port", dest="cpu_port", action="store_true",
+                    help="time the CPU oracle (port) even where /root/reference is importable")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
 

@@ -107,7 +107,8 @@ def build_reference(cfg, weights):
     assert ref_shapes == mine, (set(ref_shapes) ^ set(mine),
                                 {k: (ref_shapes[k], mine[k]) for k in ref_shapes
                                  if k in mine and ref_shapes[k] != mine[k]})
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    if weights is not None:                      # None: keep the reference's own random initialisation (bench.py timing)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
     # CogACTModelConfig._freeze_model (cogact_exp.py:106-124) with the default freeze_* = False:
     # every parameter under model.model trains (CLIPVisionTower.load_model froze the tower).
     for p_ in m.model.parameters():
