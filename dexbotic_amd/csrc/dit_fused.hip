@@ -80,13 +80,22 @@ struct Act {
   }
 };
 
+// Device-wide barrier over workgroups that must all be resident.  The launch is a plain one sized by the occupancy query
+// (a cooperative launch adds 15-19 us per forward and enforces nothing more, MI355X_MICROARCH.md "coop-launch"), so
+// co-residency holds only while nothing else occupies CUs for long: the spin is BOUNDED (~2 s).  A workgroup that gives up
+// raises a sticky abort word; every later barrier of every workgroup then falls through, the launch drains in
+// microseconds with a garbage result, and dxa_dit_blocks_status() reports it to the host, which re-runs the request on
+// the unfused path (persistent kernel needs a watchdog).
+constexpr unsigned SPIN_LIMIT = 1u << 21;
 __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch, bool sleep) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
+    unsigned* abortw = bar + 56;
     epoch += 1;
     const unsigned target = epoch * nblk;
     const unsigned arrived = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    unsigned spins = 0;
 #if !defined(DXA_DIT_COUNTER_POLL)
     // the last arrival publishes the epoch in a flag on another cache line and the others poll that flag: 3.5 us per
     // barrier against 4.7 us when everybody polls the counter (scripts/probes/grid_barrier_probe.hip), and the pollers
@@ -97,12 +106,20 @@ __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned
     } else {
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
         if (sleep) __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+          if (spins >= SPIN_LIMIT) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
       }
     }
 #else
     if (arrived != target)
       while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (sleep) __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+          if (spins >= SPIN_LIMIT) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
       }
 #endif
 #if defined(DXA_DIT_CACHED_LOADS)
@@ -359,6 +376,12 @@ int get_sync_block(hipStream_t st, unsigned** out) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = tab.find({dev, st});
   if (it == tab.end()) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      dxa_set_error("dxa_dit_blocks_fwd: first use on a stream allocates its sync block and cannot happen under stream "
+                    "capture: run the request once eagerly on this stream first");
+      return DXA_ERR_BAD_ARG;
+    }
     unsigned* p = nullptr;
     DXA_CHECK_HIP(hipMalloc((void**)&p, SYNC_BYTES));
     DXA_CHECK_HIP(hipMemset(p, 0, SYNC_BYTES));
@@ -378,6 +401,24 @@ int pick_slices(int ncb, int nkb, int grid) {
 }
 
 }  // namespace
+
+// 1 if a launch on this stream gave up at a device-wide barrier since the last call (its result is garbage); the sync block
+// is re-armed.  Synchronises the stream: call it where the host waits for the result anyway.
+extern "C" int dxa_dit_blocks_status(dxa_stream_t stream, int* timed_out) {
+  DXA_CHECK_ARG(timed_out != nullptr, "dxa_dit_blocks_status: null output");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* tail = nullptr;
+  if (int rc = get_sync_block(st, &tail)) return rc;
+  unsigned word = 0;
+  DXA_CHECK_HIP(hipMemcpyAsync(&word, tail + 56, sizeof(word), hipMemcpyDeviceToHost, st));
+  DXA_CHECK_HIP(hipStreamSynchronize(st));
+  *timed_out = word != 0;
+  if (word != 0) {
+    DXA_CHECK_HIP(hipMemsetAsync(tail, 0, SYNC_BYTES, st));
+    DXA_CHECK_HIP(hipStreamSynchronize(st));
+  }
+  return DXA_OK;
+}
 
 extern "C" size_t dxa_dit_blocks_workspace(int M, int H, int I) {
   // qkv [M,3H] + o [M,H] + a [M,I] + K-slice partials [8][M,H] floats

@@ -1243,6 +1243,12 @@ int get_split_ws(hipStream_t st, SplitWs* out) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = tab.find({dev, st});
   if (it == tab.end()) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      dxa_set_error("dxa_gemm: first split-K product on a stream allocates its scratch and cannot happen under stream "
+                    "capture: run the request once eagerly on this stream first");
+      return DXA_ERR_BAD_ARG;
+    }
     char* base = nullptr;
     const size_t ws_bytes = (size_t)NUM_CU * 256 * 256 * 4;
     DXA_CHECK_HIP(hipMalloc((void**)&base, ws_bytes + NUM_CU * sizeof(int)));

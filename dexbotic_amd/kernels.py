@@ -767,3 +767,12 @@ def dit_blocks_fwd(h: torch.Tensor, weight_table: torch.Tensor, depth: int, N: i
     L.check(lib.dxa_dit_blocks_fwd(_ptr(h), _ptr(weight_table), depth, N, T1, H, heads, I, float(eps), _ptr(ws), nbytes,
                                    _stream()), "dxa_dit_blocks_fwd")
     return h
+
+
+def dit_blocks_timed_out(stream: Optional["torch.cuda.Stream"] = None) -> bool:
+    """True if a fused DiT launch on `stream` (default: the current one) gave up at a device-wide barrier since the last
+    call (its result is garbage and the request must be re-run unfused).  Synchronises the stream."""
+    flag = C.c_int(0)
+    L.check(lib.dxa_dit_blocks_status(stream.cuda_stream if stream is not None else _stream(), C.byref(flag)),
+            "dxa_dit_blocks_status")
+    return bool(flag.value)

@@ -145,7 +145,7 @@ class DiT(nn.Module):
         # one persistent launch for all blocks of a single-request denoising call (csrc/dit_fused.hip);
         # DXA_DIT_FUSED=0 restores the block-by-block kernels
         return (not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "1") != "0" and
-                self.store.device.type == "cuda" and
+                getattr(self, "allow_fused", True) and self.store.device.type == "cuda" and
                 K.dit_blocks_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden))
 
     def _weight_table(self, st) -> torch.Tensor:
@@ -193,6 +193,7 @@ class DiT(nn.Module):
                 hcur = self._block_with_per_attn(st, k, hcur, pe, N, T + 1)
         elif self._use_fused_blocks(N, T + 1):
             # inference, one request: every block in ONE persistent launch (csrc/dit_fused.hip)
+            self.used_fused = True
             hcur = K.dit_blocks_fwd(hcur.reshape(N * (T + 1), h).contiguous(), self._weight_table(st), self.depth, N, T + 1, h,
                                     self.num_heads, self.mlp_hidden, 1e-6)
         else:

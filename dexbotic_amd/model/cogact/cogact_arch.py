@@ -154,14 +154,27 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             noise = torch.randn(B, self.config.chunk_size, self.config.action_dim, device=dev, dtype=torch.float32)
         noise = noise.to(device=dev, dtype=torch.float32)
         use_graph = inference_args.get("use_graph", os.environ.get("DXA_INFER_GRAPH", "0") != "0")
+        from ... import kernels as K
+        head.net.used_fused = False
+        graph_stream = None
         if dev.type == "cuda" and use_graph and not return_traj:
             samples = self._graph_sample(images, plan.plan.reshape(-1), B, S, noise, float(cfg_scale), int(num_ddim_steps))
             traj = None
+            graph_stream = self._infer_graphs[(tuple(images.shape), B, S, float(cfg_scale), int(num_ddim_steps))]["stream"]
         else:
             plan_t = plan.dev(dev)["plan"]
             samples, traj = self._sample_actions(images, plan_t, B, S, noise, float(cfg_scale), int(num_ddim_steps),
                                                  return_traj)
-        actions = self._denorm(samples[0].cpu().numpy(), action_norms).tolist()
+        host = samples[0].cpu().numpy()
+        if dev.type == "cuda" and head.net.used_fused and K.dit_blocks_timed_out(graph_stream):
+            # the persistent DiT kernel needs all its workgroups resident at once; something else held CUs for seconds
+            # (another process on this GPU): this request is redone on the block-by-block kernels, which this process
+            # keeps using from now on
+            head.net.allow_fused = False
+            samples, traj = self._sample_actions(images, plan.dev(dev)["plan"], B, S, noise, float(cfg_scale),
+                                                 int(num_ddim_steps), return_traj)
+            host = samples[0].cpu().numpy()
+        actions = self._denorm(host, action_norms).tolist()
         if traj is not None:
             return actions, samples, traj
         return actions

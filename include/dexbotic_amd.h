@@ -376,6 +376,10 @@ int dxa_image_preprocess(const dxa_image_desc* d, dxa_stream_t stream);
 size_t dxa_dit_blocks_workspace(int M, int H, int I);
 int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I, float eps,
                        void* workspace, size_t workspace_bytes, dxa_stream_t stream);
+/* The fused launch spins on device-wide barriers and therefore needs all its workgroups resident at once; the spin is
+ * bounded (~2 s).  *timed_out = 1 if a launch on this stream gave up since the last call (its output is garbage: re-run
+ * the request unfused); the barrier state is re-armed.  Synchronises the stream. */
+int dxa_dit_blocks_status(dxa_stream_t stream, int* timed_out);
 
 #ifdef __cplusplus
 }

@@ -725,12 +725,16 @@ def test_cross_entropy_and_argmax(dtype, rows, V):
 
 
 # ------------------------------------------------------------------------------------------------ fused DiT blocks
+@pytest.mark.parametrize("offset", [0.0, 50.0])
 @pytest.mark.parametrize("cfg", [(2, 17, 768, 12, 3072, 3), (2, 17, 128, 2, 512, 2), (1, 17, 192, 3, 768, 4), (2, 23, 256, 4, 1024, 1)])
-def test_dit_blocks_fused(cfg):
-    """the persistent DiT-block kernel (one launch, device-wide barriers) against the block arithmetic in fp64"""
+def test_dit_blocks_fused(cfg, offset):
+    """the persistent DiT-block kernel (one launch, device-wide barriers) against the block arithmetic in fp64.
+    offset 50: rows whose mean is 50x their spread — the fused LayerNorm takes its statistics as E[x^2] - mu^2 and applies
+    rs * (acc - mu * wsum) in the epilogue; both cancel ~2.5e3 : 1 here, which fp32 accumulation still resolves to ~1e-4 of
+    the result scale (the zero-mean case alone could not show that)"""
     N, T1, H, heads, I, depth = cfg
     M = N * T1
-    h0 = rnd(M, H, seed=41)
+    h0 = rnd(M, H, seed=41) + offset
     ws, ptrs = [], []
     for k in range(depth):
         blk = [rnd(3 * H, H, seed=50 + 10 * k, scale=H ** -0.5), rnd(3 * H, seed=51 + 10 * k, scale=0.1),
@@ -752,6 +756,7 @@ def test_dit_blocks_fused(cfg):
         ref = ref + F.gelu(y @ w1.double().t() + b1.double(), approximate="tanh") @ w2.double().t() + b2.double()
     for rep in range(3):                                           # the barrier counter is reset by every call
         out = K.dit_blocks_fwd(h0.clone(), table, depth, N, T1, H, heads, I, 1e-6)
-        assert_close(out, ref, 2e-4, 2e-4 * float(ref.abs().max()), f"fused DiT blocks {cfg} rep {rep}")
+        tol = 2e-4 if offset == 0.0 else 6e-4
+        assert_close(out, ref, tol, tol * float(ref.abs().max()), f"fused DiT blocks {cfg} offset {offset} rep {rep}")
     with pytest.raises(L.DxaError):
         K.dit_blocks_fwd(torch.zeros(48, H, device=DEV), table, depth, 2, 24, H, heads, I, 1e-6)     # 48 rows: no spare row for the ones trick
