@@ -1003,8 +1003,17 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
 
 // LEAN = the epilogue is C = alpha * acc + bias (+ residual) (+ C) over whole 16-byte accesses (sk_epilogue); otherwise
 // the generic epilogue of tile_finish (activation / mulgrad / aux / ragged edges).
-template <typename TO, typename TE, bool LEAN>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
+// A_KS / B_KS = that operand is K-STRIDED: element (row r of the tile, contraction index k) lives at base[k * ld + r] —
+// B of the NN product dX = dY W (W is [out, in] row-major, the contraction runs over `out`), A and B of the TN product
+// dW = dY^T X (both activations are [tokens, features]).  Such an operand is staged as it lies in memory, one piece =
+// [64 k][128 tile rows of that half] with 256-byte LDS rows (4 k-rows per DMA instruction, every 128 / 64 contiguous
+// source bytes a whole / half line), and the MFMA fragment (8 consecutive k of ONE tile row per lane) is gathered with
+// two ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 rows] block and lane i receives the 4 k of row i.  The four
+// k-rows of such a block would share banks (256-byte pitch): 64-byte chunk q of k-row t sits at chunk q ^ (t & 3).
+// No transposed copy of anything is ever made: the W^T shadow arena and the per-GEMM activation transposes are gone.
+// K need not be a multiple of 64 when every operand is k-strided (rows past K are out of the buffer's range: zeros).
+template <typename TO, typename TE, bool LEAN, bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int REG = 256 * 128;            // one operand of one K tile: 256 rows x 128 B
@@ -1033,8 +1042,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
   sk_tile_origin(p, bid, m0i, n0i);
   const int64_t m0 = m0i, n0 = n0i;
 
-  const uint32_t bytesA = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2);
-  const uint32_t bytesB = (uint32_t)(((p.N - 1) * p.ldb + p.K) * 2);
+  const uint32_t bytesA = (uint32_t)((A_KS ? (p.K - 1) * p.lda + p.M : (p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t bytesB = (uint32_t)((B_KS ? (p.K - 1) * p.ldb + p.N : (p.N - 1) * p.ldb + p.K) * 2);
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
   // DMA instruction (h, j) of a wave covers 8 consecutive tile rows; g = 2*wave + j in 0..15 selects the 8-row group:
@@ -1043,6 +1052,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
   // lane -> (row = row0 + lane / 8, LDS chunk slot = lane % 8, source chunk = slot ^ ((row >> 1) & 7))
 #define PP_A_ROW0(h, j) ((((wave * 2 + (j)) & 7) * 8) + (((wave * 2 + (j)) >> 3) * 128) + 64 * (h))
 #define PP_B_ROW0(h, j) ((((wave * 2 + (j)) >> 2) * 64) + (((wave * 2 + (j)) & 3) * 8) + 32 * (h))
+  // k-strided operand: DMA instruction (h, j) of a wave covers k-rows 4 (2 wave + j) .. +3 of piece h; lane -> (k-row =
+  // + lane / 16, LDS slot s = lane % 16 of the 256-byte row, source slot = s ^ ((k-row & 3) << 2)); source slot sigma ->
+  // tile row: A: (sigma >> 3) * 128 + 64 h + 8 (sigma & 7) (two 128-byte segments: the A-h rows of wm = 0, 1)
+  //           B: (sigma >> 2) * 64 + 32 h + 8 (sigma & 3)  (four 64-byte segments: the B-h columns of wn = 0..3)
   uint32_t voA[2][2], voB[2][2];
   {
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -1051,25 +1064,59 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int ra = PP_A_ROW0(h, j) + lrow, rb = PP_B_ROW0(h, j) + lrow;
-        const int ga = m0i + ra, gb = n0i + rb;
-        voA[h][j] = ga < (int)p.M ? (uint32_t)ga * lda2 + (uint32_t)((lslot ^ ((ra >> 1) & 7)) << 4) : 0x80000000u;
-        voB[h][j] = gb < (int)p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+        const int krow = (wave * 2 + j) * 4 + (lane >> 4);
+        const int sig = (lane & 15) ^ ((krow & 3) << 2);
+        if constexpr (A_KS) {
+          const int ga = m0i + (sig >> 3) * 128 + 64 * h + 8 * (sig & 7);
+          voA[h][j] = ga < (int)p.M ? (uint32_t)krow * lda2 + (uint32_t)ga * 2u : 0x80000000u;
+        } else {
+          const int ra = PP_A_ROW0(h, j) + lrow, ga = m0i + ra;
+          voA[h][j] = ga < (int)p.M ? (uint32_t)ga * lda2 + (uint32_t)((lslot ^ ((ra >> 1) & 7)) << 4) : 0x80000000u;
+        }
+        if constexpr (B_KS) {
+          const int gb = n0i + (sig >> 2) * 64 + 32 * h + 8 * (sig & 3);
+          voB[h][j] = gb < (int)p.N ? (uint32_t)krow * ldb2 + (uint32_t)gb * 2u : 0x80000000u;
+        } else {
+          const int rb = PP_B_ROW0(h, j) + lrow, gb = n0i + rb;
+          voB[h][j] = gb < (int)p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+        }
       }
   }
-  const int nk_tot = (int)(p.K >> 6);
+  const int nk_tot = (int)((p.K + 63) >> 6);
   const int k_lo = split_j * nk_tot / split_s;
   const int nk = (split_j + 1) * nk_tot / split_s - k_lo;   // K tiles of this workgroup (>= 1)
-#define PP_DMA(rsrc, vo, ldsoff, buf, tile)                                                                             \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(smem + (buf) * BUF + (ldsoff)), 16, vo,                 \
-                                           (k_lo + (tile)) * 128, 0, 0)
+  // K-contiguous operand: the K tile is a byte offset inside the row (scalar offset of the instruction).  K-strided: it is
+  // 64 rows further down; that goes into the VECTOR offset so that the descriptor's range check sees it (rows >= K: zeros)
+  const uint32_t ktileA = A_KS ? 64u * (uint32_t)p.lda * 2u : 0u, ktileB = B_KS ? 64u * (uint32_t)p.ldb * 2u : 0u;
+#define PP_DMA(rsrc, vo, ldsoff, buf, soff)                                                                             \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(smem + (buf) * BUF + (ldsoff)), 16, vo, soff, 0, 0)
 #if (DXA_PPV & 1)
 #define PP_LOOP(x) do { } while (0)
 #else
 #define PP_LOOP(x) x
 #endif
-#define PP_DMA_A(h, buf, tile) do { PP_DMA(rA, voA[h][0], PP_A_ROW0(h, 0) * 128, buf, tile); PP_DMA(rA, voA[h][1], PP_A_ROW0(h, 1) * 128, buf, tile); } while (0)
-#define PP_DMA_B(h, buf, tile) do { PP_DMA(rB, voB[h][0], REG + PP_B_ROW0(h, 0) * 128, buf, tile); PP_DMA(rB, voB[h][1], REG + PP_B_ROW0(h, 1) * 128, buf, tile); } while (0)
+#define PP_DMA_A(h, buf, tile)                                                                              \
+  do {                                                                                                      \
+    if constexpr (A_KS) {                                                                                   \
+      const uint32_t kb_ = (uint32_t)(k_lo + (tile)) * ktileA;                                              \
+      PP_DMA(rA, voA[h][0] + kb_, (h) * 16384 + (wave * 2 + 0) * 1024, buf, 0);                             \
+      PP_DMA(rA, voA[h][1] + kb_, (h) * 16384 + (wave * 2 + 1) * 1024, buf, 0);                             \
+    } else {                                                                                                \
+      PP_DMA(rA, voA[h][0], PP_A_ROW0(h, 0) * 128, buf, (k_lo + (tile)) * 128);                             \
+      PP_DMA(rA, voA[h][1], PP_A_ROW0(h, 1) * 128, buf, (k_lo + (tile)) * 128);                             \
+    }                                                                                                       \
+  } while (0)
+#define PP_DMA_B(h, buf, tile)                                                                              \
+  do {                                                                                                      \
+    if constexpr (B_KS) {                                                                                   \
+      const uint32_t kb_ = (uint32_t)(k_lo + (tile)) * ktileB;                                              \
+      PP_DMA(rB, voB[h][0] + kb_, REG + (h) * 16384 + (wave * 2 + 0) * 1024, buf, 0);                       \
+      PP_DMA(rB, voB[h][1] + kb_, REG + (h) * 16384 + (wave * 2 + 1) * 1024, buf, 0);                       \
+    } else {                                                                                                \
+      PP_DMA(rB, voB[h][0], REG + PP_B_ROW0(h, 0) * 128, buf, (k_lo + (tile)) * 128);                       \
+      PP_DMA(rB, voB[h][1], REG + PP_B_ROW0(h, 1) * 128, buf, (k_lo + (tile)) * 128);                       \
+    }                                                                                                       \
+  } while (0)
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -1084,29 +1131,60 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
   // address = ya ^ (ks << 5) ^ (cur << 16) with ONE per-lane register ya = row base | ((lh ^ sw) << 4) per operand.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int sw = (l32 >> 1) & 7;
-  const uint32_t ya = (lds0 + (wm * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
-  const uint32_t yb = (lds0 + REG + (wn * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
+  // k-strided operand: lane (i = lane % 16, half-group (lane >> 4) & 1, lh) passes the address of 4 consecutive tile rows
+  // (8 bytes) of k-row t = 8 lh + (i >> 2) [+ 16 ks + 4 r as immediate] of its [4 k][16 rows] block and receives row i's
+  // 4 k; the wave's 64-byte chunk of the 256-byte piece row is q = 2 wm + ii (A) / wn (B), stored at q ^ (t & 3).
+  const int i16 = lane & 15, tq = (i16 >> 2) & 3, tk = 8 * lh + (i16 >> 2);
+  const uint32_t ks_lane = (uint32_t)(tk * 256 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8);
+  const uint32_t ya = A_KS ? lds0 + ks_lane + (uint32_t)(((wm * 2) ^ tq) << 6)
+                           : (lds0 + (wm * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
+  const uint32_t yb = B_KS ? lds0 + REG + ks_lane + (uint32_t)((wn ^ tq) << 6)
+                           : (lds0 + REG + (wn * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
   u32x4_t af[2][4], bfr[4];
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #if (DXA_PPV & 2)
 #define PP_READ(dst, addr, imm) asm volatile("" : "+v"(dst) : "v"(addr))
+#define PP_READ_TR(dst, addr, imm) asm volatile("" : "+v"(dst) : "v"(addr))
 #else
 #define PP_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define PP_READ_TR(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 #endif
+  // one fragment (8 k of one tile row per lane) of a k-strided operand: k 0..3 | k 4..7
+#define PP_FRAG_TR(dst, addr, imm)                                                       \
+  do {                                                                                   \
+    u32x2_t lo_ = {0u, 0u}, hi_ = {0u, 0u};                                              \
+    PP_READ_TR(lo_, addr, imm); PP_READ_TR(hi_, addr, (imm) + 1024);                     \
+    dst = (u32x4_t){lo_[0], lo_[1], hi_[0], hi_[1]};                                     \
+  } while (0)
 #define PP_RD_A(cur, h)                                                                                     \
   do {                                                                                                      \
-    const uint32_t a0_ = ya ^ (uint32_t)((cur) * BUF), a1_ = ya ^ (uint32_t)((cur) * BUF + 32),             \
-                   a2_ = ya ^ (uint32_t)((cur) * BUF + 64), a3_ = ya ^ (uint32_t)((cur) * BUF + 96);        \
-    PP_READ(af[0][0], a0_, (2 * (h)) * 4096); PP_READ(af[1][0], a0_, (2 * (h) + 1) * 4096);                \
-    PP_READ(af[0][1], a1_, (2 * (h)) * 4096); PP_READ(af[1][1], a1_, (2 * (h) + 1) * 4096);                \
-    PP_READ(af[0][2], a2_, (2 * (h)) * 4096); PP_READ(af[1][2], a2_, (2 * (h) + 1) * 4096);                \
-    PP_READ(af[0][3], a3_, (2 * (h)) * 4096); PP_READ(af[1][3], a3_, (2 * (h) + 1) * 4096);                \
+    if constexpr (A_KS) {                                                                                   \
+      const uint32_t a0_ = ya ^ (uint32_t)((cur) * BUF + (h) * 16384), a1_ = a0_ ^ 64u;                     \
+      PP_FRAG_TR(af[0][0], a0_, 0); PP_FRAG_TR(af[1][0], a1_, 0);                                           \
+      PP_FRAG_TR(af[0][1], a0_, 4096); PP_FRAG_TR(af[1][1], a1_, 4096);                                     \
+      PP_FRAG_TR(af[0][2], a0_, 8192); PP_FRAG_TR(af[1][2], a1_, 8192);                                     \
+      PP_FRAG_TR(af[0][3], a0_, 12288); PP_FRAG_TR(af[1][3], a1_, 12288);                                   \
+    } else {                                                                                                \
+      const uint32_t a0_ = ya ^ (uint32_t)((cur) * BUF), a1_ = ya ^ (uint32_t)((cur) * BUF + 32),           \
+                     a2_ = ya ^ (uint32_t)((cur) * BUF + 64), a3_ = ya ^ (uint32_t)((cur) * BUF + 96);      \
+      PP_READ(af[0][0], a0_, (2 * (h)) * 4096); PP_READ(af[1][0], a0_, (2 * (h) + 1) * 4096);              \
+      PP_READ(af[0][1], a1_, (2 * (h)) * 4096); PP_READ(af[1][1], a1_, (2 * (h) + 1) * 4096);              \
+      PP_READ(af[0][2], a2_, (2 * (h)) * 4096); PP_READ(af[1][2], a2_, (2 * (h) + 1) * 4096);              \
+      PP_READ(af[0][3], a3_, (2 * (h)) * 4096); PP_READ(af[1][3], a3_, (2 * (h) + 1) * 4096);              \
+    }                                                                                                       \
   } while (0)
 #define PP_RD_B(cur, j)                                                                                     \
   do {                                                                                                      \
-    const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF), b1_ = yb ^ (uint32_t)((cur) * BUF + 32),             \
-                   b2_ = yb ^ (uint32_t)((cur) * BUF + 64), b3_ = yb ^ (uint32_t)((cur) * BUF + 96);        \
-    PP_READ(bfr[0], b0_, (j) * 4096); PP_READ(bfr[1], b1_, (j) * 4096);                                     \
-    PP_READ(bfr[2], b2_, (j) * 4096); PP_READ(bfr[3], b3_, (j) * 4096);                                     \
+    if constexpr (B_KS) {                                                                                   \
+      const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF + (j) * 16384);                                      \
+      PP_FRAG_TR(bfr[0], b0_, 0); PP_FRAG_TR(bfr[1], b0_, 4096);                                            \
+      PP_FRAG_TR(bfr[2], b0_, 8192); PP_FRAG_TR(bfr[3], b0_, 12288);                                        \
+    } else {                                                                                                \
+      const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF), b1_ = yb ^ (uint32_t)((cur) * BUF + 32),           \
+                     b2_ = yb ^ (uint32_t)((cur) * BUF + 64), b3_ = yb ^ (uint32_t)((cur) * BUF + 96);      \
+      PP_READ(bfr[0], b0_, (j) * 4096); PP_READ(bfr[1], b1_, (j) * 4096);                                   \
+      PP_READ(bfr[2], b2_, (j) * 4096); PP_READ(bfr[3], b3_, (j) * 4096);                                   \
+    }                                                                                                       \
   } while (0)
 #if (DXA_PPV & 4)
 #define PP_MFMA(ii, ks, i, j) asm volatile("" : "+v"(acc[i][j]) : "v"(bfr[ks]), "v"(af[ii][ks]))
@@ -1171,6 +1249,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
 #undef PP_DMA_A
 #undef PP_DMA_B
 #undef PP_READ
+#undef PP_READ_TR
+#undef PP_FRAG_TR
 #undef PP_RD_A
 #undef PP_RD_B
 #undef PP_MFMA
@@ -1190,12 +1270,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmP p) {
   tile_finish<TO, 4, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
 #endif  // __HIP_DEVICE_COMPILE__
 }
-template __global__ void gemm_nt_pp_kernel<bf16_t, bf16_t, true>(const GemmP);
-template __global__ void gemm_nt_pp_kernel<float, bf16_t, true>(const GemmP);
-template __global__ void gemm_nt_pp_kernel<float, float, true>(const GemmP);
-template __global__ void gemm_nt_pp_kernel<bf16_t, bf16_t, false>(const GemmP);
-template __global__ void gemm_nt_pp_kernel<float, bf16_t, false>(const GemmP);
-template __global__ void gemm_nt_pp_kernel<float, float, false>(const GemmP);
+// NT: every forward linear, dX against an explicit W^T (fp32 head through bf16x3); NN: dX = dY W; TN: dW = dY^T X
+template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, false, false>(const GemmP);
+template __global__ void gemm_pp_kernel<float, bf16_t, true, false, false>(const GemmP);
+template __global__ void gemm_pp_kernel<float, float, true, false, false>(const GemmP);
+template __global__ void gemm_pp_kernel<bf16_t, bf16_t, false, false, false>(const GemmP);
+template __global__ void gemm_pp_kernel<float, bf16_t, false, false, false>(const GemmP);
+template __global__ void gemm_pp_kernel<float, float, false, false, false>(const GemmP);
+template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, false, true>(const GemmP);
+template __global__ void gemm_pp_kernel<bf16_t, bf16_t, false, false, true>(const GemmP);
+template __global__ void gemm_pp_kernel<float, bf16_t, true, false, true>(const GemmP);
+template __global__ void gemm_pp_kernel<float, bf16_t, true, true, true>(const GemmP);
+template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, true, true>(const GemmP);
 
 // x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
 __global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
@@ -1329,19 +1415,33 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
   p.vecBias = d->bias && aligned_to(d->bias, 4 * ees);
 
   hipStream_t st = (hipStream_t)stream;
-  // ---- fast path (ring kernel): bf16 NT, K % 32 == 0, 16-byte aligned rows, no batching, operands < 2 GiB
-  const int64_t bytesA = ((d->M - 1) * d->lda + d->K) * 2, bytesB = ((d->N - 1) * d->ldb + d->K) * 2;
+  // ---- fast paths (bf16, no batching, 16-byte aligned rows, operands < 2 GiB): NT with K % 32 == 0 (ring) / K % 64 == 0
+  //      (ping-pong); NN and TN (k-strided operands staged as they lie, ping-pong kernel only): NN needs K % 64 == 0 for its
+  //      k-contiguous A, TN takes any K
+  const int64_t bytesA = (a_ks ? (d->K - 1) * d->lda + d->M : (d->M - 1) * d->lda + d->K) * 2;
+  const int64_t bytesB = (b_ks ? (d->K - 1) * d->ldb + d->N : (d->N - 1) * d->ldb + d->K) * 2;
   static const bool fast_off = getenv("DXA_GEMM_NO_FAST") != nullptr;
-  if (!fast_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->K >= 32 && d->K % 32 == 0 &&
-      p.vecA && p.vecB && d->M >= 64 && d->N >= 64 && (int64_t)d->M * d->N >= 128 * 128 &&
-      bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
+  static const bool ks_off = getenv("DXA_GEMM_NO_KS") != nullptr;
+  const bool ks_layout = d->layout != DXA_NT;
+  const int64_t cpl = 16 / (int64_t)os;
+  // the lean epilogue: C = alpha * acc + bias (+ residual) (+ C) made of whole 16-byte accesses
+  const bool lean_ok = d->N % cpl == 0 && d->ldc % cpl == 0 && aligned_to(d->C, 16) &&
+                       ((d->M - 1) * d->ldc + d->N) * (int64_t)os < (1ll << 31) && !d->aux_out && !d->mulgrad &&
+                       d->act == DXA_ACT_NONE && (!d->bias || aligned_to(d->bias, cpl * ees)) &&
+                       (!d->residual || (aligned_to(d->residual, cpl * ees) && d->ldr % cpl == 0 &&
+                                         ((d->M - 1) * d->ldr + d->N) * (int64_t)ees < (1ll << 31)));
+  const bool ks_ok = (d->layout == DXA_NN ? (d->out_dtype == DXA_BF16 || lean_ok) : lean_ok) && !d->epi_f32 && ks_layout && !ks_off && aligned_to(d->A, 16) && aligned_to(d->B, 16) && d->lda % 8 == 0 && d->ldb % 8 == 0 &&
+                     (d->layout == DXA_TN || d->K % 64 == 0) && d->K >= 64;
+  if (!fast_off && d->in_dtype == DXA_BF16 && nbatch == 1 &&
+      ((d->layout == DXA_NT && d->K >= 32 && d->K % 32 == 0 && p.vecA && p.vecB) || ks_ok) &&
+      d->M >= 64 && d->N >= 64 && (int64_t)d->M * d->N >= 128 * 128 && bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
     // 192-row tiles when they trim the padded row count by more than 8% (they run ~6% below the 256-row tile's rate)
     static const int force_ai = getenv("DXA_GEMM_RING_AI") ? atoi(getenv("DXA_GEMM_RING_AI")) : 0;
     const int64_t pad256 = (int64_t)dxa_cdiv(d->M, 256) * 256, pad192 = (int64_t)dxa_cdiv(d->M, 192) * 192;
-    const int ai = force_ai ? force_ai : (pad192 * 27 < pad256 * 25 ? 3 : 4);
+    const int ai = ks_layout ? 4 : (force_ai ? force_ai : (pad192 * 27 < pad256 * 25 ? 3 : 4));
     p.tm = dxa_cdiv(d->M, ai * 64);
     p.tn = dxa_cdiv(d->N, 256);
-    const int nt = p.tm * p.tn, nk_tot = (int)(d->K / 32);
+    const int nt = p.tm * p.tn, nk_tot = (int)((d->K + 31) / 32);
     p.full = nt; p.tail_r = 0; p.split_s = 1;
     static const int group_m = getenv("DXA_GEMM_GROUP_M") ? atoi(getenv("DXA_GEMM_GROUP_M")) : 4;
     p.group_m = group_m;
@@ -1374,31 +1474,31 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
   } while (0)
     // ---- ping-pong main loop: 256-row tiles, K % 64 == 0; the lean epilogue when it is made of whole 16-byte accesses
     static const bool pp_off = getenv("DXA_GEMM_NO_PP") != nullptr;
-    const bool pp = !pp_off && ai == 4 && d->K % 64 == 0;
-    const int64_t cpl = 16 / (int64_t)os;
-    const bool lean = pp && d->N % cpl == 0 && d->ldc % cpl == 0 && aligned_to(d->C, 16) &&
-                      ((d->M - 1) * d->ldc + d->N) * (int64_t)os < (1ll << 31) && !d->aux_out && !d->mulgrad &&
-                      d->act == DXA_ACT_NONE && (!d->bias || aligned_to(d->bias, cpl * ees)) &&
-                      (!d->residual || (aligned_to(d->residual, cpl * ees) && d->ldr % cpl == 0 &&
-                                        ((d->M - 1) * d->ldr + d->N) * (int64_t)ees < (1ll << 31)));
-#define LAUNCH_PP(TO_, TE_, LEAN_)                                                                              \
+    const bool pp = ks_layout || (!pp_off && ai == 4 && d->K % 64 == 0);
+    const bool lean = pp && lean_ok;
+#define LAUNCH_PP(TO_, TE_, LEAN_, AKS_, BKS_)                                                                  \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<TO_, TE_, LEAN_>),             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TO_, TE_, LEAN_, AKS_, BKS_>),    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<TO_, TE_, LEAN_>), fgrid, dim3(512), RING_LDS, st, p);                \
+    hipLaunchKernelGGL((gemm_pp_kernel<TO_, TE_, LEAN_, AKS_, BKS_>), fgrid, dim3(512), RING_LDS, st, p);       \
   } while (0)
-    if (pp && lean) {
-      if (d->epi_f32) LAUNCH_PP(float, float, true);
-      else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, true);
-      else LAUNCH_PP(float, bf16_t, true);
+    if (d->layout == DXA_NN) {          // dX = dY W: bf16 out (lean, or with the activation-gradient epilogue), fp32 out lean
+      if (d->out_dtype == DXA_BF16) { if (lean) LAUNCH_PP(bf16_t, bf16_t, true, false, true); else LAUNCH_PP(bf16_t, bf16_t, false, false, true); }
+      else LAUNCH_PP(float, bf16_t, true, false, true);
+    } else if (d->layout == DXA_TN) {   // dW = dY^T X: fp32 (accumulating) or bf16 out, plain epilogue
+      if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, true, true, true); else LAUNCH_PP(float, bf16_t, true, true, true);
+    } else if (pp && lean) {
+      if (d->epi_f32) LAUNCH_PP(float, float, true, false, false);
+      else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, true, false, false);
+      else LAUNCH_PP(float, bf16_t, true, false, false);
     } else if (pp) {
-      if (d->epi_f32) LAUNCH_PP(float, float, false);
-      else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, false);
-      else LAUNCH_PP(float, bf16_t, false);
+      if (d->epi_f32) LAUNCH_PP(float, float, false, false, false);
+      else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, false, false, false);
+      else LAUNCH_PP(float, bf16_t, false, false, false);
     }
 #undef LAUNCH_PP
     else if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }

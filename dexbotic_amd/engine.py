@@ -93,11 +93,6 @@ class ParamStore:
         self._bucket_pending: List[int] = []
         self._micro_written: set = set()
         self._uses: Dict[str, int] = {}
-        self.shadow_t: Optional[torch.Tensor] = None
-        self._wt_groups: List[Tuple[Tuple[str, ...], int, int]] = []
-        self.wt_index: set = set()
-        self._t_stream = None
-        self._t_pending = False
         # embedding-gradient rows written since the slice was last all-zero (sparse re-zero, functional.SpliceFn)
         self.sparse_embed_zero = False
         self._embed_dirty: Dict[str, Optional[List[torch.Tensor]]] = {}     # missing / None = unknown -> dense zero
@@ -134,8 +129,6 @@ class ParamStore:
             self.shadow = torch.zeros(total, device=self.device, dtype=self.compute_dtype)
         if train:
             self.grad = torch.zeros(total, device=self.device, dtype=torch.float32)
-            if self.shadow is not None and self._wt_groups and self.device.type == "cuda":
-                self.shadow_t = torch.zeros(total, device=self.device, dtype=self.compute_dtype)
         nb = self._bucket + 1
         self.bucket_ranges = [[total, 0] for _ in range(nb)]
         for s in self.slots.values():
@@ -296,51 +289,10 @@ class ParamStore:
         if self.shadow is not None:
             from . import kernels as K
             K.cast(self.master, self.shadow.dtype, out=self.shadow)
-        self.sync_transposed()
-
-    # ---- transposed bf16 weight shadows: dX = dY W runs as an NT product on the fast MFMA path -------------
-    def register_wt(self, names: Sequence[str], rows: int, cols: int) -> None:
-        """the (fused) weight `names` = [rows, cols] also needs a [cols, rows] copy for its input gradient"""
-        self._wt_groups.append((tuple(names), int(rows), int(cols)))
-        self.wt_index.add(tuple(names))
-
-    @property
-    def has_wt(self) -> bool:
-        return self.shadow_t is not None
-
-    def wt(self, *names: str, shape: Sequence[int]) -> torch.Tensor:
-        return self._view(self.shadow_t, names, shape)
-
-    def sync_transposed(self, overlap: bool = False) -> None:
-        """refresh the W^T shadows.  With ``overlap`` the ~200 HBM-bound transposes run on a side HIP stream
-        (they are first needed by the NEXT backward, so they hide under the next forward's MFMA work);
-        consumers call wait_transposed()."""
-        if self.shadow_t is None:
-            return
-        from . import kernels as K
-        if overlap and self.device.type == "cuda":
-            if self._t_stream is None:
-                self._t_stream = torch.cuda.Stream(device=self.device)
-            self._t_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._t_stream):
-                for names, rows, cols in self._wt_groups:
-                    K.transpose(self.w(*names, shape=(rows, cols)), out=self.wt(*names, shape=(cols, rows)))
-            self._t_pending = True
-            return
-        for names, rows, cols in self._wt_groups:
-            K.transpose(self.w(*names, shape=(rows, cols)), out=self.wt(*names, shape=(cols, rows)))
-
-    def wait_transposed(self) -> None:
-        if self._t_pending:
-            torch.cuda.current_stream().wait_stream(self._t_stream)
-            self._t_pending = False
-
 
 class Fp32View:
     """Same interface as ParamStore but ``w()`` hands out the fp32 masters: used by the diffusion action
     head, which the reference keeps in fp32 (cogact_arch.py:133, SURVEY.md App. A dtype notes)."""
-
-    has_wt = False        # fp32 GEMMs use the exact NN / TN kernels
 
     def __init__(self, store: ParamStore):
         self._s = store
@@ -483,7 +435,6 @@ class FusedAdamW:
         lrs, wds = self._lrs_wds(lr_scale)
         K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
                 lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
-        st.sync_transposed(overlap=True)
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:

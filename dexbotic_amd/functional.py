@@ -51,16 +51,6 @@ def _use(ctx, st: ParamStore, *groups) -> None:
         st.note_use(*[n for n in _names(g) if n is not None])
 
 
-KPAD = 64   # the transposed activations pad the token axis (= contraction axis of dW) to the GEMM K slab
-
-
-def _use_nt(st: ParamStore, names) -> bool:
-    """bf16 training runs EVERY large GEMM as an NT product on the fast MFMA kernel: dX = dY (W^T)^T against the
-    transposed bf16 weight shadow, dW = (dY^T)(X^T)^T on explicitly transposed activations (a ~2 % HBM-bound
-    extra pass).  fp32 mode / the fp32 action head keep the exact NN / TN kernels."""
-    return bool(getattr(st, "has_wt", False)) and _names(names) in st.wt_index
-
-
 def _f32_nt(dy2d: torch.Tensor) -> bool:
     """fp32 products of the action head (>= 128 rows): the tiled kernel's k-contiguous (NT) staging is ~1.5-2.5x faster
     than its k-strided NN / TN staging (scripts/gemm_f32_bench.py), so transposing a small operand first pays"""
@@ -68,11 +58,9 @@ def _f32_nt(dy2d: torch.Tensor) -> bool:
 
 
 def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor:
-    """dX = dY W for W = fused view over `names` of shape wshape = (out, in)"""
+    """dX = dY W for W = fused view over `names` of shape wshape = (out, in).  bf16: an NN product on the ping-pong MFMA
+    kernel that stages W as it lies in memory (k-strided operand, ds_read_b64_tr_b16 fragments) — no W^T copy exists."""
     names = _names(names)
-    if _use_nt(st, names):
-        st.wait_transposed()
-        return K.mm_nt(dy2d, st.wt(*names, shape=(wshape[1], wshape[0])), **kw)
     W = st.w(*names, shape=tuple(wshape))
     if _f32_nt(dy2d):
         return K.mm_nt(dy2d, K.transpose(W, 1), **kw)
@@ -80,16 +68,16 @@ def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor
 
 
 def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) -> None:
-    """dW (+)= dy^T x into the gradient arena (fused view over `names`)"""
+    """dW (+)= dy^T x into the gradient arena (fused view over `names`).  bf16: a TN product on the ping-pong MFMA kernel:
+    both activations are staged as they lie ([tokens, features], the contraction runs over the rows) — no transposed
+    copies, any token count."""
     names = _names(names)
     if not all(st.trainable(n) for n in names):
         if any(st.trainable(n) for n in names):
             raise L.DxaError(f"fused parameters {names} must be frozen/unfrozen together")
         return
     out = st.g(*names, shape=shape)
-    if _use_nt(st, names) and dy2d.dtype == torch.bfloat16:
-        K.mm_nt(K.transpose(dy2d, KPAD), K.transpose(x2d, KPAD), out=out, accumulate=st.accum_flag(*names))
-    elif _f32_nt(dy2d) and x2d.dtype == torch.float32:
+    if _f32_nt(dy2d) and x2d.dtype == torch.float32:
         K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names))
     else:
         K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names))
@@ -191,7 +179,7 @@ class Qwen2LayerFn(_StoreFn):
         del dx2n, dh2
         # ---- attention: dO written head-major by a (b, h)-batched NN GEMM so the GQA group folds into
         #      the rows of the dK/dV GEMMs (attention.hip)
-        if _use_nt(st, sp.o_w):
+        if dx2.dtype == torch.bfloat16:
             do = K.permute_bshd(_dx(st, sp.o_w, (d, Hq * D), dx2), B, S, Hq, D, True)
         else:
             wo = st.w(sp.o_w)                                    # [d, Hq*D]
@@ -601,7 +589,7 @@ class LmHeadLossFn(_StoreFn):
     (dexbotic_arch.py:483-488; transformers/loss/loss_utils.py ForCausalLMLoss): loss = mean over the non-ignored
     rows of logsumexp(logits) - logits[label], in fp32 on the stored logits.  Returns (loss, logits).  The vocabulary
     GEMMs are the only other large contractions of the path (4592 x 152064 x 3584 at the CogACT batch): bf16 runs them
-    on the NT ring kernel — dW = (dZ^T)(H^T)^T and dH = dZ (W^T)^T through explicit transposes."""
+    on the ping-pong MFMA kernel — logits NT, dW = dZ^T H as a TN and dH = dZ W as an NN product, operands as they lie."""
 
     @staticmethod
     def forward(ctx, hidden, anchor, st: ParamStore, wn: str, labels_shifted: torch.Tensor, n_valid: int):
@@ -626,18 +614,12 @@ class LmHeadLossFn(_StoreFn):
         h2, logits, lse, labels = ctx.saved_tensors
         W = st.w(wn)
         dz = K.cross_entropy_bwd(logits, labels, lse, g.reshape(1).float().contiguous(), 1.0 / max(ctx.n_valid, 1))
-        half = dz.dtype == torch.bfloat16
         if st.trainable(wn):
-            out = st.g(wn)
-            if half:
-                K.mm_nt(K.transpose(dz, KPAD), K.transpose(h2, KPAD), out=out, accumulate=st.accum_flag(wn))
-            else:
-                K.mm_tn(dz, h2, out=out, accumulate=st.accum_flag(wn))
+            K.mm_tn(dz, h2, out=st.g(wn), accumulate=st.accum_flag(wn))
             st.mark_written(wn)
         dh = None
         if ctx.needs_input_grad[0]:
-            dh = K.mm_nt(dz, K.transpose(W, KPAD)) if half else K.mm_nn(dz, W)
-            dh = dh.view(ctx.hshape)
+            dh = K.mm_nn(dz, W).view(ctx.hshape)
         return dh, None, None, None, None, None
 
 

@@ -74,10 +74,6 @@ class GemmaExpert(nn.Module):
             store.register([(lp + "post_attention_layernorm.weight", (d,))])
             store.register([(gu[0], (f, d)), (gu[1], (f, d))])
             store.register([(lp + "mlp.down_proj.weight", (d, f))])
-            store.register_wt(qkv, (Hq + 2 * Hkv) * hd, d)         # W^T shadows: dX = dY W runs as an NT ring GEMM
-            store.register_wt((lp + "self_attn.o_proj.weight",), d, Hq * hd)
-            store.register_wt(gu, 2 * f, d)
-            store.register_wt((lp + "mlp.down_proj.weight",), d, f)
             self.layer_names.append(dict(ln1=lp + "input_layernorm.weight", qkv=qkv, o=lp + "self_attn.o_proj.weight",
                                     ln2=lp + "post_attention_layernorm.weight", gu=gu, down=lp + "mlp.down_proj.weight"))
             self.layer_specs.append(Fn.GemmaLayerSpec(d=d, F=f, eps=c.rms_norm_eps, **self.layer_names[-1]))

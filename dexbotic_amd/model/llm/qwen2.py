@@ -78,10 +78,6 @@ class Qwen2Backbone(nn.Module):
             gu = (lp + "mlp.gate_proj.weight", lp + "mlp.up_proj.weight")
             store.register([(gu[0], (f, d)), (gu[1], (f, d))])
             store.register([(lp + "mlp.down_proj.weight", (d, f))])
-            store.register_wt(qkv_w, (Hq + 2 * Hkv) * hd, d)
-            store.register_wt((lp + "self_attn.o_proj.weight",), d, Hq * hd)
-            store.register_wt(gu, 2 * f, d)
-            store.register_wt((lp + "mlp.down_proj.weight",), d, f)
             self.layer_specs.append(Fn.Qwen2LayerSpec(
                 ln1=lp + "input_layernorm.weight", qkv_w=qkv_w, qkv_b=qkv_b, o_w=lp + "self_attn.o_proj.weight",
                 ln2=lp + "post_attention_layernorm.weight", gu_w=gu, down_w=lp + "mlp.down_proj.weight",

@@ -25,10 +25,8 @@ class MlpProjector(nn.Module):
         self.store, self.p, self.depth = store, prefix, depth
         store.new_bucket()
         store.register([(prefix + "0.weight", (out_dim, in_dim)), (prefix + "0.bias", (out_dim,))])
-        store.register_wt((prefix + "0.weight",), out_dim, in_dim)
         if depth == 2:
             store.register([(prefix + "2.weight", (out_dim, out_dim)), (prefix + "2.bias", (out_dim,))])
-            store.register_wt((prefix + "2.weight",), out_dim, out_dim)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         st, p = self.store, self.p

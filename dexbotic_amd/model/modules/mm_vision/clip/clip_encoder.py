@@ -92,10 +92,6 @@ class CLIPVisionTower(nn.Module):
             store.register([(lp + "layer_norm2.weight", (C_,)), (lp + "layer_norm2.bias", (C_,))], layernorm=True)
             store.register([(lp + "mlp.fc1.weight", (I, C_)), (lp + "mlp.fc1.bias", (I,))])
             store.register([(lp + "mlp.fc2.weight", (C_, I)), (lp + "mlp.fc2.bias", (C_,))])
-            store.register_wt(qkv_w, 3 * C_, C_)
-            store.register_wt((lp + "self_attn.out_proj.weight",), C_, C_)
-            store.register_wt((lp + "mlp.fc1.weight",), I, C_)
-            store.register_wt((lp + "mlp.fc2.weight",), C_, I)
             self.layer_specs.append(Fn.VitBlockSpec(
                 ln1_w=lp + "layer_norm1.weight", ln1_b=lp + "layer_norm1.bias", qkv_w=qkv_w, qkv_b=qkv_b,
                 out_w=lp + "self_attn.out_proj.weight", out_b=lp + "self_attn.out_proj.bias",

@@ -151,6 +151,43 @@ def test_gemm_pingpong(shape, f32out):
         assert torch.equal(out, first), f"ping-pong result changed between repetitions (rep {rep})"
 
 
+@pytest.mark.parametrize("case", [("nn", 4592, 3584, 4608), ("nn", 1000, 520, 1024), ("nn", 512, 2048, 192), ("nn", 300, 264, 64),
+                                  ("tn", 4608, 3584, 4592), ("tn", 1024, 768, 4592), ("tn", 520, 264, 1000), ("tn", 256, 256, 24),
+                                  ("tn", 300, 136, 70), ("tn", 2304, 1024, 4112)])
+def test_gemm_pingpong_strided_operands(case):
+    """bf16 NN (dX = dY W) and TN (dW = dY^T X) on the ping-pong kernel with K-STRIDED operands staged as they lie (LDS-DMA of
+    [64 k][128 rows] pieces, ds_read_b64_tr_b16 fragments): every output element against fp64; ragged M / N, K that is not a
+    multiple of 64 (TN: rows past K must read as zeros), split-K tails, bf16 output with bias + residual and fp32
+    accumulating output (the gradient-arena form), repetitions bitwise equal"""
+    lay, M, N, Kd = case
+    if lay == "nn":
+        a, b = rnd(M, Kd, dtype=torch.bfloat16, seed=45), rnd(Kd, N, dtype=torch.bfloat16, seed=46, scale=0.1)
+        ref, fn = a.double() @ b.double(), K.mm_nn
+    else:
+        a, b = rnd(Kd, M, dtype=torch.bfloat16, seed=45), rnd(Kd, N, dtype=torch.bfloat16, seed=46, scale=0.1)
+        ref, fn = a.double().t() @ b.double(), K.mm_tn
+    first = {}
+    for rep in range(2):
+        out32 = torch.full((M, N), 0.25, device=DEV, dtype=torch.float32)
+        fn(a, b, out=out32, accumulate=True)
+        assert_close(out32, ref + 0.25, 2e-5, 2e-3 * math.sqrt(max(Kd, 320) / 320), f"{lay} f32 accumulate {case} rep {rep}")
+        bias, res = rnd(N, dtype=torch.bfloat16, seed=47), rnd(M, N, dtype=torch.bfloat16, seed=48)
+        out16 = fn(a, b, bias=bias, residual=res)
+        rtol, atol = tol_for(torch.bfloat16, Kd)
+        assert_close(out16, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"{lay} bf16 {case} rep {rep}")
+        for k_, o_ in (("f32", out32), ("bf16", out16)):
+            if k_ in first:
+                assert torch.equal(first[k_], o_), f"{lay} {k_} result changed between repetitions"
+            first[k_] = o_.clone()
+    if lay == "nn":                                   # the activation-gradient epilogue of the ViT / projector dX products
+        pre = rnd(M, N, dtype=torch.bfloat16, seed=49)
+        g = K.mm_nn(a, b, mulgrad=pre, act=3)
+        xg = pre.double().requires_grad_(True)
+        ACTS[3](xg).backward(ref)
+        rtol, atol = tol_for(torch.bfloat16, Kd)
+        assert_close(g, xg.grad, 3 * rtol, 3 * atol, f"nn mulgrad {case}")
+
+
 @pytest.mark.parametrize("shape", [(543, 4608, 3584), (543, 3584, 18944), (514, 1024, 4096), (130, 300, 64), (330, 260, 96),
                                    (192, 256, 32), (1050, 777, 2048)])
 @pytest.mark.parametrize("f32out", [False, True])
