@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("bias", _vp), ("residual", _vp), ("ldr", _i64), ("aux_out", _vp), ("mulgrad", _vp), ("ldg", _i64),
         ("alpha", _f32), ("accumulate", _i32), ("nb", _i32 * 3),
         ("sA", _i64 * 3), ("sB", _i64 * 3), ("sC", _i64 * 3), ("sR", _i64 * 3), ("sG", _i64 * 3),
-        ("epi_f32", _i32),
+        ("epi_f32", _i32), ("mirror", _vp),
     ]
 
 

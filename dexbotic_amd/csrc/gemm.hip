@@ -48,6 +48,7 @@ struct GemmP {
   // ring kernel, split-K tail: tiles [0, full) run whole; the last tail_r tiles are cut into split_s K-ranges
   int full, tail_r, split_s;
   int group_m;  // ring kernel: row-tiles per group of the tile order
+  char* mirror; // bf16 copy of the fp32 output (same ldc), or null
   float* ws;    // fp32 partial accumulators, tail_r * (split_s - 1) slots of 256x256
   int* flags;   // per tail tile arrival counter (self-resetting)
 };
@@ -502,18 +503,13 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// Everything after the K loop of the 256-column-tile bf16 NT kernels (ring and ping-pong main loops share it): the
-// split-K hand-off of tail tiles and the fused epilogue.  acc[i][j] = 32x32 block (32-row block i of the wave's rows,
-// 32-column block j of its 64 columns) in the v_mfma_f32_32x32x16 accumulator layout with swapped operands.
-// SMALL = false: 17 KiB staging slab per wave at the start of LDS (the K-loop buffers are dead by then).
-// SMALL = true : 4 KiB per wave above the 128 KiB of K-loop buffers (persistent ping-pong kernel: the next tile's
-//                LDS-DMA pieces are already landing in those buffers while this epilogue runs).
-template <typename TO, int AI, typename TE, bool SMALL = false>
-__device__ __forceinline__ void tile_finish(const GemmP& p, f32x16_t (&acc)[AI][2], char* smem, int tid, int lane, int wave,
-                                            int wm, int wn, int l32, int lh, int64_t m0, int64_t n0, int split_j,
-                                            int split_s, int tail_i) {
+// Split-K hand-off of a tail tile: every piece but the last stores its fp32 partial (lane-linear slots, sc1 write-through)
+// and bumps the tile's arrival counter; the last piece waits for them and adds them in slice order.  Returns false for a
+// workgroup that is done (it only contributed a partial).
+template <int AI>
+__device__ __forceinline__ bool tile_split_exchange(const GemmP& p, f32x16_t (&acc)[AI][2], int tid, int split_j, int split_s,
+                                                    int tail_i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BMR = AI * 64;
   // ---- split-K tail: partial accumulators travel through a lane-linear fp32 slot (8 KiB per wave store).
   // sc1 (agent scope) stores write through the XCD-private L2 and sc1 loads miss in it, so no cache-wide
   // write-back / invalidate is needed; 16-byte accesses keep the gatherer off the instruction-issue limit.
@@ -536,7 +532,7 @@ __device__ __forceinline__ void tile_finish(const GemmP& p, f32x16_t (&acc)[AI][
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(p.flags + tail_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
+      return false;
     }
     // gatherer: it has the highest block ids of its tile, so its partners were dispatched before it
     if (tid == 0) {
@@ -568,6 +564,24 @@ __device__ __forceinline__ void tile_finish(const GemmP& p, f32x16_t (&acc)[AI][
   // 64-column row segment, so stores (and the residual / mulgrad / accumulate reads) are full 128/256-byte
   // lines.  Two passes of 64 rows; the slab is private to the wave, so no workgroup barrier is needed (the
   // loop's last barrier already retired every ring read and LDS-DMA).
+#endif
+  return true;
+}
+
+// Everything after the K loop of the 256-column-tile bf16 NT kernels (ring and ping-pong main loops share it): the
+// split-K hand-off of tail tiles and the fused epilogue.  acc[i][j] = 32x32 block (32-row block i of the wave's rows,
+// 32-column block j of its 64 columns) in the v_mfma_f32_32x32x16 accumulator layout with swapped operands.
+// SMALL = false: 17 KiB staging slab per wave at the start of LDS (the K-loop buffers are dead by then).
+// SMALL = true : 4 KiB per wave above the 128 KiB of K-loop buffers (persistent ping-pong kernel: the next tile's
+//                LDS-DMA pieces are already landing in those buffers while this epilogue runs).
+template <typename TO, int AI, typename TE, bool SMALL = false>
+__device__ __forceinline__ void tile_finish(const GemmP& p, f32x16_t (&acc)[AI][2], char* smem, int tid, int lane, int wave,
+                                            int wm, int wn, int l32, int lh, int64_t m0, int64_t n0, int split_j,
+                                            int split_s, int tail_i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BMR = AI * 64;
+  if (!tile_split_exchange<AI>(p, acc, tid, split_j, split_s, tail_i)) return;
+
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
   const TE* R = reinterpret_cast<const TE*>(p.R);
@@ -947,7 +961,9 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
     const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.bias), 0, (int)(p.N * esE), 0x00020000);
     SkIO<TE>::template ld<CPL>(bv, rBias, (uint32_t)n * esE);
   }
-  const bool has_R = p.R != nullptr, accum = p.accumulate != 0;
+  const bool has_R = p.R != nullptr, accum = p.accumulate != 0, has_mirror = p.mirror != nullptr;
+  const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.mirror ? p.mirror : (char*)p.C, 0,
+                                                                      p.mirror ? (int)(((p.M - 1) * p.ldc + p.N) * 2) : 0, 0x00020000);
   const float alpha = p.alpha;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -992,6 +1008,13 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
         }
 #if !(DXA_PPV & 32)
         SkIO<TO>::template st<CPL>(v, rC, oc);
+        if constexpr (sizeof(TO) == 4) {
+          if (has_mirror) {                                    // bf16 communication copy: 8 bytes per lane, same rows
+            typedef uint32_t u32x2_t_ __attribute__((ext_vector_type(2)));
+            const u32x2_t_ o2 = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(o2, rM, ok ? (offC0 + rr * ldcB) >> 1 : 0x80000000u, 0, 0);
+          }
+        }
 #endif
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1210,24 +1233,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   // (vmcnt(4): the two younger pieces stay in flight) at the END of M_{q-1} by every wave; both groups' M_{q-1} end before
   // the interval in which the first M_q starts, so wait + barrier order the DMA before every read.  A piece of tile
   // t+1 overwrites bytes last read in tile t-1 (>= 2 barriers earlier).
+#if (DXA_PPV & 64)   /* tuning variant: LDS-DMA issue ahead of the fragment reads of the same memory cluster */
+#define PP_M(reads, dma) do { dma; PP_SB(); reads; PP_SB(); } while (0)
+#else
+#define PP_M(reads, dma) do { reads; PP_SB(); dma; PP_SB(); } while (0)
+#endif
 #define PP_TILE(cur, t)                                                                                     \
   do {                                                                                                      \
     const bool more = (t) + 1 < nk;                                                                         \
     /* phase 0 */                                                                                           \
-    PP_RD_A(cur, 0); PP_RD_B(cur, 0); PP_SB();                                                              \
-    if (more) { PP_LOOP(PP_DMA_A(0, (cur) ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(4); } else { PP_VMCNT(2); }    \
+    PP_M(PP_RD_A(cur, 0); PP_RD_B(cur, 0), if (more) { PP_LOOP(PP_DMA_A(0, (cur) ^ 1, (t) + 1)); });        \
+    if (more) { PP_VMCNT(4); } else { PP_VMCNT(2); }                                                        \
     PP_BAR(); PP_COMPUTE(0, 0); PP_BAR();                                                                   \
     /* phase 1 */                                                                                           \
-    PP_RD_B(cur, 1); PP_SB();                                                                               \
-    if (more) { PP_LOOP(PP_DMA_B(0, (cur) ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(4); } else { PP_VMCNT(0); }    \
+    PP_M(PP_RD_B(cur, 1), if (more) { PP_LOOP(PP_DMA_B(0, (cur) ^ 1, (t) + 1)); });                         \
+    if (more) { PP_VMCNT(4); } else { PP_VMCNT(0); }                                                        \
     PP_BAR(); PP_COMPUTE(0, 1); PP_BAR();                                                                   \
     /* phase 2 */                                                                                           \
-    PP_RD_A(cur, 1); PP_SB();                                                                               \
-    if (more) { PP_LOOP(PP_DMA_B(1, (cur) ^ 1, (t) + 1)); PP_SB(); }                                        \
+    PP_M(PP_RD_A(cur, 1), if (more) { PP_LOOP(PP_DMA_B(1, (cur) ^ 1, (t) + 1)); });                         \
     PP_BAR(); PP_COMPUTE(1, 1); PP_BAR();                                                                   \
     /* phase 3 */                                                                                           \
-    PP_RD_B(cur, 0); PP_SB();                                                                               \
-    if (more) { PP_LOOP(PP_DMA_A(1, (cur) ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(4); }                           \
+    PP_M(PP_RD_B(cur, 0), if (more) { PP_LOOP(PP_DMA_A(1, (cur) ^ 1, (t) + 1)); });                         \
+    if (more) { PP_VMCNT(4); }                                                                              \
     PP_BAR(); PP_COMPUTE(1, 0); PP_BAR();                                                                   \
   } while (0)
 
@@ -1259,15 +1286,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #undef PP_COMPUTE
 #undef PP_VMCNT
 #undef PP_TILE
+#undef PP_M
 
   if constexpr (LEAN) {
-    if (split_s == 1) {
-      __builtin_amdgcn_sched_barrier(0);
-      sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i);
-      return;
-    }
+    if (!tile_split_exchange<4>(p, acc, tid, split_j, split_s, tail_i)) return;
+    __builtin_amdgcn_sched_barrier(0);
+    sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i);
+  } else {
+    tile_finish<TO, 4, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
   }
-  tile_finish<TO, 4, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 // NT: every forward linear, dX against an explicit W^T (fp32 head through bf16x3); NN: dX = dY W; TN: dW = dY^T X
@@ -1368,7 +1395,18 @@ inline bool strides_mult(const int64_t s[3], int64_t m) { return s[0] % m == 0 &
 
 }  // namespace
 
+namespace {
+int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored);
+}
 extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
+  bool mirrored = false;
+  if (int rc = gemm_dispatch(d, stream, &mirrored)) return rc;
+  if (d->mirror && !mirrored && d->M > 0 && d->N > 0)   // kernels without the mirror epilogue: one narrow copy pass
+    return dxa_copy2d(d->C, d->ldc, d->mirror, d->ldc, d->M, d->N, d->N, DXA_F32, DXA_BF16, stream);
+  return DXA_OK;
+}
+namespace {
+int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored) {
   DXA_CHECK_ARG(d != nullptr, "dxa_gemm: null desc");
   DXA_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "dxa_gemm: negative dims");
   DXA_CHECK_ARG(d->layout >= DXA_NT && d->layout <= DXA_TN, "dxa_gemm: bad layout %d", d->layout);
@@ -1394,6 +1432,7 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
   p.aux = (char*)d->aux_out;
   p.G = (const char*)d->mulgrad; p.ldg = d->ldg;
   p.alpha = d->alpha; p.act = d->act; p.accumulate = d->accumulate;
+  DXA_CHECK_ARG(!d->mirror || (d->out_dtype == DXA_F32 && nbatch == 1), "dxa_gemm: mirror needs an fp32, unbatched output");
   p.nb1 = d->nb[1]; p.nb2 = d->nb[2];
   for (int i = 0; i < 3; ++i) {
     p.sA[i] = d->sA[i]; p.sB[i] = d->sB[i]; p.sC[i] = d->sC[i]; p.sR[i] = d->sR[i]; p.sG[i] = d->sG[i];
@@ -1486,6 +1525,7 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     }                                                                                                           \
     hipLaunchKernelGGL((gemm_pp_kernel<TO_, TE_, LEAN_, AKS_, BKS_>), fgrid, dim3(512), RING_LDS, st, p);       \
   } while (0)
+    if (lean) { p.mirror = (char*)d->mirror; *mirrored = d->mirror != nullptr; }
     if (d->layout == DXA_NN) {          // dX = dY W: bf16 out (lean, or with the activation-gradient epilogue), fp32 out lean
       if (d->out_dtype == DXA_BF16) { if (lean) LAUNCH_PP(bf16_t, bf16_t, true, false, true); else LAUNCH_PP(bf16_t, bf16_t, false, false, true); }
       else LAUNCH_PP(float, bf16_t, true, false, true);
@@ -1556,6 +1596,7 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
+}  // namespace
 
 extern "C" int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t cols, int side, dxa_stream_t stream) {
   DXA_CHECK_ARG(rows >= 0 && cols >= 0 && (side == 0 || side == 1), "dxa_split3: bad arguments");

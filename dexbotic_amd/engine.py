@@ -622,7 +622,19 @@ class GradReducer:
 
     def _exchange(self, buf: torch.Tensor) -> None:
         d, w = self.dist, self.world
-        native_avg = buf.is_cuda
+        # AVG is native on RCCL.  With ONE rank (force=True: the path is exercised on a single GPU) the mean is the
+        # identity and SUM is asked for instead: RCCL's one-rank AVG runs a separate pre-multiply pass over the whole
+        # buffer (oneRankReduce<FuncPreMulSum>, 43 ms per step for the 30 GB arena) that no multi-rank ring contains
+        native_avg = buf.is_cuda and w > 1
+        if w == 1:
+            if self.algo == "allreduce":
+                d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group)
+                self.collectives += 1
+            else:
+                d.reduce_scatter_tensor(buf, buf, op=d.ReduceOp.SUM, group=self.group)
+                d.all_gather_into_tensor(buf, buf, group=self.group)
+                self.collectives += 2
+            return
         n = buf.numel()
         per = n // w
         if self.algo == "allreduce" or per == 0:

@@ -77,10 +77,12 @@ def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) 
             raise L.DxaError(f"fused parameters {names} must be frozen/unfrozen together")
         return
     out = st.g(*names, shape=shape)
+    # bf16 data parallelism: the product's epilogue also writes the bf16 communication copy of this gradient
+    mirror = st.mirror_out(*names, shape=shape)
     if _f32_nt(dy2d) and x2d.dtype == torch.float32:
-        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names))
+        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names), mirror=mirror)
     else:
-        K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names))
+        K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names), mirror=mirror)
     st.mark_written(*names)
 
 
@@ -615,7 +617,7 @@ class LmHeadLossFn(_StoreFn):
         W = st.w(wn)
         dz = K.cross_entropy_bwd(logits, labels, lse, g.reshape(1).float().contiguous(), 1.0 / max(ctx.n_valid, 1))
         if st.trainable(wn):
-            K.mm_tn(dz, h2, out=st.g(wn), accumulate=st.accum_flag(wn))
+            K.mm_tn(dz, h2, out=st.g(wn), accumulate=st.accum_flag(wn), mirror=st.mirror_out(wn))
             st.mark_written(wn)
         dh = None
         if ctx.needs_input_grad[0]:

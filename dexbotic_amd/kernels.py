@@ -90,11 +90,13 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
          aux_out: Optional[torch.Tensor] = None, mulgrad: Optional[torch.Tensor] = None, ldg: int = 0,
          alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = (1, 1, 1),
          sA: Sequence[int] = (0, 0, 0), sB: Sequence[int] = (0, 0, 0), sC: Sequence[int] = (0, 0, 0),
-         sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0), epi_f32: bool = False) -> torch.Tensor:
+         sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0), epi_f32: bool = False,
+         mirror: Optional[torch.Tensor] = None) -> torch.Tensor:
     if not epi_f32 and _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb):
         a3, b3 = split3(a, M, K, lda, 0), split3(b, N, K, ldb, 1)
         return gemm(L.NT, a3, b3, M, N, 3 * K, 3 * K, 3 * K, out, ldc, bias=bias, residual=residual, ldr=ldr, act=act,
-                    aux_out=aux_out, mulgrad=mulgrad, ldg=ldg, alpha=alpha, accumulate=accumulate, epi_f32=True)
+                    aux_out=aux_out, mulgrad=mulgrad, ldg=ldg, alpha=alpha, accumulate=accumulate, epi_f32=True,
+                    mirror=mirror)
     d = L.GemmDesc()
     d.layout, d.in_dtype, d.out_dtype, d.act = layout, dt(a), dt(out), act
     d.epi_f32 = int(epi_f32)
@@ -110,6 +112,11 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
     d.bias, d.residual, d.ldr = _ptr(bias), _ptr(residual), ldr
     d.aux_out, d.mulgrad, d.ldg = _ptr(aux_out), _ptr(mulgrad), ldg
     d.alpha, d.accumulate = alpha, int(accumulate)
+    if mirror is not None:
+        if mirror.dtype != torch.bfloat16 or out.dtype != torch.float32 or tuple(nb) != (1, 1, 1) or \
+                _row_major(mirror, "mirror") != ldc:
+            raise L.DxaError("gemm: mirror must be a bf16 [M, N] view with the output's leading dimension (fp32 output)")
+        d.mirror = _ptr(mirror)
     for i in range(3):
         d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
     prof = GEMM_PROFILE

@@ -87,6 +87,10 @@ typedef struct dxa_gemm_desc {
   int64_t sA[3], sB[3], sC[3], sR[3], sG[3]; /* batch strides in elements */
   int32_t epi_f32;    /* 1: bias / residual / mulgrad are fp32 although A, B are bf16 (needs out_dtype fp32 and the
                          shapes of the bf16 NT fast path) — the epilogue of a split-bf16 fp32 product, see dxa_split3 */
+  void* mirror;       /* fp32 output only, or NULL: a bf16 copy of the final C (after accumulate), same ldc — the
+                         communication copy of a weight gradient that the data-parallel reducer exchanges instead of the
+                         fp32 values (the reference's DeepSpeed bf16 run reduces bf16 gradients, script/deepspeed/zero2.json);
+                         written by the dW product's own epilogue, so no cast pass over the gradient arena exists */
 } dxa_gemm_desc;
 int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream);
 

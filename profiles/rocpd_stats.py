@@ -28,8 +28,9 @@ def main(path):
         print(f"{short(n):110s} {c:7d} {s/1e6:10.2f} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f} {100*s/total:6.2f}")
 
 
-def pmc(path):
-    """per-kernel sums of the hardware counters of a `rocprofv3 --pmc ... --kernel-trace` run (view counters_collection)"""
+def pmc(path, only=None):
+    """per-kernel sums of the hardware counters of a `rocprofv3 --pmc ... --kernel-trace` run (view counters_collection);
+    `only`: comma-separated kernel-name substrings -> every counter of those kernels, not just the 60 largest rows"""
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
@@ -40,12 +41,17 @@ def pmc(path):
     rows = cur.execute(f"select {kcol}, {ccol}, count(distinct dispatch_id), sum({vcol}) from counters_collection "
                        f"group by {kcol}, {ccol} order by 4 desc").fetchall()
     print(f"{'kernel':90s} {'counter':28s} {'dispatches':>10s} {'sum':>16s} {'per_dispatch':>16s}")
-    for n, c, k, v in rows[:60]:
+    if only:
+        rows = [r for r in rows if any(o in r[0] for o in only.split(","))]
+    else:
+        rows = rows[:60]
+    for n, c, k, v in rows:
         print(f"{short(n)[:90]:90s} {c:28s} {k:10d} {v:16.4g} {v / max(k, 1):16.4g}")
 
 
 if __name__ == "__main__":
     if "--pmc" in sys.argv:
-        pmc([a for a in sys.argv[1:] if a != "--pmc"][0])
+        rest = [a for a in sys.argv[1:] if a != "--pmc"]
+        pmc(rest[0], rest[1] if len(rest) > 1 else None)
     else:
         main(sys.argv[1])

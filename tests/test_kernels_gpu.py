@@ -169,8 +169,11 @@ def test_gemm_pingpong_strided_operands(case):
     first = {}
     for rep in range(2):
         out32 = torch.full((M, N), 0.25, device=DEV, dtype=torch.float32)
-        fn(a, b, out=out32, accumulate=True)
+        mirror = torch.zeros((M, N), device=DEV, dtype=torch.bfloat16)
+        fn(a, b, out=out32, accumulate=True, mirror=mirror)
         assert_close(out32, ref + 0.25, 2e-5, 2e-3 * math.sqrt(max(Kd, 320) / 320), f"{lay} f32 accumulate {case} rep {rep}")
+        # the bf16 communication copy written by the same epilogue (or, off the lean path, by one copy pass)
+        assert torch.equal(mirror, out32.to(torch.bfloat16)), f"{lay} mirror {case}"
         bias, res = rnd(N, dtype=torch.bfloat16, seed=47), rnd(M, N, dtype=torch.bfloat16, seed=48)
         out16 = fn(a, b, bias=bias, residual=res)
         rtol, atol = tol_for(torch.bfloat16, Kd)
