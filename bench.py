@@ -277,7 +277,10 @@ def main():
         trainer.step(batch)
     sync()
     in_dt = L.BF16 if args.dtype == "bfloat16" else L.F32
-    prof = K.GemmProfile(L.NT, in_dt, in_dt)       # dominant kernel: the bf16 NT ring GEMM (forward linears + dX)
+    # dominant kernel: gemm_pp_kernel, whose three instantiations carry every large product of the step:
+    # NT (forward linears, bf16 out), NN (dX = dY W, bf16 out), TN (dW = dY^T X, fp32 out into the gradient arena)
+    prof_keys = {"NT fwd": (L.NT, in_dt, in_dt), "NN dX": (L.NN, in_dt, in_dt), "TN dW": (L.TN, in_dt, L.F32)}
+    prof = K.GemmProfile(*set(prof_keys.values()))
     K.GEMM_PROFILE = prof if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -311,23 +314,30 @@ def main():
         result["grad_comm_dtype"] = args.grad_comm
         result["allreduce_gb_per_step"] = round(trainer.reducer.bytes_reduced / (args.steps + args.warmup) / 1e9, 3)
     if rank == 0:
-        n, ms, fl = prof.summary()
+        n, ms, fl, by = prof.summary()
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes per launch of that kernel come from the committed rocprofv3 PMC passes over this same command
-        # (separate --pmc runs; FETCH_SIZE scaled by the factor calibrated on a known byte count, see the json)
+        # (separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, checked on a known byte count)
         traffic = None
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
         if os.path.exists(pmc_path) and in_dt == L.BF16:
             with open(pmc_path) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
+        by_layout = {}
+        for tag, key in prof_keys.items():
+            kn, kms, kfl, kby = prof.summary(key)
+            if kn:
+                by_layout[tag] = {"launches": kn, "avg_launch_us": round(1e3 * kms / kn, 1),
+                                  "achieved": round(kfl / (kms * 1e-3) / 1e12, 1)}
         result["roofline"] = {"bound": "mfma",
-                              "kernel": "gemm_nt_pp_kernel<bf16 out> (dxa_gemm bf16 NT, bf16 output: every forward linear and dX "
-                                        "product of the step; a few ViT products with activation epilogues included)",
+                              "kernel": "gemm_pp_kernel (dxa_gemm, 16-bit operands: the NT / NN / TN instantiations of the one "
+                                        "256x256x64 ping-pong MFMA kernel = every forward linear, dX and dW product of the step)",
                               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                              "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, separate passes)",
+                              "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, separate passes)",
                               "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
-                              "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 2)}
+                              "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 2),
+                              "algorithmic_bytes_per_launch": int(by / max(n, 1)), "by_layout": by_layout}
         if not args.no_latency and world == 1:
             model.eval()
             b1 = synthetic_batch(1, 2, args.s_text, device, seed=7)     # BASELINE.json configs[1]: batch 1, 2 views

@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
                            : (lds0 + (wm * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
   const uint32_t yb = B_KS ? lds0 + REG + ks_lane + (uint32_t)((wn ^ tq) << 6)
                            : (lds0 + REG + (wn * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
-  u32x4_t af[2][4], bfr[4];
+  u32x4_t af[2][4], bq[2][4];            // B fragments of both halves stay in registers: B0 serves phases 0 and 3
   typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #if (DXA_PPV & 2)
 #define PP_READ(dst, addr, imm) asm volatile("" : "+v"(dst) : "v"(addr))
@@ -1200,19 +1200,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   do {                                                                                                      \
     if constexpr (B_KS) {                                                                                   \
       const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF + (j) * 16384);                                      \
-      PP_FRAG_TR(bfr[0], b0_, 0); PP_FRAG_TR(bfr[1], b0_, 4096);                                            \
-      PP_FRAG_TR(bfr[2], b0_, 8192); PP_FRAG_TR(bfr[3], b0_, 12288);                                        \
+      PP_FRAG_TR(bq[j][0], b0_, 0); PP_FRAG_TR(bq[j][1], b0_, 4096);                                        \
+      PP_FRAG_TR(bq[j][2], b0_, 8192); PP_FRAG_TR(bq[j][3], b0_, 12288);                                    \
     } else {                                                                                                \
       const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF), b1_ = yb ^ (uint32_t)((cur) * BUF + 32),           \
                      b2_ = yb ^ (uint32_t)((cur) * BUF + 64), b3_ = yb ^ (uint32_t)((cur) * BUF + 96);      \
-      PP_READ(bfr[0], b0_, (j) * 4096); PP_READ(bfr[1], b1_, (j) * 4096);                                   \
-      PP_READ(bfr[2], b2_, (j) * 4096); PP_READ(bfr[3], b3_, (j) * 4096);                                   \
+      PP_READ(bq[j][0], b0_, (j) * 4096); PP_READ(bq[j][1], b1_, (j) * 4096);                               \
+      PP_READ(bq[j][2], b2_, (j) * 4096); PP_READ(bq[j][3], b3_, (j) * 4096);                               \
     }                                                                                                       \
   } while (0)
 #if (DXA_PPV & 4)
-#define PP_MFMA(ii, ks, i, j) asm volatile("" : "+v"(acc[i][j]) : "v"(bfr[ks]), "v"(af[ii][ks]))
+#define PP_MFMA(ii, ks, i, j) asm volatile("" : "+v"(acc[i][j]) : "v"(bq[j][ks]), "v"(af[ii][ks]))
 #else
-#define PP_MFMA(ii, ks, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks]), __builtin_bit_cast(bf16x8_t, af[ii][ks]), acc[i][j], 0, 0, 0)
+#define PP_MFMA(ii, ks, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bq[j][ks]), __builtin_bit_cast(bf16x8_t, af[ii][ks]), acc[i][j], 0, 0, 0)
 #endif
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_BAR() do { PP_SB(); __builtin_amdgcn_s_barrier(); PP_SB(); } while (0)
@@ -1228,11 +1228,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     PP_SB();                                                                                      \
   } while (0)
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-  // one K tile in buffer `cur`; `more` = another tile follows: its pieces are issued here into the other buffer, one
-  // per phase in the order of their first read (A0, B0, B1, A1).  A piece read in memory cluster M_q is waited for
-  // (vmcnt(4): the two younger pieces stay in flight) at the END of M_{q-1} by every wave; both groups' M_{q-1} end before
-  // the interval in which the first M_q starts, so wait + barrier order the DMA before every read.  A piece of tile
-  // t+1 overwrites bytes last read in tile t-1 (>= 2 barriers earlier).
+  // one K tile in buffer `cur = t & 1`.  LDS-DMA runs SIX pieces (96 KiB) ahead of the reads, in the two 64 KiB buffers
+  // alone: the B0 fragments stay in registers from phase 0 to phase 3, so every piece is read from LDS in exactly one
+  // memory cluster (A0, B0: M0; B1: M1; A1: M2; M3 reads nothing) and its bytes are free again two phases later.  The global
+  // issue order is A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) | B1(t+1) A1(t+1) A0(t+2) B0(t+2) in phases 0..3 of tile t: each
+  // piece is issued 5-6 phases (~1.5 K tiles, > 1.5 us) before its read instead of 2-3 — the loaded L2 -> LDS latency no
+  // longer stalls the MFMA clusters.  A piece read in M_q is waited for at the END of M_{q-1} by every wave (vmcnt(8): the
+  // four younger pieces stay in flight); both groups' M_{q-1} end before the interval in which the first M_q starts, so
+  // wait + barrier order the DMA before every read.  Reads of M_q have completed for BOTH staggered groups two phases on
+  // (group 1's reads of M_q retire in barrier interval 2q+2, group 0 issues M_{q+2} in interval 2q+4): a piece may be
+  // overwritten from phase q+2 onward — A0(t+2) in phase 2, B0(t+2) in phase 3 of tile t (read in M0 of tile t), B1(t+1) /
+  // A1(t+1) in phases 0 / 1 of tile t (read in M1 / M2 of tile t-1).
 #if (DXA_PPV & 64)   /* tuning variant: LDS-DMA issue ahead of the fragment reads of the same memory cluster */
 #define PP_M(reads, dma) do { dma; PP_SB(); reads; PP_SB(); } while (0)
 #else
@@ -1240,28 +1246,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #endif
 #define PP_TILE(cur, t)                                                                                     \
   do {                                                                                                      \
-    const bool more = (t) + 1 < nk;                                                                         \
+    const bool more1 = (t) + 1 < nk, more2 = (t) + 2 < nk;                                                  \
     /* phase 0 */                                                                                           \
-    PP_M(PP_RD_A(cur, 0); PP_RD_B(cur, 0), if (more) { PP_LOOP(PP_DMA_A(0, (cur) ^ 1, (t) + 1)); });        \
-    if (more) { PP_VMCNT(4); } else { PP_VMCNT(2); }                                                        \
+    PP_M(PP_RD_A(cur, 0); PP_RD_B(cur, 0), if (more1) { PP_LOOP(PP_DMA_B(1, (cur) ^ 1, (t) + 1)); });       \
+    if (more1) { PP_VMCNT(8); } else { PP_VMCNT(2); }                 /* B1(t) landed */                    \
     PP_BAR(); PP_COMPUTE(0, 0); PP_BAR();                                                                   \
     /* phase 1 */                                                                                           \
-    PP_M(PP_RD_B(cur, 1), if (more) { PP_LOOP(PP_DMA_B(0, (cur) ^ 1, (t) + 1)); });                         \
-    if (more) { PP_VMCNT(4); } else { PP_VMCNT(0); }                                                        \
+    PP_M(PP_RD_B(cur, 1), if (more1) { PP_LOOP(PP_DMA_A(1, (cur) ^ 1, (t) + 1)); });                        \
+    if (more1) { PP_VMCNT(8); } else { PP_VMCNT(0); }                 /* A1(t) landed */                    \
     PP_BAR(); PP_COMPUTE(0, 1); PP_BAR();                                                                   \
     /* phase 2 */                                                                                           \
-    PP_M(PP_RD_A(cur, 1), if (more) { PP_LOOP(PP_DMA_B(1, (cur) ^ 1, (t) + 1)); });                         \
+    PP_M(PP_RD_A(cur, 1), if (more2) { PP_LOOP(PP_DMA_A(0, cur, (t) + 2)); });                              \
     PP_BAR(); PP_COMPUTE(1, 1); PP_BAR();                                                                   \
-    /* phase 3 */                                                                                           \
-    PP_M(PP_RD_B(cur, 0), if (more) { PP_LOOP(PP_DMA_A(1, (cur) ^ 1, (t) + 1)); });                         \
-    if (more) { PP_VMCNT(4); }                                                                              \
+    /* phase 3: B0 fragments are still in bq[0] */                                                          \
+    PP_M(, if (more2) { PP_LOOP(PP_DMA_B(0, cur, (t) + 2)); });                                             \
+    if (more2) { PP_VMCNT(8); } else if (more1) { PP_VMCNT(4); }      /* A0(t+1), B0(t+1) landed */         \
     PP_BAR(); PP_COMPUTE(1, 0); PP_BAR();                                                                   \
   } while (0)
 
-  // ---- prologue: the four pieces of tile 0; A0 and B0 landed for every wave before the first read
+  // ---- prologue: the four pieces of tile 0 and the first two of tile 1; A0(0) and B0(0) landed for every wave before
+  //      the first read
   PP_DMA_A(0, 0, 0); PP_DMA_B(0, 0, 0); PP_DMA_B(1, 0, 0); PP_DMA_A(1, 0, 0);
+  if (nk > 1) { PP_DMA_A(0, 1, 1); PP_DMA_B(0, 1, 1); }
   PP_SB();
-  PP_VMCNT(4);
+  if (nk > 1) { PP_VMCNT(8); } else { PP_VMCNT(4); }
   PP_BAR();
   if (!(DXA_PPV & 16) && wm == 1) PP_BAR();    // group 1 runs one barrier interval behind group 0
   for (int t = 0; t < nk; t += 2) {

@@ -125,30 +125,37 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
         e0.record()
         L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm")
         e1.record()
-        prof.add(e0, e1, 2.0 * M * N * K * nb[0] * nb[1] * nb[2])
+        batches = nb[0] * nb[1] * nb[2]
+        esz = {L.BF16: 2, L.F32: 4}
+        prof.add((layout, d.in_dtype, d.out_dtype), e0, e1, 2.0 * M * N * K * batches,
+                 float((M * K + N * K) * esz.get(d.in_dtype, 2) + M * N * esz.get(d.out_dtype, 2)) * batches)
         return out
     L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm")
     return out
 
 
 class GemmProfile:
-    """HIP-event timing of every launch of ONE gemm kernel instantiation (layout, in dtype, out dtype) on
-    the stream it is launched on — bench.py's live roofline measurement."""
+    """HIP-event timing of every launch of the chosen gemm instantiations — keys (layout, in dtype, out dtype) — on the
+    stream they are launched on: bench.py's live roofline measurement.  Per launch it also records the algorithmic
+    flops (2 M N K) and the algorithmic bytes (A and B read once, C written once)."""
 
-    def __init__(self, layout: int, in_dtype: int, out_dtype: int):
-        self.key = (layout, in_dtype, out_dtype)
+    def __init__(self, *keys):
+        if len(keys) == 3 and all(isinstance(k, int) for k in keys):
+            keys = (tuple(keys),)
+        self.keys = set(tuple(k) for k in keys)
         self.events = []
 
     def wants(self, layout, in_dtype, out_dtype) -> bool:
-        return (layout, in_dtype, out_dtype) == self.key
+        return (layout, in_dtype, out_dtype) in self.keys
 
-    def add(self, e0, e1, flops: float) -> None:
-        self.events.append((e0, e1, flops))
+    def add(self, key, e0, e1, flops: float, nbytes: float = 0.0) -> None:
+        self.events.append((key, e0, e1, flops, nbytes))
 
-    def summary(self):
-        """(launches, total_ms, total_flops) — call after a device synchronize"""
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
-        return len(self.events), ms, sum(f for _, _, f in self.events)
+    def summary(self, key=None):
+        """(launches, total_ms, total_flops, total_algorithmic_bytes), of one key or of all — call after a device sync"""
+        ev = [e for e in self.events if key is None or e[0] == tuple(key)]
+        ms = sum(a.elapsed_time(b) for _, a, b, _, _ in ev)
+        return len(ev), ms, sum(e[3] for e in ev), sum(e[4] for e in ev)
 
 
 GEMM_PROFILE: Optional[GemmProfile] = None

@@ -3,6 +3,8 @@
 
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o NAME -- python bench.py ...
     python profiles/rocpd_stats.py gpurun_out/prof/NAME_results.db > profiles/NAME_kernel_stats.txt
+    python profiles/rocpd_stats.py --per-step A_results.db 3 B_results.db 9      # exact per-step table from two traces
+    python profiles/rocpd_stats.py --pmc PMC_results.db [kernel-substring,...]    # hardware counters per kernel
 """
 import re
 import sqlite3
@@ -28,6 +30,24 @@ def main(path):
         print(f"{short(n):110s} {c:7d} {s/1e6:10.2f} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f} {100*s/total:6.2f}")
 
 
+def per_step(path_a, steps_a, path_b, steps_b):
+    """two traces of the same command with steps_a < steps_b timed+warm-up steps: (B - A) / (steps_b - steps_a) is the exact
+    per-step kernel time, free of model construction / initialisation launches"""
+    tabs = []
+    for p in (path_a, path_b):
+        cur = sqlite3.connect(p).cursor()
+        tabs.append({n: (c, s) for n, c, s in cur.execute("select name, count(*), sum(end-start) from kernels group by name")})
+    a, b = tabs
+    d = float(steps_b - steps_a)
+    rows = sorted(((n, (b[n][0] - a.get(n, (0, 0))[0]) / d, (b[n][1] - a.get(n, (0, 0))[1]) / d) for n in b), key=lambda r: -r[2])
+    total = sum(r[2] for r in rows)
+    print(f"# per training step = ({path_b} - {path_a}) / {int(d)}: {sum(r[1] for r in rows):.0f} launches, {total/1e6:.2f} ms GPU kernel time")
+    print(f"{'kernel':110s} {'calls/step':>10s} {'ms/step':>10s} {'avg_us':>10s} {'%':>6s}")
+    for n, c, s in rows[:60]:
+        if c > 0:
+            print(f"{short(n):110s} {c:10.1f} {s/1e6:10.3f} {s/1e3/c:10.1f} {100*s/total:6.2f}")
+
+
 def pmc(path, only=None):
     """per-kernel sums of the hardware counters of a `rocprofv3 --pmc ... --kernel-trace` run (view counters_collection);
     `only`: comma-separated kernel-name substrings -> every counter of those kernels, not just the 60 largest rows"""
@@ -50,7 +70,10 @@ def pmc(path, only=None):
 
 
 if __name__ == "__main__":
-    if "--pmc" in sys.argv:
+    if "--per-step" in sys.argv:
+        r = [a for a in sys.argv[1:] if a != "--per-step"]
+        per_step(r[0], int(r[1]), r[2], int(r[3]))
+    elif "--pmc" in sys.argv:
         rest = [a for a in sys.argv[1:] if a != "--pmc"]
         pmc(rest[0], rest[1] if len(rest) > 1 else None)
     else:

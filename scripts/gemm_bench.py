@@ -29,7 +29,9 @@ SHAPES = [  # (name, layout, M, N, K)
 
 def main():
     dev = "cuda"
-    only = sys.argv[1] if len(sys.argv) > 1 else None
+    argv = [a for a in sys.argv[1:] if a != "--lib"]
+    yard = "--lib" in sys.argv      # yardstick column: torch.matmul (hipBLASLt / rocBLAS) on the same operands — never a product path
+    only = argv[0] if argv else None
     for name, lay, m, n, k in SHAPES:
         if only and not any(o == lay or o in name for o in only.split(",")):
             continue
@@ -57,7 +59,20 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        print(f"{name} {lay} M={m:6d} N={n:6d} K={k:6d}  {ms*1e3:9.1f} us  {2*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+        extra = ""
+        if yard:
+            ta, tb = (a.t() if lay == "tn" else a), (b.t() if lay == "nt" else b)
+            for _ in range(3):
+                torch.matmul(ta, tb, out=out)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                torch.matmul(ta, tb, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            lms = e0.elapsed_time(e1) / reps
+            extra = f"   | library {lms*1e3:9.1f} us {2*m*n*k/lms/1e9:8.1f} TFLOP/s"
+        print(f"{name} {lay} M={m:6d} N={n:6d} K={k:6d}  {ms*1e3:9.1f} us  {2*m*n*k/ms/1e9:8.1f} TFLOP/s{extra}", flush=True)
 
 
 if __name__ == "__main__":
