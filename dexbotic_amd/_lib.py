@@ -89,9 +89,9 @@ SIGNATURES = {
     "dxa_gemm": (_int, [C.POINTER(GemmDesc), _vp]),
     "dxa_split3": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),
     "dxa_rmsnorm_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
-    "dxa_rmsnorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "dxa_rmsnorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
-    "dxa_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
+    "dxa_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_norm_bwd_blocks": (_int, [_i64]),
     "dxa_colsum": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _sz, _vp]),
     "dxa_rope_split": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),

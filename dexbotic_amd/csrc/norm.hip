@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, co
 template <typename T, typename TW, int VEC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const TW* __restrict__ w, const float* __restrict__ rstd,
-                                                     T* __restrict__ dx, float* __restrict__ partial,
-                                                     int64_t rows, int64_t cols) {
+                                                     T* __restrict__ dx, const T* __restrict__ res,
+                                                     float* __restrict__ partial, int64_t rows, int64_t cols) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* slab = w ? partial + (int64_t)blockIdx.x * cols : nullptr;
   if (w) {
@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ dy, c
         for (int i = 0; i < VEC; ++i) {
           const float xh = xv[i] * rs;
           o[i] = rs * (gv[i] * (w ? wv[i] : 1.f) - xh * cterm);
+        }
+        if (res) {
+          float rv[VEC];
+          Vec<T, VEC>::ld(rv, res + row * cols + c);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += rv[i];
         }
         Vec<T, VEC>::st(dxr + c, o);
       }
@@ -154,7 +160,8 @@ template <typename T, typename TW, int VEC>
 __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
                                                        const TW* __restrict__ w, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, T* __restrict__ dx,
-                                                       float* __restrict__ partial, int64_t rows, int64_t cols) {
+                                                       const T* __restrict__ res, float* __restrict__ partial,
+                                                       int64_t rows, int64_t cols) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* slab = partial ? partial + (int64_t)blockIdx.x * 2 * cols : nullptr;
   if (slab) {
@@ -194,6 +201,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ dy,
         for (int i = 0; i < VEC; ++i) {
           const float g = gv[i] * (w ? wv[i] : 1.f);
           o[i] = rs * (g - c1 - (xv[i] - mu) * rs * c2);
+        }
+        if (res) {
+          float rv[VEC];
+          Vec<T, VEC>::ld(rv, res + row * cols + c);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) o[i] += rv[i];
         }
         Vec<T, VEC>::st(dxr + c, o);
       }
@@ -265,14 +278,16 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
 // Fast backward (cols % 4 == 0, cols <= 4096): a wave owns whole rows, keeps its weight/bias-gradient partial
-// sums in REGISTERS (16 x 4 columns per lane) over all its rows and writes ONE partial row at the end:
-// no LDS, no barriers, no serialisation between the waves of a workgroup; x/dy are read twice (second pass
-// from L1/L2).  partial: [4*gridDim.x][(LN ? 2 : 1) * cols].
+// sums in REGISTERS (16 x 4 columns per lane) over all its rows; no LDS, no barriers, no serialisation between the
+// waves of a workgroup until the very end, where the four waves fold into ONE partial row; x/dy are read twice
+// (second pass from L1/L2).  `res` (optional) is added to dx: the gradient of the residual branch around the norm'd
+// sub-block, which used to be a separate add kernel.  partial: [gridDim.x][(LN ? 2 : 1) * cols].
 template <typename T, typename TW, bool LN>
 __global__ __launch_bounds__(256) void norm_bwd_fast_k(const T* __restrict__ dy, const T* __restrict__ x,
                                                        const TW* __restrict__ w, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, T* __restrict__ dx,
-                                                       float* __restrict__ partial, int64_t rows, int64_t cols) {
+                                                       const T* __restrict__ res, float* __restrict__ partial,
+                                                       int64_t rows, int64_t cols) {
   constexpr int NIT = 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t prow = (int64_t)blockIdx.x * 4 + wave;
@@ -321,18 +336,54 @@ __global__ __launch_bounds__(256) void norm_bwd_fast_k(const T* __restrict__ dy,
           aw[it][i] += gv[i] * (LN ? xh : rnd<T>(xh));
           ab[it][i] += gv[i];
         }
+        if (res) {                     // residual branch of the block: dx = norm backward + the gradient that bypassed it
+          float rv[4];
+          Vec<T, 4>::ld(rv, res + row * cols + c);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] += rv[i];
+        }
         Vec<T, 4>::st(dxr + c, o);
       }
     }
   }
   if (partial) {
-    float* pr = partial + prow * (LN ? 2 : 1) * cols;
+    // the four waves fold their register partials through LDS in a fixed order (3, 2, 1, then wave 0 adds its own and
+    // writes): ONE partial row per workgroup — a quarter of the former partial traffic and of the column sum after it
+    __shared__ float sh[(LN ? 2 : 1) * 4096];
+    for (int turn = 3; turn >= 1; --turn) {
+      if (wave == turn) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int64_t c = ((int64_t)it * 64 + lane) * 4;
-      if (c < cols) {
-        *reinterpret_cast<float4*>(pr + c) = make_float4(aw[it][0], aw[it][1], aw[it][2], aw[it][3]);
-        if (LN) *reinterpret_cast<float4*>(pr + cols + c) = make_float4(ab[it][0], ab[it][1], ab[it][2], ab[it][3]);
+        for (int it = 0; it < NIT; ++it) {
+          const int64_t c = ((int64_t)it * 64 + lane) * 4;
+          if (c < cols) {
+            float4* pw = reinterpret_cast<float4*>(sh + c);
+            float4* pb = reinterpret_cast<float4*>(sh + cols + c);
+            if (turn == 3) {
+              *pw = make_float4(aw[it][0], aw[it][1], aw[it][2], aw[it][3]);
+              if (LN) *pb = make_float4(ab[it][0], ab[it][1], ab[it][2], ab[it][3]);
+            } else {
+              float4 t = *pw;
+              *pw = make_float4(t.x + aw[it][0], t.y + aw[it][1], t.z + aw[it][2], t.w + aw[it][3]);
+              if (LN) { t = *pb; *pb = make_float4(t.x + ab[it][0], t.y + ab[it][1], t.z + ab[it][2], t.w + ab[it][3]); }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+      float* pr = partial + (int64_t)blockIdx.x * (LN ? 2 : 1) * cols;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int64_t c = ((int64_t)it * 64 + lane) * 4;
+        if (c < cols) {
+          const float4 t = *reinterpret_cast<const float4*>(sh + c);
+          *reinterpret_cast<float4*>(pr + c) = make_float4(t.x + aw[it][0], t.y + aw[it][1], t.z + aw[it][2], t.w + aw[it][3]);
+          if (LN) {
+            const float4 u = *reinterpret_cast<const float4*>(sh + cols + c);
+            *reinterpret_cast<float4*>(pr + cols + c) = make_float4(u.x + ab[it][0], u.y + ab[it][1], u.z + ab[it][2], u.w + ab[it][3]);
+          }
+        }
       }
     }
   }
@@ -343,29 +394,29 @@ constexpr int64_t NORM_BWD_FAST_MAX_COLS = 4096;
 
 template <bool LN>
 bool launch_norm_bwd_fast(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
-                          float* partial, int64_t rows, int64_t cols, int dtype, int w_dtype, bool vec_ok, hipStream_t st) {
+                          const void* res, float* partial, int64_t rows, int64_t cols, int dtype, int w_dtype, bool vec_ok, hipStream_t st) {
   if (!vec_ok || cols % 4 != 0 || cols > NORM_BWD_FAST_MAX_COLS) return false;
   int64_t g = (rows + 3) / 4;
   if (g > NORM_BWD_MAX_BLOCKS) g = NORM_BWD_MAX_BLOCKS;
   dim3 grid((unsigned)g);
   if (dtype == DXA_BF16 && w_dtype == DXA_BF16)
-    hipLaunchKernelGGL((norm_bwd_fast_k<bf16_t, bf16_t, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, partial, rows, cols);
+    hipLaunchKernelGGL((norm_bwd_fast_k<bf16_t, bf16_t, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)res, partial, rows, cols);
   else if (dtype == DXA_BF16)
-    hipLaunchKernelGGL((norm_bwd_fast_k<bf16_t, float, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, partial, rows, cols);
+    hipLaunchKernelGGL((norm_bwd_fast_k<bf16_t, float, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)res, partial, rows, cols);
   else
-    hipLaunchKernelGGL((norm_bwd_fast_k<float, float, LN>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, partial, rows, cols);
+    hipLaunchKernelGGL((norm_bwd_fast_k<float, float, LN>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, (const float*)res, partial, rows, cols);
   return true;
 }
 
 }  // namespace
 
-// number of partial rows both backward kernels write: 4 per workgroup of the fast kernel; the generic
-// fallback launches that many workgroups (one slab each)
+// number of partial rows both backward kernels write: one per workgroup (the generic fallback launches as many
+// workgroups as the fast kernel, one slab each)
 extern "C" int dxa_norm_bwd_blocks(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   if (g < 1) g = 1;
   if (g > NORM_BWD_MAX_BLOCKS) g = NORM_BWD_MAX_BLOCKS;
-  return (int)(4 * g);
+  return (int)g;
 }
 
 static int check_norm_dtypes(int dtype, int w_dtype, const char* who) {
@@ -400,28 +451,28 @@ extern "C" int dxa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
 }
 
 extern "C" int dxa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
-                               float* partial_dw, int64_t rows, int64_t cols, int dtype, int w_dtype,
+                               const void* residual, float* partial_dw, int64_t rows, int64_t cols, int dtype, int w_dtype,
                                dxa_stream_t stream) {
   if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_rmsnorm_bwd")) return rc;
   DXA_CHECK_ARG(dy && x && rstd && dx && rows >= 0 && cols > 0, "dxa_rmsnorm_bwd: bad args");
   DXA_CHECK_ARG(!w || partial_dw, "dxa_rmsnorm_bwd: partial_dw required when w is given");
   if (rows == 0) return DXA_OK;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w)) && (!partial_dw || al16(partial_dw));
-  if (launch_norm_bwd_fast<false>(dy, x, w, nullptr, rstd, dx, w ? partial_dw : nullptr, rows, cols, dtype, w_dtype, vec_ok, st)) {
+  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w)) && (!partial_dw || al16(partial_dw)) && (!residual || al16(residual));
+  if (launch_norm_bwd_fast<false>(dy, x, w, nullptr, rstd, dx, residual, w ? partial_dw : nullptr, rows, cols, dtype, w_dtype, vec_ok, st)) {
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
   dim3 grid((unsigned)dxa_norm_bwd_blocks(rows));
   if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
-    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
-    else hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, (const bf16_t*)residual, partial_dw, rows, cols);
+    else hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (bf16_t*)dx, (const bf16_t*)residual, partial_dw, rows, cols);
   } else if (dtype == DXA_BF16) {
-    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
-    else hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, rstd, (bf16_t*)dx, partial_dw, rows, cols);
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, rstd, (bf16_t*)dx, (const bf16_t*)residual, partial_dw, rows, cols);
+    else hipLaunchKernelGGL((rmsnorm_bwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, rstd, (bf16_t*)dx, (const bf16_t*)residual, partial_dw, rows, cols);
   } else {
-    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, rstd, (float*)dx, partial_dw, rows, cols);
-    else hipLaunchKernelGGL((rmsnorm_bwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, rstd, (float*)dx, partial_dw, rows, cols);
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_bwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, rstd, (float*)dx, (const float*)residual, partial_dw, rows, cols);
+    else hipLaunchKernelGGL((rmsnorm_bwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, rstd, (float*)dx, (const float*)residual, partial_dw, rows, cols);
   }
   DXA_CHECK_LAUNCH();
   return DXA_OK;
@@ -451,29 +502,29 @@ extern "C" int dxa_layernorm_fwd(const void* x, const void* w, const void* b, vo
 }
 
 extern "C" int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean,
-                                 const float* rstd, void* dx, float* partial_dwdb, int64_t rows, int64_t cols,
-                                 int dtype, int w_dtype, dxa_stream_t stream) {
+                                 const float* rstd, void* dx, const void* residual, float* partial_dwdb, int64_t rows,
+                                 int64_t cols, int dtype, int w_dtype, dxa_stream_t stream) {
   if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_layernorm_bwd")) return rc;
   DXA_CHECK_ARG(dy && x && mean && rstd && dx && rows >= 0 && cols > 0, "dxa_layernorm_bwd: bad args");
   DXA_CHECK_ARG(!w || partial_dwdb, "dxa_layernorm_bwd: partial_dwdb required when w is given");
   if (rows == 0) return DXA_OK;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w)) && (!partial_dwdb || al16(partial_dwdb));
-  if (launch_norm_bwd_fast<true>(dy, x, w, mean, rstd, dx, w ? partial_dwdb : nullptr, rows, cols, dtype, w_dtype, vec_ok, st)) {
+  const bool vec_ok = al16(x) && al16(dy) && al16(dx) && (!w || al16(w)) && (!partial_dwdb || al16(partial_dwdb)) && (!residual || al16(residual));
+  if (launch_norm_bwd_fast<true>(dy, x, w, mean, rstd, dx, residual, w ? partial_dwdb : nullptr, rows, cols, dtype, w_dtype, vec_ok, st)) {
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
   dim3 grid((unsigned)dxa_norm_bwd_blocks(rows));
   float* part = w ? partial_dwdb : nullptr;
   if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
-    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
-    else hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)residual, part, rows, cols);
+    else hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)residual, part, rows, cols);
   } else if (dtype == DXA_BF16) {
-    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
-    else hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, part, rows, cols);
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, 4>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)residual, part, rows, cols);
+    else hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, 1>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const float*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)residual, part, rows, cols);
   } else {
-    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, part, rows, cols);
-    else hipLaunchKernelGGL((layernorm_bwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, part, rows, cols);
+    if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((layernorm_bwd_k<float, float, 4>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, (const float*)residual, part, rows, cols);
+    else hipLaunchKernelGGL((layernorm_bwd_k<float, float, 1>), grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, (float*)dx, (const float*)residual, part, rows, cols);
   }
   DXA_CHECK_LAUNCH();
   return DXA_OK;

@@ -173,12 +173,11 @@ class Qwen2LayerFn(_StoreFn):
         _wgrad(st, sp.gu_w, dgu, h2, (2 * F_, d))
         del dgu
         tr2 = st.trainable(sp.ln2)
-        dx2n, _ = K.rmsnorm_bwd(dh2, x2, st.w(sp.ln2), rstd2, dw_out=st.g(sp.ln2) if tr2 else None,
-                                accumulate=st.accum_flag(sp.ln2), want_dw=tr2)
+        dx2, _ = K.rmsnorm_bwd(dh2, x2, st.w(sp.ln2), rstd2, dw_out=st.g(sp.ln2) if tr2 else None,
+                               accumulate=st.accum_flag(sp.ln2), want_dw=tr2, residual=dy)     # dy + norm backward
         if tr2:
             st.mark_written(sp.ln2)
-        dx2 = K.add(dy, dx2n)
-        del dx2n, dh2
+        del dh2
         # ---- attention: dO written head-major by a (b, h)-batched NN GEMM so the GQA group folds into
         #      the rows of the dK/dV GEMMs (attention.hip)
         if dx2.dtype == torch.bfloat16:
@@ -199,11 +198,10 @@ class Qwen2LayerFn(_StoreFn):
         _bgrad(st, sp.qkv_b, dqkv)
         del dqkv
         tr1 = st.trainable(sp.ln1)
-        dxn, _ = K.rmsnorm_bwd(dh1, x, st.w(sp.ln1), rstd1, dw_out=st.g(sp.ln1) if tr1 else None,
-                               accumulate=st.accum_flag(sp.ln1), want_dw=tr1)
+        dx, _ = K.rmsnorm_bwd(dh1, x, st.w(sp.ln1), rstd1, dw_out=st.g(sp.ln1) if tr1 else None,
+                              accumulate=st.accum_flag(sp.ln1), want_dw=tr1, residual=dx2)
         if tr1:
             st.mark_written(sp.ln1)
-        dx = K.add(dx2, dxn)
         return dx, None, None, None, None, None, None, None
 
 
@@ -290,7 +288,7 @@ class VitBlockFn(_StoreFn):
         _wgrad(st, sp.fc1_w, dpre, h2, (I, C_))
         _bgrad(st, sp.fc1_b, dpre)
         del dpre
-        dx2 = K.add(dy, _ln_bwd(st, dh2, x2, sp.ln2_w, sp.ln2_b, mean2, rstd2))
+        dx2 = _ln_bwd(st, dh2, x2, sp.ln2_w, sp.ln2_b, mean2, rstd2, residual=dy.reshape(x2.shape))
         del dh2
         # ---- attention
         do = _dx(st, sp.out_w, (C_, C_), dx2)                   # [M, C] token-major
@@ -313,17 +311,18 @@ class VitBlockFn(_StoreFn):
         _wgrad(st, sp.qkv_w, dqkv, h1, (3 * C_, C_))
         _bgrad(st, sp.qkv_b, dqkv)
         del dqkv
-        dx = K.add(dx2, _ln_bwd(st, dh1, x, sp.ln1_w, sp.ln1_b, mean1, rstd1))
+        dx = _ln_bwd(st, dh1, x, sp.ln1_w, sp.ln1_b, mean1, rstd1, residual=dx2.reshape(x.shape))
         return dx.view(N, T, C_), None, None, None
 
 
-def _ln_bwd(st: ParamStore, dy, x, wn: Optional[str], bn: Optional[str], mean, rstd) -> torch.Tensor:
+def _ln_bwd(st: ParamStore, dy, x, wn: Optional[str], bn: Optional[str], mean, rstd, residual=None) -> torch.Tensor:
+    """LayerNorm backward; `residual` (gradient of the skip connection around the sub-block) is added inside the kernel"""
     if wn is None:
-        dx, _, _ = K.layernorm_bwd(dy, x, None, mean, rstd)
+        dx, _, _ = K.layernorm_bwd(dy, x, None, mean, rstd, residual=residual)
         return dx
     tr = st.trainable(wn)
     dx, _, _ = K.layernorm_bwd(dy, x, st.w(wn), mean, rstd, dw_out=st.g(wn) if tr else None,
-                               db_out=st.g(bn) if tr else None, accumulate=st.accum_flag(wn), want_dw=tr)
+                               db_out=st.g(bn) if tr else None, accumulate=st.accum_flag(wn), want_dw=tr, residual=residual)
     if tr:
         st.mark_written(wn, bn)
     return dx
@@ -770,11 +769,10 @@ class Pi0MotLayerFn(_StoreFn):
             dh2 = _dx(st, sp.gu, (2 * sp.F, sp.d), dgu)
             _wgrad(st, sp.gu, dgu, h2, (2 * sp.F, sp.d))
             tr = st.trainable(sp.ln2)
-            drn, _ = K.rmsnorm_bwd(dh2, r, st.w(sp.ln2).float() + 1.0, rs2, dw_out=st.g(sp.ln2) if tr else None,
-                                   accumulate=st.accum_flag(sp.ln2), want_dw=tr)
+            dr, _ = K.rmsnorm_bwd(dh2, r, st.w(sp.ln2).float() + 1.0, rs2, dw_out=st.g(sp.ln2) if tr else None,
+                                  accumulate=st.accum_flag(sp.ln2), want_dw=tr, residual=dy)
             if tr:
                 st.mark_written(sp.ln2)
-            dr = K.add(dy, drn)
             da = _dx(st, sp.o, (sp.d, Hq * D), dr)
             _wgrad(st, sp.o, dr, a, (sp.d, Hq * D))
             do[:, off:off + Sn].copy_(da.view(B, Sn, Hq, D))
@@ -795,10 +793,10 @@ class Pi0MotLayerFn(_StoreFn):
             _wgrad(st, sp.qkv, dqkv, h1[i], (nq, sp.d))
             tr = st.trainable(sp.ln1)
             dxn, _ = K.rmsnorm_bwd(dh, xs[i], st.w(sp.ln1).float() + 1.0, rstd1[i], dw_out=st.g(sp.ln1) if tr else None,
-                                   accumulate=st.accum_flag(sp.ln1), want_dw=tr)
+                                   accumulate=st.accum_flag(sp.ln1), want_dw=tr, residual=drs[i])
             if tr:
                 st.mark_written(sp.ln1)
-            dxs.append(dxn if drs[i] is None else K.add(drs[i], dxn))
+            dxs.append(dxn)
         return (dxs[0], dxs[1]) + (None,) * 12
 
 

@@ -223,9 +223,18 @@ def norm_bwd_blocks(rows: int) -> int:
     return int(lib.dxa_norm_bwd_blocks(rows))
 
 
+def _residual2d(residual, x2):
+    if residual is None:
+        return None
+    r2 = residual.reshape(-1, x2.shape[-1])
+    assert r2.is_contiguous() and r2.shape == x2.shape and r2.dtype == x2.dtype
+    return r2
+
+
 def rmsnorm_bwd(dy, x, w, rstd, dw_out: Optional[torch.Tensor] = None, accumulate: bool = False,
-                want_dw: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """returns (dx, dw_fp32 or None); dw is (accumulated) into dw_out when given"""
+                want_dw: bool = True, residual: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """returns (dx, dw_fp32 or None); dw is (accumulated) into dw_out when given.  `residual` (the gradient that bypassed
+    the normalised sub-block) is added to dx inside the kernel."""
     x2 = x.reshape(-1, x.shape[-1])
     dy2 = dy.reshape(-1, x.shape[-1])
     assert x2.is_contiguous() and dy2.is_contiguous()
@@ -238,7 +247,8 @@ def rmsnorm_bwd(dy, x, w, rstd, dw_out: Optional[torch.Tensor] = None, accumulat
     if w is not None and part is None:
         part = torch.empty((norm_bwd_blocks(rows), cols), device=x.device, dtype=torch.float32)
         want_dw = False
-    L.check(lib.dxa_rmsnorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(rstd), _ptr(dx), _ptr(part), rows, cols, dt(x2),
+    L.check(lib.dxa_rmsnorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(rstd), _ptr(dx), _ptr(_residual2d(residual, x2)), _ptr(part),
+                                rows, cols, dt(x2),
                                 dt(w) if w is not None else dt(x2), _stream()), "dxa_rmsnorm_bwd")
     dw = colsum(part, out=dw_out, accumulate=accumulate) if (part is not None and want_dw) else None
     return dx.view(x.shape), dw
@@ -256,8 +266,10 @@ def layernorm_fwd(x, w, b, eps):
     return y.view(x.shape), mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dw_out=None, db_out=None, accumulate: bool = False, want_dw: bool = True):
-    """returns (dx, dw_fp32 or None, db_fp32 or None); dw/db are (accumulated) into dw_out/db_out when given"""
+def layernorm_bwd(dy, x, w, mean, rstd, dw_out=None, db_out=None, accumulate: bool = False, want_dw: bool = True,
+                  residual: Optional[torch.Tensor] = None):
+    """returns (dx, dw_fp32 or None, db_fp32 or None); dw/db are (accumulated) into dw_out/db_out when given; `residual` is
+    added to dx inside the kernel"""
     x2 = x.reshape(-1, x.shape[-1])
     dy2 = dy.reshape(-1, x.shape[-1])
     assert x2.is_contiguous() and dy2.is_contiguous()
@@ -266,8 +278,8 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw_out=None, db_out=None, accumulate: bo
     part = None
     if w is not None:
         part = torch.empty((norm_bwd_blocks(rows), 2 * cols), device=x.device, dtype=torch.float32)
-    L.check(lib.dxa_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(part), rows,
-                                  cols, dt(x2), dt(w) if w is not None else dt(x2), _stream()), "dxa_layernorm_bwd")
+    L.check(lib.dxa_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                  _ptr(_residual2d(residual, x2)), _ptr(part), rows, cols, dt(x2), dt(w) if w is not None else dt(x2), _stream()), "dxa_layernorm_bwd")
     if part is None or not want_dw:
         return dx.view(x.shape), None, None
     if dw_out is not None:

@@ -107,19 +107,20 @@ int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t co
  * RMSNorm follows HF:qwen2/modeling_qwen2.py:238-253: y = w * round_to_dtype(x * rsqrt(mean(x^2)+eps)).
  * LayerNorm follows torch.nn.LayerNorm as used by HF:clip/modeling_clip.py (eps 1e-5, affine) and
  * cogact/action_model/dit.py:143-147,170 (eps 1e-6, no affine).  Statistics in fp32, saved for bwd.
- * Backward writes dx and per-block partial dw/db into `partial` ([nblk, 2*cols] fp32; nblk returned by
+ * Backward writes dx (+ `residual` when given: the gradient that bypassed the normalised sub-block, same shape and
+ * dtype as dx) and per-block partial dw/db into `partial` ([nblk, 2*cols] fp32; nblk returned by
  * dxa_norm_bwd_blocks(rows)); reduce them with dxa_colsum.
  * ---------------------------------------------------------------------------------------------- */
 int dxa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t cols,
                     float eps, int dtype, int w_dtype, dxa_stream_t stream);
 int dxa_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
-                    float* partial_dw, int64_t rows, int64_t cols, int dtype, int w_dtype,
+                    const void* residual, float* partial_dw, int64_t rows, int64_t cols, int dtype, int w_dtype,
                     dxa_stream_t stream);
 int dxa_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
                       int64_t rows, int64_t cols, float eps, int dtype, int w_dtype, dxa_stream_t stream);
 int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
-                      void* dx, float* partial_dwdb, int64_t rows, int64_t cols, int dtype, int w_dtype,
-                      dxa_stream_t stream);
+                      void* dx, const void* residual, float* partial_dwdb, int64_t rows, int64_t cols, int dtype,
+                      int w_dtype, dxa_stream_t stream);
 int dxa_norm_bwd_blocks(int64_t rows);
 /* out[c] (+)= sum_r x[r*ld + c]   (bias gradients, norm-weight gradients, pos-emb gradients).
  * Deterministic two-stage reduction; scratch >= min(64, ceil(rows/128)) * cols floats. */

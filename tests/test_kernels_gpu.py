@@ -310,6 +310,11 @@ def test_rmsnorm(dtype, wdtype, rows, cols):
     dx, dw = K.rmsnorm_bwd(dy, x, w, rstd)
     assert_close(dx, xr.grad, rtol, atol * 2, "rmsnorm dx")
     assert_close(dw, wr.grad, rtol, atol * math.sqrt(rows), "rmsnorm dw")
+    # residual branch folded into the kernel: dx + res in one rounding, same weight gradient
+    res = rnd(rows, cols, dtype=dtype, seed=28)
+    dx2, dw2 = K.rmsnorm_bwd(dy, x, w, rstd, residual=res)
+    assert_close(dx2, xr.grad + res.double(), rtol, atol * 2, "rmsnorm dx + residual")
+    assert torch.equal(dw2, dw)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -333,6 +338,11 @@ def test_layernorm(dtype, affine, rows, cols):
     if affine:
         assert_close(dw, wr.grad, rtol, atol * math.sqrt(rows), "layernorm dw")
         assert_close(db, br.grad, rtol, atol * math.sqrt(rows), "layernorm db")
+    res = rnd(rows, cols, dtype=dtype, seed=29)
+    dx2, dw2, db2 = K.layernorm_bwd(dy, x, w, mean, rstd, residual=res)
+    assert_close(dx2, xr.grad + res.double(), rtol, atol * 2, "layernorm dx + residual")
+    if affine:
+        assert torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
