@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("bias", _vp), ("residual", _vp), ("ldr", _i64), ("aux_out", _vp), ("mulgrad", _vp), ("ldg", _i64),
         ("alpha", _f32), ("accumulate", _i32), ("nb", _i32 * 3),
         ("sA", _i64 * 3), ("sB", _i64 * 3), ("sC", _i64 * 3), ("sR", _i64 * 3), ("sG", _i64 * 3),
-        ("epi_f32", _i32), ("mirror", _vp),
+        ("epi_f32", _i32), ("mirror", _vp), ("sumsq", _vp),
     ]
 
 
@@ -132,6 +132,9 @@ SIGNATURES = {
     "dxa_ddim_step": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _f32, _f32, _f32, _vp]),
     "dxa_adamw": (_int, [C.POINTER(AdamWDesc), _vp]),
     "dxa_sumsq": (_int, [_vp, _i64, _int, _vp, _vp, _int, _vp]),
+    "dxa_sumsq_ranges": (_int, [_vp, _int, _vp, _vp, _int, _vp, _vp, _int, _vp]),
+    "dxa_sum_f32": (_int, [_vp, _i64, _vp, _int, _vp]),
+    "dxa_gemm_sumsq_slots": (_i64, [_i64, _i64]),
     "dxa_cross_entropy_fwd": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "dxa_cross_entropy_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dxa_argmax_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),

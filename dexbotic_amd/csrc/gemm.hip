@@ -49,6 +49,7 @@ struct GemmP {
   int full, tail_r, split_s;
   int group_m;  // ring kernel: row-tiles per group of the tile order
   char* mirror; // bf16 copy of the fp32 output (same ldc), or null
+  float* sumsq; // fp32 output: per-tile sum of squares of the final C values (one float per 256x256 tile), or null
   float* ws;    // fp32 partial accumulators, tail_r * (split_s - 1) slots of 256x256
   int* flags;   // per tail tile arrival counter (self-resetting)
 };
@@ -937,7 +938,7 @@ template <> struct SkIO<bf16_t> {
 // whose epilogue carries the whole menu.
 template <typename TO, typename TE>
 __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2], char* slab, int lane, int wm, int wn,
-                                            int m0, int n0) {
+                                            int m0, int n0, float* red, int tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int CPL = 16 / (int)sizeof(TO);        // columns per lane: 16 bytes of output
   constexpr int LPR = 64 / CPL;                    // lanes per 64-column row (8 | 16)
@@ -965,6 +966,7 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
   const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.mirror ? p.mirror : (char*)p.C, 0,
                                                                       p.mirror ? (int)(((p.M - 1) * p.ldc + p.N) * 2) : 0, 0x00020000);
   const float alpha = p.alpha;
+  float ssq = 0.f;                                   // sum of squares of the values this lane stores (p.sumsq)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1009,6 +1011,10 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
 #if !(DXA_PPV & 32)
         SkIO<TO>::template st<CPL>(v, rC, oc);
         if constexpr (sizeof(TO) == 4) {
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) ssq += v[e] * v[e];
+          }
           if (has_mirror) {                                    // bf16 communication copy: 8 bytes per lane, same rows
             typedef uint32_t u32x2_t_ __attribute__((ext_vector_type(2)));
             const u32x2_t_ o2 = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -1021,6 +1027,23 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);   // passes stay in order: no hoisting of the next pass's work (register pressure)
     }
+  if constexpr (sizeof(TO) == 4) {
+    // global-norm clip: this tile's share of sum(g^2), folded lane -> wave -> workgroup in a fixed order and written to
+    // the tile's own slot (the host adds the slots in index order): the separate 30 GB pass over the gradient arena that
+    // used to read every dW back is not needed for gradients a single product writes
+    if (p.sumsq != nullptr) {                  // uniform over the workgroup
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o, 64);
+      if (lane == 0) red[wm * 4 + wn] = ssq;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) t += red[w8];
+        p.sumsq[tile] = t;
+      }
+    }
+  }
 #endif
 }
 
@@ -1299,7 +1322,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   if constexpr (LEAN) {
     if (!tile_split_exchange<4>(p, acc, tid, split_j, split_s, tail_i)) return;
     __builtin_amdgcn_sched_barrier(0);
-    sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i);
+    sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i, reinterpret_cast<float*>(smem + 8 * 4096), bid);
   } else {
     tile_finish<TO, 4, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
   }
@@ -1404,17 +1427,44 @@ inline bool strides_mult(const int64_t s[3], int64_t m) { return s[0] % m == 0 &
 }  // namespace
 
 namespace {
-int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored);
+int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, bool* summed);
+
+// sum of squares of C [M, N] (fp32, leading dimension ldc) into `slots` per-"tile" partials for products whose kernel has no
+// sum-of-squares epilogue: workgroup b folds rows b, b + slots, ... in a fixed order, so every slot is written
+__global__ __launch_bounds__(256) void sumsq_rows_k(const float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
+                                                    float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t r = blockIdx.x; r < M; r += gridDim.x) {
+    const float* row = C + r * ldc;
+    for (int64_t c = threadIdx.x; c < N; c += 256) { const float v = row[c]; s += v * v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+}
+extern "C" int64_t dxa_gemm_sumsq_slots(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  return ((M + 255) / 256) * ((N + 255) / 256);
 }
 extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
-  bool mirrored = false;
-  if (int rc = gemm_dispatch(d, stream, &mirrored)) return rc;
-  if (d->mirror && !mirrored && d->M > 0 && d->N > 0)   // kernels without the mirror epilogue: one narrow copy pass
-    return dxa_copy2d(d->C, d->ldc, d->mirror, d->ldc, d->M, d->N, d->N, DXA_F32, DXA_BF16, stream);
+  bool mirrored = false, summed = false;
+  if (int rc = gemm_dispatch(d, stream, &mirrored, &summed)) return rc;
+  if (d->mirror && !mirrored && d->M > 0 && d->N > 0) {   // kernels without the mirror epilogue: one narrow copy pass
+    if (int rc = dxa_copy2d(d->C, d->ldc, d->mirror, d->ldc, d->M, d->N, d->N, DXA_F32, DXA_BF16, stream)) return rc;
+  }
+  if (d->sumsq && !summed && d->M > 0 && d->N > 0) {      // ... and without the sum-of-squares epilogue: one read of C
+    hipLaunchKernelGGL(sumsq_rows_k, dim3((unsigned)dxa_gemm_sumsq_slots(d->M, d->N)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)d->C, d->ldc, d->M, d->N, d->sumsq);
+    DXA_CHECK_LAUNCH();
+  }
   return DXA_OK;
 }
 namespace {
-int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored) {
+int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, bool* summed) {
   DXA_CHECK_ARG(d != nullptr, "dxa_gemm: null desc");
   DXA_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "dxa_gemm: negative dims");
   DXA_CHECK_ARG(d->layout >= DXA_NT && d->layout <= DXA_TN, "dxa_gemm: bad layout %d", d->layout);
@@ -1441,6 +1491,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored) {
   p.G = (const char*)d->mulgrad; p.ldg = d->ldg;
   p.alpha = d->alpha; p.act = d->act; p.accumulate = d->accumulate;
   DXA_CHECK_ARG(!d->mirror || (d->out_dtype == DXA_F32 && nbatch == 1), "dxa_gemm: mirror needs an fp32, unbatched output");
+  DXA_CHECK_ARG(!d->sumsq || (d->out_dtype == DXA_F32 && nbatch == 1), "dxa_gemm: sumsq needs an fp32, unbatched output");
   p.nb1 = d->nb[1]; p.nb2 = d->nb[2];
   for (int i = 0; i < 3; ++i) {
     p.sA[i] = d->sA[i]; p.sB[i] = d->sB[i]; p.sC[i] = d->sC[i]; p.sR[i] = d->sR[i]; p.sG[i] = d->sG[i];
@@ -1534,6 +1585,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored) {
     hipLaunchKernelGGL((gemm_pp_kernel<TO_, TE_, LEAN_, AKS_, BKS_>), fgrid, dim3(512), RING_LDS, st, p);       \
   } while (0)
     if (lean) { p.mirror = (char*)d->mirror; *mirrored = d->mirror != nullptr; }
+    if (lean && d->out_dtype == DXA_F32) { p.sumsq = d->sumsq; *summed = d->sumsq != nullptr; }
     if (d->layout == DXA_NN) {          // dX = dY W: bf16 out (lean, or with the activation-gradient epilogue), fp32 out lean
       if (d->out_dtype == DXA_BF16) { if (lean) LAUNCH_PP(bf16_t, bf16_t, true, false, true); else LAUNCH_PP(bf16_t, bf16_t, false, false, true); }
       else LAUNCH_PP(float, bf16_t, true, false, true);

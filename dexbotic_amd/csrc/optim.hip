@@ -164,6 +164,33 @@ __global__ __launch_bounds__(256) void sumsq_stage2_k(const double* __restrict__
   }
   if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)red[0] : (float)red[0];
 }
+// sum(x^2) over up to 4096 short ranges [start, start + len) of one arena: one workgroup per range -> one double partial
+// each, stage 2 folds them.  The slots of a gradient bucket that no GEMM epilogue accounts for (norm weights, biases,
+// position embeddings ...) are a handful of kilobyte-sized slices: one launch per bucket instead of one per slice.
+template <typename TG>
+__global__ __launch_bounds__(256) void sumsq_ranges_k(const TG* __restrict__ base, const int64_t* __restrict__ starts,
+                                                      const int64_t* __restrict__ lens, double* __restrict__ part) {
+  __shared__ float red[16];
+  const TG* x = base + starts[blockIdx.x];
+  const int64_t n = lens[blockIdx.x];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) { const float t = ldf<TG>(x + i); s += t * t; }
+  const float t = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = (double)t;
+}
+// out (+)= sum of n floats, one workgroup, double accumulation in a fixed order (the per-tile partials of dxa_gemm's sumsq)
+__global__ __launch_bounds__(1024) void sum_f32_k(const float* __restrict__ x, int64_t n, float* __restrict__ out, int accumulate) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)red[0] : (float)red[0];
+}
 __global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, float* __restrict__ norm_out,
                             float* __restrict__ coef_out) {
   const float norm = sqrtf(sumsq[0]);
@@ -208,6 +235,25 @@ extern "C" int dxa_sumsq(const void* x, int64_t n, int dtype, double* scratch, f
   if (dtype == DXA_BF16) hipLaunchKernelGGL(sumsq_stage1_k<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n, scratch);
   else hipLaunchKernelGGL(sumsq_stage1_k<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, scratch);
   hipLaunchKernelGGL(sumsq_stage2_k, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, out, accumulate);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_sumsq_ranges(const void* base, int dtype, const int64_t* starts, const int64_t* lens, int n_ranges,
+                                double* scratch, float* out, int accumulate, dxa_stream_t stream) {
+  DXA_CHECK_ARG(base && starts && lens && scratch && out && (dtype == DXA_F32 || dtype == DXA_BF16), "dxa_sumsq_ranges: bad args");
+  DXA_CHECK_ARG(n_ranges >= 0 && n_ranges <= 4096, "dxa_sumsq_ranges: 0..4096 ranges (got %d)", n_ranges);
+  if (n_ranges == 0) return DXA_OK;
+  if (dtype == DXA_BF16) hipLaunchKernelGGL(sumsq_ranges_k<bf16_t>, dim3(n_ranges), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)base, starts, lens, scratch);
+  else hipLaunchKernelGGL(sumsq_ranges_k<float>, dim3(n_ranges), dim3(256), 0, (hipStream_t)stream, (const float*)base, starts, lens, scratch);
+  hipLaunchKernelGGL(sumsq_stage2_k, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, n_ranges, out, accumulate);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_sum_f32(const float* x, int64_t n, float* out, int accumulate, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && out && n >= 0, "dxa_sum_f32: bad args");
+  hipLaunchKernelGGL(sum_f32_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out, accumulate);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

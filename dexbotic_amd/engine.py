@@ -77,6 +77,13 @@ class ParamStore:
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
         self.slots: Dict[str, Slot] = {}
+        self.epi_sumsq = False                  # the trainer turns it on: one GPU, clip enabled, no gradient accumulation
+        self._ssq_buf: Optional[torch.Tensor] = None
+        self._ssq_cursor = 0
+        self._ssq_covered: set = set()
+        self._excluded: set = set()
+        self._slot_order = None
+        self._slot_starts = None
         self.layernorm_modules: set = set()          # dotted module paths that are nn.LayerNorm in the reference
         self._groups: List[List[str]] = []
         self._cursor = 0
@@ -230,6 +237,7 @@ class ParamStore:
         """(re)count, per bucket, the slots a backward pass is expected to write: trainable and not in
         ``exclude`` (parameters the path never touches, e.g. lm_head / the unused last CLIP layer)."""
         exclude = set(exclude)
+        self._excluded = exclude
         self._bucket_total = [0] * len(self.bucket_ranges)
         for s in self.slots.values():
             if self.params[s.name].requires_grad and s.name not in exclude:
@@ -252,6 +260,59 @@ class ParamStore:
         self.begin_micro()
         for nm in zero_names:
             self.g(nm).zero_()
+        self._ssq_cursor = 0
+        self._ssq_covered = set()
+
+    # ---- sum(g^2) shares produced by the dW products' own epilogues (single-GPU global-norm clip) -------------------
+    def sumsq_out(self, names: Sequence[str], M: int, N: int) -> Optional[torch.Tensor]:
+        """where the product that writes g(*names) as an [M, N] matrix should leave the per-tile partial sums of squares of
+        what it writes (``dxa_gemm_desc.sumsq``), or None.  Only when that write is the slot's final value of the step:
+        nothing written to it yet and no other consumer of the parameter still owes a gradient (``note_use``)."""
+        if not self.epi_sumsq or self.grad is None or not self.grad.is_cuda:
+            return None
+        if self.grad_written[names[0]] or any(self._uses.get(nm, 0) > 1 for nm in names):
+            return None
+        from . import kernels as K
+        n = K.gemm_sumsq_slots(M, N)
+        if self._ssq_buf is None:
+            self._ssq_buf = torch.zeros(1 << 21, device=self.device, dtype=torch.float32)
+        if self._ssq_cursor + n > self._ssq_buf.numel():
+            return None                                   # full: this gradient is read back by the ordinary pass
+        out = self._ssq_buf[self._ssq_cursor:self._ssq_cursor + n]
+        self._ssq_cursor += n
+        self._ssq_covered.update(names)
+        return out
+
+    def sumsq_partials(self) -> Optional[torch.Tensor]:
+        """the partials handed out since begin_step (their plain sum is the covered slots' sum of squares)"""
+        if self._ssq_buf is None or self._ssq_cursor == 0:
+            return None
+        return self._ssq_buf[:self._ssq_cursor]
+
+    def uncovered_ranges(self, lo: int, hi: int) -> List[Tuple[int, int]]:
+        """[lo, hi) of the gradient arena minus the slots whose sum of squares an epilogue already produced this step and
+        minus the slots the path never writes (exact zeros); neighbours separated only by alignment padding (zeros) merge"""
+        if self._slot_order is None:
+            self._slot_order = sorted(self.slots.values(), key=lambda sl: sl.offset)
+            self._slot_starts = [sl.offset for sl in self._slot_order]
+        import bisect
+        i = bisect.bisect_left(self._slot_starts, lo)
+        out: List[Tuple[int, int]] = []
+        prev_covered = True
+        while i < len(self._slot_order) and self._slot_order[i].offset < hi:
+            sl = self._slot_order[i]
+            i += 1
+            skip = sl.name in self._ssq_covered or sl.name in self._excluded or not self.params[sl.name].requires_grad
+            if skip:
+                prev_covered = True
+                continue
+            a, b = sl.offset, min(sl.offset + sl.numel, hi)
+            if out and not prev_covered:
+                out[-1] = (out[-1][0], b)               # only padding in between
+            else:
+                out.append((a, b))
+            prev_covered = False
+        return out
 
     def zero_embed_grad(self, name: str) -> None:
         """make the dense embedding-gradient slice all-zero before this step's first scatter into it: only the rows
@@ -463,6 +524,9 @@ class GradNormTracker:
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._lo: Optional[int] = None
         self._hi: Optional[int] = None
+        self._range_cache: Dict[tuple, tuple] = {}
+
+    BIG = 1 << 18     # uncovered slices at least this long get the two-stage pass of their own, shorter ones share a launch
 
     def begin(self) -> None:
         self.acc.zero_()                       # on the compute stream; every fold waits for that stream first
@@ -481,7 +545,24 @@ class GradNormTracker:
             return
         self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
+            if not self.store.epi_sumsq:
+                K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
+                return
+            # the dW products already left their share in the store's partial buffer: read back only what they do not cover
+            small = []
+            for a, b in self.store.uncovered_ranges(lo, hi):
+                if b - a >= self.BIG:
+                    K.sumsq(src[a:b], self.acc, self.scratch, accumulate=True)
+                else:
+                    small.append((a, b - a))
+            for i in range(0, len(small), 4096):
+                chunk = tuple(small[i:i + 4096])
+                dev = self._range_cache.get(chunk)
+                if dev is None:
+                    dev = (torch.tensor([c[0] for c in chunk], dtype=torch.int64, device=src.device),
+                           torch.tensor([c[1] for c in chunk], dtype=torch.int64, device=src.device))
+                    self._range_cache[chunk] = dev
+                K.sumsq_ranges(src, dev[0], dev[1], self.acc, self.scratch, accumulate=True)
 
     def bucket_ready(self, b: int) -> None:
         lo, hi = self.store.bucket_ranges[b]
@@ -512,6 +593,12 @@ class GradNormTracker:
             self.fold(self._lo, self._hi)
             self._lo = self._hi = None
         if self.stream is not None:
+            part = st.sumsq_partials() if st.epi_sumsq else None
+            if part is not None:
+                from . import kernels as K
+                self.stream.wait_stream(torch.cuda.current_stream())        # the last products' epilogues
+                with torch.cuda.stream(self.stream):
+                    K.sum_f32(part, self.acc, accumulate=True)
             torch.cuda.current_stream().wait_stream(self.stream)
         return self.acc
 

@@ -79,10 +79,12 @@ def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) 
     out = st.g(*names, shape=shape)
     # bf16 data parallelism: the product's epilogue also writes the bf16 communication copy of this gradient
     mirror = st.mirror_out(*names, shape=shape)
+    # single-GPU clip: ... and this gradient's share of sum(g^2)
+    ssq = st.sumsq_out(names, out.shape[0], out.shape[1]) if out.dim() == 2 else None
     if _f32_nt(dy2d) and x2d.dtype == torch.float32:
-        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names), mirror=mirror)
+        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names), mirror=mirror, sumsq=ssq)
     else:
-        K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names), mirror=mirror)
+        K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names), mirror=mirror, sumsq=ssq)
     st.mark_written(*names)
 
 

@@ -91,12 +91,12 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
          alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = (1, 1, 1),
          sA: Sequence[int] = (0, 0, 0), sB: Sequence[int] = (0, 0, 0), sC: Sequence[int] = (0, 0, 0),
          sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0), epi_f32: bool = False,
-         mirror: Optional[torch.Tensor] = None) -> torch.Tensor:
+         mirror: Optional[torch.Tensor] = None, sumsq: Optional[torch.Tensor] = None) -> torch.Tensor:
     if not epi_f32 and _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb):
         a3, b3 = split3(a, M, K, lda, 0), split3(b, N, K, ldb, 1)
         return gemm(L.NT, a3, b3, M, N, 3 * K, 3 * K, 3 * K, out, ldc, bias=bias, residual=residual, ldr=ldr, act=act,
                     aux_out=aux_out, mulgrad=mulgrad, ldg=ldg, alpha=alpha, accumulate=accumulate, epi_f32=True,
-                    mirror=mirror)
+                    mirror=mirror, sumsq=sumsq)
     d = L.GemmDesc()
     d.layout, d.in_dtype, d.out_dtype, d.act = layout, dt(a), dt(out), act
     d.epi_f32 = int(epi_f32)
@@ -117,6 +117,11 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
                 _row_major(mirror, "mirror") != ldc:
             raise L.DxaError("gemm: mirror must be a bf16 [M, N] view with the output's leading dimension (fp32 output)")
         d.mirror = _ptr(mirror)
+    if sumsq is not None:
+        if sumsq.dtype != torch.float32 or out.dtype != torch.float32 or tuple(nb) != (1, 1, 1) or not sumsq.is_contiguous() \
+                or sumsq.numel() != gemm_sumsq_slots(M, N):
+            raise L.DxaError("gemm: sumsq must be gemm_sumsq_slots(M, N) contiguous floats (fp32, unbatched output)")
+        d.sumsq = _ptr(sumsq)
     for i in range(3):
         d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
     prof = GEMM_PROFILE
@@ -634,6 +639,26 @@ def sumsq(x: torch.Tensor, out: torch.Tensor, scratch: torch.Tensor, accumulate:
     assert x.is_contiguous() and scratch.dtype == torch.float64 and scratch.numel() >= 4096
     L.check(lib.dxa_sumsq(_ptr(x), x.numel(), dt(x), _ptr(scratch), _ptr(out), int(accumulate), _stream()), "dxa_sumsq")
     return out
+
+
+def sumsq_ranges(base: torch.Tensor, starts: torch.Tensor, lens: torch.Tensor, out: torch.Tensor, scratch: torch.Tensor,
+                 accumulate: bool = False) -> torch.Tensor:
+    """out (+)= sum over the slices base[starts[i] : starts[i] + lens[i]] of x^2 (int64 device arrays, <= 4096 slices)"""
+    assert base.is_contiguous() and starts.dtype == torch.int64 and lens.dtype == torch.int64 and starts.numel() == lens.numel()
+    assert scratch.dtype == torch.float64 and scratch.numel() >= 4096
+    L.check(lib.dxa_sumsq_ranges(_ptr(base), dt(base), _ptr(starts), _ptr(lens), starts.numel(), _ptr(scratch), _ptr(out),
+                                 int(accumulate), _stream()), "dxa_sumsq_ranges")
+    return out
+
+
+def sum_f32(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    assert x.is_contiguous() and x.dtype == torch.float32 and out.dtype == torch.float32
+    L.check(lib.dxa_sum_f32(_ptr(x), x.numel(), _ptr(out), int(accumulate), _stream()), "dxa_sum_f32")
+    return out
+
+
+def gemm_sumsq_slots(M: int, N: int) -> int:
+    return int(lib.dxa_gemm_sumsq_slots(M, N))
 
 
 def clip_coef(sumsq_t, max_norm: float, norm_out, coef_out):

@@ -47,6 +47,8 @@ class NativeTrainer:
         self.store.attach_grads()
         # single GPU: nobody but the splice backward writes the dense embedding gradient, so it can be re-zeroed row-wise
         self.store.sparse_embed_zero = self.reducer is None
+        # single GPU, one micro-batch per step: sum(g^2) of the weight gradients comes out of the dW products' epilogues
+        self.store.epi_sumsq = self.reducer is None and self.norm_tracker is not None and grad_accum == 1
         self.store.invalidate_embed_tracking()
         self._zeroed_unused = False
 

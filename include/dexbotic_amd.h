@@ -91,8 +91,14 @@ typedef struct dxa_gemm_desc {
                          communication copy of a weight gradient that the data-parallel reducer exchanges instead of the
                          fp32 values (the reference's DeepSpeed bf16 run reduces bf16 gradients, script/deepspeed/zero2.json);
                          written by the dW product's own epilogue, so no cast pass over the gradient arena exists */
+  float* sumsq;       /* fp32 output only, or NULL: dxa_gemm_sumsq_slots(M, N) floats, ALL of them written: partial sums of
+                         squares of the final C (after accumulate) whose total, added in index order, is sum(C^2) — the
+                         weight gradient's share of the global-norm clip (torch.nn.utils.clip_grad_norm_ in the reference's
+                         Trainer, dexbotic/exp/base_exp.py:250 max_grad_norm), produced by the dW product's own epilogue
+                         instead of a pass that reads the gradient back; deterministic (fixed fold order per slot) */
 } dxa_gemm_desc;
 int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream);
+int64_t dxa_gemm_sumsq_slots(int64_t M, int64_t N);
 
 /* fp32 product on the bf16 MFMA path ("bf16x3", the counterpart of the TF32 matmuls the reference's trainer enables
  * with tf32=True, dexbotic/exp/base_exp.py:254, for the fp32 action head under autocast(float32),
@@ -297,6 +303,12 @@ typedef struct dxa_adamw_desc {
 int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream);
 /* out[0] = sum x^2 over n fp32 / bf16 elements (deterministic two-stage; scratch >= 4096 doubles) */
 int dxa_sumsq(const void* x, int64_t n, int dtype, double* scratch, float* out, int accumulate, dxa_stream_t stream);
+/* the same over n_ranges <= 4096 short slices base[starts[i] .. starts[i] + lens[i]) (device arrays, element units): the
+ * slots of a gradient bucket that no dW epilogue accounts for (dxa_gemm_desc.sumsq), in one launch */
+int dxa_sumsq_ranges(const void* base, int dtype, const int64_t* starts, const int64_t* lens, int n_ranges, double* scratch,
+                     float* out, int accumulate, dxa_stream_t stream);
+/* out[0] (+)= sum of n floats: one workgroup, fixed order, double accumulation (folds dxa_gemm_desc.sumsq partials) */
+int dxa_sum_f32(const float* x, int64_t n, float* out, int accumulate, dxa_stream_t stream);
 /* norm = sqrt(sumsq); coef = min(1, max_norm/(norm+1e-6))  (torch.nn.utils.clip_grad_norm_) */
 int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream);
 int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream);

@@ -810,3 +810,45 @@ def test_dit_blocks_fused(cfg, offset):
         assert_close(out, ref, tol, tol * float(ref.abs().max()), f"fused DiT blocks {cfg} offset {offset} rep {rep}")
     with pytest.raises(L.DxaError):
         K.dit_blocks_fwd(torch.zeros(48, H, device=DEV), table, depth, 2, 24, H, heads, I, 1e-6)     # 48 rows: no spare row for the ones trick
+
+
+# --------------------------------------------------------------- sum(g^2) out of the dW product's epilogue
+@pytest.mark.parametrize("M,N,Kd,accum", [(512, 768, 300, False), (770, 520, 4592, True), (3584, 4608, 1024, False),
+                                         (70, 50, 96, False)])
+def test_gemm_sumsq_epilogue(M, N, Kd, accum):
+    """dxa_gemm_desc.sumsq: per-tile partials whose plain sum is sum(C^2) of the FINAL C (after accumulate); every slot is
+    written; reproducible bit for bit; kernels without that epilogue (last shape: generic tile kernel) take the fallback"""
+    dy = rnd(Kd, M, dtype=torch.bfloat16, seed=71)
+    x = rnd(Kd, N, dtype=torch.bfloat16, seed=72)
+    slots = K.gemm_sumsq_slots(M, N)
+    assert slots == ((M + 255) // 256) * ((N + 255) // 256)
+    outs = []
+    for rep in range(2):
+        out = rnd(M, N, seed=73).contiguous() if accum else torch.empty(M, N, device=DEV)
+        part = torch.full((slots,), float("nan"), device=DEV)
+        K.mm_tn(dy, x, out=out, accumulate=accum, sumsq=part)
+        assert torch.isfinite(part).all()
+        ref = out.double().pow(2).sum().item()
+        assert abs(part.double().sum().item() - ref) <= 1e-5 * ref
+        tot = torch.ones(1, device=DEV)
+        K.sum_f32(part, tot, accumulate=True)
+        assert abs(tot.item() - 1.0 - ref) <= 1e-5 * ref
+        outs.append((out, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(Exception):
+        K.mm_tn(dy, x, out=torch.empty(M, N, device=DEV), sumsq=torch.empty(slots + 1, device=DEV))
+
+
+def test_sumsq_ranges():
+    base = rnd(200000, seed=74)
+    starts = torch.tensor([0, 64, 1000, 150000, 199999], dtype=torch.int64, device=DEV)
+    lens = torch.tensor([10, 700, 0, 40001, 1], dtype=torch.int64, device=DEV)
+    scratch = torch.empty(4096, device=DEV, dtype=torch.float64)
+    out = torch.full((1,), 2.0, device=DEV)
+    K.sumsq_ranges(base, starts, lens, out, scratch, accumulate=True)
+    ref = sum(base[a:a + n].double().pow(2).sum().item() for a, n in zip(starts.tolist(), lens.tolist()))
+    assert abs(out.item() - 2.0 - ref) <= 1e-6 * ref
+    hb = base.bfloat16()
+    K.sumsq_ranges(hb, starts, lens, out, scratch)
+    ref = sum(hb[a:a + n].double().pow(2).sum().item() for a, n in zip(starts.tolist(), lens.tolist()))
+    assert abs(out.item() - ref) <= 1e-6 * ref

@@ -73,12 +73,17 @@ def test_rccl_reducer_path_equals_plain_step(golden_dir, algo):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         res = {}
-        for tag, force, comm in (("plain", False, torch.float32), ("fp32", True, torch.float32),
-                                 ("bf16", True, torch.bfloat16)):
+        for tag, force, comm in (("plain", False, torch.float32), ("plain_epi", False, torch.float32),
+                                 ("fp32", True, torch.float32), ("bf16", True, torch.bfloat16)):
             m = build_product(cfg, w, "float32", DEV, train=True)
             m.train()
             tr = _trainer(m, force_reducer=force, grad_comm_dtype=comm, min_bucket_bytes=1 << 16, grad_sync=algo)
             assert (tr.reducer is not None) == force
+            # one GPU without a reducer takes sum(g^2) from the dW epilogues (another summation order): "plain" is the
+            # read-back pass the reducer path also uses, "plain_epi" the default
+            assert m.store.epi_sumsq == (not force)
+            if tag == "plain":
+                m.store.epi_sumsq = False
             losses = [tr.step(_batch(g)).item() for _ in range(2)]
             torch.cuda.synchronize()
             res[tag] = (losses, tr.opt.norm.clone(), m.store.master.clone())
@@ -88,6 +93,10 @@ def test_rccl_reducer_path_equals_plain_step(golden_dir, algo):
         assert res["fp32"][0] == res["plain"][0]
         assert torch.equal(res["fp32"][1], res["plain"][1])
         assert torch.equal(res["fp32"][2], res["plain"][2])
+        # the epilogue sums give the same norm up to fp32 summation order, hence the same step up to that
+        assert abs(res["plain_epi"][1].item() - res["plain"][1].item()) <= 2e-6 * res["plain"][1].item()
+        assert res["plain_epi"][0][0] == res["plain"][0][0]
+        torch.testing.assert_close(res["plain_epi"][2], res["plain"][2], rtol=1e-5, atol=1e-7)
         # bf16 communication: gradients pass through one bf16 rounding (2^-9 relative per element)
         n_plain = res["plain"][1].item()
         assert abs(res["bf16"][1].item() - n_plain) <= 4e-3 * n_plain
