@@ -26,6 +26,9 @@
 namespace {
 
 typedef uint32_t u32x4n_t __attribute__((ext_vector_type(4)));   // native 16-byte vector (nontemporal builtins)
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 128;              // bytes per LDS row (K slab)
 constexpr int TILE_BYTES = BM * ROWB;  // 16 KiB per operand per buffer
@@ -378,6 +381,141 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 }
 
 // =====================================================================================================
+// Few-row bf16 NT kernel: 128x128 tiles, 4 waves, LDS-DMA ring.  The batch-1 action request runs every linear of the
+// ViT (2 x 257 tokens) and of the decoder prefill (S = 543) on a few hundred rows: 256-row tiles waste up to 29 % of
+// their MFMA work on padding (543 = 2 x 256 + 31) and leave most of the 256 CUs without a tile (3 x 18 for qkv, 3 x 14
+// for o_proj).  Here a workgroup of 4 waves (2 x 2, 64 x 64 per wave = 2 x 2 v_mfma_f32_32x32x16_bf16 blocks) owns a
+// 128 x 128 tile: 5 x 36 = 180 tiles for qkv.  K tile = 64 (whole 128-byte lines), operands staged by LDS-DMA into a ring
+// of FOUR 32 KiB stages (three K tiles = 96 KiB in flight: with one wave per SIMD nothing else hides the L2 latency),
+// same LDS image as the ping-pong kernel (16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7), swizzle applied on
+// the SOURCE address).  One barrier per K tile; inside a tile the fragment reads of k-step s+1 are in flight under the
+// MFMAs of k-step s (counted lgkmcnt).  The epilogue runs from the registers through epilogue4 (bias / activation / aux /
+// mulgrad / residual / accumulate: the whole menu).  Tiles are ordered row-tile fastest inside an XCD's contiguous run, so
+// the row tiles that share a weight panel hit the same L2.
+// Requirements: K % 64 == 0, 16-byte aligned A/B rows, no batching, operands < 2 GiB.
+// =====================================================================================================
+template <typename TO, int NS>
+__global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 32768, A_ST = 16384;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, lh = lane >> 5;
+  const int nt = p.tm * p.tn;
+  int bid = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int pm = bid % p.tm, pn = bid / p.tm;
+  const int m0 = pm * 128, n0 = pn * 128;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, (int)(((p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, (int)(((p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
+  // DMA instruction j of a wave covers tile rows (4 wave + j) * 8 .. + 7: lane -> (row = + lane / 8, LDS chunk slot = lane % 8,
+  // source chunk = slot ^ ((row >> 1) & 7))
+  uint32_t voA[4], voB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const uint32_t ch = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    const int ga = m0 + row, gb = n0 + row;
+    voA[j] = ga < (int)p.M ? (uint32_t)ga * (uint32_t)p.lda * 2u + ch : 0x80000000u;
+    voB[j] = gb < (int)p.N ? (uint32_t)gb * (uint32_t)p.ldb * 2u + ch : 0x80000000u;
+  }
+  const int nk = (int)(p.K >> 6);
+#define T1_DMA(slot, t)                                                                                                  \
+  do {                                                                                                                   \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + (slot) * STAGE + (wave * 4 + j_) * 1024), 16, voA[j_], (t) * 128, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + (slot) * STAGE + A_ST + (wave * 4 + j_) * 1024), 16, voB[j_], (t) * 128, 0, 0); \
+    }                                                                                                                    \
+  } while (0)
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int sw = (l32 >> 1) & 7;
+  const uint32_t ya = (lds0 + (wm * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
+  const uint32_t yb = (lds0 + A_ST + (wn * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
+#define T1_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define T1_SB() __builtin_amdgcn_sched_barrier(0)
+  // prologue: three K tiles in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) T1_DMA(s, s);
+  for (int t = 0; t < nk; ++t) {
+    const int rem = nk - 1 - t;                  // K tiles after this one (up to NS - 2 of them already requested)
+    if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T1_SB();
+    __builtin_amdgcn_s_barrier();                // tile t landed for every wave; every wave is done reading tile t - 1
+    T1_SB();
+    if (t + NS - 1 < nk) T1_DMA((t + NS - 1) % NS, t + NS - 1);
+    T1_SB();
+    const uint32_t so = (uint32_t)((t % NS) * STAGE);
+    const uint32_t a_s = ya + so, b_s = yb + so;
+    u32x4_t af[2][2], bf[2][2];                  // [k-step parity][block]
+    T1_READ(af[0][0], a_s, 0); T1_READ(af[0][1], a_s, 4096); T1_READ(bf[0][0], b_s, 0); T1_READ(bf[0][1], b_s, 4096);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks & 1, nx = c ^ 1;
+      if (ks < 3) {
+        const uint32_t a_k = a_s ^ (uint32_t)((ks + 1) << 5), b_k = b_s ^ (uint32_t)((ks + 1) << 5);
+        T1_READ(af[nx][0], a_k, 0); T1_READ(af[nx][1], a_k, 4096); T1_READ(bf[nx][0], b_k, 0); T1_READ(bf[nx][1], b_k, 4096);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      T1_SB();
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf[c][j]), __builtin_bit_cast(bf16x8_t, af[c][i]), acc[i][j], 0, 0, 0);
+      T1_SB();
+    }
+  }
+#undef T1_DMA
+#undef T1_READ
+#undef T1_SB
+  // ---- epilogue from the registers: lane (l32, lh) holds, per block (i, j), row 32 i + l32 and columns 32 j + 8 q + 4 lh + {0..3}
+  TO* C = reinterpret_cast<TO*>(p.C);
+  TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
+  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t n = n0 + wn * 64 + 32 * j + 8 * q + 4 * lh;
+      if (n >= p.N) continue;
+      const int n_ok = (int)min((int64_t)4, p.N - n);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + wm * 64 + 32 * i + l32;
+        if (m >= p.M) continue;
+        const float a4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+      }
+    }
+#endif
+}
+template __global__ void gemm_nt_t128_kernel<bf16_t, 2>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 2>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<bf16_t, 4>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 4>(const GemmP);
+
+// =====================================================================================================
 // Skinny fp32 NT kernel (M <= 64 rows): the DiT head at inference time is ~50 linears per DDIM step on 36 rows
 // (2 x 18 tokens), i.e. a stream over each weight matrix with almost no arithmetic.  The tiled kernel puts such a
 // problem on N/64 workgroups that each walk all of K serially (measured 44 us per call).  Here a workgroup owns
@@ -500,9 +638,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
 }
 
 constexpr int NUM_CU_D = 256;   // split-K scratch slots (one per CU)
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void_t;
 
 // Split-K hand-off of a tail tile: every piece but the last stores its fp32 partial (lane-linear slots, sc1 write-through)
 // and bumps the tile's arrival counter; the last piece waits for them and adds them in slice order.  Returns false for a
@@ -1530,6 +1665,43 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
                                          ((d->M - 1) * d->ldr + d->N) * (int64_t)ees < (1ll << 31)));
   const bool ks_ok = (d->layout == DXA_NN ? (d->out_dtype == DXA_BF16 || lean_ok) : lean_ok) && !d->epi_f32 && ks_layout && !ks_off && aligned_to(d->A, 16) && aligned_to(d->B, 16) && d->lda % 8 == 0 && d->ldb % 8 == 0 &&
                      (d->layout == DXA_TN || d->K % 64 == 0) && d->K >= 64;
+  // ---- few-row NT products (batch-1 prefill, ViT on a couple of images): 128x128 tiles fill the chip where 256-row tiles
+  //      cannot; any epilogue of the bf16 menu
+  static const bool t128_off = getenv("DXA_GEMM_NO_T128") != nullptr;
+  static const int t128_max_m = getenv("DXA_GEMM_T128_MAX_M") ? atoi(getenv("DXA_GEMM_T128_MAX_M")) : 1024;
+  // measured (scripts/gemm_bench.py pre, M = 543 / 514): wins where its tiles fit one round of the 256 CUs and K is short
+  // (qkv 45 vs 50 us, o_proj 44 vs 52, ViT fc1 20 vs 31); loses to the 192-row ring kernel + split-K tail on wide N or deep K
+  // (gate_up 211 vs 181, down 181 vs 120): an LDS-DMA instruction costs its wave 60-180 issue cycles, and a 128x128 tile
+  // needs twice as many of them per MFMA as a 256x256 tile
+  const int64_t t128_tiles = (int64_t)dxa_cdiv(d->M, 128) * dxa_cdiv(d->N, 128);
+  static const bool t128_all = getenv("DXA_GEMM_T128_NS") != nullptr;     // tuning: every admissible shape
+  if (!fast_off && !t128_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && !d->epi_f32 &&
+      d->M >= 64 && d->M <= t128_max_m && d->N >= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB &&
+      bytesA < (1ll << 31) && bytesB < (1ll << 31) &&
+      (t128_all || (t128_tiles >= 64 && t128_tiles <= NUM_CU && d->K <= 4096))) {
+    p.tm = dxa_cdiv(d->M, 128);
+    p.tn = dxa_cdiv(d->N, 128);
+    dim3 tgrid((unsigned)(p.tm * p.tn));
+    // two stages (64 KiB): two workgroups share a CU and hide each other's LDS-DMA issue and barriers; four stages when a CU
+    // gets one workgroup anyway
+    static const int force_ns = getenv("DXA_GEMM_T128_NS") ? atoi(getenv("DXA_GEMM_T128_NS")) : 0;
+    const int ns = force_ns ? force_ns : (p.tm * p.tn > NUM_CU ? 2 : 4);
+#define LAUNCH_T128(TO_, NS_)                                                                                        \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_t128_kernel<TO_, NS_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, NS_ * 32768);                            \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gemm_nt_t128_kernel<TO_, NS_>), tgrid, dim3(256), NS_ * 32768, st, p);                       \
+  } while (0)
+    if (ns == 2) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 2); else LAUNCH_T128(float, 2); }
+    else { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4); else LAUNCH_T128(float, 4); }
+#undef LAUNCH_T128
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   if (!fast_off && d->in_dtype == DXA_BF16 && nbatch == 1 &&
       ((d->layout == DXA_NT && d->K >= 32 && d->K % 32 == 0 && p.vecA && p.vecB) || ks_ok) &&
       d->M >= 64 && d->N >= 64 && (int64_t)d->M * d->N >= 128 * 128 && bytesA < (1ll << 31) && bytesB < (1ll << 31)) {

@@ -25,7 +25,7 @@ def main():
     norms = {"min": [-1.0] * 7, "max": [1.0] * 7}
     for use_graph in ([False, True] if mode == "both" else [mode == "graph"]):
         lat = []
-        for _ in range(25):
+        for _ in range(int(os.environ.get("REQS", "25"))):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             model.inference_action(b1["input_ids"], b1["images"], {"cfg_scale": 1.5, "num_ddim_steps": 10,

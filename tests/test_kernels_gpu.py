@@ -124,15 +124,16 @@ def test_gemm_ring_split_tail(shape, f32out):
             assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"split tail bf16 rep {rep}")
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 64), (512, 520, 128), (1000, 520, 192), (770, 129, 320), (4592, 4608, 3584),
-                                   (2304, 1024, 4608), (512, 2048, 18944), (700, 300, 4096)])
+@pytest.mark.parametrize("shape", [(1280, 256, 64), (1536, 520, 128), (2024, 520, 192), (1794, 129, 320), (4592, 4608, 3584),
+                                   (2304, 1024, 4608), (1536, 2048, 18944), (1724, 300, 4096)])
 @pytest.mark.parametrize("f32out", [False, True])
 def test_gemm_pingpong(shape, f32out):
     """bf16 NT ping-pong kernel (256-row tiles, K % 64 == 0): 1, 2, 3 and many K tiles (odd and even counts: the two LDS
     buffers alternate), ragged M / N edges, the split-K tail, fused epilogue, fp32 accumulate output; every output element
     against an fp64 reference, several repetitions (the staggered wave groups must never read a K tile early)"""
     M, N, Kd = shape
-    assert Kd % 64 == 0 and not (-(-M // 192) * 192 * 27 < -(-M // 256) * 256 * 25)   # dispatch: ping-pong main loop
+    # dispatch: ping-pong main loop (more than 1024 rows: below that the few-row 128x128 kernel takes NT products)
+    assert M > 1024 and Kd % 64 == 0 and not (-(-M // 192) * 192 * 27 < -(-M // 256) * 256 * 25)
     a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=35), rnd(N, Kd, dtype=torch.bfloat16, seed=36, scale=0.1)
     ref = a.double() @ w.double().t()
     first = None
@@ -852,3 +853,36 @@ def test_sumsq_ranges():
     K.sumsq_ranges(hb, starts, lens, out, scratch)
     ref = sum(hb[a:a + n].double().pow(2).sum().item() for a, n in zip(starts.tolist(), lens.tolist()))
     assert abs(out.item() - ref) <= 1e-6 * ref
+
+
+# ------------------------------------------------------------------- few-row NT kernel (128x128 tiles, M <= 1024)
+@pytest.mark.parametrize("shape", [(543, 4608, 3584), (543, 3584, 18944), (514, 1024, 4096), (514, 4096, 1024), (64, 64, 64),
+                                   (130, 300, 64), (1024, 200, 128), (700, 136, 192), (543, 37888, 3584)])
+def test_gemm_few_rows_t128(shape):
+    """bf16 NT products on a few hundred rows (batch-1 prefill S = 543, ViT on 2 x 257 tokens): 128x128-tile LDS-DMA ring
+    kernel; 1, 2, 3, 4 and many K tiles (the ring has 4 stages), ragged M / N, the whole epilogue menu (bias, residual,
+    activation + pre-activation copy, activation gradient, fp32 accumulate), every element against fp64, repetitions bitwise"""
+    M, N, Kd = shape
+    a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=91), rnd(N, Kd, dtype=torch.bfloat16, seed=92, scale=0.1)
+    ref = a.double() @ w.double().t()
+    rtol, atol = tol_for(torch.bfloat16, Kd)
+    bias, res = rnd(N, dtype=torch.bfloat16, seed=93), rnd(M, N, dtype=torch.bfloat16, seed=94)
+    first = None
+    for rep in range(3):
+        out = K.mm_nt(a, w, bias=bias, residual=res)
+        assert_close(out, ref + bias.double() + res.double(), 2 * rtol, 2 * atol, f"t128 bias+residual rep {rep}")
+        if first is None:
+            first = out.clone()
+        assert torch.equal(out, first), f"t128 result changed between repetitions (rep {rep})"
+    out32 = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+    K.mm_nt(a, w, out=out32, accumulate=True)
+    assert_close(out32, ref + 0.5, 2e-5, 2e-3 * math.sqrt(max(Kd, 320) / 320), "t128 f32 accumulate")
+    if N <= 8192:
+        pre = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+        y = K.mm_nt(a, w, bias=bias, act=3, aux_out=pre)                       # CLIP fc1: quick_gelu, pre-activation saved
+        assert_close(pre, ref + bias.double(), 2 * rtol, 2 * atol, "t128 aux")
+        assert_close(y, ACTS[3](ref + bias.double()), 2 * rtol, 2 * atol, "t128 act")
+        g = K.mm_nt(a, w, mulgrad=res, act=3)
+        xg = res.double().requires_grad_(True)
+        ACTS[3](xg).backward(ref)
+        assert_close(g, xg.grad, 3 * rtol, 3 * atol, "t128 mulgrad")
