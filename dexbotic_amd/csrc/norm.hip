@@ -235,9 +235,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ dy,
 
 // -------------------------------------------------------------------------------------------- colsum
 // stage 1: grid (col tiles of 256, row splits); block 256 = 4 waves; lane owns 4 consecutive columns
-template <typename T>
+// DIRECT: a single row split — the block's sums are the result: written (or accumulated) straight into `part` = out
+template <typename T, bool DIRECT = false>
 __global__ __launch_bounds__(256) void colsum_stage1_k(const T* __restrict__ x, int64_t ld, float* __restrict__ part,
-                                                       int64_t rows, int64_t cols, int vec) {
+                                                       int64_t rows, int64_t cols, int vec, int accumulate = 0) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c0 = (int64_t)blockIdx.x * 256 + lane * 4;
@@ -263,7 +264,11 @@ __global__ __launch_bounds__(256) void colsum_stage1_k(const T* __restrict__ x, 
   __syncthreads();
   const int t = threadIdx.x;
   const int64_t c = (int64_t)blockIdx.x * 256 + t;
-  if (c < cols) part[(int64_t)blockIdx.y * cols + c] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  if (c < cols) {
+    const float sum = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (DIRECT) part[c] = accumulate ? part[c] + sum : sum;
+    else part[(int64_t)blockIdx.y * cols + c] = sum;
+  }
 }
 __global__ void colsum_stage2_k(const float* __restrict__ part, float* __restrict__ out, int nsplit, int64_t cols,
                                 int accumulate) {
@@ -543,6 +548,17 @@ extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, i
   dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nsplit);
   const size_t es = dtype == DXA_BF16 ? 2 : 4;
   const int vec = ((reinterpret_cast<uintptr_t>(x) % (4 * es)) == 0) && (ld % 4 == 0);
+  if (rows <= 1024) {
+    // few rows (the per-workgroup partial rows of a norm backward: <= 512): one launch, same summation order for a given
+    // row count on every call (deterministic)
+    dim3 g1((unsigned)((cols + 255) / 256), 1);
+    if (dtype == DXA_BF16)
+      hipLaunchKernelGGL((colsum_stage1_k<bf16_t, true>), g1, dim3(256), 0, st, (const bf16_t*)x, ld, out, rows, cols, vec, accumulate);
+    else
+      hipLaunchKernelGGL((colsum_stage1_k<float, true>), g1, dim3(256), 0, st, (const float*)x, ld, out, rows, cols, vec, accumulate);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   if (dtype == DXA_BF16)
     hipLaunchKernelGGL((colsum_stage1_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ld, scratch, rows, cols, vec);
   else

@@ -288,8 +288,13 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw_out=None, db_out=None, accumulate: bo
     if part is None or not want_dw:
         return dx.view(x.shape), None, None
     if dw_out is not None:
-        colsum(part[:, :cols], out=dw_out, accumulate=accumulate)
-        colsum(part[:, cols:], out=db_out, accumulate=accumulate)
+        if db_out is not None and db_out.data_ptr() == dw_out.data_ptr() + 4 * cols:
+            # weight and bias gradient slots lie back to back (they are registered as one group): one column sum
+            both = torch.as_strided(dw_out, (2 * cols,), (1,))
+            colsum(part, out=both, accumulate=accumulate)
+        else:
+            colsum(part[:, :cols], out=dw_out, accumulate=accumulate)
+            colsum(part[:, cols:], out=db_out, accumulate=accumulate)
         return dx.view(x.shape), dw_out, db_out
     s = colsum(part)
     return dx.view(x.shape), s[:cols], s[cols:]
