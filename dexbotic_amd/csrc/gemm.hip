@@ -1276,28 +1276,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #else
 #define PP_LOOP(x) x
 #endif
-#define PP_DMA_A(h, buf, tile)                                                                              \
+#define PP_DMA_A1(h, j, buf, tile)                                                                          \
   do {                                                                                                      \
     if constexpr (A_KS) {                                                                                   \
       const uint32_t kb_ = (uint32_t)(k_lo + (tile)) * ktileA;                                              \
-      PP_DMA(rA, voA[h][0] + kb_, (h) * 16384 + (wave * 2 + 0) * 1024, buf, 0);                             \
-      PP_DMA(rA, voA[h][1] + kb_, (h) * 16384 + (wave * 2 + 1) * 1024, buf, 0);                             \
+      PP_DMA(rA, voA[h][j] + kb_, (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);                           \
     } else {                                                                                                \
-      PP_DMA(rA, voA[h][0], PP_A_ROW0(h, 0) * 128, buf, (k_lo + (tile)) * 128);                             \
-      PP_DMA(rA, voA[h][1], PP_A_ROW0(h, 1) * 128, buf, (k_lo + (tile)) * 128);                             \
+      PP_DMA(rA, voA[h][j], PP_A_ROW0(h, j) * 128, buf, (k_lo + (tile)) * 128);                             \
     }                                                                                                       \
   } while (0)
-#define PP_DMA_B(h, buf, tile)                                                                              \
+#define PP_DMA_B1(h, j, buf, tile)                                                                          \
   do {                                                                                                      \
     if constexpr (B_KS) {                                                                                   \
       const uint32_t kb_ = (uint32_t)(k_lo + (tile)) * ktileB;                                              \
-      PP_DMA(rB, voB[h][0] + kb_, REG + (h) * 16384 + (wave * 2 + 0) * 1024, buf, 0);                       \
-      PP_DMA(rB, voB[h][1] + kb_, REG + (h) * 16384 + (wave * 2 + 1) * 1024, buf, 0);                       \
+      PP_DMA(rB, voB[h][j] + kb_, REG + (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);                     \
     } else {                                                                                                \
-      PP_DMA(rB, voB[h][0], REG + PP_B_ROW0(h, 0) * 128, buf, (k_lo + (tile)) * 128);                       \
-      PP_DMA(rB, voB[h][1], REG + PP_B_ROW0(h, 1) * 128, buf, (k_lo + (tile)) * 128);                       \
+      PP_DMA(rB, voB[h][j], REG + PP_B_ROW0(h, j) * 128, buf, (k_lo + (tile)) * 128);                       \
     }                                                                                                       \
   } while (0)
+#define PP_DMA_A(h, buf, tile) do { PP_DMA_A1(h, 0, buf, tile); PP_DMA_A1(h, 1, buf, tile); } while (0)
+#define PP_DMA_B(h, buf, tile) do { PP_DMA_B1(h, 0, buf, tile); PP_DMA_B1(h, 1, buf, tile); } while (0)
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -1402,22 +1400,48 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #else
 #define PP_M(reads, dma) do { reads; PP_SB(); dma; PP_SB(); } while (0)
 #endif
+  // The eight LDS-DMA instructions a wave issues per K tile, in their (fixed) order: slots 0-1 = B1(t+1), 2-3 = A1(t+1) into
+  // the other buffer, 4-5 = A0(t+2), 6-7 = B0(t+2) into this one.  They are dealt to the four memory clusters as PPD0..PPD3
+  // instructions: M0 already carries 12 fragment reads, M1 4, M2 8 and M3 none, and a memory cluster longer than the other
+  // group's compute cluster (8 MFMAs = 256 cycles) stalls the MFMA pipe — so the DMA issue goes where the reads are few
+  // (default 1, 2, 2, 3; DXA_PPD=2222 is the even deal).  Slots 4-7 overwrite bytes read in M0 of this tile: not before M2.
+#ifndef DXA_PPD
+#define DXA_PPD 1223
+#endif
+  constexpr int PPD0 = DXA_PPD / 1000, PPD1 = DXA_PPD / 100 % 10, PPD2 = DXA_PPD / 10 % 10, PPD3 = DXA_PPD % 10;
+  static_assert(PPD0 + PPD1 + PPD2 + PPD3 == 8 && PPD0 + PPD1 <= 4, "eight LDS-DMA instructions per K tile; slots 4-7 from phase 2 on");
+#define PP_SLOT(k, cur, t)                                                                                  \
+  do {                                                                                                      \
+    if ((k) < 4 ? more1 : more2) {                                                                          \
+      if ((k) == 0) PP_LOOP(PP_DMA_B1(1, 0, (cur) ^ 1, (t) + 1));                                           \
+      else if ((k) == 1) PP_LOOP(PP_DMA_B1(1, 1, (cur) ^ 1, (t) + 1));                                      \
+      else if ((k) == 2) PP_LOOP(PP_DMA_A1(1, 0, (cur) ^ 1, (t) + 1));                                      \
+      else if ((k) == 3) PP_LOOP(PP_DMA_A1(1, 1, (cur) ^ 1, (t) + 1));                                      \
+      else if ((k) == 4) PP_LOOP(PP_DMA_A1(0, 0, cur, (t) + 2));                                            \
+      else if ((k) == 5) PP_LOOP(PP_DMA_A1(0, 1, cur, (t) + 2));                                            \
+      else if ((k) == 6) PP_LOOP(PP_DMA_B1(0, 0, cur, (t) + 2));                                            \
+      else PP_LOOP(PP_DMA_B1(0, 1, cur, (t) + 2));                                                          \
+    }                                                                                                       \
+  } while (0)
+#define PP_SLOTS(from, to, cur, t) do { _Pragma("unroll") for (int k_ = (from); k_ < (to); ++k_) PP_SLOT(k_, cur, t); } while (0)
+#define PP_VMCNT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define PP_TILE(cur, t)                                                                                     \
   do {                                                                                                      \
     const bool more1 = (t) + 1 < nk, more2 = (t) + 2 < nk;                                                  \
     /* phase 0 */                                                                                           \
-    PP_M(PP_RD_A(cur, 0); PP_RD_B(cur, 0), if (more1) { PP_LOOP(PP_DMA_B(1, (cur) ^ 1, (t) + 1)); });       \
-    if (more1) { PP_VMCNT(8); } else { PP_VMCNT(2); }                 /* B1(t) landed */                    \
+    PP_M(PP_RD_A(cur, 0); PP_RD_B(cur, 0), PP_SLOTS(0, PPD0, cur, t));                                      \
+    /* B1(t) landed: younger = A1(t) (2) + A0, B0 of t+1 (4) + this tile's slots so far */                  \
+    if (more1) { PP_VMCNT_N(6 + PPD0); } else { PP_VMCNT(2); }                                              \
     PP_BAR(); PP_COMPUTE(0, 0); PP_BAR();                                                                   \
     /* phase 1 */                                                                                           \
-    PP_M(PP_RD_B(cur, 1), if (more1) { PP_LOOP(PP_DMA_A(1, (cur) ^ 1, (t) + 1)); });                        \
-    if (more1) { PP_VMCNT(8); } else { PP_VMCNT(0); }                 /* A1(t) landed */                    \
+    PP_M(PP_RD_B(cur, 1), PP_SLOTS(PPD0, PPD0 + PPD1, cur, t));                                             \
+    if (more1) { PP_VMCNT_N(4 + PPD0 + PPD1); } else { PP_VMCNT(0); }     /* A1(t) landed */               \
     PP_BAR(); PP_COMPUTE(0, 1); PP_BAR();                                                                   \
     /* phase 2 */                                                                                           \
-    PP_M(PP_RD_A(cur, 1), if (more2) { PP_LOOP(PP_DMA_A(0, cur, (t) + 2)); });                              \
+    PP_M(PP_RD_A(cur, 1), PP_SLOTS(PPD0 + PPD1, PPD0 + PPD1 + PPD2, cur, t));                               \
     PP_BAR(); PP_COMPUTE(1, 1); PP_BAR();                                                                   \
     /* phase 3: B0 fragments are still in bq[0] */                                                          \
-    PP_M(, if (more2) { PP_LOOP(PP_DMA_B(0, cur, (t) + 2)); });                                             \
+    PP_M(, PP_SLOTS(PPD0 + PPD1 + PPD2, 8, cur, t));                                                        \
     if (more2) { PP_VMCNT(8); } else if (more1) { PP_VMCNT(4); }      /* A0(t+1), B0(t+1) landed */         \
     PP_BAR(); PP_COMPUTE(1, 0); PP_BAR();                                                                   \
   } while (0)
@@ -1452,6 +1476,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #undef PP_COMPUTE
 #undef PP_VMCNT
 #undef PP_TILE
+#undef PP_SLOT
+#undef PP_SLOTS
+#undef PP_VMCNT_N
+#undef PP_DMA_A1
+#undef PP_DMA_B1
 #undef PP_M
 
   if constexpr (LEAN) {
