@@ -371,7 +371,8 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
     @torch.no_grad()
     def generate(self, input_ids, images=None, max_new_tokens: int = 64, do_sample: bool = False,
                  temperature: float = 1.0, eos_token_id: Optional[int] = None, stopping_criteria=None,
-                 return_dict_in_generate: bool = False, generator: Optional[torch.Generator] = None, **kwargs):
+                 return_dict_in_generate: bool = False, generator: Optional[torch.Generator] = None,
+                 attention_mask=None, **kwargs):
         """Token-by-token continuation over a KV cache — the subset of GenerationMixin.generate the reference uses
         (discrete_vla_arch.py:33-41: batch 1, greedy or temperature sampling, stopping criteria on the decoded tail).
         Prefill = vision tower + splice + decoder with the cache filled; each step = one cached decoder pass on the
@@ -379,18 +380,28 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         dev = self.store.device
         imgs = images.to(device=dev, dtype=self.store.compute_dtype)
         feats = self.model._extract_vision_features(imgs)
-        plan = build_splice_plan(input_ids.detach().cpu().numpy(), None, None, feats.shape[1],
+        plan = build_splice_plan(input_ids.detach().cpu().numpy(),
+                                 None if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool),
+                                 None, feats.shape[1],
                                  getattr(self.config, "tokenizer_model_max_length", None),
                                  getattr(self.config, "tokenizer_padding_side", "right"))
         B, S = plan.plan.shape
+        pad = None
         if not plan.attention_mask.all():
-            raise NotImplementedError("generate(): prompts of unequal length need per-sample key ranges in the cache")
+            # prompts of unequal length: HF's generate wants them LEFT padded (new tokens continue every prompt directly);
+            # every sample then attends to its own key range [pad_b, ...) of the cache and counts positions from its
+            # first real token.  Right-padded batches leave a hole between prompt and continuation: refused.
+            if not (plan.attention_mask[:, -1].all() and
+                    all(plan.attention_mask[b, int(plan.kv_start[b]):].all() for b in range(B))):
+                raise ValueError("generate(): a batch of unequal-length prompts must be LEFT padded "
+                                 "(tokenizer.padding_side = 'left'), as with HF generate")
+            pad = [int(v) for v in plan.kv_start]
         llm = self.model.llm
         embed = self.store.params[llm.embed_name]
         x = Fn.SpliceFn.apply(feats, embed, self.store, llm.embed_name,
                               torch.from_numpy(plan.plan.reshape(-1)).to(dev)).view(B, S, -1)
         cache = llm.new_cache(B, S + max_new_tokens, dev, x.dtype)
-        last = llm.forward_cached(x, cache)[:, -1].contiguous()
+        last = llm.forward_cached(x, cache, pad)[:, -1].contiguous()
         W_lm, W_emb = self.store.w("lm_head.weight"), self.store.w(llm.embed_name)
         seq = input_ids.to(dev)
         new_tokens, step_logits = [], []
@@ -410,7 +421,7 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
                 done = any(bool(torch.as_tensor(sc(seq, None)).all()) for sc in stopping_criteria)
             if done:
                 break
-            last = llm.forward_cached(W_emb[nxt].view(B, 1, -1), cache)[:, -1].contiguous()
+            last = llm.forward_cached(W_emb[nxt].view(B, 1, -1), cache, pad)[:, -1].contiguous()
         if return_dict_in_generate:
             return GenerateOutput(sequences=seq, logits=tuple(step_logits) if step_logits else None)
         return seq

@@ -8,7 +8,7 @@ final norm — ``hidden_states[-1]`` is post-norm).  Parameter
 from __future__ import annotations
 
 from dataclasses import dataclass, asdict
-from typing import Optional
+from typing import Sequence, Optional
 
 import torch
 import torch.nn as nn
@@ -126,18 +126,30 @@ class Qwen2Backbone(nn.Module):
         return KVCache(c.num_hidden_layers, batch, c.num_key_value_heads, max_len, c.head_dim, device, dtype)
 
     @torch.no_grad()
-    def forward_cached(self, inputs_embeds: torch.Tensor, cache: "KVCache") -> torch.Tensor:
+    def forward_cached(self, inputs_embeds: torch.Tensor, cache: "KVCache", pad: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Prefill (S > 1) or decode (S = 1) step over a key/value cache: the use_cache=True path of HF Qwen2Model
         that GenerationMixin.generate drives (discrete_vla_arch.py:33-41).  Post-RoPE keys and values of every
         layer are appended at positions [cache.length, cache.length + S); attention is causal over the whole cache
-        (queries sit at the END of the key range).  No padding support: generation runs at batch 1 or on equal-length
-        prompts, like the reference's single-request inference."""
+        (queries sit at the END of the key range).
+        ``pad``: per-sample count of LEFT padding slots in front of the prompt (prompts of unequal length in one batch,
+        right-aligned like HF's generate wants them): sample b attends to the keys [pad[b], total) only and its rotary
+        positions count from its first real token, position = slot - pad[b] — what HF derives from the attention mask
+        (GenerationMixin: position_ids = attention_mask.cumsum(-1) - 1)."""
         B, S, d = inputs_embeds.shape
         past, total = cache.length, cache.length + S
         if total > cache.max_len:
             raise ValueError(f"KV cache of {cache.max_len} positions cannot take {total}")
         cos_all, sin_all = self.rope_tables(total, inputs_embeds.device)
         cos_t, sin_t = cos_all[past:total], sin_all[past:total]
+        pos = kv_start = kv_end = None
+        if pad is not None and any(int(p_) != 0 for p_ in pad):
+            dev = inputs_embeds.device
+            padt = torch.tensor([int(p_) for p_ in pad], dtype=torch.int32, device=dev)
+            slots = torch.arange(past, total, dtype=torch.int32, device=dev)
+            pos = (slots.view(1, S) - padt.view(B, 1)).clamp_(min=0).reshape(-1).contiguous()      # row of the full tables
+            cos_t, sin_t = cos_all, sin_all
+            kv_start = padt
+            kv_end = torch.full((B,), total, dtype=torch.int32, device=dev)
         st = self.store
         x = inputs_embeds.reshape(B * S, d).contiguous()
         for i, sp in enumerate(self.layer_specs):
@@ -145,12 +157,12 @@ class Qwen2Backbone(nn.Module):
             nq = (Hq + 2 * Hkv) * D
             h1, _ = K.rmsnorm_fwd(x, st.w(sp.ln1), sp.eps)
             qkv = K.mm_nt(h1, st.w(*sp.qkv_w, shape=(nq, d)), bias=st.w(*sp.qkv_b, shape=(nq,)))
-            q, k, v = K.rope_split(qkv, cos_t, sin_t, None, B, S, Hq, Hkv, D)
+            q, k, v = K.rope_split(qkv, cos_t, sin_t, pos, B, S, Hq, Hkv, D)
             cache.k[i][:, :, past:total].copy_(k)
             cache.v[i][:, :, past:total].copy_(v)
             o = torch.empty((B, S, Hq, D), device=x.device, dtype=x.dtype)
             K.attn_fwd(q, cache.k[i][:, :, :total], cache.v[i][:, :, :total], o.permute(0, 2, 1, 3), causal=True,
-                       scale=D ** -0.5)
+                       scale=D ** -0.5, kv_start=kv_start, kv_end=kv_end)
             x2 = K.mm_nt(o.view(B * S, Hq * D), st.w(sp.o_w), residual=x)
             h2, _ = K.rmsnorm_fwd(x2, st.w(sp.ln2), sp.eps)
             a = K.swiglu_fwd(K.mm_nt(h2, st.w(*sp.gu_w, shape=(2 * F_, d))))

@@ -67,6 +67,32 @@ def test_fp32_greedy_decode_token_ids_exact(golden_dir):
     assert seq.shape[1] == L0 + 3 and int(seq[0, -1]) == eos
 
 
+def test_generate_left_padded_unequal_prompts(golden_dir):
+    """a batch of two prompts of different length (left padded + attention mask, like HF generate wants them): each sample
+    continues exactly as it does alone — per-sample key ranges in the cache and rotary positions counted from the first
+    real token; right-padded batches are refused"""
+    g, cfg, w = load_lm_golden(golden_dir)
+    m = build_lm_product(cfg, w, "float32", DEV, train=False)
+    m.eval()
+    long_p = g["decode_prompt"][0]
+    short_p = np.concatenate([long_p[:-3], long_p[-1:]])          # same image placeholder, three text tokens fewer
+    assert (short_p == -200).sum() == (long_p == -200).sum() == 1
+    n_new = 6
+    img = T(g["images"][:1])
+    alone = [m.generate(T(p_[None]), images=img, max_new_tokens=n_new)[0, len(p_):].cpu().numpy() for p_ in (long_p, short_p)]
+    pad = len(long_p) - len(short_p)
+    ids = np.stack([long_p, np.concatenate([np.zeros(pad, dtype=long_p.dtype), short_p])])
+    mask = np.ones_like(ids, dtype=bool)
+    mask[1, :pad] = False
+    m.config.tokenizer_padding_side = "left"
+    seq = m.generate(T(ids), images=torch.cat([img, img]), max_new_tokens=n_new, attention_mask=T(mask))
+    assert np.array_equal(seq[0, ids.shape[1]:].cpu().numpy(), alone[0])
+    assert np.array_equal(seq[1, ids.shape[1]:].cpu().numpy(), alone[1])
+    m.config.tokenizer_padding_side = "right"
+    with pytest.raises(ValueError):
+        m.generate(T(ids), images=torch.cat([img, img]), max_new_tokens=2, attention_mask=T(mask))
+
+
 class _FakeTokenizer:
     """ids -> text: token i decodes to ' {i % 255}', id 7 is the stop string '</s>'"""
     bos_token_id = None
