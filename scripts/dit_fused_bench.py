@@ -11,7 +11,7 @@ from dexbotic_amd import kernels as K  # noqa: E402
 
 
 def main():
-    N, T1, H, heads, I, depth = 2, 17, 768, 12, 3072, 12
+    N, T1, H, heads, I, depth = int(os.environ.get("DIT_N", "2")), int(os.environ.get("DIT_T", "17")), 768, 12, 3072, 12
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
