@@ -724,6 +724,8 @@ class GradReducer:
             return
         n = buf.numel()
         per = n // w
+        if per >= 64:
+            per -= per % 16            # every rank's shard starts on a 32-byte boundary of the slice (bf16: 16 elements)
         if self.algo == "allreduce" or per == 0:
             self._avg(buf, native_avg)
             self.collectives += 1

@@ -183,7 +183,11 @@ def test_cosine_and_bucket_layout():
     assert st.accum_flag("blk0.w") and not st.accum_flag("blk0.b")
 
 
-def test_torchrun_launch_contract_dry_run():
+import pytest
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_torchrun_launch_contract_dry_run(nproc):
     """the driver's multi-GPU launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py ...), dry-run on CPU: scripts/dp_dryrun.py reads the same environment as bench.py,
     uses gloo instead of RCCL and runs the rank-sharded reducer step (RS+AG, fp32 and bf16 exchange)"""
@@ -191,10 +195,10 @@ def test_torchrun_launch_contract_dry_run():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
                         "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "scripts", "dp_dryrun.py")],
                        capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["dryrun"] == "ok" and out["world"] == 2
+    assert out["dryrun"] == "ok" and out["world"] == nproc
