@@ -57,7 +57,12 @@ def main():
             s = st.slots[n]
             got = arena[s.offset:s.offset + s.numel].float().view(s.shape)
             mean = sum((g[n].to(comm).float() if comm == torch.bfloat16 else g[n]) for g in gathered) / world
-            ok &= bool(torch.allclose(got, mean, rtol=2e-2 if comm == torch.bfloat16 else 1e-6, atol=1e-6))
+            # bf16 exchange: every partial sum of the ring is rounded to bf16 (2^-9 of the running sum per step)
+            ok_n = bool(torch.allclose(got, mean, rtol=2e-2, atol=4e-2)) if comm == torch.bfloat16 else \
+                bool(torch.allclose(got, mean, rtol=1e-5, atol=1e-6))
+            if not ok_n:
+                print(f"rank {rank}: {n} {comm} max abs err {(got - mean).abs().max().item():.3e}", flush=True)
+            ok &= ok_n
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.barrier()
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)               # bench.py reports the max over ranks
