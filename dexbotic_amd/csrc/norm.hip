@@ -433,6 +433,59 @@ static int check_norm_dtypes(int dtype, int w_dtype, const char* who) {
   return DXA_OK;
 }
 
+namespace {
+// bf16 rows of up to 8192 columns (cols % 8 == 0): the wave requests its whole row at once (16 bytes per lane per request, all
+// of them in flight together), keeps it in registers for the statistics and the normalisation: ONE read of x, no second pass
+template <typename TW>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_fast_k(const bf16_t* __restrict__ x, const TW* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd_out, int64_t rows,
+                                                          int64_t cols, float eps) {
+  constexpr int NIT = 16;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * cols;
+  u32x4 v[NIT];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t c = ((int64_t)it * 64 + lane) * 8;
+    v[it] = c < cols ? *reinterpret_cast<const u32x4*>(xr + c) : (u32x4){0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = __uint_as_float(v[it][e] << 16), b = __uint_as_float(v[it][e] & 0xffff0000u);
+      ss += a * a + b * b;
+    }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)cols + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+  bf16_t* yr = y + row * cols;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t c = ((int64_t)it * 64 + lane) * 8;
+    if (c < cols) {
+      float g0[4] = {1.f, 1.f, 1.f, 1.f}, g1[4] = {1.f, 1.f, 1.f, 1.f};
+      if (w) {
+        Vec<TW, 4>::ld(g0, w + c);
+        Vec<TW, 4>::ld(g1, w + c + 4);
+      }
+      const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = __uint_as_float(v[it][e] << 16), b = __uint_as_float(v[it][e] & 0xffff0000u);
+        o[e] = pack_bf16x2(g[2 * e] * rnd<bf16_t>(a * rstd), g[2 * e + 1] * rnd<bf16_t>(b * rstd));
+      }
+      *reinterpret_cast<u32x4*>(yr + c) = o;
+    }
+  }
+}
+}  // namespace
+
 extern "C" int dxa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t cols,
                                float eps, int dtype, int w_dtype, dxa_stream_t stream) {
   if (int rc = check_norm_dtypes(dtype, w_dtype, "dxa_rmsnorm_fwd")) return rc;
@@ -441,6 +494,12 @@ extern "C" int dxa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
   hipStream_t st = (hipStream_t)stream;
   const bool vec_ok = al16(x) && al16(y) && (!w || al16(w));
   dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == DXA_BF16 && vec_ok && cols % 8 == 0 && cols <= 8192) {
+    if (w_dtype == DXA_BF16) hipLaunchKernelGGL((rmsnorm_fwd_fast_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, cols, eps);
+    else hipLaunchKernelGGL((rmsnorm_fwd_fast_k<float>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)w, (bf16_t*)y, rstd, rows, cols, eps);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   if (dtype == DXA_BF16 && w_dtype == DXA_BF16) {
     if (vec_ok && cols % 4 == 0) hipLaunchKernelGGL((rmsnorm_fwd_k<bf16_t, bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, cols, eps);
     else hipLaunchKernelGGL((rmsnorm_fwd_k<bf16_t, bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, cols, eps);
