@@ -58,7 +58,7 @@ class AttnDesc(C.Structure):
         ("dk", _vp), ("dk_sb", _i64), ("dk_sh", _i64), ("dk_ss", _i64),
         ("dv", _vp), ("dv_sb", _i64), ("dv_sh", _i64), ("dv_ss", _i64),
         ("force_generic", _i32),
-        ("q_limit", _vp), ("key_valid", _vp),
+        ("q_limit", _vp), ("key_valid", _vp), ("drop_mask", _vp),
     ]
 
 

@@ -32,6 +32,7 @@ struct AttnP {
   const int32_t* kv_end;
   const int32_t* q_limit;      // [B,Sq] or NULL: query i sees keys j < q_limit[b,i] (block-prefix masks, pi0)
   const uint8_t* key_valid;    // [B,Sk] or NULL: key j takes part at all (padding / missing camera)
+  const void* drop_mask;       // [B,Hq,Sq,Sk] or NULL: attention dropout, P <- P * mask (0 or 1 / (1 - p)) after the softmax
 };
 
 // ------------------------------------------------------------------------------------ generic forward
@@ -88,7 +89,13 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_k(const AttnP p) {
   sum = wave_sum(sum);
   const bool any = sum > 0.f;
   const float inv = any ? 1.f / sum : 0.f;
-  for (int j = j0 + lane; j < j1; j += 64) ps[j] = rnd<T>(ps[j] * inv);
+  // attention dropout (torch SDPA: dropout on the attention weights AFTER the softmax; the normaliser is untouched)
+  const T* dm = p.drop_mask ? reinterpret_cast<const T*>(p.drop_mask) + row * p.Sk : nullptr;
+  for (int j = j0 + lane; j < j1; j += 64) {
+    float pj = rnd<T>(ps[j] * inv);
+    if (dm) pj = rnd<T>(pj * ldf<T>(dm + j));
+    ps[j] = pj;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   for (int d = lane; d < p.D; d += 64) {
@@ -320,13 +327,19 @@ __global__ __launch_bounds__(256) void attn_delta_k(const T* __restrict__ dO, in
   if (lane == 0) delta[row] = s;
 }
 // dS = P * (dP - delta) * scale   (dP fp32 -> dS dtype T)
+// with attention dropout (mask m): dP <- dP * m before the softmax backward, and P is overwritten with P * m, the matrix
+// dV = (P * m)^T dO needs (delta = rowsum(dO * O) already equals rowsum(P * m * dP))
 template <typename T>
-__global__ __launch_bounds__(256) void attn_ds_k(const T* __restrict__ P, const float* __restrict__ dP,
-                                                 const float* __restrict__ delta, T* __restrict__ dS, int64_t rows, int Sk, float scale) {
+__global__ __launch_bounds__(256) void attn_ds_k(T* __restrict__ P, const float* __restrict__ dP,
+                                                 const float* __restrict__ delta, T* __restrict__ dS, int64_t rows, int Sk, float scale,
+                                                 const T* __restrict__ mask) {
   const int64_t total = rows * Sk;
   for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
     const int64_t row = it / Sk;
-    stf<T>(dS + it, ldf<T>(P + it) * (dP[it] - delta[row]) * scale);
+    const float pv = ldf<T>(P + it);
+    const float m = mask ? ldf<T>(mask + it) : 1.f;
+    stf<T>(dS + it, pv * (dP[it] * m - delta[row]) * scale);
+    if (mask) stf<T>(P + it, pv * m);
   }
 }
 
@@ -673,7 +686,7 @@ AttnP make_params(const dxa_attn_desc* d) {
   p.v = (const char*)d->v; p.v_sb = d->v_sb; p.v_sh = d->v_sh; p.v_ss = d->v_ss;
   p.o = (char*)d->o; p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_ss = d->o_ss;
   p.lse = d->lse; p.kv_start = d->kv_start; p.kv_end = d->kv_end;
-  p.q_limit = d->q_limit; p.key_valid = d->key_valid;
+  p.q_limit = d->q_limit; p.key_valid = d->key_valid; p.drop_mask = d->drop_mask;
   return p;
 }
 
@@ -698,7 +711,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
   const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
                         d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
                         d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
-  const bool flash_ok = !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && strides8 &&
+  const bool flash_ok = !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && strides8 &&
                         al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
   if (flash_ok) {
     dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
@@ -732,7 +745,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
 static bool bwd_flash_ok(const dxa_attn_desc* d) {
   auto s8 = [](int64_t a, int64_t b, int64_t c) { return a % 8 == 0 && b % 8 == 0 && c % 8 == 0; };
   auto s4 = [](int64_t a, int64_t b, int64_t c) { return a % 4 == 0 && b % 4 == 0 && c % 4 == 0; };
-  return !d->force_generic && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && d->B <= 65535 && d->Hq <= 65535 &&
+  return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && d->B <= 65535 && d->Hq <= 65535 &&
          s8(d->q_sb, d->q_sh, d->q_ss) && s8(d->k_sb, d->k_sh, d->k_ss) && s8(d->v_sb, d->v_sh, d->v_ss) &&
          s8(d->do_sb, d->do_sh, d->do_ss) && s4(d->o_sb, d->o_sh, d->o_ss) && s4(d->dq_sb, d->dq_sh, d->dq_ss) &&
          s4(d->dk_sb, d->dk_sh, d->dk_ss) && s4(d->dv_sb, d->dv_sh, d->dv_ss) && al(d->q, 16) && al(d->k, 16) &&
@@ -841,9 +854,9 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     dim3 grid(dxa_grid1d((int64_t)n, 256));
     const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
     if (d->dtype == DXA_BF16)
-      hipLaunchKernelGGL((attn_ds_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)P, Sf, delta, (bf16_t*)dS, rows, d->Sk, d->scale);
+      hipLaunchKernelGGL((attn_ds_k<bf16_t>), grid, dim3(256), 0, st, (bf16_t*)P, Sf, delta, (bf16_t*)dS, rows, d->Sk, d->scale, (const bf16_t*)d->drop_mask);
     else
-      hipLaunchKernelGGL((attn_ds_k<float>), grid, dim3(256), 0, st, (const float*)P, Sf, delta, (float*)dS, rows, d->Sk, d->scale);
+      hipLaunchKernelGGL((attn_ds_k<float>), grid, dim3(256), 0, st, (float*)P, Sf, delta, (float*)dS, rows, d->Sk, d->scale, (const float*)d->drop_mask);
   }
   // 6. dQ = dS K  (NN), batch (b, hkv, g)
   reset(DXA_NN, d->dtype);

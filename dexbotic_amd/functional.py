@@ -818,15 +818,17 @@ class AddFn(Function):
 class AttnFn(Function):
     """softmax(q k^T / sqrt(D)) v for [B,S,H,D] VIEWS (any strides with D contiguous) -> [B,Sq,H*D]: the cross
     attention of CrossTransformerBlock (memvla_arch.py:84-127) and of the DiT per-attention (nn.MultiheadAttention,
-    memvla/action_model/dit.py:158-185)"""
+    memvla/action_model/dit.py:158-185).  ``drop_mask`` ([B,H,Sq,Sk], entries 0 or 1/(1-p)): SDPA's dropout_p on the
+    attention weights (memvla_arch.py:120-123), the mask drawn by the caller."""
 
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, drop_mask=None):
         B, Sq, H, D = q.shape
         o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
         lse = K.attn_fwd(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), o.permute(0, 2, 1, 3),
-                         causal=False, scale=D ** -0.5)
+                         causal=False, scale=D ** -0.5, drop_mask=drop_mask)
         ctx.save_for_backward(q, k, v, o, lse)
+        ctx.drop_mask = drop_mask
         return o.view(B, Sq, H * D)
 
     @staticmethod
@@ -837,8 +839,24 @@ class AttnFn(Function):
         dq, dk, dv = torch.empty(q.shape, device=q.device, dtype=q.dtype), torch.empty(k.shape, device=q.device, dtype=q.dtype), \
             torch.empty(v.shape, device=q.device, dtype=q.dtype)
         P = lambda t: t.permute(0, 2, 1, 3)
-        K.attn_bwd(P(q), P(k), P(v), P(o), lse, P(do), P(dq), P(dk), P(dv), causal=False, scale=D ** -0.5)
-        return dq, dk, dv
+        K.attn_bwd(P(q), P(k), P(v), P(o), lse, P(do), P(dq), P(dk), P(dv), causal=False, scale=D ** -0.5,
+                   drop_mask=ctx.drop_mask)
+        return dq, dk, dv, None
+
+
+class DropFn(Function):
+    """x * mask with mask entries 0 or 1/(1-p): nn.Dropout with the mask drawn by the caller (the FFN of the retrieval
+    blocks, memvla_arch.py:99-105)"""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return K.mul(x.contiguous(), mask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return K.mul(dy.contiguous(), mask), None
 
 
 class GateFuseFn(Function):

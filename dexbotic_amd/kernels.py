@@ -340,7 +340,7 @@ def _bhsd_strides(t: torch.Tensor) -> Tuple[int, int, int]:
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit=None, key_valid=None) -> L.AttnDesc:
+def _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit=None, key_valid=None, drop_mask=None) -> L.AttnDesc:
     d = L.AttnDesc()
     B, Hq, Sq, D = q.shape
     _, Hkv, Sk, _ = k.shape
@@ -356,23 +356,26 @@ def _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit=None, k
     if key_valid is not None:
         assert key_valid.dtype == torch.uint8 and key_valid.is_contiguous() and key_valid.shape == (B, Sk)
     d.q_limit, d.key_valid = _ptr(q_limit), _ptr(key_valid)
+    if drop_mask is not None:
+        assert drop_mask.dtype == q.dtype and drop_mask.is_contiguous() and drop_mask.shape == (B, Hq, Sq, Sk)
+        d.drop_mask = _ptr(drop_mask)
     return d
 
 
 def attn_fwd(q, k, v, o, *, causal: bool, scale: float, kv_start=None, kv_end=None, force_generic=False,
-             q_limit=None, key_valid=None):
+             q_limit=None, key_valid=None, drop_mask=None):
     """q/k/v/o: [B,H,S,D] views (token-major or head-major memory); returns lse [B,Hq,Sq] fp32"""
     B, Hq, Sq, _ = q.shape
     lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32)
-    d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit, key_valid)
+    d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit, key_valid, drop_mask)
     d.force_generic = int(force_generic)
     L.check(lib.dxa_attn_fwd(C.byref(d), _stream()), "dxa_attn_fwd")
     return lse
 
 
 def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, causal: bool, scale: float, kv_start=None, kv_end=None,
-             force_generic=False, q_limit=None, key_valid=None):
-    d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit, key_valid)
+             force_generic=False, q_limit=None, key_valid=None, drop_mask=None):
+    d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit, key_valid, drop_mask)
     d.force_generic = int(force_generic)
     d.d_o, (d.do_sb, d.do_sh, d.do_ss) = _ptr(do), _bhsd_strides(do)
     d.dq, (d.dq_sb, d.dq_sh, d.dq_ss) = _ptr(dq), _bhsd_strides(dq)

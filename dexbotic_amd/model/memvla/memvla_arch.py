@@ -44,9 +44,9 @@ class MemVLAConfig(CogActConfig):
         self.per_token_size, self.dataloader_type, self.group_size = per_token_size, dataloader_type, group_size
         self.mem_length, self.retrieval_layers, self.use_timestep_pe = mem_length, retrieval_layers, use_timestep_pe
         self.fusion_type, self.consolidate_type, self.update_fused = fusion_type, consolidate_type, update_fused
-        self.retrieval_dropout = retrieval_dropout
-        if retrieval_dropout:
-            raise NotImplementedError("attention / FFN dropout inside the retrieval blocks is not reproduced")
+        # dropout of the retrieval blocks (memvla_arch.py:83: the reference constructs them with dropout=0.1, not configurable):
+        # 0.1 trains like the reference; 0.0 (default) is the deterministic setting the round-1 goldens pin
+        self.retrieval_dropout = float(retrieval_dropout)
 
 
 register_with_hf(MemVLAConfig)
@@ -82,12 +82,17 @@ class BottleneckSE(nn.Module):
 
 
 class CrossTransformerBlock(nn.Module):
-    """memvla_arch.py:84-127 (dropout 0): post-LN cross attention, 4 heads, GELU(erf) FFN"""
+    """memvla_arch.py:84-127: post-LN cross attention, 4 heads, GELU(erf) FFN.  ``dropout`` p > 0: SDPA's dropout on the
+    attention weights (:120-123) and the two nn.Dropout of the FFN (:99-105), applied while training; the masks come from
+    ``mask_fn(shape) -> tensor of 0 | 1/(1-p)`` (default: a device draw), in the order attention, FFN hidden, FFN output.
+    The reference also hands dropout_p to SDPA in eval (stochastic inference); here eval is deterministic."""
 
-    def __init__(self, store: ParamStore, prefix: str, feature_dim: int, num_heads: int = 4):
+    def __init__(self, store: ParamStore, prefix: str, feature_dim: int, num_heads: int = 4, dropout: float = 0.0):
         super().__init__()
         assert feature_dim % num_heads == 0, "feature_dim % num_heads must be 0"
         self.store, self.p, self.D, self.H = store, prefix, feature_dim, num_heads
+        self.dropout = float(dropout)
+        self.mask_fn = None
         D = feature_dim
         for n in ("q_proj", "k_proj", "v_proj"):
             store.register([(prefix + n + ".weight", (D, D)), (prefix + n + ".bias", (D,))])
@@ -96,20 +101,34 @@ class CrossTransformerBlock(nn.Module):
         store.register([(prefix + "ffn.3.weight", (D, 4 * D)), (prefix + "ffn.3.bias", (D,))])
         store.register([(prefix + "ffn_norm.weight", (D,)), (prefix + "ffn_norm.bias", (D,))], layernorm=True)
 
+    def _mask(self, shape, like: torch.Tensor) -> torch.Tensor:
+        if self.mask_fn is not None:
+            m = self.mask_fn(tuple(shape))
+            return torch.as_tensor(m).to(device=like.device, dtype=like.dtype).reshape(shape).contiguous()
+        keep = torch.rand(shape, device=like.device) >= self.dropout
+        return (keep.to(torch.float32) / (1.0 - self.dropout)).to(like.dtype)
+
     def forward(self, query: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         st, p, D, H = self.store, self.p, self.D, self.H
         B, N, _ = query.shape
         M = k.shape[1]
         hd = D // H
+        drop = self.dropout > 0.0 and self.training
         q2 = query.reshape(B * N, D)
         qp = _lin(st, q2, p + "q_proj.weight", p + "q_proj.bias").view(B, N, H, hd)
         kp = _lin(st, k.reshape(B * M, D), p + "k_proj.weight", p + "k_proj.bias").view(B, M, H, hd)
         vp = _lin(st, v.reshape(B * M, D), p + "v_proj.weight", p + "v_proj.bias").view(B, M, H, hd)
-        o = Fn.AttnFn.apply(qp, kp, vp).reshape(B * N, D)
+        o = Fn.AttnFn.apply(qp, kp, vp, self._mask((B, H, N, M), qp) if drop else None).reshape(B * N, D)
         anchor = st.params[p + "attn_norm.weight"]
         x = Fn.NormFn.apply(Fn.AddFn.apply(q2, o), anchor, st, "ln", p + "attn_norm.weight", p + "attn_norm.bias", 1e-5)
-        f = Fn.MlpFn.apply(x, anchor, st, p + "ffn.0.weight", p + "ffn.0.bias", p + "ffn.3.weight", p + "ffn.3.bias",
-                           L.ACT_GELU_ERF)
+        if drop:
+            h = _lin(st, x, p + "ffn.0.weight", p + "ffn.0.bias", L.ACT_GELU_ERF)
+            h = Fn.DropFn.apply(h, self._mask((B * N, 4 * D), h))
+            f = _lin(st, h, p + "ffn.3.weight", p + "ffn.3.bias")
+            f = Fn.DropFn.apply(f, self._mask((B * N, D), f))
+        else:
+            f = Fn.MlpFn.apply(x, anchor, st, p + "ffn.0.weight", p + "ffn.0.bias", p + "ffn.3.weight", p + "ffn.3.bias",
+                               L.ACT_GELU_ERF)
         y = Fn.NormFn.apply(Fn.AddFn.apply(x, f), anchor, st, "ln", p + "ffn_norm.weight", p + "ffn_norm.bias", 1e-5)
         return y.view(B, N, D)
 
@@ -120,7 +139,7 @@ class PerCogMemBank(nn.Module):
 
     def __init__(self, store: ParamStore, dataloader_type: str, group_size: int, per_token_size: int, cog_token_size: int,
                  mem_length: int = 16, retrieval_layers: int = 2, use_timestep_pe: bool = True, fusion_type: str = "gate",
-                 consolidate_type: str = "tome", update_fused: bool = True):
+                 consolidate_type: str = "tome", update_fused: bool = True, retrieval_dropout: float = 0.0):
         super().__init__()
         assert dataloader_type in ("stream", "group", "parallel_stream")
         assert fusion_type in ("gate", "add") and consolidate_type in ("fifo", "tome")
@@ -134,7 +153,8 @@ class PerCogMemBank(nn.Module):
         self.retrieval_layers, self.consolidate_type, self.update_fused = retrieval_layers, consolidate_type, update_fused
         self.token_dim = {"per": per_token_size, "cog": cog_token_size}
         store.new_bucket()
-        self.blocks = {r: [CrossTransformerBlock(store, f"{BANK}retrieval_blocks.{r}.{i}.", self.token_dim[r])
+        self.blocks = {r: [CrossTransformerBlock(store, f"{BANK}retrieval_blocks.{r}.{i}.", self.token_dim[r],
+                                                 dropout=retrieval_dropout)
                            for i in range(retrieval_layers)] for r in self.roles}
         for r in self.roles:
             D = self.token_dim[r]
@@ -151,6 +171,20 @@ class PerCogMemBank(nn.Module):
 
     def reset(self):
         self.banks: Dict[str, Dict[tuple, List[Tuple[torch.Tensor, torch.Tensor]]]] = {r: {} for r in self.roles}
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        for blks in self.blocks.values():           # held in a plain dict (the parameters live in the arena)
+            for b in blks:
+                b.train(mode)
+        return self
+
+    def set_mask_fn(self, fn) -> None:
+        """tests: ``fn(shape) -> array of 0 | 1/(1-p)`` replaces the device draw of every dropout mask of the retrieval blocks
+        (called in the order the blocks run: per sample, per role, per layer: attention, FFN hidden, FFN output)"""
+        for blks in self.blocks.values():
+            for b in blks:
+                b.mask_fn = fn
 
     # ---- pieces -------------------------------------------------------------------------------------------
     def _encode_time(self, role: str, t: torch.Tensor, dtype) -> torch.Tensor:
@@ -243,7 +277,8 @@ class MemVLAModel(CogActModel):
             self.per_cog_mem_bank = PerCogMemBank(
                 store, config.dataloader_type, config.group_size, config.per_token_size, config.hidden_size,
                 config.mem_length, config.retrieval_layers, config.use_timestep_pe, config.fusion_type,
-                config.consolidate_type, getattr(config, "update_fused", True))
+                config.consolidate_type, getattr(config, "update_fused", True),
+                retrieval_dropout=float(getattr(config, "retrieval_dropout", 0.0) or 0.0))
         if action_type is not None:
             self.action_head = self._build_action_head_module(config)
 

@@ -180,6 +180,10 @@ typedef struct dxa_attn_desc {
    * per-key validity.  Either may be NULL.  With one of them set the generic kernels run. */
   const int32_t* q_limit;   /* [B,Sq]: query i attends keys j < q_limit[b,i] */
   const uint8_t* key_valid; /* [B,Sk]: 0 = key j is padding / a missing camera */
+  /* attention dropout as torch SDPA applies it (dropout_p on the weights after the softmax): the retrieval blocks of
+   * MemVLA, dexbotic/model/memvla/memvla_arch.py:120-123.  [B,Hq,Sq,Sk] contiguous in the attention dtype, entries 0 or
+   * 1/(1-p), drawn by the caller; NULL = no dropout.  Runs the generic kernels. */
+  const void* drop_mask;
 } dxa_attn_desc;
 int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream);
 size_t dxa_attn_bwd_workspace(const dxa_attn_desc* d);

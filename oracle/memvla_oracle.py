@@ -84,8 +84,11 @@ def bottleneck_se(sd: SD, x: torch.Tensor, prefix: str = "model.per_compr.") -> 
     return F.linear(y, w("reduce.2.weight").flatten(1), w("reduce.2.bias"))
 
 
-def cross_block(sd: SD, bp: str, query: torch.Tensor, k_in: torch.Tensor, v_in: torch.Tensor, heads: int = 4) -> torch.Tensor:
-    """CrossTransformerBlock (memvla_arch.py:84-127), dropout 0: post-LN cross attention + GELU(erf) FFN"""
+def cross_block(sd: SD, bp: str, query: torch.Tensor, k_in: torch.Tensor, v_in: torch.Tensor, heads: int = 4,
+                mask_fn=None) -> torch.Tensor:
+    """CrossTransformerBlock (memvla_arch.py:84-127): post-LN cross attention + GELU(erf) FFN.  ``mask_fn(shape)`` (training
+    with the reference's dropout 0.1 left on): the three dropout masks (0 | 1/(1-p)) in the order the reference draws them —
+    SDPA's dropout on the attention weights (:120-123), nn.Dropout after the GELU and after the second FFN linear (:99-105)"""
     B, N, D = query.shape
     M = k_in.shape[1]
     hd = D // heads
@@ -93,9 +96,12 @@ def cross_block(sd: SD, bp: str, query: torch.Tensor, k_in: torch.Tensor, v_in: 
     k = F.linear(k_in, sd[bp + "k_proj.weight"], sd[bp + "k_proj.bias"]).reshape(B, M, heads, hd).transpose(1, 2)
     v = F.linear(v_in, sd[bp + "v_proj.weight"], sd[bp + "v_proj.bias"]).reshape(B, M, heads, hd).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+    draw = (lambda t_: t_ * torch.as_tensor(mask_fn(tuple(t_.shape))).to(t_.dtype)) if mask_fn is not None else (lambda t_: t_)
+    att = draw(att)
     o = (att @ v).transpose(1, 2).reshape(B, N, D)
     x = F.layer_norm(query + o, (D,), sd[bp + "attn_norm.weight"], sd[bp + "attn_norm.bias"], 1e-5)
-    f = F.linear(F.gelu(F.linear(x, sd[bp + "ffn.0.weight"], sd[bp + "ffn.0.bias"])), sd[bp + "ffn.3.weight"], sd[bp + "ffn.3.bias"])
+    h = draw(F.gelu(F.linear(x, sd[bp + "ffn.0.weight"], sd[bp + "ffn.0.bias"])))
+    f = draw(F.linear(h, sd[bp + "ffn.3.weight"], sd[bp + "ffn.3.bias"]))
     return F.layer_norm(x + f, (D,), sd[bp + "ffn_norm.weight"], sd[bp + "ffn_norm.bias"], 1e-5)
 
 
@@ -110,8 +116,9 @@ def encode_time(sd: SD, role: str, t: torch.Tensor) -> torch.Tensor:
 class MemBank:
     """PerCogMemBank state + _process_batch (memvla_arch.py:190-409), gate fusion, token-merge consolidation"""
 
-    def __init__(self, mem_length: int, retrieval_layers: int = 2, dataloader_type: str = "group"):
+    def __init__(self, mem_length: int, retrieval_layers: int = 2, dataloader_type: str = "group", mask_fn=None):
         self.mem_length, self.retrieval_layers, self.dataloader_type = mem_length, retrieval_layers, dataloader_type
+        self.mask_fn = mask_fn                    # training with retrieval dropout: see cross_block
         self.banks = {"per": {}, "cog": {}}
 
     def reset(self):
@@ -153,7 +160,8 @@ class MemBank:
                 pe = encode_time(sd, role, timesteps[i].reshape(1))[None].repeat_interleave(N, dim=1)
             q = working
             for li in range(self.retrieval_layers):
-                q = cross_block(sd, f"{BANK}retrieval_blocks.{role}.{li}.", q, mem + pe, mem)
+                q = cross_block(sd, f"{BANK}retrieval_blocks.{role}.{li}.", q, mem + pe, mem,
+                                mask_fn=self.mask_fn if training else None)
             gp = f"{BANK}gate_fusion_blocks.{role}."
             scale = torch.sigmoid(F.linear(torch.cat([working, q], -1), sd[gp + "proj.weight"], sd[gp + "proj.bias"]))
             fused = scale * working + (1 - scale) * q

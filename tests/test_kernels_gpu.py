@@ -886,3 +886,30 @@ def test_gemm_few_rows_t128(shape):
         xg = res.double().requires_grad_(True)
         ACTS[3](xg).backward(ref)
         assert_close(g, xg.grad, 3 * rtol, 3 * atol, "t128 mulgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_dropout_mask(dtype):
+    """dxa_attn_desc.drop_mask: torch SDPA's dropout on the attention weights (after the softmax, normaliser untouched) with the
+    mask handed in, forward and backward, against autograd on the written-out formula"""
+    B, H, Sq, Sk, D, p = 2, 4, 9, 21, 16, 0.1
+    q, k, v = (rnd(B, H, s_, D, dtype=dtype, seed=100 + i) for i, s_ in enumerate((Sq, Sk, Sk)))
+    do = rnd(B, H, Sq, D, dtype=dtype, seed=104)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    mask = ((torch.rand(B, H, Sq, Sk, generator=g) >= p).float() / (1 - p)).to(DEV).to(dtype)
+    o = torch.empty_like(q)
+    lse = K.attn_fwd(q, k, v, o, causal=False, scale=D ** -0.5, drop_mask=mask)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    w = torch.softmax(qr @ kr.transpose(-1, -2) * D ** -0.5, dim=-1) * mask.double()
+    ref = w @ vr
+    rtol, atol = (1e-5, 1e-5) if dtype == torch.float32 else (1.0 / 64, 2e-2)
+    assert_close(o, ref, rtol, atol, "attention + dropout mask fwd")
+    ref.backward(do.double())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=False, scale=D ** -0.5, drop_mask=mask)
+    for got, want, nm in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+        assert_close(got, want, rtol * 2, atol * 2, f"attention + dropout mask {nm}")
+    # without the mask the same call is the plain attention
+    o2 = torch.empty_like(q)
+    K.attn_fwd(q, k, v, o2, causal=False, scale=D ** -0.5, force_generic=True)
+    assert_close(o2, torch.softmax(q.double() @ k.double().transpose(-1, -2) * D ** -0.5, dim=-1) @ v.double(), rtol, atol, "no mask")

@@ -21,7 +21,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a)).to(DEV)
 
 
-def build(golden_dir, dtype, train):
+def build(golden_dir, dtype, train, retrieval_dropout=0.0):
     from dexbotic_amd.model.memvla.memvla_arch import MemVLAConfig, MemVLAForCausalLM
     g = np.load(os.path.join(golden_dir, "memvla_t1.npz"), allow_pickle=False)
     cfg = O.OracleConfig()
@@ -32,7 +32,7 @@ def build(golden_dir, dtype, train):
                       action_model_type="DiT-T", action_dim=cfg.action_dim, chunk_size=cfg.chunk_size,
                       compute_dtype=dtype, per_token_size=int(g["per_token_size"]), dataloader_type="group", group_size=3,
                       mem_length=int(g["mem_length"]), retrieval_layers=2, use_timestep_pe=True, fusion_type="gate",
-                      consolidate_type="tome")
+                      consolidate_type="tome", retrieval_dropout=retrieval_dropout)
     m = MemVLAForCausalLM(mc, device=DEV, train=train)
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in w.items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
@@ -57,6 +57,48 @@ def test_fp32_memvla_training_step_matches_reference(golden_dir):
             gn = float(g[key])
             assert st.grad_written[key[6:]], key
             assert abs(st.g(key[6:]).double().norm().item() - gn) < FP32_TOL * gn + 1e-6 * float(g["grad_norm"]), key
+
+
+def test_fp32_memvla_training_step_with_retrieval_dropout_matches_reference(golden_dir):
+    """retrieval_dropout = 0.1 = how the reference always trains (memvla_arch.py:83, 99-105, 120-123): attention-weight
+    dropout inside the attention kernels (dxa_attn_desc.drop_mask) and the two FFN dropouts, with the masks of the golden
+    run injected in the reference's order; eval stays deterministic"""
+    from oracle.gen_golden_memvla import MaskFeed
+    gd = np.load(os.path.join(golden_dir, "memvla_drop_t1.npz"), allow_pickle=False)
+    g, cfg, m = build(golden_dir, "float32", True, retrieval_dropout=float(gd["p_drop"]))
+    m.train()
+    feed = MaskFeed(int(gd["mask_seed"]), float(gd["p_drop"]))
+    m.model.per_cog_mem_bank.set_mask_fn(feed)
+    st = m.store
+    st.set_expected(m.unused_parameter_names())
+    st.begin_step()
+    kw = dict(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]), actions=T(g["actions"]),
+              indexes=[list(map(int, r)) for r in g["indexes"]], noise=T(g["noise"]), timesteps=T(g["timesteps"]),
+              drop_ids=T(g["drop_u"]) < 0.1)
+    out = m(**kw)
+    assert feed.k == int(gd["masks_drawn"])
+    assert abs(out.loss.item() - float(gd["loss"])) < FP32_TOL * abs(float(gd["loss"]))
+    out.loss.backward()
+    for key in gd.files:
+        if key.startswith("grad/"):
+            assert rel_err(st.g(key[5:]).cpu().numpy(), gd[key]) < FP32_TOL, key
+        elif key.startswith("gradN/"):
+            gn = float(gd[key])
+            assert abs(st.g(key[6:]).double().norm().item() - gn) < FP32_TOL * gn + 1e-6 * float(gd["grad_norm"]), key
+    # the device draw (no injected masks): a different, finite loss each step; eval: no dropout at all
+    m.model.per_cog_mem_bank.set_mask_fn(None)
+    st.begin_step()
+    l1 = m(**kw).loss.item()
+    st.begin_step()
+    l2 = m(**kw).loss.item()
+    assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2
+    m.eval()
+    with torch.no_grad():
+        m.model.per_cog_mem_bank.reset()           # (eval keeps the episode memory between calls)
+        e1 = m(**kw).loss.item()
+        m.model.per_cog_mem_bank.reset()
+        e2 = m(**kw).loss.item()
+    assert e1 == e2
 
 
 def test_fp32_memvla_inference_episode_matches_reference(golden_dir):

@@ -53,3 +53,27 @@ def test_memvla_inference_episode_matches_reference(golden_dir):
             acts, _ = M.memvla_inference_action(sd, cfg, bank, f, t(g["infer_prompt"]), t(g["infer_frames"][f:f + 1]),
                                                 t(g["infer_inits"][f]), norms)
             assert rel(acts, g["infer_actions"][f]) < 2e-5, f
+
+
+def test_memvla_training_step_with_retrieval_dropout_matches_reference(golden_dir):
+    """the reference's retrieval blocks are built with dropout 0.1 (SDPA weights + two nn.Dropout in the FFN); golden
+    memvla_drop_t1.npz = the same batch through the reference with that dropout ON and every mask injected (MaskFeed)"""
+    from oracle.gen_golden_memvla import MaskFeed
+    g, cfg, w = load(golden_dir)
+    gd = np.load(os.path.join(golden_dir, "memvla_drop_t1.npz"), allow_pickle=False)
+    assert int(gd["weights_crc"]) == int(g["weights_crc"])
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    t = torch.from_numpy
+    feed = MaskFeed(int(gd["mask_seed"]), float(gd["p_drop"]))
+    bank = M.MemBank(int(g["mem_length"]), mask_fn=feed)
+    out = M.memvla_forward(sd, cfg, bank, t(g["input_ids"]), t(g["attention_mask"]), t(g["images"]), t(g["actions"]),
+                           [list(map(int, r)) for r in g["indexes"]], t(g["noise"]), t(g["timesteps"]), t(g["drop_u"]) < 0.1)
+    assert feed.k == int(gd["masks_drawn"])
+    assert abs(float(out["loss"]) - float(gd["loss"])) < 1e-5 * abs(float(gd["loss"]))
+    assert abs(float(gd["loss"]) - float(g["loss"])) > 1e-4          # the masks do change the result
+    out["loss"].backward()
+    for key in gd.files:
+        if key.startswith("grad/"):
+            assert rel(sd[key[5:]].grad.numpy(), gd[key]) < 5e-5, key
+    gsq = sum(float(v.grad.double().pow(2).sum()) for v in sd.values() if v.grad is not None)
+    assert abs(gsq ** 0.5 - float(gd["grad_norm"])) < 1e-4 * float(gd["grad_norm"])
