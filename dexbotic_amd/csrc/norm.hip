@@ -599,7 +599,8 @@ extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, i
   DXA_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "dxa_colsum: bad args");
   DXA_CHECK_ARG(dtype == DXA_F32 || dtype == DXA_BF16, "dxa_colsum: bad dtype");
   hipStream_t st = (hipStream_t)stream;
-  int nsplit = (int)((rows + 127) / 128);
+  // row splits of >= 32 rows, at most 64 of them: the <= 512 partial rows of a norm backward become 16 x 14 workgroups
+  int nsplit = (int)((rows + 31) / 32);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > 64) nsplit = 64;
   DXA_CHECK_ARG(scratch && scratch_bytes >= (size_t)nsplit * cols * sizeof(float),
@@ -607,9 +608,8 @@ extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, i
   dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nsplit);
   const size_t es = dtype == DXA_BF16 ? 2 : 4;
   const int vec = ((reinterpret_cast<uintptr_t>(x) % (4 * es)) == 0) && (ld % 4 == 0);
-  if (rows <= 1024) {
-    // few rows (the per-workgroup partial rows of a norm backward: <= 512): one launch, same summation order for a given
-    // row count on every call (deterministic)
+  if (rows <= 32) {
+    // a handful of rows: one launch, the block's sums are the result
     dim3 g1((unsigned)((cols + 255) / 256), 1);
     if (dtype == DXA_BF16)
       hipLaunchKernelGGL((colsum_stage1_k<bf16_t, true>), g1, dim3(256), 0, st, (const bf16_t*)x, ld, out, rows, cols, vec, accumulate);

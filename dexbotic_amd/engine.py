@@ -526,7 +526,8 @@ class GradNormTracker:
         self._hi: Optional[int] = None
         self._range_cache: Dict[tuple, tuple] = {}
 
-    BIG = 1 << 18     # uncovered slices at least this long get the two-stage pass of their own, shorter ones share a launch
+    BIG = 1 << 20     # uncovered slices at least this long get the two-stage pass of their own, shorter ones share a launch
+    CHUNK = 1 << 13   # ... cut into chunks of this many elements, one workgroup each
 
     def begin(self) -> None:
         self.acc.zero_()                       # on the compute stream; every fold waits for that stream first
@@ -554,7 +555,8 @@ class GradNormTracker:
                 if b - a >= self.BIG:
                     K.sumsq(src[a:b], self.acc, self.scratch, accumulate=True)
                 else:
-                    small.append((a, b - a))
+                    for c in range(a, b, self.CHUNK):                   # one workgroup per chunk
+                        small.append((c, min(self.CHUNK, b - c)))
             for i in range(0, len(small), 4096):
                 chunk = tuple(small[i:i + 4096])
                 dev = self._range_cache.get(chunk)

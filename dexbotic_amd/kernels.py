@@ -307,7 +307,7 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     if out is None:
         out = torch.empty(cols, device=x.device, dtype=torch.float32)
         accumulate = False
-    nsplit = max(1, min(64, (rows + 127) // 128))
+    nsplit = max(1, min(64, (rows + 31) // 32))
     scratch = torch.empty(nsplit * cols, device=x.device, dtype=torch.float32)
     L.check(lib.dxa_colsum(_ptr(x), ld, _ptr(out), rows, cols, dt(x), int(accumulate), _ptr(scratch),
                            scratch.numel() * 4, _stream()), "dxa_colsum")

@@ -129,7 +129,7 @@ int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, const float*
                       int w_dtype, dxa_stream_t stream);
 int dxa_norm_bwd_blocks(int64_t rows);
 /* out[c] (+)= sum_r x[r*ld + c]   (bias gradients, norm-weight gradients, pos-emb gradients).
- * Deterministic two-stage reduction; scratch >= min(64, ceil(rows/128)) * cols floats. */
+ * Deterministic two-stage reduction; scratch >= min(64, ceil(rows/32)) * cols floats. */
 int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, int64_t cols, int dtype,
                int accumulate, float* scratch, size_t scratch_bytes, dxa_stream_t stream);
 
