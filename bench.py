@@ -158,9 +158,9 @@ def _cpu_reference_step(cfg_llm, cfg_vis, L_llm, L_vit, L_dit, B, args):
 def cpu_baseline(args, cfg_llm, cfg_vis):
     """Reported baseline (never the target): the reference algorithm on the host cores, fp32, fwd + bwd + AdamW at the REAL
     widths.  A full 28-layer 7 B step on CPU takes minutes, so a bounded sample is timed (BASELINE.md §2 protocol:
-    torch.set_num_threads(all physical cores), 2 warm-ups, median of up to 5 timed steps): depth 1 and 2 decoder layers
-    give the marginal cost of a layer, a 4-layer run is measured beside the linear extrapolation it is checked against, and
-    the full depth is extrapolated linearly in layer count (ViT layers by FLOP ratio to a decoder layer).  kind =
+    torch.set_num_threads(all physical cores), 2 warm-ups, median of up to 5 timed steps): decoder depths 1, 2 and 4 are
+    timed, the least-squares line through them gives the marginal cost of a layer, and the full depth is extrapolated linearly
+    in layer count (ViT layers by FLOP ratio to a decoder layer).  kind =
     "reference" when /root/reference is importable (its own CogACTForCausalLM + torch.optim.AdamW), else "port" (the CPU
     oracle, oracle/cogact_oracle.py)."""
     try:
@@ -176,8 +176,14 @@ def cpu_baseline(args, cfg_llm, cfg_vis):
     t1, n1 = _time_steps(make(cfg_llm, cfg_vis, 1, L_vit, L_dit, B, args), 2, 5, budget * 0.25)
     t2, n2 = _time_steps(make(cfg_llm, cfg_vis, 2, L_vit, L_dit, B, args), 2, 5, budget * 0.35)
     t4, n4 = _time_steps(make(cfg_llm, cfg_vis, 4, L_vit, L_dit, B, args), 1, 3, budget * 0.4)
-    per_layer = max(t2 - t1, 1e-6)
-    lin4 = t1 + 3 * per_layer
+    # marginal cost of a decoder layer = slope of the least-squares line through the three depths (the 1 -> 2 difference
+    # alone is two noisy ~15 s timings apart; the depth-4 point triples the lever arm); lin4 = what the 1 -> 2 difference alone
+    # would have predicted for depth 4, reported beside the measurement
+    xs, ts = (1.0, 2.0, 4.0), (t1, t2, t4)
+    xm, tm = sum(xs) / 3, sum(ts) / 3
+    per_layer = max(sum((x - xm) * (t - tm) for x, t in zip(xs, ts)) / sum((x - xm) ** 2 for x in xs), 1e-6)
+    base = tm - per_layer * xm                       # everything that is not a decoder layer (ViT sample, DiT, embeddings, AdamW)
+    lin4 = t1 + 3 * max(t2 - t1, 1e-6)
     # ViT layer / decoder layer forward-FLOP ratio (SURVEY.md section 8d formulas), per view
     npv = (cfg_vis.image_size // cfg_vis.patch_size) ** 2 + 1
     C, I = cfg_vis.hidden_size, cfg_vis.intermediate_size
@@ -187,7 +193,7 @@ def cpu_baseline(args, cfg_llm, cfg_vis):
     vit_layer = 2 * (4 * C * C + 2 * C * I) * npv + 4 * npv * npv * C
     llm_layer = 2 * (d * (cfg_llm.num_attention_heads + 2 * cfg_llm.num_key_value_heads) * hd + d * d + 3 * d * f) * S \
         + 4 * S * S * d
-    est_full = t1 + per_layer * (cfg_llm.num_hidden_layers - 1) \
+    est_full = base + per_layer * cfg_llm.num_hidden_layers \
         + per_layer * (vit_layer / llm_layer) * (cfg_vis.num_hidden_layers - 1 - L_vit) * args.views
     return {"value": round(B / est_full, 5), "unit": "episodes/s", "cores": int(cores),
             "kind": "reference" if use_ref else "port",
@@ -196,7 +202,8 @@ def cpu_baseline(args, cfg_llm, cfg_vis):
                        f"fp32, B={B} (GPU leg: {args.batch}; per-sample cost on the CPU is flat in B at these sizes), real "
                        f"widths, {L_vit} of 23 used ViT layers, DiT-B 12 layers, decoder depth 1 / 2 / 4 measured: "
                        f"{t1:.2f} s ({n1} steps) / {t2:.2f} s ({n2}) / {t4:.2f} s ({n4}) per step, median after warm-up; "
-                       f"full depth (28 decoder + 23 ViT layers) extrapolated linearly from depth 1 -> 2")}
+                       f"full depth (28 decoder + 23 ViT layers) from the least-squares line through the three depths "
+                       f"({per_layer:.2f} s per decoder layer)")}
 
 
 def secondary_workloads(timeout_s: float = 150.0) -> dict:
