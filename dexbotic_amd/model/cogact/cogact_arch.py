@@ -186,7 +186,12 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
         if ent is None:
             # first request of this shape: eager on a private stream (this also lets every lazily created
             # resource — split-K scratch of that stream, device tables, kernel attributes — come into being)
-            ent = {"stream": torch.cuda.Stream(device=images.device), "graph": None,
+            # ONE private stream for every request shape of this model: the library keeps per-stream scratch (64 MiB of split-K
+            # partials, the DiT sync block) for the life of the process, so a stream per shape would grow without bound
+            shared = self.__dict__.get("_infer_stream")
+            if shared is None:
+                shared = self.__dict__["_infer_stream"] = torch.cuda.Stream(device=images.device)
+            ent = {"stream": shared, "graph": None,
                    "images": images.clone(), "noise": noise.clone(),
                    "plan_host": torch.from_numpy(plan_np.copy()).pin_memory(),
                    "plan": torch.from_numpy(plan_np).to(images.device)}
