@@ -158,48 +158,71 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
   const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
   const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
 
+  // K / V tiles travel global -> registers -> LDS; the NEXT tile's global loads are issued right after this tile has been
+  // written to LDS, so they are in flight under this tile's MFMAs and softmax instead of in front of them
+  constexpr int RPI = 256 / NCH;           // K rows per pass
+  constexpr int KPT = 64 / RPI;            // K chunks (16 B) per thread
+  constexpr int VWI = (8 * (D / 4) + 255) / 256;   // V work items (8 keys x 4 d) per thread
+  uint4 kreg[KPT];
+  uint2 vreg[VWI][8];
+  auto load_tile = [&](int kt) {
+    const int key0 = kt * 64;
+    const int c = tid % NCH;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int key = key0 + tid / NCH + RPI * i;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      if (key < p.Sk) kreg[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + c * 8);
+    }
+#pragma unroll
+    for (int w = 0; w < VWI; ++w) {
+      const int wi = tid + 256 * w;
+      const int kc = wi & 7, dg = wi >> 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = key0 + kc * 8 + e;
+        vreg[w][e] = make_uint2(0, 0);
+        if (wi < 8 * (D / 4) && key < p.Sk) vreg[w][e] = *reinterpret_cast<const uint2*>(vb + (int64_t)key * p.v_ss + dg * 4);
+      }
+    }
+  };
+  if (t_lo < t_hi) load_tile(t_lo);
   for (int kt = t_lo; kt < t_hi; ++kt) {
     const int key0 = kt * 64;
     __syncthreads();  // previous tile fully consumed
     // ---- stage K tile: [64][D] row-major, chunk ^= row & (NCH-1)
     {
-      constexpr int RPI = 256 / NCH;       // rows per pass
       const int c = tid % NCH;
 #pragma unroll
-      for (int i = 0; i < 64 / RPI; ++i) {
+      for (int i = 0; i < KPT; ++i) {
         const int r = tid / NCH + RPI * i;
-        const int key = key0 + r;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (key < p.Sk) val = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + c * 8);
-        *reinterpret_cast<uint4*>(Ks + r * KROW + ((c ^ (r & (NCH - 1))) << 4)) = val;
+        *reinterpret_cast<uint4*>(Ks + r * KROW + ((c ^ (r & (NCH - 1))) << 4)) = kreg[i];
       }
     }
     // ---- stage V^T tile: work item (kc = key chunk of 8, dg = group of 4 d) transposes 8x4 -> 4x8
-    for (int wi = tid; wi < 8 * (D / 4); wi += 256) {
-      const int kc = wi & 7, dg = wi >> 3;
-      uint2 vv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int key = key0 + kc * 8 + e;
-        vv[e] = make_uint2(0, 0);
-        if (key < p.Sk) vv[e] = *reinterpret_cast<const uint2*>(vb + (int64_t)key * p.v_ss + dg * 4);
-      }
+    for (int w = 0; w < VWI; ++w) {
+      const int wi = tid + 256 * w;
+      if (wi >= 8 * (D / 4)) break;
+      const int kc = wi & 7, dg = wi >> 3;
+      const uint2* vv = vreg[w];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int d = dg * 4 + qd;
-        uint32_t w[4];
+        uint32_t w4[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const uint32_t lo = (qd & 2) ? vv[2 * m].y : vv[2 * m].x;
           const uint32_t hi = (qd & 2) ? vv[2 * m + 1].y : vv[2 * m + 1].x;
           const uint32_t lo16 = (qd & 1) ? (lo >> 16) : (lo & 0xffffu);
           const uint32_t hi16 = (qd & 1) ? (hi >> 16) : (hi & 0xffffu);
-          w[m] = lo16 | (hi16 << 16);
+          w4[m] = lo16 | (hi16 << 16);
         }
-        *reinterpret_cast<uint4*>(Vs + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(Vs + d * 128 + ((kc ^ ((d >> 1) & 7)) << 4)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
       }
     }
     __syncthreads();
+    if (kt + 1 < t_hi) load_tile(kt + 1);
 
     // ---- S^T = K Q^T : sacc[n][r] = score(query l16, key key0 + 16n + 4lg + r)
     f32x4_t sacc[4];

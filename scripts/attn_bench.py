@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dexbotic_amd import kernels as K  # noqa: E402
 
-CASES = [("qwen2 causal gqa", 16, 28, 4, 287, 128, True), ("clip vit", 16, 16, 16, 257, 64, False)]
+CASES = [("qwen2 causal gqa", 16, 28, 4, 287, 128, True), ("clip vit", 16, 16, 16, 257, 64, False),
+         ("prefill B=1", 1, 28, 4, 543, 128, True), ("pi0 hd256", 16, 8, 1, 816, 256, False)]
 
 
 def timeit(fn, reps=20):
