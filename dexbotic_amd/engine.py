@@ -78,6 +78,12 @@ class ParamStore:
         self.compute_dtype = compute_dtype
         self.slots: Dict[str, Slot] = {}
         self.epi_sumsq = False                  # the trainer turns it on: one GPU, clip enabled, no gradient accumulation
+        # weight gradients of a parameter applied k times in one forward (MemVLA's per-sample retrieval blocks): the k
+        # (dY, X) pairs are collected and ONE product over all their rows writes dW once (functional._wgrad), instead of k
+        # read-modify-write passes over the gradient (k rank-1 updates of a 14336 x 3584 matrix for the one-token cognition
+        # stream).  The trainer turns it on and flushes what a pruned backward left behind.
+        self.defer_wgrad = False
+        self._wg_stash: Dict[tuple, dict] = {}
         self._ssq_buf: Optional[torch.Tensor] = None
         self._ssq_cursor = 0
         self._ssq_covered: set = set()
@@ -227,6 +233,16 @@ class ParamStore:
                     self._bucket_fired[b] = True
                     self.on_bucket_ready(b)
 
+    def flush_wgrads(self) -> None:
+        """weight-gradient products still waiting for a last use that never came (autograd pruned one of the consumers)"""
+        if not self._wg_stash:
+            return
+        from .functional import _wgrad_flush
+        for key in list(self._wg_stash):
+            for nm in key:
+                self._uses[nm] = 1
+            _wgrad_flush(self, key)
+
     def unfired_touched(self) -> List[int]:
         """buckets (highest first = backward order) that received gradient writes this micro-batch but never
         completed their countdown: a frozen / unused slot, or a Function whose backward autograd pruned"""
@@ -264,13 +280,16 @@ class ParamStore:
         self._ssq_covered = set()
 
     # ---- sum(g^2) shares produced by the dW products' own epilogues (single-GPU global-norm clip) -------------------
-    def sumsq_out(self, names: Sequence[str], M: int, N: int) -> Optional[torch.Tensor]:
+    def sumsq_out(self, names: Sequence[str], M: int, N: int, first_write: Optional[bool] = None) -> Optional[torch.Tensor]:
         """where the product that writes g(*names) as an [M, N] matrix should leave the per-tile partial sums of squares of
         what it writes (``dxa_gemm_desc.sumsq``), or None.  Only when that write is the slot's final value of the step:
         nothing written to it yet and no other consumer of the parameter still owes a gradient (``note_use``)."""
         if not self.epi_sumsq or self.grad is None or not self.grad.is_cuda:
             return None
-        if self.grad_written[names[0]] or any(self._uses.get(nm, 0) > 1 for nm in names):
+        # (first_write: the caller knows — the one deferred product of a multiply-used parameter — that nothing has been
+        # written to the slot this step although its consumers were already counted down)
+        written = self.grad_written[names[0]] if first_write is None else not first_write
+        if written or any(self._uses.get(nm, 0) > 1 for nm in names):
             return None
         from . import kernels as K
         n = K.gemm_sumsq_slots(M, N)

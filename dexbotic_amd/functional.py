@@ -70,21 +70,48 @@ def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor
 def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) -> None:
     """dW (+)= dy^T x into the gradient arena (fused view over `names`).  bf16: a TN product on the ping-pong MFMA kernel:
     both activations are staged as they lie ([tokens, features], the contraction runs over the rows) — no transposed
-    copies, any token count."""
+    copies, any token count.  A parameter with several consumers in this forward (``ParamStore.note_use``) collects their
+    (dy, x) pairs and writes dW with ONE product over all rows when the last consumer's backward arrives
+    (``ParamStore.defer_wgrad``)."""
     names = _names(names)
     if not all(st.trainable(n) for n in names):
         if any(st.trainable(n) for n in names):
             raise L.DxaError(f"fused parameters {names} must be frozen/unfrozen together")
         return
+    key = tuple(names)
+    pending = st._uses.get(names[0], 0)                  # consumers whose backward has not run yet, this one included
+    if st.defer_wgrad and (pending > 1 or key in st._wg_stash):
+        ent = st._wg_stash.get(key)
+        if ent is None:
+            ent = st._wg_stash[key] = {"acc0": st.accum_flag(*names), "dy": [], "x": [], "shape": shape}
+        ent["dy"].append(dy2d)
+        ent["x"].append(x2d)
+        if pending > 1:
+            st.mark_written(*names)                      # counts this consumer down; the bucket waits for the last one
+            return
+        _wgrad_flush(st, key)
+        return
+    _wgrad_now(st, names, dy2d, x2d, shape, st.accum_flag(*names))
+
+
+def _wgrad_flush(st: ParamStore, key: tuple) -> None:
+    ent = st._wg_stash.pop(key)
+    dy = ent["dy"][0] if len(ent["dy"]) == 1 else torch.cat(ent["dy"], dim=0)
+    x = ent["x"][0] if len(ent["x"]) == 1 else torch.cat(ent["x"], dim=0)
+    _wgrad_now(st, key, dy.contiguous(), x.contiguous(), ent["shape"], ent["acc0"], first_write=not ent["acc0"])
+
+
+def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape, accumulate: bool,
+               first_write: Optional[bool] = None) -> None:
     out = st.g(*names, shape=shape)
     # bf16 data parallelism: the product's epilogue also writes the bf16 communication copy of this gradient
     mirror = st.mirror_out(*names, shape=shape)
     # single-GPU clip: ... and this gradient's share of sum(g^2)
-    ssq = st.sumsq_out(names, out.shape[0], out.shape[1]) if out.dim() == 2 else None
+    ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 else None
     if _f32_nt(dy2d) and x2d.dtype == torch.float32:
-        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=st.accum_flag(*names), mirror=mirror, sumsq=ssq)
+        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     else:
-        K.mm_tn(dy2d, x2d, out=out, accumulate=st.accum_flag(*names), mirror=mirror, sumsq=ssq)
+        K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     st.mark_written(*names)
 
 

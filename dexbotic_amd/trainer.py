@@ -49,6 +49,7 @@ class NativeTrainer:
         self.store.sparse_embed_zero = self.reducer is None
         # single GPU, one micro-batch per step: sum(g^2) of the weight gradients comes out of the dW products' epilogues
         self.store.epi_sumsq = self.reducer is None and self.norm_tracker is not None and grad_accum == 1
+        self.store.defer_wgrad = True           # parameters with several consumers per forward: one dW product for all of them
         self.store.invalidate_embed_tracking()
         self._zeroed_unused = False
 
@@ -79,6 +80,7 @@ class NativeTrainer:
             out = self.model(**batch)
             loss = out.loss
             (loss / self.grad_accum if self.grad_accum > 1 else loss).backward()
+        self.store.flush_wgrads()               # (only when autograd pruned a consumer of a multiply-used parameter)
         self.micro += 1
         if last:
             if not self._zeroed_unused:
