@@ -274,8 +274,17 @@ __global__ void colsum_stage2_k(const float* __restrict__ part, float* __restric
                                 int accumulate) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
+  // fixed order (split 0, 1, 2, ...), eight independent loads in flight
   float s = 0.f;
-  for (int i = 0; i < nsplit; ++i) s += part[(int64_t)i * cols + c];
+  int i = 0;
+  for (; i + 8 <= nsplit; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(i + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < nsplit; ++i) s += part[(int64_t)i * cols + c];
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -622,8 +631,8 @@ extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, i
     hipLaunchKernelGGL((colsum_stage1_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ld, scratch, rows, cols, vec);
   else
     hipLaunchKernelGGL((colsum_stage1_k<float>), grid, dim3(256), 0, st, (const float*)x, ld, scratch, rows, cols, vec);
-  hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, scratch, out, nsplit,
-                     cols, accumulate);
+  hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)((cols + 63) / 64)), dim3(64), 0, st, scratch, out, nsplit,
+                     cols, accumulate);    // one wave per 64 columns: 56 workgroups for 3584 columns instead of 14
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
