@@ -65,6 +65,21 @@ template <> struct Vec<bf16_t, 4> {
     *reinterpret_cast<uint2*>(p) = o;
   }
 };
+template <> struct Vec<bf16_t, 8> {          // 16 bytes per lane: the widest access, for the HBM-bound row kernels
+  static __device__ __forceinline__ void ld(float (&o)[8], const bf16_t* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
 template <typename T> struct Vec<T, 1> {
   static __device__ __forceinline__ void ld(float (&o)[1], const T* p) { o[0] = ldf<T>(p); }
   static __device__ __forceinline__ void st(T* p, const float (&v)[1]) { stf<T>(p, v[0]); }

@@ -504,7 +504,8 @@ extern "C" int dxa_swiglu_fwd(const void* gu, void* out, int64_t rows, int64_t F
   if (rows == 0) return DXA_OK;
   const bool vec = F % 4 == 0 && al(gu, 16) && al(out, 16);
   if (dtype == DXA_BF16) {
-    if (vec) hipLaunchKernelGGL((swiglu_fwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F);
+    if (vec && F % 8 == 0) hipLaunchKernelGGL((swiglu_fwd_k<bf16_t, 8>), dim3(dxa_grid1d(rows * F / 8, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F);
+    else if (vec) hipLaunchKernelGGL((swiglu_fwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F);
     else hipLaunchKernelGGL((swiglu_fwd_k<bf16_t, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F);
   } else {
     if (vec) hipLaunchKernelGGL((swiglu_fwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (float*)out, rows, F);
@@ -519,7 +520,8 @@ extern "C" int dxa_swiglu_bwd(const void* gu, const void* dout, void* dgu, int64
   if (rows == 0) return DXA_OK;
   const bool vec = F % 4 == 0 && al(gu, 16) && al(dout, 16) && al(dgu, 16);
   if (dtype == DXA_BF16) {
-    if (vec) hipLaunchKernelGGL((swiglu_bwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F);
+    if (vec && F % 8 == 0) hipLaunchKernelGGL((swiglu_bwd_k<bf16_t, 8>), dim3(dxa_grid1d(rows * F / 8, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F);
+    else if (vec) hipLaunchKernelGGL((swiglu_bwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F);
     else hipLaunchKernelGGL((swiglu_bwd_k<bf16_t, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F);
   } else {
     if (vec) hipLaunchKernelGGL((swiglu_bwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (const float*)dout, (float*)dgu, rows, F);

@@ -527,7 +527,8 @@ bool launch_norm_bwd_fast(const void* dy, const void* x, const void* w, const fl
   int64_t g = (rows + 3) / 4;
   if (g > NORM_BWD_MAX_BLOCKS) g = NORM_BWD_MAX_BLOCKS;
   dim3 grid((unsigned)g);
-  if (dtype == DXA_BF16 && cols % 8 == 0) {          // 16-byte accesses, one read of x and dy
+  if (dtype == DXA_BF16 && cols % 8 == 0 && !LN) {   // RMSNorm: 16-byte accesses, one read of x and dy (LayerNorm's second
+                                                     // set of partial sums costs it the registers: measured 27 vs 24 us)
     if (w_dtype == DXA_BF16)
       hipLaunchKernelGGL((norm_bwd_fast8_k<bf16_t, LN>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, mean, rstd, (bf16_t*)dx, (const bf16_t*)res, partial, rows, cols);
     else
