@@ -10,13 +10,13 @@ namespace {
 constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------ RoPE
-// work item = (token, head-slot, group of 4 dims in the first half)
-template <typename T, bool MERGE>
+// work item = (token, head-slot, group of VEC dims in the first half); VEC = 8 for bf16 heads with D % 16 == 0: 16-byte accesses
+template <typename T, bool MERGE, int VEC = 4>
 __global__ __launch_bounds__(TPB) void rope_k(const T* __restrict__ tok, T* __restrict__ tok_out,
                                               T* __restrict__ q, T* __restrict__ k, T* __restrict__ v,
                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                               const int32_t* __restrict__ pos, int B, int S, int Hq, int Hkv, int D) {
-  const int HS = Hq + 2 * Hkv, half = D / 2, qn = half / 4;
+  const int HS = Hq + 2 * Hkv, half = D / 2, qn = half / VEC;
   const int64_t total = (int64_t)B * S * HS * qn;
   const int64_t ld = (int64_t)HS * D;
   for (int64_t it = (int64_t)blockIdx.x * TPB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TPB) {
@@ -24,46 +24,54 @@ __global__ __launch_bounds__(TPB) void rope_k(const T* __restrict__ tok, T* __re
     const int hs = (int)((it / qn) % HS);
     const int64_t t = it / ((int64_t)qn * HS);
     const int b = (int)(t / S), s = (int)(t % S);
-    const int d0 = qd * 4;
+    const int d0 = qd * VEC;
     T* hm;  // head-major row of this (b, head, s)
     bool rot = true;
     if (hs < Hq) hm = q + (((int64_t)b * Hq + hs) * S + s) * D;
     else if (hs < Hq + Hkv) hm = k + (((int64_t)b * Hkv + (hs - Hq)) * S + s) * D;
     else { hm = v + (((int64_t)b * Hkv + (hs - Hq - Hkv)) * S + s) * D; rot = false; }
     const int64_t toff = t * ld + (int64_t)hs * D;
-    float c[4] = {1.f, 1.f, 1.f, 1.f}, sn[4] = {0.f, 0.f, 0.f, 0.f};
+    float c[VEC], sn[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { c[i] = 1.f; sn[i] = 0.f; }
     if (rot) {
       const int64_t pr = pos ? pos[t] : s;
-      Vec<float, 4>::ld(c, cos_t + pr * half + d0);
-      Vec<float, 4>::ld(sn, sin_t + pr * half + d0);
-    }
-    float x1[4], x2[4], o1[4], o2[4];
-    if (!MERGE) {
-      Vec<T, 4>::ld(x1, tok + toff + d0);
-      Vec<T, 4>::ld(x2, tok + toff + d0 + half);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int u = 0; u < VEC / 4; ++u) {
+        float c4[4], s4[4];
+        Vec<float, 4>::ld(c4, cos_t + pr * half + d0 + 4 * u);
+        Vec<float, 4>::ld(s4, sin_t + pr * half + d0 + 4 * u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[4 * u + i] = c4[i]; sn[4 * u + i] = s4[i]; }
+      }
+    }
+    float x1[VEC], x2[VEC], o1[VEC], o2[VEC];
+    if (!MERGE) {
+      Vec<T, VEC>::ld(x1, tok + toff + d0);
+      Vec<T, VEC>::ld(x2, tok + toff + d0 + half);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
         if (rot) {
           const float cc = rnd<T>(c[i]), ss = rnd<T>(sn[i]);
           o1[i] = rnd<T>(x1[i] * cc) + rnd<T>(-x2[i] * ss);
           o2[i] = rnd<T>(x2[i] * cc) + rnd<T>(x1[i] * ss);
         } else { o1[i] = x1[i]; o2[i] = x2[i]; }
       }
-      Vec<T, 4>::st(hm + d0, o1);
-      Vec<T, 4>::st(hm + d0 + half, o2);
+      Vec<T, VEC>::st(hm + d0, o1);
+      Vec<T, VEC>::st(hm + d0 + half, o2);
     } else {
-      Vec<T, 4>::ld(x1, hm + d0);
-      Vec<T, 4>::ld(x2, hm + d0 + half);
+      Vec<T, VEC>::ld(x1, hm + d0);
+      Vec<T, VEC>::ld(x2, hm + d0 + half);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < VEC; ++i) {
         if (rot) {
           const float cc = rnd<T>(c[i]), ss = rnd<T>(sn[i]);
           o1[i] = x1[i] * cc + x2[i] * ss;
           o2[i] = x2[i] * cc - x1[i] * ss;
         } else { o1[i] = x1[i]; o2[i] = x2[i]; }
       }
-      Vec<T, 4>::st(tok_out + toff + d0, o1);
-      Vec<T, 4>::st(tok_out + toff + d0 + half, o2);
+      Vec<T, VEC>::st(tok_out + toff + d0, o1);
+      Vec<T, VEC>::st(tok_out + toff + d0 + half, o2);
     }
   }
 }
@@ -476,7 +484,10 @@ extern "C" int dxa_rope_split(const void* qkv, void* q, void* k, void* v, const 
   const int64_t total = (int64_t)B * S * (Hq + 2 * Hkv) * (D / 8);
   if (total == 0) return DXA_OK;
   dim3 grid(dxa_grid1d(total, TPB));
-  if (dtype == DXA_BF16)
+  const bool wide = dtype == DXA_BF16 && D % 16 == 0 && al(qkv, 16) && al(q, 16) && al(k, 16) && al(v, 16);
+  if (wide)
+    hipLaunchKernelGGL((rope_k<bf16_t, false, 8>), dim3(dxa_grid1d(total / 2, TPB)), dim3(TPB), 0, ST, (const bf16_t*)qkv, (bf16_t*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
+  else if (dtype == DXA_BF16)
     hipLaunchKernelGGL((rope_k<bf16_t, false>), grid, dim3(TPB), 0, ST, (const bf16_t*)qkv, (bf16_t*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
   else
     hipLaunchKernelGGL((rope_k<float, false>), grid, dim3(TPB), 0, ST, (const float*)qkv, (float*)nullptr, (float*)q, (float*)k, (float*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
@@ -491,7 +502,10 @@ extern "C" int dxa_rope_merge(const void* dq, const void* dk, const void* dv, vo
   const int64_t total = (int64_t)B * S * (Hq + 2 * Hkv) * (D / 8);
   if (total == 0) return DXA_OK;
   dim3 grid(dxa_grid1d(total, TPB));
-  if (dtype == DXA_BF16)
+  const bool wide = dtype == DXA_BF16 && D % 16 == 0 && al(dqkv, 16) && al(dq, 16) && al(dk, 16) && al(dv, 16);
+  if (wide)
+    hipLaunchKernelGGL((rope_k<bf16_t, true, 8>), dim3(dxa_grid1d(total / 2, TPB)), dim3(TPB), 0, ST, (const bf16_t*)nullptr, (bf16_t*)dqkv, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
+  else if (dtype == DXA_BF16)
     hipLaunchKernelGGL((rope_k<bf16_t, true>), grid, dim3(TPB), 0, ST, (const bf16_t*)nullptr, (bf16_t*)dqkv, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
   else
     hipLaunchKernelGGL((rope_k<float, true>), grid, dim3(TPB), 0, ST, (const float*)nullptr, (float*)dqkv, (float*)dq, (float*)dk, (float*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D);

@@ -96,7 +96,9 @@ def test_rccl_reducer_path_equals_plain_step(golden_dir, algo):
         # the epilogue sums give the same norm up to fp32 summation order, hence the same step up to that
         assert abs(res["plain_epi"][1].item() - res["plain"][1].item()) <= 2e-6 * res["plain"][1].item()
         assert res["plain_epi"][0][0] == res["plain"][0][0]
-        torch.testing.assert_close(res["plain_epi"][2], res["plain"][2], rtol=1e-5, atol=1e-7)
+        # (parameters whose gradient is mathematically zero — k_proj biases: softmax shift invariance — carry rounding noise
+        # of either sign, which AdamW turns into +-lr * g / eps ~ 1e-5 steps: hence the absolute floor of 5 % of one lr step)
+        torch.testing.assert_close(res["plain_epi"][2], res["plain"][2], rtol=1e-5, atol=5e-5)
         # bf16 communication: gradients pass through one bf16 rounding (2^-9 relative per element)
         n_plain = res["plain"][1].item()
         assert abs(res["bf16"][1].item() - n_plain) <= 4e-3 * n_plain
