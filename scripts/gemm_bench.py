@@ -47,7 +47,7 @@ def main():
             a = (torch.rand(k, m, device=dev) * 2 - 1).bfloat16()
             b = (torch.rand(k, n, device=dev) * 2 - 1).bfloat16()
             fn = K.mm_tn
-        out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        out = torch.empty(m, n, device=dev, dtype=torch.float32 if lay == "tn" else torch.bfloat16)   # dW goes to the fp32 arena
         for _ in range(3):
             fn(a, b, out=out)
         torch.cuda.synchronize()
