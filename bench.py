@@ -235,6 +235,11 @@ def main():
                     help="debug: run the RCCL gradient reducer even at world size 1 (exercises the DP code path)")
     ap.add_argument("--grad-comm", dest="grad_comm", default="bfloat16", choices=["bfloat16", "float32"],
                     help="dtype of the data-parallel gradient all-reduce (the reference's DeepSpeed bf16 run reduces bf16)")
+    ap.add_argument("--grad-dtype", dest="grad_dtype", default="float32", choices=["bfloat16", "float32"],
+                    help="dtype of the gradient arena the dW products write and AdamW reads: float32 (default: every gradient in "
+                         "fp32); bfloat16 = the reference's DeepSpeed bf16 recipe (script/deepspeed/zero3.json: bf16 gradients, "
+                         "fp32 masters in the optimizer) — measured 248.3 vs 249.6 ms/step, i.e. no real gain: inside the "
+                         "power-limited step the dW products take the same time whatever they store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the DB-pi0 / MemVLA secondary workloads (BASELINE.json configs[3], [4]; run as isolated "
@@ -272,7 +277,8 @@ def main():
     model.train()
     trainer = NativeTrainer(model, OptimConfig(base_lr=2e-5, weight_decay=0.0, max_grad_norm=1.0),
                             total_steps=1000, force_reducer=args.force_reducer,
-                            grad_comm_dtype=getattr(torch, args.grad_comm))
+                            grad_comm_dtype=getattr(torch, args.grad_comm),
+                            grad_dtype=getattr(torch, args.grad_dtype) if args.dtype == "bfloat16" else torch.float32)
     batch = synthetic_batch(args.batch, args.views, args.s_text, device, seed=1234 + rank)
 
     def sync():
@@ -317,7 +323,8 @@ def main():
         "tflops_per_gpu_model": round(value * 3 * f_fwd / world / 1e12, 1),
         "mfu_bf16": round(value * 3 * f_fwd / world / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
-    if trainer.reducer is not None:
+    result["grad_dtype"] = "bf16" if model.store.bf16_grads else "f32"
+    if trainer.reducer is not None and not trainer.reducer.local_only:
         result["grad_comm_dtype"] = args.grad_comm
         result["allreduce_gb_per_step"] = round(trainer.reducer.bytes_reduced / (args.steps + args.warmup) / 1e9, 3)
     if rank == 0:

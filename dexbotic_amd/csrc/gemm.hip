@@ -1101,6 +1101,7 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
   const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(p.mirror ? p.mirror : (char*)p.C, 0,
                                                                       p.mirror ? (int)(((p.M - 1) * p.ldc + p.N) * 2) : 0, 0x00020000);
   const float alpha = p.alpha;
+  const bool want_ssq = p.sumsq != nullptr;
   float ssq = 0.f;                                   // sum of squares of the values this lane stores (p.sumsq)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1145,6 +1146,12 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
         }
 #if !(DXA_PPV & 32)
         SkIO<TO>::template st<CPL>(v, rC, oc);
+        if constexpr (sizeof(TO) == 2) {
+          if (want_ssq && ok) {                                // bf16 gradient arena: the norm is taken over what is stored
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) { const float t = rnd<bf16_t>(v[e]); ssq += t * t; }
+          }
+        }
         if constexpr (sizeof(TO) == 4) {
           if (ok) {
 #pragma unroll
@@ -1162,7 +1169,7 @@ __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);   // passes stay in order: no hoisting of the next pass's work (register pressure)
     }
-  if constexpr (sizeof(TO) == 4) {
+  {
     // global-norm clip: this tile's share of sum(g^2), folded lane -> wave -> workgroup in a fixed order and written to
     // the tile's own slot (the host adds the slots in index order): the separate 30 GB pass over the gradient arena that
     // used to read every dW back is not needed for gradients a single product writes
@@ -1595,13 +1602,14 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
 
 // sum of squares of C [M, N] (fp32, leading dimension ldc) into `slots` per-"tile" partials for products whose kernel has no
 // sum-of-squares epilogue: workgroup b folds rows b, b + slots, ... in a fixed order, so every slot is written
-__global__ __launch_bounds__(256) void sumsq_rows_k(const float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_rows_k(const T* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
                                                     float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
   for (int64_t r = blockIdx.x; r < M; r += gridDim.x) {
-    const float* row = C + r * ldc;
-    for (int64_t c = threadIdx.x; c < N; c += 256) { const float v = row[c]; s += v * v; }
+    const T* row = C + r * ldc;
+    for (int64_t c = threadIdx.x; c < N; c += 256) { const float v = ldf<T>(row + c); s += v * v; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -1621,8 +1629,11 @@ extern "C" int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream) {
     if (int rc = dxa_copy2d(d->C, d->ldc, d->mirror, d->ldc, d->M, d->N, d->N, DXA_F32, DXA_BF16, stream)) return rc;
   }
   if (d->sumsq && !summed && d->M > 0 && d->N > 0) {      // ... and without the sum-of-squares epilogue: one read of C
-    hipLaunchKernelGGL(sumsq_rows_k, dim3((unsigned)dxa_gemm_sumsq_slots(d->M, d->N)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)d->C, d->ldc, d->M, d->N, d->sumsq);
+    const dim3 sgrid((unsigned)dxa_gemm_sumsq_slots(d->M, d->N));
+    if (d->out_dtype == DXA_F32)
+      hipLaunchKernelGGL(sumsq_rows_k<float>, sgrid, dim3(256), 0, (hipStream_t)stream, (const float*)d->C, d->ldc, d->M, d->N, d->sumsq);
+    else
+      hipLaunchKernelGGL(sumsq_rows_k<bf16_t>, sgrid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d->C, d->ldc, d->M, d->N, d->sumsq);
     DXA_CHECK_LAUNCH();
   }
   return DXA_OK;
@@ -1655,7 +1666,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   p.G = (const char*)d->mulgrad; p.ldg = d->ldg;
   p.alpha = d->alpha; p.act = d->act; p.accumulate = d->accumulate;
   DXA_CHECK_ARG(!d->mirror || (d->out_dtype == DXA_F32 && nbatch == 1), "dxa_gemm: mirror needs an fp32, unbatched output");
-  DXA_CHECK_ARG(!d->sumsq || (d->out_dtype == DXA_F32 && nbatch == 1), "dxa_gemm: sumsq needs an fp32, unbatched output");
+  DXA_CHECK_ARG(!d->sumsq || nbatch == 1, "dxa_gemm: sumsq needs an unbatched output");
   p.nb1 = d->nb[1]; p.nb2 = d->nb[2];
   for (int i = 0; i < 3; ++i) {
     p.sA[i] = d->sA[i]; p.sB[i] = d->sB[i]; p.sC[i] = d->sC[i]; p.sR[i] = d->sR[i]; p.sG[i] = d->sG[i];
@@ -1786,7 +1797,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     hipLaunchKernelGGL((gemm_pp_kernel<TO_, TE_, LEAN_, AKS_, BKS_>), fgrid, dim3(512), RING_LDS, st, p);       \
   } while (0)
     if (lean) { p.mirror = (char*)d->mirror; *mirrored = d->mirror != nullptr; }
-    if (lean && d->out_dtype == DXA_F32) { p.sumsq = d->sumsq; *summed = d->sumsq != nullptr; }
+    if (lean) { p.sumsq = d->sumsq; *summed = d->sumsq != nullptr; }
     if (d->layout == DXA_NN) {          // dX = dY W: bf16 out (lean, or with the activation-gradient epilogue), fp32 out lean
       if (d->out_dtype == DXA_BF16) { if (lean) LAUNCH_PP(bf16_t, bf16_t, true, false, true); else LAUNCH_PP(bf16_t, bf16_t, false, false, true); }
       else LAUNCH_PP(float, bf16_t, true, false, true);

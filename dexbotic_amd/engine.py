@@ -84,6 +84,11 @@ class ParamStore:
         # stream).  The trainer turns it on and flushes what a pruned backward left behind.
         self.defer_wgrad = False
         self._wg_stash: Dict[tuple, dict] = {}
+        # bf16 gradient arena (the reference's DeepSpeed bf16 recipe, script/deepspeed/zero3.json "bf16": gradients are bf16,
+        # the optimizer keeps fp32 masters): the bf16 dW products write ONLY the bf16 arena (gradc) — half the epilogue bytes and
+        # half of AdamW's gradient read.  Gradients other kernels produce (norm weights, biases, embeddings, the fp32 head) land
+        # in the fp32 arena and are cast per slot when their bucket completes (GradReducer._fill_mirror).
+        self.bf16_grads = False
         self._ssq_buf: Optional[torch.Tensor] = None
         self._ssq_cursor = 0
         self._ssq_covered: set = set()
@@ -649,16 +654,19 @@ class GradReducer:
 
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
                  skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32,
-                 algo: str = "rs_ag"):
+                 algo: str = "rs_ag", local_only: bool = False):
         import torch.distributed as dist
         self.dist = dist
-        self.force = force          # run the collectives even at world size 1 (exercises the RCCL path)
+        self.force = force or local_only   # run the bucket pipeline even at world size 1 (exercises the RCCL path)
+        # local_only: no process group at all — the per-bucket pipeline (bf16 copy of the slots no epilogue wrote, sum of squares
+        # on the side stream) without any collective: the single-GPU bf16-gradient step
+        self.local_only = local_only
         assert comm_dtype in (torch.float32, torch.bfloat16)
         assert algo in ("rs_ag", "allreduce")
         self.comm_dtype, self.algo = comm_dtype, algo
         self.store = store
         self.group = group
-        init = dist.is_available() and dist.is_initialized()
+        init = dist.is_available() and dist.is_initialized() and not local_only
         self.world = dist.get_world_size(group) if init else 1
         self.rank = dist.get_rank(group) if init else 0
         self.min_bucket_bytes = min_bucket_bytes
@@ -729,6 +737,8 @@ class GradReducer:
             t.copy_((t.float() / self.world).to(t.dtype))
 
     def _exchange(self, buf: torch.Tensor) -> None:
+        if self.local_only:
+            return
         d, w = self.dist, self.world
         # AVG is native on RCCL.  With ONE rank (force=True: the path is exercised on a single GPU) the mean is the
         # identity and SUM is asked for instead: RCCL's one-rank AVG runs a separate pre-multiply pass over the whole
@@ -772,7 +782,8 @@ class GradReducer:
         self._pending_lo = self._pending_hi = None
         half = self.comm_dtype == torch.bfloat16
         buf = (self.store.gradc if half else self.store.grad)[lo:hi]
-        self.bytes_reduced += buf.numel() * (2 if half else 4)
+        if not self.local_only:
+            self.bytes_reduced += buf.numel() * (2 if half else 4)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -813,6 +824,7 @@ class GradReducer:
             st._bucket_fired[b] = True
             self.bucket_ready(b)
         self._flush()
-        st.invalidate_embed_tracking()                     # other ranks' token rows are now non-zero here too
+        if not self.local_only:
+            st.invalidate_embed_tracking()                 # other ranks' token rows are now non-zero here too
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -103,11 +103,20 @@ def _wgrad_flush(st: ParamStore, key: tuple) -> None:
 
 def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape, accumulate: bool,
                first_write: Optional[bool] = None) -> None:
+    if st.bf16_grads and st.gradc is not None and dy2d.dtype == torch.bfloat16 and x2d.dtype == torch.bfloat16:
+        # bf16 gradient arena: the product writes bf16 only (ParamStore.bf16_grads); the slots count as already copied
+        out = st.gc(*names, shape=shape)
+        ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 else None
+        K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, sumsq=ssq)
+        st._mirrored.update(names)
+        st.mark_written(*names)
+        return
     out = st.g(*names, shape=shape)
     # bf16 data parallelism: the product's epilogue also writes the bf16 communication copy of this gradient
     mirror = st.mirror_out(*names, shape=shape)
-    # single-GPU clip: ... and this gradient's share of sum(g^2)
-    ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 else None
+    # single-GPU clip: ... and this gradient's share of sum(g^2) (bf16 gradient arena: the norm is taken over the bf16 copy
+    # AdamW reads, so an fp32 product's share is read back from that copy instead)
+    ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 and not st.bf16_grads else None
     if _f32_nt(dy2d) and x2d.dtype == torch.float32:
         K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     else:

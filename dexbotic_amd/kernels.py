@@ -118,9 +118,9 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
             raise L.DxaError("gemm: mirror must be a bf16 [M, N] view with the output's leading dimension (fp32 output)")
         d.mirror = _ptr(mirror)
     if sumsq is not None:
-        if sumsq.dtype != torch.float32 or out.dtype != torch.float32 or tuple(nb) != (1, 1, 1) or not sumsq.is_contiguous() \
+        if sumsq.dtype != torch.float32 or tuple(nb) != (1, 1, 1) or not sumsq.is_contiguous() \
                 or sumsq.numel() != gemm_sumsq_slots(M, N):
-            raise L.DxaError("gemm: sumsq must be gemm_sumsq_slots(M, N) contiguous floats (fp32, unbatched output)")
+            raise L.DxaError("gemm: sumsq must be gemm_sumsq_slots(M, N) contiguous floats (unbatched output)")
         d.sumsq = _ptr(sumsq)
     for i in range(3):
         d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]

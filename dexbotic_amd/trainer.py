@@ -21,7 +21,8 @@ from .engine import FusedAdamW, GradNormTracker, GradReducer, OptimConfig, cosin
 class NativeTrainer:
     def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
-                 force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag"):
+                 force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag",
+                 grad_dtype: torch.dtype = torch.float32):
         import torch.distributed as dist
         self.model = model
         self.store = model.store
@@ -33,10 +34,21 @@ class NativeTrainer:
         self.micro = 0
         self.store.set_expected(unused)
         use_dist = (dist.is_available() and dist.is_initialized()) if distributed is None else distributed
+        # grad_dtype = bfloat16: the reference's DeepSpeed bf16 recipe (bf16 gradients, fp32 masters in the optimizer): the dW
+        # products write the bf16 gradient arena only, AdamW and the norm read it.  Needs one micro-batch per step (accumulating
+        # micro-batches in bf16 would lose bits) and a bf16 compute model; implies bf16 exchange under data parallelism.
+        bf16_grads = grad_dtype == torch.bfloat16 and grad_accum == 1 and self.store.compute_dtype == torch.bfloat16 \
+            and self.store.device.type == "cuda"
+        if bf16_grads:
+            grad_comm_dtype = torch.bfloat16
         self.reducer = None
         if use_dist and (dist.get_world_size() > 1 or force_reducer):
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
                                        comm_dtype=grad_comm_dtype, algo=grad_sync)
+        elif bf16_grads:
+            self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, comm_dtype=torch.bfloat16,
+                                       local_only=True)
+        self.store.bf16_grads = bf16_grads
         # global-norm clip: sum(g^2) is folded in bucket by bucket under the backward (after the all-reduce under DP)
         self.norm_tracker = None
         if self.cfg.max_grad_norm is not None and self.store.device.type == "cuda":
@@ -46,9 +58,10 @@ class NativeTrainer:
                 self.norm_tracker.src = self.reducer.result_arena
         self.store.attach_grads()
         # single GPU: nobody but the splice backward writes the dense embedding gradient, so it can be re-zeroed row-wise
-        self.store.sparse_embed_zero = self.reducer is None
+        local = self.reducer is None or self.reducer.local_only        # nobody else writes this rank's gradient arenas
+        self.store.sparse_embed_zero = local
         # single GPU, one micro-batch per step: sum(g^2) of the weight gradients comes out of the dW products' epilogues
-        self.store.epi_sumsq = self.reducer is None and self.norm_tracker is not None and grad_accum == 1
+        self.store.epi_sumsq = local and self.norm_tracker is not None and grad_accum == 1
         self.store.defer_wgrad = True           # parameters with several consumers per forward: one dW product for all of them
         self.store.invalidate_embed_tracking()
         self._zeroed_unused = False

@@ -91,8 +91,9 @@ typedef struct dxa_gemm_desc {
                          communication copy of a weight gradient that the data-parallel reducer exchanges instead of the
                          fp32 values (the reference's DeepSpeed bf16 run reduces bf16 gradients, script/deepspeed/zero2.json);
                          written by the dW product's own epilogue, so no cast pass over the gradient arena exists */
-  float* sumsq;       /* fp32 output only, or NULL: dxa_gemm_sumsq_slots(M, N) floats, ALL of them written: partial sums of
-                         squares of the final C (after accumulate) whose total, added in index order, is sum(C^2) — the
+  float* sumsq;       /* unbatched output, or NULL: dxa_gemm_sumsq_slots(M, N) floats, ALL of them written: partial sums of
+                         squares of the final C as stored (after accumulate; bf16 output: of the rounded values) whose total,
+                         added in index order, is sum(C^2) — the
                          weight gradient's share of the global-norm clip (torch.nn.utils.clip_grad_norm_ in the reference's
                          Trainer, dexbotic/exp/base_exp.py:250 max_grad_norm), produced by the dW product's own epilogue
                          instead of a pass that reads the gradient back; deterministic (fixed fold order per slot) */

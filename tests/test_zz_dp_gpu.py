@@ -128,3 +128,32 @@ def test_memvla_through_trainer_norm_and_buckets(golden_dir):
     assert abs(tr.opt.norm.item() - full) <= 1e-6 * full, (tr.opt.norm.item(), full)
     assert abs(tr.opt.norm.item() - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
     assert len(fired) == len(set(fired)), "a bucket fired twice"
+
+
+def test_bf16_gradient_arena_step_tracks_fp32_gradient_step(golden_dir):
+    """grad_dtype=bfloat16 (the reference's DeepSpeed bf16 recipe: bf16 gradients, fp32 masters): the bf16 dW products write the
+    bf16 gradient arena only, the other gradients are cast per slot, AdamW and the clip norm read that arena.  Against the
+    fp32-gradient step of the same bf16-compute model: identical first loss, norm within one bf16 rounding per element,
+    parameters after two steps within the AdamW step size, and the run is bit-reproducible"""
+    g, cfg, w = load_golden(golden_dir, "t1")
+    res = {}
+    for tag, gd in (("f32", torch.float32), ("bf16", torch.bfloat16), ("bf16_again", torch.bfloat16)):
+        m = build_product(cfg, w, "bfloat16", DEV, train=True)
+        m.train()
+        tr = _trainer(m, min_bucket_bytes=1 << 14, grad_dtype=gd)
+        assert m.store.bf16_grads == (gd == torch.bfloat16)
+        assert (tr.reducer is not None and tr.reducer.local_only) == (gd == torch.bfloat16)
+        assert m.store.epi_sumsq
+        losses = [tr.step(_batch(g)).item() for _ in range(2)]
+        torch.cuda.synchronize()
+        res[tag] = (losses, tr.opt.norm.item(), m.store.master.clone())
+        if gd == torch.bfloat16:
+            # the norm the clip used is the norm of the bf16 arena AdamW read
+            full = m.store.gradc.double().norm().item()
+            assert abs(tr.opt.norm.item() - full) <= 1e-5 * full, (tr.opt.norm.item(), full)
+    assert res["bf16"][0][0] == res["f32"][0][0]
+    assert abs(res["bf16"][1] - res["f32"][1]) <= 4e-3 * res["f32"][1]
+    assert abs(res["bf16"][0][1] - res["f32"][0][1]) <= 2e-2 * abs(res["f32"][0][1])
+    assert (res["bf16"][2] - res["f32"][2]).abs().max().item() <= 2.5e-3      # lr 1e-3: at most ~2 AdamW steps apart
+    assert res["bf16_again"][0] == res["bf16"][0] and res["bf16_again"][1] == res["bf16"][1]
+    assert torch.equal(res["bf16_again"][2], res["bf16"][2])
