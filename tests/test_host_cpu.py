@@ -173,3 +173,44 @@ def test_action_norm_and_2string_bit_exact(golden_dir):
     assert np.allclose(tf2({"action": a.copy(), "prompt": ["zz"], "meta_data": {"dataset": "d1"}})["action"], 0.5)
     assert np.allclose(tf2({"action": a.copy(), "prompt": ["open"], "meta_data": {"dataset": "d1"}})["action"], 0.25)
     assert np.allclose(tf2({"action": a.copy(), "prompt": ["open"], "meta_data": {"dataset": "other"}})["action"], 1.0, atol=1e-7)
+
+
+def test_uncovered_ranges_of_the_gradient_arena():
+    """host bookkeeping of the single-GPU clip norm: [lo, hi) minus the slots a dW epilogue already accounted for, minus the
+    slots the path never writes and the frozen ones; neighbours separated only by alignment padding merge"""
+    import torch
+    from dexbotic_amd.engine import ALIGN, ParamStore
+    st = ParamStore("cpu", torch.float32)
+    st.new_bucket()
+    st.register([("a.ln", (10,))])
+    st.register([("a.w", (8, 16)), ("a.b", (16,))])
+    st.new_bucket()
+    st.register([("b.w", (4, 4))])
+    st.register([("b.frozen", (5,))])
+    st.register([("b.unused", (7,))])
+    st.finalize(train=True)
+    st.params["b.frozen"].requires_grad_(False)
+    st.set_expected(["b.unused"])
+    st.begin_step()
+    total = st.total
+    off = {n: (s.offset, s.offset + s.numel) for n, s in st.slots.items()}
+    # nothing covered: every trainable, expected slot; slots of one group are adjacent, groups are ALIGN apart (padding merges)
+    r = st.uncovered_ranges(0, total)
+    assert r[0][0] == off["a.ln"][0] and r[-1][1] == off["b.w"][1]
+    assert all(b - a > 0 for a, b in r)
+    covered_elems = sum(b - a for a, b in r)
+    assert covered_elems >= 10 + 8 * 16 + 16 + 16 and covered_elems <= total
+    assert not any(a <= off["b.unused"][0] < b for a, b in r) and not any(a <= off["b.frozen"][0] < b for a, b in r)
+    # the big weight covered by its product's epilogue: its neighbours remain, split around it
+    st._ssq_covered.add("a.w")
+    r = st.uncovered_ranges(0, total)
+    assert (off["a.ln"][0], off["a.ln"][1]) in r
+    assert any(a <= off["a.b"][0] and off["a.b"][1] <= b for a, b in r)       # (merged with b.w across the alignment gap)
+    assert not any(a < off["a.w"][1] and off["a.w"][0] < b for a, b in r)
+    # a sub-range (one bucket)
+    lo, hi = st.bucket_ranges[2]
+    r2 = st.uncovered_ranges(lo, hi)
+    assert r2 == [off["b.w"]]
+    st.begin_step()
+    assert not st._ssq_covered
+    assert ALIGN == 64
