@@ -404,7 +404,13 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, lh = lane >> 5;
   const int nt = p.tm * p.tn;
-  int bid = blockIdx.x;
+  // split-K (few tiles, deep K: ViT fc2 / o_proj on 514 rows): block ids [j * nt, (j + 1) * nt) are K slice j of every tile; the
+  // slices 0 .. S-2 leave their fp32 partial in a lane-linear 64 KiB slot (write-through) and count themselves in, slice S-1 —
+  // the highest block ids of a tile, dispatched after its partners — waits for them, adds the partials in slice order and
+  // runs the epilogue: deterministic, same protocol as the tail split of the 256-row kernels
+  const int split_s = p.split_s > 1 ? p.split_s : 1;
+  const int split_j = (int)blockIdx.x / nt;
+  int bid = (int)blockIdx.x - split_j * nt;
   {
     const int q = nt >> 3, r = nt & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -424,12 +430,14 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
     voA[j] = ga < (int)p.M ? (uint32_t)ga * (uint32_t)p.lda * 2u + ch : 0x80000000u;
     voB[j] = gb < (int)p.N ? (uint32_t)gb * (uint32_t)p.ldb * 2u + ch : 0x80000000u;
   }
-  const int nk = (int)(p.K >> 6);
+  const int nk_tot = (int)(p.K >> 6);
+  const int k_lo = split_j * nk_tot / split_s;
+  const int nk = (split_j + 1) * nk_tot / split_s - k_lo;      // K tiles of this workgroup (>= 1)
 #define T1_DMA(slot, t)                                                                                                  \
   do {                                                                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                   \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + (slot) * STAGE + (wave * 4 + j_) * 1024), 16, voA[j_], (t) * 128, 0, 0); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + (slot) * STAGE + A_ST + (wave * 4 + j_) * 1024), 16, voB[j_], (t) * 128, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + (slot) * STAGE + (wave * 4 + j_) * 1024), 16, voA[j_], (k_lo + (t)) * 128, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + (slot) * STAGE + A_ST + (wave * 4 + j_) * 1024), 16, voB[j_], (k_lo + (t)) * 128, 0, 0); \
     }                                                                                                                    \
   } while (0)
   f32x16_t acc[2][2];
@@ -485,6 +493,47 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
 #undef T1_DMA
 #undef T1_READ
 #undef T1_SB
+  if (split_s > 1) {
+    constexpr int SC1 = 16;
+    constexpr uint32_t SLOT = 128 * 128 * 4;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(1024u * SLOT), 0x00020000);
+    const uint32_t slot0 = (uint32_t)bid * (uint32_t)(split_s - 1) * SLOT + (uint32_t)tid * 16u;
+    if (split_j < split_s - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rW,
+                                                   slot0 + (uint32_t)split_j * SLOT + ((i * 2 + j) * 4 + q) * 4096, 0, SC1);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(p.flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_s - 1)
+        __builtin_amdgcn_s_sleep(4);
+      __hip_atomic_store(p.flags + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int sj = 0; sj < split_s - 1; ++sj) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                rW, slot0 + (uint32_t)sj * SLOT + ((i * 2 + j) * 4 + q) * 4096, 0, SC1));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[c];
+          }
+    }
+  }
   // ---- epilogue from the registers: lane (l32, lh) holds, per block (i, j), row 32 i + l32 and columns 32 j + 8 q + 4 lh + {0..3}
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
@@ -1718,10 +1767,22 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   if (!fast_off && !t128_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && !d->epi_f32 &&
       d->M >= 64 && d->M <= t128_max_m && d->N >= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB &&
       bytesA < (1ll << 31) && bytesB < (1ll << 31) &&
-      (t128_all || (t128_tiles >= 64 && t128_tiles <= NUM_CU && d->K <= 4096))) {
+      (t128_all || (t128_tiles >= 32 && t128_tiles <= NUM_CU && d->K <= 4096))) {
     p.tm = dxa_cdiv(d->M, 128);
     p.tn = dxa_cdiv(d->N, 128);
-    dim3 tgrid((unsigned)(p.tm * p.tn));
+    // few tiles over a deep K: cut K so that every CU gets a workgroup (>= 8 K tiles of 64 per slice, <= 4 slices)
+    static const bool t128_nosplit = getenv("DXA_GEMM_NO_SPLIT") != nullptr;
+    int t_split = 1;
+    if (!t128_nosplit && t128_tiles <= NUM_CU / 4)      // (120 tiles x K 1024 measured slower cut in two: 21.2 vs 18.7 us)
+      t_split = (int)std::min<int64_t>(std::min<int64_t>(4, NUM_CU / t128_tiles), (d->K / 64) / 8);
+    if (t_split >= 2) {
+      SplitWs w;
+      if (int rc = get_split_ws(st, &w)) return rc;
+      p.split_s = t_split; p.ws = w.ws; p.flags = w.flags;
+    } else {
+      p.split_s = 1;
+    }
+    dim3 tgrid((unsigned)(p.tm * p.tn * p.split_s));
     // two stages (64 KiB): two workgroups share a CU and hide each other's LDS-DMA issue and barriers; four stages when a CU
     // gets one workgroup anyway
     static const int force_ns = getenv("DXA_GEMM_T128_NS") ? atoi(getenv("DXA_GEMM_T128_NS")) : 0;

@@ -23,6 +23,7 @@ SHAPES = [  # (name, layout, M, N, K)
     ("epi K=64   ", "nt", M, 37888, 64), ("epi K=512  ", "nt", M, 37888, 512), ("epi K=1024 ", "nt", M, 37888, 1024),
     ("pre qkv    ", "nt", 543, 4608, 3584), ("pre o_proj ", "nt", 543, 3584, 3584), ("pre gate_up", "nt", 543, 37888, 3584),
     ("pre down   ", "nt", 543, 3584, 18944), ("pre vit fc1", "nt", 514, 4096, 1024), ("pre vit fc2", "nt", 514, 1024, 4096),
+    ("pre vit o  ", "nt", 514, 1024, 1024), ("pre vit qkv", "nt", 514, 3072, 1024),
     ("dWgu as nt ", "nt", 37888, 3584, 4608), ("dWdown  nt ", "nt", 3584, 18944, 4608), ("da as nt   ", "nt", M, 18944, 3584),
 ]
 

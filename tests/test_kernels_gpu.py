@@ -857,10 +857,12 @@ def test_sumsq_ranges():
 
 # ------------------------------------------------------------------- few-row NT kernel (128x128 tiles, M <= 1024)
 @pytest.mark.parametrize("shape", [(543, 4608, 3584), (543, 3584, 18944), (514, 1024, 4096), (514, 4096, 1024), (64, 64, 64),
-                                   (130, 300, 64), (1024, 200, 128), (700, 136, 192), (543, 37888, 3584)])
+                                   (130, 300, 64), (1024, 200, 128), (700, 136, 192), (543, 37888, 3584), (514, 1024, 1024),
+                                   (640, 1000, 2048), (400, 1536, 3072)])
 def test_gemm_few_rows_t128(shape):
     """bf16 NT products on a few hundred rows (batch-1 prefill S = 543, ViT on 2 x 257 tokens): 128x128-tile LDS-DMA ring
-    kernel; 1, 2, 3, 4 and many K tiles (the ring has 4 stages), ragged M / N, the whole epilogue menu (bias, residual,
+    kernel; 1, 2, 3, 4 and many K tiles (the ring has 4 stages), split-K over 2 / 3 / 4 slices where few tiles meet a deep K
+    (40 tiles x K 4096 / 1024, 40 x 2048, 48 x 3072), ragged M / N, the whole epilogue menu (bias, residual,
     activation + pre-activation copy, activation gradient, fp32 accumulate), every element against fp64, repetitions bitwise"""
     M, N, Kd = shape
     a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=91), rnd(N, Kd, dtype=torch.bfloat16, seed=92, scale=0.1)
