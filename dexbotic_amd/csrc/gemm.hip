@@ -565,6 +565,78 @@ template __global__ void gemm_nt_t128_kernel<bf16_t, 4>(const GemmP);
 template __global__ void gemm_nt_t128_kernel<float, 4>(const GemmP);
 
 // =====================================================================================================
+// Few-row NN product (M <= 8): out[M, N] = A[M, K] W[K, N] with W as it lies — the dX of a linear layer applied to a handful
+// of tokens (MemVLA's one-token cognition stream through its retrieval blocks, memvla_arch.py:194-216: dy [1, 14336] against a
+// [14336, 3584] weight).  It is a stream over W: thread -> 8 consecutive output columns (16-byte loads of W rows), the K range is
+// cut into `ksplit` slices so that a few hundred workgroups share the stream, per-slice fp32 partials go to the split-K scratch
+// and a second launch adds them in slice order (deterministic).  The 64x64-tile kernel it replaces spent 93 us per call.
+// =====================================================================================================
+constexpr int GV_MAXM = 8;
+template <int M_>
+__global__ __launch_bounds__(256) void gemv_nn_stage1_k(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                        int64_t ldb, float* __restrict__ part, int M, int64_t N, int64_t K,
+                                                        int kper) {
+  __shared__ float as[GV_MAXM][512];
+  const int ks = blockIdx.y;
+  const int64_t k0 = (int64_t)ks * kper, k1 = min(K, k0 + kper);
+  for (int i = threadIdx.x; i < M_ * kper; i += 256) {
+    const int m = i / kper, kk = i - m * kper;
+    as[m][kk] = (m < M && k0 + kk < k1) ? bf2f(A[(int64_t)m * lda + k0 + kk]) : 0.f;
+  }
+  __syncthreads();
+  const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (n >= N) return;
+  float acc[M_][8];
+#pragma unroll
+  for (int m = 0; m < M_; ++m)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[m][e] = 0.f;
+  const bf16_t* wp = W + k0 * ldb + n;
+  const int nkk = (int)(k1 - k0);
+  int kk = 0;
+  for (; kk + 4 <= nkk; kk += 4) {                     // four independent 16-byte loads in flight
+    float w[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Vec<bf16_t, 8>::ld(w[u], wp + (int64_t)(kk + u) * ldb);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < M_; ++m) {
+        const float a = as[m][kk + u];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[m][e] += a * w[u][e];
+      }
+  }
+  for (; kk < nkk; ++kk) {
+    float w[8];
+    Vec<bf16_t, 8>::ld(w, wp + (int64_t)kk * ldb);
+#pragma unroll
+    for (int m = 0; m < M_; ++m) {
+      const float a = as[m][kk];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[m][e] += a * w[e];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M_; ++m)
+    if (m < M) {
+      float* pp = part + ((int64_t)ks * M + m) * N + n;
+      *reinterpret_cast<float4*>(pp) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+      *reinterpret_cast<float4*>(pp + 4) = make_float4(acc[m][4], acc[m][5], acc[m][6], acc[m][7]);
+    }
+}
+template <typename TO>
+__global__ __launch_bounds__(256) void gemv_nn_stage2_k(const float* __restrict__ part, TO* __restrict__ C, int64_t ldc, int M,
+                                                        int64_t N, int ksplit, float alpha) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  const int64_t m = i / N, n = i - m * N;
+  float s = 0.f;
+  for (int ks = 0; ks < ksplit; ++ks) s += part[((int64_t)ks * M + m) * N + n];
+  stf<TO>(C + m * ldc + n, s * alpha);
+}
+
+// =====================================================================================================
 // Skinny fp32 NT kernel (M <= 64 rows): the DiT head at inference time is ~50 linears per DDIM step on 36 rows
 // (2 x 18 tokens), i.e. a stream over each weight matrix with almost no arithmetic.  The tiled kernel puts such a
 // problem on N/64 workgroups that each walk all of K serially (measured 44 us per call).  Here a workgroup owns
@@ -1883,6 +1955,34 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   }
   DXA_CHECK_ARG(!d->epi_f32, "dxa_gemm: epi_f32 is only implemented on the bf16 NT fast path (K %% 32 == 0, M, N >= 64, "
                               "16-byte aligned rows, no batching)");
+  // ---- few-row NN (dX of a linear on <= 8 tokens): a stream over W as it lies, K cut into slices, partials in the split scratch
+  static const bool gemv_off = getenv("DXA_GEMM_NO_GEMV") != nullptr;
+  if (!gemv_off && d->layout == DXA_NN && d->in_dtype == DXA_BF16 && nbatch == 1 && d->M <= GV_MAXM && d->K >= 64 &&
+      d->N >= 64 && d->N % 8 == 0 && d->ldb % 8 == 0 && aligned_to(d->B, 16) && !d->bias && !d->residual && !d->aux_out &&
+      !d->mulgrad && d->act == DXA_ACT_NONE && !d->accumulate && !d->epi_f32) {
+    const int nbn = dxa_cdiv(d->N, 2048);
+    int ksplit = (int)std::min<int64_t>(std::min<int64_t>(64, d->K / 32), dxa_cdiv(512, nbn));
+    if (ksplit < 1) ksplit = 1;
+    int kper = dxa_cdiv(d->K, ksplit);
+    if (kper > 512) { kper = 512; ksplit = dxa_cdiv(d->K, kper); }
+    if ((size_t)ksplit * d->M * d->N * sizeof(float) <= (size_t)NUM_CU * 256 * 256 * 4) {
+      SplitWs w;
+      if (int rc = get_split_ws(st, &w)) return rc;
+      dim3 g1((unsigned)nbn, (unsigned)ksplit);
+      const bf16_t* A_ = (const bf16_t*)d->A;
+      const bf16_t* W_ = (const bf16_t*)d->B;
+#define LAUNCH_GV(M_) hipLaunchKernelGGL((gemv_nn_stage1_k<M_>), g1, dim3(256), 0, st, A_, d->lda, W_, d->ldb, w.ws, (int)d->M, d->N, d->K, kper)
+      if (d->M <= 1) LAUNCH_GV(1); else if (d->M <= 2) LAUNCH_GV(2); else if (d->M <= 4) LAUNCH_GV(4); else LAUNCH_GV(8);
+#undef LAUNCH_GV
+      dim3 g2((unsigned)dxa_cdiv(d->M * d->N, 256));
+      if (d->out_dtype == DXA_BF16)
+        hipLaunchKernelGGL(gemv_nn_stage2_k<bf16_t>, g2, dim3(256), 0, st, w.ws, (bf16_t*)d->C, d->ldc, (int)d->M, d->N, ksplit, d->alpha);
+      else
+        hipLaunchKernelGGL(gemv_nn_stage2_k<float>, g2, dim3(256), 0, st, w.ws, (float*)d->C, d->ldc, (int)d->M, d->N, ksplit, d->alpha);
+      DXA_CHECK_LAUNCH();
+      return DXA_OK;
+    }
+  }
   // ---- skinny bf16 path: M <= 64 (KV-cached decode, few-row products): a stream over the weights
   if (!skinny_off_g() && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->M <= 64 && d->K >= 64 &&
       d->K % 64 == 0 && p.vecA && p.vecB) {

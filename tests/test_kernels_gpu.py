@@ -915,3 +915,18 @@ def test_attention_dropout_mask(dtype):
     o2 = torch.empty_like(q)
     K.attn_fwd(q, k, v, o2, causal=False, scale=D ** -0.5, force_generic=True)
     assert_close(o2, torch.softmax(q.double() @ k.double().transpose(-1, -2) * D ** -0.5, dim=-1) @ v.double(), rtol, atol, "no mask")
+
+
+@pytest.mark.parametrize("M,Kd,N", [(1, 14336, 3584), (1, 3584, 3584), (3, 3584, 14336), (8, 200, 520), (5, 64, 64), (2, 1030, 72)])
+def test_gemv_few_row_nn(M, Kd, N):
+    """dX of a linear applied to a handful of tokens (MemVLA's one-token cognition stream): out[M <= 8, N] = dy[M, K] W[K, N]
+    as a K-sliced stream over W as it lies; against fp64, bf16 and fp32 outputs, repetitions bitwise equal"""
+    dy = rnd(M, Kd, dtype=torch.bfloat16, seed=111)
+    w = rnd(Kd, N, dtype=torch.bfloat16, seed=112, scale=0.1)
+    ref = dy.double() @ w.double()
+    rtol, atol = tol_for(torch.bfloat16, Kd)
+    o1 = K.mm_nn(dy, w)
+    assert_close(o1, ref, 2 * rtol, 2 * atol, "few-row nn bf16")
+    o32 = K.mm_nn(dy, w, out_dtype=torch.float32)
+    assert_close(o32, ref, 2e-5, 2e-3 * math.sqrt(max(Kd, 320) / 320), "few-row nn f32")
+    assert torch.equal(o1, K.mm_nn(dy, w)) and torch.equal(o32, K.mm_nn(dy, w, out_dtype=torch.float32))
