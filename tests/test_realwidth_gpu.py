@@ -107,3 +107,89 @@ def test_bf16_real_width_tracks_bf16_autocast_reference(real):
 # observed on the MI355X (round 2): loss 1.3e-4, cognition 7.8e-3 (max-norm: one bf16 ulp of the largest feature is 3.9e-3),
 # gradient norms 4e-4 .. 1e-3, DDIM result 2.5e-3
 BF16_LOSS, BF16_ACT, BF16_GNORM = 5e-4, 2e-2, 3e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same path pinned to the REFERENCE'S OWN CLASSES (round-2 verdict item 1): tests/golden/cogact_real_ref.npz holds
+# dexbotic's CogACTForCausalLM at the BASELINE widths with FOUR decoder layers, run in fp32 and under
+# torch.autocast("cpu", bfloat16) exactly as HF Trainer runs it for bf16=True (oracle/gen_golden_realwidth_ref.py; head in
+# fp32 as cogact_arch.py:133 makes it on the reference's real device).  The product's bf16 mode — what bench.py times —
+# is held to reference-under-autocast, gradient SAMPLES included.
+import zlib
+
+from oracle import gen_golden_realwidth_ref as RR
+
+
+@pytest.fixture(scope="module")
+def real_ref(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cogact_real_ref.npz"), allow_pickle=False)
+    x = RR.inputs()
+    assert zlib.crc32(x["images"].tobytes()) == int(g["images_crc"])
+    assert zlib.crc32(x["infer_images"].tobytes()) == int(g["infer_images_crc"])
+    w = make_weights(cogact_shapes(RR.REAL4), int(g["seed"]))
+    assert weights_crc(w) == int(g["weights_crc"])
+    return g, x, w
+
+
+def _step_ref(m, x):
+    st = m.store
+    st.set_expected(m.unused_parameter_names())
+    st.begin_step()
+    cap = {}
+    h = m.model.action_head.net.register_forward_hook(lambda mod, i, o: cap.__setitem__("eps_hat", o.detach().float()))
+    out = m(input_ids=T(x["input_ids"]), attention_mask=T(x["attention_mask"]), images=T(x["images"]),
+            actions=T(x["actions"]), labels=T(x["input_ids"]), noise=T(x["noise"]), timesteps=T(x["timesteps"]),
+            drop_ids=T(x["drop_u"]) < 0.1)
+    h.remove()
+    out.loss.backward()
+    torch.cuda.synchronize()
+    plan = m.model._last_plan
+    hid = out.logits.detach().float()
+    res = {"loss": out.loss.item(), "eps_hat": cap["eps_hat"].cpu().numpy(),
+           "cognition": torch.stack([hid[b, int(plan.last_index[b])] for b in range(hid.shape[0])])[:, None, :].cpu().numpy()}
+    for name, pre in RR.GROUPS.items():
+        sq = sum(float(st.g(n).double().pow(2).sum()) for n in st.slots if n.startswith(pre) and st.grad_written[n])
+        res[f"gnorm/{name}"] = sq ** 0.5
+    for n in RR.GSAMP:
+        res["gsamp/" + n] = st.g(n).reshape(-1)[::RR.STRIDE].float().cpu().numpy()
+    m.eval()
+    _, samples, _ = m.inference_action(T(x["infer_ids"]), T(x["infer_images"]),
+                                       {"cfg_scale": 1.5, "num_ddim_steps": 10,
+                                        "action_norms": {"min": [-1.0] * 7, "max": [1.0] * 7}},
+                                       noise=T(x["infer_init"]), return_trajectory=True)
+    res["infer_samples"] = samples.float().cpu().numpy()
+    return res
+
+
+def test_fp32_four_layers_real_width_matches_reference_classes(real_ref):
+    g, x, w = real_ref
+    m = build_product(RR.REAL4, w, "float32", DEV, train=True)
+    m.train()
+    got = _step_ref(m, x)
+    for k, v in got.items():
+        d = rel_err(v, g["fp32/" + k])
+        assert d < 1e-3, (k, d)                       # north-star tolerance
+
+
+# bf16 product vs the reference under bf16 autocast.  Yardstick for "how far apart may two bf16 evaluations of this stack
+# be": the CPU oracle under autocast sits at loss 2.4e-4, cognition 6.6e-3, eps_hat 1.1e-3, gradient norms <= 6.3e-4, gradient
+# samples (max-norm relative) <= 2.2e-2, DDIM result 7.8e-4 from the same vectors (fixture keys oracle_vs_ref/bf16/*).
+REF_BF16 = {"loss": 1.5e-3, "cognition": 2.5e-2, "eps_hat": 6e-3, "gnorm": 4e-3, "gsamp": 8e-2, "infer_samples": 5e-3}
+
+
+def test_bf16_four_layers_real_width_tracks_reference_under_autocast(real_ref):
+    g, x, w = real_ref
+    m = build_product(RR.REAL4, w, "bfloat16", DEV, train=True)
+    m.train()
+    from dexbotic_amd import kernels as K
+    with K.f32_gemm_mode("bf16x3"):
+        got = _step_ref(m, x)
+    print("bf16 product vs reference-under-autocast | oracle-under-autocast vs the same | product vs fp32 reference:")
+    worst = {}
+    for k, v in got.items():
+        d = rel_err(v, g["bf16/" + k])
+        print(f"  {k:70s} {d:.2e} | {float(g['oracle_vs_ref/bf16/' + k]):.2e} | {rel_err(v, g['fp32/' + k]):.2e}")
+        bound = next(b for pre, b in REF_BF16.items() if k.startswith(pre))
+        if d >= bound:
+            worst[k] = (d, bound)
+    assert not worst, worst
