@@ -114,6 +114,20 @@ class ParamStore:
         # embedding-gradient rows written since the slice was last all-zero (sparse re-zero, functional.SpliceFn)
         self.sparse_embed_zero = False
         self._embed_dirty: Dict[str, Optional[List[torch.Tensor]]] = {}     # missing / None = unknown -> dense zero
+        # optimizer overlapped with the next forward (FusedAdamW(overlap=True)): bucket -> HIP event recorded on the optimizer
+        # stream after that bucket's parameters / shadows / moments were updated.  Any arena view of the bucket handed out
+        # afterwards (w / w32 / g / gc) first makes the CURRENT stream wait for the event, so layer i of the next step starts
+        # as soon as bucket i is done while the HBM-bound update of the later buckets still runs under the MFMA-bound forward.
+        self._pending: Dict[int, "torch.cuda.Event"] = {}
+        # ---- driven from outside (HF Trainer / the reference's DexboticTrainer / a hand-written loop) -----------------------
+        # managed: a NativeTrainer (or exp.trainer.NativeDexboticTrainer) calls begin_step / begin_micro itself.  Otherwise the
+        # model's forward pre-hook does (external_prelude): gradients re-attached after zero_grad(set_to_none=True), a new
+        # optimizer step recognised by the dropped / touched gradients, and the bf16 shadows re-derived when a foreign
+        # optimizer (torch.optim.AdamW on the arena views) moved the fp32 masters (w(): version counter of the arena).
+        self.managed = False
+        self._shadow_version: Optional[int] = None
+        self._grad_version: Optional[int] = None
+        self._external_fresh = True                     # nothing written since the last begin_step
 
     # ---- layout -------------------------------------------------------------------------------------
     def new_bucket(self) -> int:
@@ -159,8 +173,25 @@ class ParamStore:
         self.set_expected(())
 
     # ---- views --------------------------------------------------------------------------------------
+    def wait_pending(self, bucket: Optional[int] = None) -> None:
+        """make the current stream wait for the overlapped optimizer update of ``bucket`` (None: of every bucket still
+        pending).  Readers that bypass the view accessors (raw master pointers, ``state_dict()``, ``p.data``) call this."""
+        if not self._pending:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if bucket is None:
+            for ev in set(self._pending.values()):
+                cur.wait_event(ev)
+            self._pending.clear()
+            return
+        ev = self._pending.pop(bucket, None)
+        if ev is not None:
+            cur.wait_event(ev)
+
     def _view(self, arena: torch.Tensor, names: Sequence[str], shape: Optional[Sequence[int]]) -> torch.Tensor:
         s0 = self.slots[names[0]]
+        if self._pending:
+            self.wait_pending(s0.bucket)
         n = 0
         for nm in names:                      # must be packed back to back
             s = self.slots[nm]
@@ -172,6 +203,8 @@ class ParamStore:
     def w(self, *names: str, shape: Optional[Sequence[int]] = None) -> torch.Tensor:
         """compute-dtype weight view (bf16 shadow, or the fp32 master in fp32 mode); several adjacent
         names give the fused matrix"""
+        if self.shadow is not None and self.master._version != self._shadow_version:
+            self.sync_shadow()            # an in-place torch op (foreign optimizer, load, user code) moved the masters
         arena = self.shadow if self.shadow is not None else self.master
         return self._view(arena, names, shape)
 
@@ -281,6 +314,7 @@ class ParamStore:
         self.begin_micro()
         for nm in zero_names:
             self.g(nm).zero_()
+        self._own_grad_write()
         self._ssq_cursor = 0
         self._ssq_covered = set()
 
@@ -349,7 +383,14 @@ class ParamStore:
                 K.zero_rows(plan, g)
         else:
             g.zero_()
+            self._own_grad_write()
         self._embed_dirty[name] = []
+
+    def _own_grad_write(self) -> None:
+        """an in-place torch op of this package's own on the gradient arena (external_prelude watches the arena's version
+        counter for FOREIGN writes: zero_grad(set_to_none=False), clip_grad_norm_)"""
+        if self._grad_version is not None and self.grad is not None:
+            self._grad_version = self.grad._version
 
     def note_embed_rows(self, name: str, plan: torch.Tensor) -> None:
         dirty = self._embed_dirty.get(name)
@@ -364,16 +405,59 @@ class ParamStore:
         return [nm for nm, wtn in self.grad_written.items() if not wtn and self.params[nm].requires_grad]
 
     def attach_grads(self) -> None:
-        """expose the arena views as ``param.grad`` (HF Trainer / user code compatibility)"""
+        """expose the arena views as ``param.grad`` (HF Trainer / user code compatibility).  Parameters the path never
+        writes (``set_expected``'s exclusions: lm_head, the CLIP layer after hidden_states[-2]) keep ``grad = None`` like in
+        the reference, so torch.optim skips them (no weight decay, no moments).  With a bf16 gradient arena
+        (``bf16_grads``) the weight matrices' gradients live in ``gradc`` as bf16, which torch does not accept as the
+        ``.grad`` of an fp32 parameter: that mode exposes no ``p.grad`` at all (read ``store.gc(name)`` / ``store.g(name)``)
+        rather than stale fp32 views."""
+        if self.grad is None:
+            return
         for nm, p in self.params.items():
-            if p.requires_grad and self.grad is not None:
+            if not p.requires_grad:
+                continue
+            if nm in self._excluded or self.bf16_grads:
+                p.grad = None
+            else:
                 p.grad = self.g(nm)
 
     def sync_shadow(self) -> None:
         """re-derive the bf16 shadows from the fp32 masters (after load_state_dict / init)"""
+        self.wait_pending()
         if self.shadow is not None:
             from . import kernels as K
             K.cast(self.master, self.shadow.dtype, out=self.shadow)
+            self._shadow_version = self.master._version
+
+    def external_prelude(self, unused: Iterable[str] = ()) -> None:
+        """what a managing trainer does before a training forward, for loops this package does not drive (the model's forward
+        pre-hook calls it while ``managed`` is False): HF ``Trainer.training_step`` -> ``optimizer.step()`` ->
+        ``model.zero_grad()`` (dexbotic/exp/trainer.py:18-36 inherits exactly that loop).  A NEW optimizer step is recognised by
+        gradients that were dropped (``zero_grad(set_to_none=True)``), zeroed / clipped in place (version counter of the
+        gradient arena) or reset through the model's own ``zero_grad``; otherwise this forward is a further micro-batch of the
+        same step and its gradients accumulate."""
+        if self.grad is None:
+            return
+        unused = set(unused)
+        if unused != self._excluded:
+            self.set_expected(unused)
+        probe = next((self.params[n] for n in self.slots if self.params[n].requires_grad and n not in self._excluded), None)
+        dropped = probe is not None and probe.grad is None
+        if dropped:
+            self.attach_grads()
+        if dropped or self._external_fresh or self.grad._version != self._grad_version:
+            self.begin_step()
+            if dropped or self.grad._version != self._grad_version:
+                self.invalidate_embed_tracking()          # somebody else wrote the gradient arena: dense re-zero
+        else:
+            self.begin_micro()
+        self._external_fresh = False
+        self._grad_version = self.grad._version
+
+    def external_zero_grad(self) -> None:
+        """``model.zero_grad()`` of an external loop: gradients stay attached (they are views of the arena, overwritten by the
+        next backward's first write); the step boundary is recorded"""
+        self._external_fresh = True
 
 class Fp32View:
     """Same interface as ParamStore but ``w()`` hands out the fp32 masters: used by the diffusion action
@@ -446,11 +530,19 @@ class FusedAdamW:
     """One-launch AdamW over the arena + device-side global-norm clipping."""
 
     def __init__(self, store: ParamStore, cfg: OptimConfig, prefixes: Dict[str, str] | None = None,
-                 exclude: Iterable[str] = ()):
+                 exclude: Iterable[str] = (), overlap: bool = False, segment_elems: int = 48 << 20,
+                 groups: Optional[List[dict]] = None):
         """``exclude``: parameters that never receive a gradient (torch.optim skips ``grad is None``
-        parameters entirely — no weight decay either)."""
+        parameters entirely — no weight decay either).
+        ``overlap``: run the update on a side HIP stream, cut along bucket boundaries into segments of >= ``segment_elems``
+        parameters in FORWARD order, one event per segment (``ParamStore._pending``): the next step's forward waits
+        per bucket instead of for the whole 224 GB sweep — the update is HBM-bound, the forward MFMA-bound.
+        ``groups``: explicit parameter groups ``[{"names": [...]}, ...]`` (<= 8; exp.trainer.ArenaAdamW passes the groups the
+        reference's OptimizerConfig built) instead of the name rule below; learning rate and weight decay of group i are then
+        given per step (``step(lrs=, wds=)``).  Parameters in no group are not updated."""
         from . import kernels as K  # noqa: F401  (fail early if the library is missing)
         self.store, self.cfg = store, cfg
+        self.overlap = bool(overlap) and store.device.type == "cuda"
         exclude = set(exclude)
         dev = store.device
         self.m = torch.zeros_like(store.master)
@@ -461,17 +553,26 @@ class FusedAdamW:
         self.group_keys: List[Tuple[str, bool]] = []
         self.group_of: Dict[str, Tuple[str, bool]] = {}      # parameter name -> (lr key, weight-decayed?)
         cs, cl, cg = [], [], []
+        explicit = None
+        if groups is not None:
+            explicit = {nm: gi for gi, g in enumerate(groups) for nm in g["names"]}
+            self.group_keys = [(f"group{gi}", True) for gi in range(len(groups))]
         for s in sorted(store.slots.values(), key=lambda s: s.offset):
             if not store.params[s.name].requires_grad or s.name in exclude:
                 continue
-            lr_key = "base"
-            if cfg.mm_projector_lr is not None and prefixes["mm_projector"] in s.name:
-                lr_key = "mm_projector"
-            elif cfg.mm_vision_lr is not None and prefixes["mm_vision"] in s.name:
-                lr_key = "mm_vision"
-            elif cfg.action_head_lr is not None and prefixes["action_head"] in s.name:
-                lr_key = "action_head"
-            key = (lr_key, not no_decay_name(s.name, store))
+            if explicit is not None:
+                if s.name not in explicit:
+                    continue
+                key = self.group_keys[explicit[s.name]]
+            else:
+                lr_key = "base"
+                if cfg.mm_projector_lr is not None and prefixes["mm_projector"] in s.name:
+                    lr_key = "mm_projector"
+                elif cfg.mm_vision_lr is not None and prefixes["mm_vision"] in s.name:
+                    lr_key = "mm_vision"
+                elif cfg.action_head_lr is not None and prefixes["action_head"] in s.name:
+                    lr_key = "action_head"
+                key = (lr_key, not no_decay_name(s.name, store))
             self.group_of[s.name] = key
             if key not in self.group_keys:
                 self.group_keys.append(key)
@@ -484,6 +585,27 @@ class FusedAdamW:
                 cg.append(gi)
                 o += ln
         assert len(self.group_keys) <= 8
+        # segments for the overlapped update: [first chunk, one past the last chunk, buckets covered]
+        self.segments: List[Tuple[int, int, List[int]]] = []
+        self.stream = None
+        if self.overlap:
+            import bisect
+            prio = int(__import__("os").environ.get("DXA_OPT_STREAM_PRIO", "0"))
+            self.stream = torch.cuda.Stream(device=dev, priority=prio)
+            i0, buckets, elems = 0, [], 0
+            for b, (lo, hi) in enumerate(store.bucket_ranges):
+                if hi <= lo:
+                    continue
+                buckets.append(b)
+                i1 = bisect.bisect_left(cs, hi)
+                elems = sum(cl[i0:i1])
+                if elems >= segment_elems:
+                    self.segments.append((i0, i1, buckets))
+                    i0, buckets = i1, []
+            if buckets or i0 < len(cs):
+                self.segments.append((i0, len(cs), buckets))
+            self.segments = [sg for sg in self.segments if sg[1] > sg[0] or sg[2]]
+            self._events = [torch.cuda.Event() for _ in self.segments]
         self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
         self.chunk_len = torch.tensor(cl, dtype=torch.int32, device=dev)
         self.chunk_grp = torch.tensor(cg, dtype=torch.int32, device=dev)
@@ -496,12 +618,13 @@ class FusedAdamW:
         c = self.cfg
         lr_of = {"base": c.base_lr, "mm_projector": c.mm_projector_lr, "mm_vision": c.mm_vision_lr,
                  "action_head": c.action_head_lr}
-        lrs = [lr_of[k] * lr_scale for k, _ in self.group_keys]
+        lrs = [lr_of.get(k, c.base_lr) * lr_scale for k, _ in self.group_keys]
         wds = [c.weight_decay if dec else 0.0 for _, dec in self.group_keys]
         return lrs, wds
 
     def step(self, lr_scale: float = 1.0, sumsq: Optional[torch.Tensor] = None,
-             grads: Optional[torch.Tensor] = None) -> None:
+             grads: Optional[torch.Tensor] = None, lrs: Optional[Sequence[float]] = None,
+             wds: Optional[Sequence[float]] = None) -> None:
         """``sumsq``: device scalar holding sum(g^2) over the arena if someone already accumulated it (GradNormTracker
         does, bucket by bucket under the backward); otherwise one pass over the gradient arena computes it here.
         ``grads``: arena to read the gradients from (default the fp32 gradient arena; the averaged bf16 communication
@@ -510,6 +633,8 @@ class FusedAdamW:
         st, c = self.store, self.cfg
         grads = st.grad if grads is None else grads
         self.step_count += 1
+        if self.overlap:
+            st.wait_pending()                      # a previous update nobody consumed still reads the clip coefficient
         clip = None
         if c.max_grad_norm is not None:
             if sumsq is None:
@@ -517,9 +642,29 @@ class FusedAdamW:
                 sumsq = self.sumsq
             K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef)
             clip = self.coef
-        lrs, wds = self._lrs_wds(lr_scale)
-        K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
-                lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
+        d_lrs, d_wds = self._lrs_wds(lr_scale)
+        lrs = d_lrs if lrs is None else [float(x) for x in lrs]
+        wds = d_wds if wds is None else [float(x) for x in wds]
+        assert len(lrs) == len(wds) == len(self.group_keys)
+        if not self.overlap:
+            K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
+                    lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
+            return
+        cur = torch.cuda.current_stream(st.device)
+        self.stream.wait_stream(cur)               # gradients, sum(g^2) and the clip coefficient are final on `cur`
+        with torch.cuda.stream(self.stream):
+            for (i0, i1, buckets), ev in zip(self.segments, self._events):
+                if i1 > i0:
+                    K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start[i0:i1], self.chunk_len[i0:i1],
+                            self.chunk_grp[i0:i1], lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count,
+                            clip=clip)
+                ev.record(self.stream)
+                for b in buckets:
+                    st._pending[b] = ev
+
+    def synchronize(self) -> None:
+        """the current stream waits for an overlapped update still in flight"""
+        self.store.wait_pending()
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:
@@ -654,13 +799,21 @@ class GradReducer:
 
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
                  skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32,
-                 algo: str = "rs_ag", local_only: bool = False):
+                 algo: str = "rs_ag", local_only: bool = False, native_avg_world1: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.force = force or local_only   # run the bucket pipeline even at world size 1 (exercises the RCCL path)
         # local_only: no process group at all — the per-bucket pipeline (bf16 copy of the slots no epilogue wrote, sum of squares
         # on the side stream) without any collective: the single-GPU bf16-gradient step
         self.local_only = local_only
+        # world size 1 normally asks RCCL for SUM (the mean of one rank is the identity; RCCL's one-rank AVG is a separate
+        # pre-multiply pass).  native_avg_world1=True takes the EXACT call sequence every N > 1 run takes instead — in-place
+        # reduce_scatter_tensor(AVG) into this rank's shard + all_gather_into_tensor, shard alignment, all-reduced tail — so
+        # that path executes on hardware with one GPU (tests/test_zz_dp_gpu.py)
+        self.native_avg_world1 = native_avg_world1
+        self.time_comm = False                          # bench.py: record the per-step communication window
+        self._t0 = None
+        self._windows: List[tuple] = []
         assert comm_dtype in (torch.float32, torch.bfloat16)
         assert algo in ("rs_ag", "allreduce")
         self.comm_dtype, self.algo = comm_dtype, algo
@@ -743,8 +896,8 @@ class GradReducer:
         # AVG is native on RCCL.  With ONE rank (force=True: the path is exercised on a single GPU) the mean is the
         # identity and SUM is asked for instead: RCCL's one-rank AVG runs a separate pre-multiply pass over the whole
         # buffer (oneRankReduce<FuncPreMulSum>, 43 ms per step for the 30 GB arena) that no multi-rank ring contains
-        native_avg = buf.is_cuda and w > 1
-        if w == 1:
+        native_avg = buf.is_cuda and (w > 1 or self.native_avg_world1)
+        if w == 1 and not self.native_avg_world1:
             if self.algo == "allreduce":
                 d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group)
                 self.collectives += 1
@@ -787,6 +940,9 @@ class GradReducer:
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
+                if self.time_comm and self._t0 is None:
+                    self._t0 = torch.cuda.Event(enable_timing=True)
+                    self._t0.record(self.comm_stream)
                 if half:
                     self._fill_mirror(lo, hi)
                 self._exchange(buf)
@@ -827,4 +983,16 @@ class GradReducer:
         if not self.local_only:
             st.invalidate_embed_tracking()                 # other ranks' token rows are now non-zero here too
         if self.comm_stream is not None:
+            if self.time_comm and self._t0 is not None:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(self.comm_stream)
+                self._windows.append((self._t0, t1))
+                self._t0 = None
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def comm_window_ms(self) -> List[float]:
+        """per step: time from the first collective's start to the last collective's end on the communication stream
+        (``time_comm`` must be on; call after a device synchronize)"""
+        out = [a.elapsed_time(b) for a, b in self._windows]
+        self._windows = []
+        return out

@@ -1,0 +1,176 @@
+"""``NativeDexboticTrainer``: the reference's ``DexboticTrainer(transformers.Trainer)`` (dexbotic/exp/trainer.py:18-138) for
+the native policy — what an exp script gets instead of ``DexboticTrainer`` when the native backend is opted in.
+
+Same constructor (``exp_config=`` plus the HF ``Trainer`` arguments), same ``_link_exp_config`` mapping from the exp's
+``trainer_config`` / ``optimizer_config`` to ``TrainingArguments``, same ``*_loss`` logging; HF's loop (dataloader, LR
+scheduler, logging, checkpoint cadence, callbacks) stays in charge.  What changes underneath:
+
+  * ``create_optimizer`` takes the groups ``OptimizerConfig._get_optimizer_grouped_parameters`` builds (base_exp.py:95-203; the
+    reference's own function runs unmodified on the native model) and hands them to ``ArenaAdamW``: a ``torch.optim.Optimizer``
+    whose ``step()`` is ONE fused launch over the arena (engine.FusedAdamW: global-norm clip on the device + AdamW + bf16 shadow
+    refresh).  HF's scheduler drives ``param_groups[i]["lr"]`` as usual.
+  * ``training_step`` = ``trainer.NativeTrainer.micro_step``: forward + backward into the gradient arenas, data-parallel
+    exchange by engine.GradReducer (not DDP: the weight gradients are written by the dW kernels' epilogues, autograd never
+    sees them), sum of squares folded under the backward.  ``max_grad_norm`` (1.0, trainer.py:122) is applied inside the fused
+    step, so HF's own ``clip_grad_norm_`` pass is switched off (``TrainingArguments.max_grad_norm = 0``).
+  * ``gradient_checkpointing`` and ``deepspeed`` of the exp config are NOT forwarded: activations stay resident (288 GB HBM)
+    and the optimizer state is not sharded (144 GB resident, engine.py header).
+  * integer inputs stay on the host (``_prepare_inputs``): the splice plan is host arithmetic (splice.py).
+
+The unmodified ``DexboticTrainer`` / plain HF ``Trainer`` + ``torch.optim.AdamW`` also train the native model on ONE GPU
+(ParamStore.external_prelude: gradients re-attached, stale bf16 shadows re-derived) — slower (a foreach AdamW over ~800 arena
+views + an 8 B-element shadow cast per step); see INTEGRATION.md.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+from transformers import Trainer, TrainingArguments
+
+from ..data.feeder import HOST_KEYS
+from ..engine import OptimConfig
+from ..trainer import NativeTrainer
+
+
+class ArenaAdamW(torch.optim.Optimizer):
+    """torch.optim.Optimizer facade over engine.FusedAdamW.  ``param_groups`` are the reference's groups (lr / weight_decay
+    per group, mutable by LR schedulers); ``step()`` runs the fused clip + AdamW launch of the owning NativeTrainer."""
+
+    def __init__(self, params, core: NativeTrainer, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.core = core
+        assert len(self.param_groups) == len(core.opt.group_keys), "core was built from other parameter groups"
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None, "ArenaAdamW takes no closure"
+        self.core.apply_update(lrs=[float(g["lr"]) for g in self.param_groups],
+                               wds=[float(g["weight_decay"]) for g in self.param_groups])
+
+    def zero_grad(self, set_to_none: bool = True):
+        # gradients are arena views overwritten by the next backward's first write (ParamStore.begin_step)
+        self.core.store.external_zero_grad()
+
+    def state_dict(self) -> Dict[str, Any]:
+        sd = super().state_dict()
+        self.core.synchronize()
+        sd["arena"] = {"m": self.core.opt.m, "v": self.core.opt.v, "step": self.core.opt.step_count}
+        return sd
+
+    def load_state_dict(self, state_dict) -> None:
+        arena = state_dict.get("arena")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "arena"})
+        if arena is not None:
+            if arena["m"].data_ptr() != self.core.opt.m.data_ptr():          # (accelerate round-trips the state dict in place)
+                self.core.opt.m.copy_(arena["m"])
+                self.core.opt.v.copy_(arena["v"])
+            self.core.opt.step_count = int(arena["step"])
+
+
+def link_exp_config(exp_config, **overrides) -> TrainingArguments:
+    """trainer_config / optimizer_config -> TrainingArguments, the mapping of DexboticTrainer._link_exp_config
+    (trainer.py:88-124), minus what the native backend does itself (module docstring)."""
+    tc, oc = exp_config.trainer_config, exp_config.optimizer_config
+    args = dict(output_dir=tc.output_dir, num_train_epochs=tc.num_train_epochs, max_steps=tc.num_train_steps,
+                per_device_train_batch_size=tc.per_device_train_batch_size,
+                gradient_accumulation_steps=tc.gradient_accumulation_steps, save_strategy=tc.save_strategy,
+                save_steps=tc.save_steps, save_total_limit=tc.save_total_limit, save_only_model=tc.save_only_model,
+                logging_steps=tc.logging_steps, dataloader_num_workers=tc.dataloader_num_workers, bf16=tc.bf16,
+                lr_scheduler_type=tc.lr_scheduler_type, lr_scheduler_kwargs=getattr(tc, "lr_scheduler_kwargs", {}) or {},
+                run_name=getattr(tc, "run_name", None), remove_unused_columns=False, learning_rate=oc.base_lr,
+                adam_beta1=oc.adam_beta1, adam_beta2=oc.adam_beta2, warmup_steps=oc.warmup_steps,
+                weight_decay=oc.weight_decay,
+                gradient_checkpointing=False, deepspeed=None,       # resident activations, unsharded optimizer state
+                max_grad_norm=0.0)                                   # the 1.0 clip runs inside the fused optimizer step
+    args.update(overrides)
+    return TrainingArguments(**args)
+
+
+class NativeDexboticTrainer(Trainer):
+    MAX_GRAD_NORM = 1.0            # DexboticTrainer._link_exp_config: linked_args["max_grad_norm"] = 1.0 (trainer.py:122)
+
+    def __init__(self, *args, **kwargs):
+        self.exp_config = kwargs.pop("exp_config")
+        self._core: Optional[NativeTrainer] = None
+        self._core_kw = dict(kwargs.pop("native", None) or {})
+        training_args = kwargs.pop("args", None) or link_exp_config(self.exp_config)
+        super().__init__(*args, args=training_args, **kwargs)
+        self.loss_cache: Dict[str, float] = {}
+
+    # ---- the native machinery behind HF's loop ---------------------------------------------------------------------------
+    def _grouped_parameters(self) -> List[dict]:
+        if getattr(self, "_grouped", None) is None:
+            self._grouped = self.exp_config.optimizer_config._get_optimizer_grouped_parameters(self.model)
+        return self._grouped
+
+    @property
+    def core(self) -> NativeTrainer:
+        if self._core is None:
+            oc = self.exp_config.optimizer_config
+            cfg = OptimConfig(base_lr=oc.base_lr, weight_decay=oc.weight_decay, adam_beta1=self.args.adam_beta1,
+                              adam_beta2=self.args.adam_beta2, adam_epsilon=self.args.adam_epsilon,
+                              max_grad_norm=self.MAX_GRAD_NORM)
+            name_of = {id(p): n for n, p in self.model.store.params.items()}
+            groups = [{"names": [name_of[id(p)] for p in g["params"] if id(p) in name_of]} for g in self._grouped_parameters()]
+            self._core = NativeTrainer(self.model, cfg, grad_accum=self.args.gradient_accumulation_steps,
+                                       optimizer_groups=groups, **self._core_kw)
+        return self._core
+
+    def create_optimizer(self) -> torch.optim.Optimizer:
+        if self.optimizer is None:
+            self.optimizer = ArenaAdamW(self._grouped_parameters(), self.core, lr=self.args.learning_rate,
+                                        betas=(self.args.adam_beta1, self.args.adam_beta2), eps=self.args.adam_epsilon,
+                                        weight_decay=self.args.weight_decay)
+        return self.optimizer
+
+    def create_accelerator_and_postprocess(self):
+        super().create_accelerator_and_postprocess()
+        orig = self.accelerator.prepare_model
+        from ..model.dexbotic_arch import NativePreTrainedMixin
+
+        def prepare_model(model, *a, **k):
+            if isinstance(model, NativePreTrainedMixin):
+                return model              # no DDP wrapper: engine.GradReducer averages the gradient arenas
+            return orig(model, *a, **k)
+        self.accelerator.prepare_model = prepare_model
+
+    def _wrap_model(self, model, training=True, dataloader=None):
+        return model
+
+    def _prepare_inputs(self, inputs):
+        host = {k: inputs[k] for k in HOST_KEYS if k in inputs and torch.is_tensor(inputs[k]) and not inputs[k].is_cuda}
+        rest = super()._prepare_inputs({k: v for k, v in inputs.items() if k not in host})
+        rest.update(host)
+        return rest
+
+    def training_step(self, model, inputs, num_items_in_batch=None):
+        model.train()
+        inputs = self._prepare_inputs(inputs)
+        # HF does NOT divide the loss by the accumulation steps for a model whose forward takes **kwargs once it passes
+        # num_items_in_batch (Trainer.training_step; true of the reference's forwards under its pinned transformers 4.51): the
+        # micro-batch gradients are then summed, not averaged, before the 1.0 clip.  Mirrored here.
+        summed = bool(getattr(self, "model_accepts_loss_kwargs", False)) and num_items_in_batch is not None
+        loss = self.core.micro_step(inputs, loss_scale=1.0 if summed else None)
+        self._cache_losses(self.core.last_output)
+        accum = self.args.gradient_accumulation_steps
+        return loss if (summed or accum == 1) else loss / accum
+
+    def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
+        """evaluation-side path (no backward): same *_loss bookkeeping as the reference (trainer.py:126-134)"""
+        loss, outputs = super().compute_loss(model, inputs, return_outputs=True)
+        self._cache_losses(outputs)
+        return (loss, outputs) if return_outputs else loss
+
+    def _cache_losses(self, outputs) -> None:
+        for key in [k for k in outputs.keys() if k.endswith("_loss")]:
+            val = outputs[key]
+            if val is None or float(val) == 0.0:
+                self.loss_cache.setdefault(key, 0.0)
+                continue
+            self.loss_cache[key] = float(val.detach())
+
+    def log(self, logs: Dict[str, float], start_time: Optional[float] = None) -> None:
+        logs.update(self.loss_cache)
+        super().log(logs, start_time)

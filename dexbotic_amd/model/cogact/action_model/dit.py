@@ -194,6 +194,7 @@ class DiT(nn.Module):
         elif self._use_fused_blocks(N, T + 1):
             # inference, one request: every block in ONE persistent launch (csrc/dit_fused.hip)
             self.used_fused = True
+            self.store.wait_pending()                  # the kernel reads the masters through raw pointers (_weight_table)
             hcur = K.dit_blocks_fwd(hcur.reshape(N * (T + 1), h).contiguous(), self._weight_table(st), self.depth, N, T + 1, h,
                                     self.num_heads, self.mlp_hidden, 1e-6)
         else:

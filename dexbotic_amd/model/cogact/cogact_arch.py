@@ -160,7 +160,11 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
         if dev.type == "cuda" and use_graph and not return_traj:
             samples = self._graph_sample(images, plan.plan.reshape(-1), B, S, noise, float(cfg_scale), int(num_ddim_steps))
             traj = None
-            graph_stream = self._infer_graphs[(tuple(images.shape), B, S, float(cfg_scale), int(num_ddim_steps))]["stream"]
+            ent = self._infer_graphs[(tuple(images.shape), B, S, float(cfg_scale), int(num_ddim_steps))]
+            graph_stream = ent["stream"]
+            # a replay runs no Python of DiT.forward: whether the captured work contains the persistent kernel was recorded
+            # when the entry was built, so its abort word is checked after EVERY replay of such an entry
+            head.net.used_fused = bool(ent.get("fused"))
         else:
             plan_t = plan.dev(dev)["plan"]
             samples, traj = self._sample_actions(images, plan_t, B, S, noise, float(cfg_scale), int(num_ddim_steps),
@@ -171,6 +175,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             # (another process on this GPU): this request is redone on the block-by-block kernels, which this process
             # keeps using from now on
             head.net.allow_fused = False
+            self.__dict__.pop("_infer_graphs", None)      # every captured graph may hold the persistent kernel: re-capture
             samples, traj = self._sample_actions(images, plan.dev(dev)["plan"], B, S, noise, float(cfg_scale),
                                                  int(num_ddim_steps), return_traj)
             host = samples[0].cpu().numpy()
@@ -199,6 +204,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             ent["stream"].wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(ent["stream"]):
                 out, _ = self._sample_actions(ent["images"], ent["plan"], B, S, ent["noise"], cfg_scale, num_ddim_steps)
+            ent["fused"] = bool(self.model.action_head.net.used_fused)
             torch.cuda.current_stream().wait_stream(ent["stream"])
             return out
         ent["plan_host"].copy_(torch.from_numpy(plan_np))
@@ -213,6 +219,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
                     ent["out"], _ = self._sample_actions(ent["images"], ent["plan"], B, S, ent["noise"], cfg_scale,
                                                          num_ddim_steps)
                 ent["graph"] = g
+                ent["fused"] = bool(self.model.action_head.net.used_fused)
             ent["graph"].replay()
         torch.cuda.current_stream().wait_stream(ent["stream"])
         return ent["out"]

@@ -235,10 +235,11 @@ class DexboticVLMModel(nn.Module):
         B, S = plan.plan.shape
         embeds = Fn.SpliceFn.apply(image_features, self.store.params[self.llm.embed_name], self.store,
                                    self.llm.embed_name, pd["plan"]).view(B, S, -1)
-        new_labels = None if labels is None else pd["labels"]
+        # copies (a few KB): callers may edit labels / mask in place (HF-style loss code does); the plan cache keeps its own
+        new_labels = None if labels is None else pd["labels"].clone()
         new_mask = None
         if attention_mask is not None:
-            new_mask = pd["mask"] if attention_mask.dtype == torch.bool else pd["mask"].to(attention_mask.dtype)
+            new_mask = pd["mask"].clone() if attention_mask.dtype == torch.bool else pd["mask"].to(attention_mask.dtype)
         return None, position_ids, new_mask, past_key_values, embeds, new_labels, cache_position
 
     def run_llm(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
@@ -259,6 +260,39 @@ class NativePreTrainedMixin:
     def _finish_init(self, train: bool) -> None:
         self.store.finalize(train=train)
         attach_parameters(self, self.store)
+        self.register_forward_pre_hook(NativePreTrainedMixin._external_loop_prelude)
+        self.register_state_dict_pre_hook(lambda *a, **k: self.store.wait_pending())
+
+    @staticmethod
+    def _external_loop_prelude(self, args) -> None:
+        """training forward of a loop this package does not manage (HF Trainer.training_step, the reference's
+        DexboticTrainer, a hand-written loop): ParamStore.external_prelude does what NativeTrainer would have done"""
+        st = self.store
+        if st.managed or st.grad is None or not self.training or not torch.is_grad_enabled():
+            return
+        unused = self.unused_parameter_names() if hasattr(self, "unused_parameter_names") else ()
+        st.external_prelude(unused)
+
+    def _apply(self, fn, recurse: bool = True):
+        """``model.to(device)`` / ``.cuda()`` (HF Trainer moves the model in its constructor) must not rebuild the parameters:
+        they are views of the arenas.  A conversion that would change nothing is accepted and ignored, anything else refused."""
+        probe = fn(torch.empty(0, device=self.store.device, dtype=torch.float32))
+        if probe.device.type != self.store.device.type or probe.dtype != torch.float32:
+            raise NotImplementedError("dexbotic_amd: the parameters live in device arenas built at construction "
+                                      f"({self.store.device}, fp32 masters + {self.store.compute_dtype} shadows); "
+                                      "construct the model with device= / compute_dtype instead of converting it")
+        return self
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """HF Trainer calls ``model.zero_grad()`` after every optimizer step.  The gradients are views of the arena and the
+        next backward's first write replaces them, so nothing is zeroed or dropped: only the step boundary is recorded."""
+        if self.store.grad is None:
+            return
+        self.store.external_zero_grad()
+        if self.store.managed:
+            return
+        if not set_to_none:
+            self.store.grad.zero_()
 
     def post_load(self) -> None:
         self.store.sync_shadow()
@@ -267,8 +301,17 @@ class NativePreTrainedMixin:
         """base_exp.py:245 / trainer.py:120 turn this on to fit 80 GB parts (a 4th forward per step).  The native blocks
         keep their activations — ~0.75 GB per decoder layer at 16 x 287 tokens against 288 GB of HBM — and have no
         recompute path: refuse loudly rather than pretend."""
+        if os.environ.get("DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING", "0") != "0" or \
+                getattr(self.config, "accept_gradient_checkpointing", False):
+            # explicit opt-in (env / config flag) for unmodified exp scripts whose TrainerConfig defaults to
+            # gradient_checkpointing=True (base_exp.py:243): accepted and IGNORED — activations stay resident
+            import warnings
+            warnings.warn("dexbotic_amd: gradient_checkpointing requested and ignored (activations stay resident in HBM)")
+            return None
         raise NotImplementedError("dexbotic_amd keeps block activations resident (MI355X: 288 GB HBM); activation "
-                                  "recompute is not implemented — run with gradient_checkpointing=False")
+                                  "recompute is not implemented — run with gradient_checkpointing=False (or opt in to "
+                                  "accept-and-ignore: DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING=1 / "
+                                  "config.accept_gradient_checkpointing=True)")
 
     def gradient_checkpointing_disable(self) -> None:
         return None

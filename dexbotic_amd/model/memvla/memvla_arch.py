@@ -8,9 +8,10 @@ token-merge consolidation) and a DiT whose blocks also cross-attend to the perce
 order dependent exactly like the reference: the samples of a batch are walked in order, each retrieving from what the
 earlier frames of its episode left behind (detached).  That loop is host logic; every tensor op in it is a kernel.
 
-Deviation (also pinned in the goldens, oracle/memvla_oracle.py): the reference's retrieval blocks pass dropout 0.1 to
-F.scaled_dot_product_attention unconditionally — random even in eval.  Here the retrieval attention is deterministic
-(``retrieval_dropout`` = 0; a non-zero value raises).
+Retrieval dropout: the reference hard-codes ``dropout=0.1`` in its CrossTransformerBlocks (memvla_arch.py:83, 99-105,
+120-123; no config key).  ``MemVLAConfig.retrieval_dropout`` defaults to that 0.1 and applies it while TRAINING (attention
+weights inside the attention kernels + the two FFN dropouts); the deterministic goldens pass 0.0 explicitly.  Deviation: the
+reference also hands dropout_p to SDPA in eval (stochastic inference); eval is deterministic here.
 """
 from __future__ import annotations
 
@@ -38,7 +39,7 @@ class MemVLAConfig(CogActConfig):
     def __init__(self, per_token_size: Optional[int] = None, dataloader_type: Optional[str] = None,
                  group_size: Optional[int] = None, mem_length: Optional[int] = None, retrieval_layers: Optional[int] = None,
                  use_timestep_pe: Optional[bool] = None, fusion_type: Optional[str] = None,
-                 consolidate_type: Optional[str] = None, update_fused: bool = True, retrieval_dropout: float = 0.0,
+                 consolidate_type: Optional[str] = None, update_fused: bool = True, retrieval_dropout: float = 0.1,
                  **kwargs):
         super().__init__(**kwargs)
         self.per_token_size, self.dataloader_type, self.group_size = per_token_size, dataloader_type, group_size
@@ -278,7 +279,7 @@ class MemVLAModel(CogActModel):
                 store, config.dataloader_type, config.group_size, config.per_token_size, config.hidden_size,
                 config.mem_length, config.retrieval_layers, config.use_timestep_pe, config.fusion_type,
                 config.consolidate_type, getattr(config, "update_fused", True),
-                retrieval_dropout=float(getattr(config, "retrieval_dropout", 0.0) or 0.0))
+                retrieval_dropout=float(getattr(config, "retrieval_dropout", 0.1) or 0.0))
         if action_type is not None:
             self.action_head = self._build_action_head_module(config)
 

@@ -23,14 +23,18 @@ from ... import _lib as L
 from ... import functional as Fn
 from ... import kernels as K
 from ...engine import ParamStore
-from ..dexbotic_arch import ActionOutputForCausalLM, CausalLMOutputDexbotic, NativePreTrainedMixin, _DTYPES
+from ..dexbotic_arch import (ActionOutputForCausalLM, CausalLMOutputDexbotic, NativePreTrainedMixin, _DTYPES, _hf_config_base,
+                             register_with_hf)
 from ..llm.gemma import GemmaConfig, GemmaExpert
 from ..modules.mm_projector.builder import build_vision_projector
 from ..modules.mm_vision.builder import build_vision_tower
 from ..modules.mm_vision.siglip.siglip_encoder import SiglipVisionConfig
 
 
-class Pi0Config:
+class Pi0Config(_hf_config_base()):
+    """``transformers.PretrainedConfig`` subclass registered with ``AutoConfig`` under the reference's ``model_type``
+    (pi0_arch.py:54-110): ``AutoConfig.from_pretrained`` on a reference pi0 checkpoint directory resolves to it, the nested
+    vision / llm / action-expert configs round-trip through ``config.json``."""
     model_type = "dexbotic_pi0"
 
     def __init__(self, vision_config=None, processor_config=None, action_config=None, llm_config=None,
@@ -43,26 +47,54 @@ class Pi0Config:
         self.mm_projector_type = mm_projector_type
         self.action_dim, self.chunk_size = action_dim, chunk_size
         self.compute_dtype = compute_dtype if isinstance(compute_dtype, str) else str(compute_dtype).replace("torch.", "")
-        self.hidden_size = self.llm_config.hidden_size
-        self.vocab_size = self.llm_config.vocab_size
         a, l_ = self.action_config, self.llm_config
         if (a.num_hidden_layers, a.num_attention_heads, a.num_key_value_heads, a.head_dim) != (
                 l_.num_hidden_layers, l_.num_attention_heads, l_.num_key_value_heads, l_.head_dim):
             raise ValueError("the two experts share one attention: depth, heads and head_dim must match")
-        for k, v in kwargs.items():
-            setattr(self, k, v)
+        for k in ("model_type", "architectures", "transformers_version"):
+            kwargs.pop(k, None)
+        hidden, vocab = kwargs.pop("hidden_size", None), kwargs.pop("vocab_size", None)
+        super().__init__(**kwargs)
+        self.hidden_size = self.llm_config.hidden_size if hidden is None else hidden
+        self.vocab_size = self.llm_config.vocab_size if vocab is None else vocab
 
     def to_dict(self):
-        d = {k: (v.to_dict() if hasattr(v, "to_dict") else v) for k, v in self.__dict__.items() if not k.startswith("_")}
-        d["model_type"] = self.model_type
-        return d
+        out = {}
+        for k, v in super().to_dict().items():
+            if hasattr(v, "to_dict"):
+                v = v.to_dict()
+            elif isinstance(v, torch.dtype):
+                v = str(v).replace("torch.", "")
+            out[k] = v
+        out["model_type"] = self.model_type
+        return out
+
+    def to_diff_dict(self):
+        return self.to_dict()
 
     @classmethod
-    def from_dict(cls, d):
+    def from_dict(cls, d, **kwargs):
         d = dict(d)
-        d.pop("model_type", None)
-        d.pop("architectures", None)
+        for k in ("model_type", "architectures", "transformers_version"):
+            d.pop(k, None)
         return cls(**d)
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs):
+        import json
+        import os
+        with open(os.path.join(path, "config.json")) as f:
+            return cls.from_dict(json.load(f))
+
+    def save_pretrained(self, path: str, **kwargs) -> None:
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, default=str)
+
+
+register_with_hf(Pi0Config)
 
 
 class Pi0Model(nn.Module):

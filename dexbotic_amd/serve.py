@@ -54,6 +54,12 @@ class InferenceServer:
             self.log(f"process_frame: {len(frames)} view(s), {self.last_ms:.1f} ms")
         return out
 
+    def inference_single(self, image_path, prompt: str) -> list:
+        """the exp scripts' ``--task inference_single`` (playground/benchmarks/libero/libero_cogact.py:70-72):
+        ``_get_response(prompt, [image_path])`` on one image file (or a list of view files)"""
+        paths = [image_path] if isinstance(image_path, (str, bytes)) or hasattr(image_path, "read") else list(image_path)
+        return self.get_response(prompt, paths)
+
     # ---- Flask plumbing ---------------------------------------------------------------------------------------
     def create_app(self):
         from flask import Flask, jsonify, request

@@ -35,17 +35,38 @@ class SplicePlan:
 
     def dev(self, device) -> dict:
         """device copies of the integer arrays the kernels consume, uploaded once per plan (a cached plan re-used by
-        the next step costs no host->device traffic at all)"""
+        the next step costs no host->device traffic at all).  A fresh plan — every step of a real fine-tune has new token
+        ids — costs ONE asynchronous copy: the six arrays are packed into one pinned host buffer and sent with a single
+        non-blocking transfer on the current stream (pageable sources would make each of six small copies wait for the
+        stream to drain), the device tensors are typed views of that one allocation."""
         import torch
         cache = self.__dict__.setdefault("_dev", {})
         key = str(device)
         ent = cache.get(key)
         if ent is None:
             B, S = self.plan.shape
-            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
-            ent = {"plan": up(self.plan.reshape(-1)), "labels": up(self.labels), "mask": up(self.attention_mask),
-                   "kv_start": up(self.kv_start), "kv_end": up(self.kv_end),
-                   "last_flat": up(np.arange(B, dtype=np.int64) * S + self.last_index)}
+            parts = (("plan", self.plan.reshape(-1), np.int64), ("labels", self.labels.reshape(-1), np.int64),
+                     ("last_flat", np.arange(B, dtype=np.int64) * S + self.last_index, np.int64),
+                     ("kv_start", self.kv_start, np.int32), ("kv_end", self.kv_end, np.int32),
+                     ("mask", self.attention_mask.reshape(-1), np.bool_))
+            offs, total = [], 0
+            for _, a, dt in parts:
+                offs.append(total)
+                total += (a.size * np.dtype(dt).itemsize + 15) // 16 * 16
+            cuda = torch.device(device).type == "cuda"
+            host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=cuda)
+            hv = host.numpy()
+            for (_, a, dt), o in zip(parts, offs):
+                n = a.size * np.dtype(dt).itemsize
+                hv[o:o + n] = np.ascontiguousarray(a, dtype=dt).view(np.uint8).reshape(-1)
+            buf = host.to(device, non_blocking=True)
+            tdt = {np.int64: torch.int64, np.int32: torch.int32, np.bool_: torch.bool}
+            ent = {"_host": host, "_buf": buf}
+            for (name, a, dt), o in zip(parts, offs):
+                n = a.size * np.dtype(dt).itemsize
+                ent[name] = buf[o:o + n].view(tdt[dt])
+            ent["labels"] = ent["labels"].view(B, S)
+            ent["mask"] = ent["mask"].view(B, S)
             cache[key] = ent
         return ent
 

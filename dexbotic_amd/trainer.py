@@ -22,13 +22,19 @@ class NativeTrainer:
     def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
                  force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag",
-                 grad_dtype: torch.dtype = torch.float32):
+                 grad_dtype: torch.dtype = torch.float32, overlap_optimizer: bool = False, optimizer_groups=None):
         import torch.distributed as dist
         self.model = model
         self.store = model.store
         self.cfg = optim or OptimConfig()
         unused = list(model.unused_parameter_names()) if hasattr(model, "unused_parameter_names") else []
-        self.opt = FusedAdamW(self.store, self.cfg, exclude=unused)
+        # overlap_optimizer: the fused AdamW runs bucket by bucket in forward order on a side stream and the NEXT step's
+        # forward waits per bucket (engine.FusedAdamW(overlap=True)).  step() then returns with the update still in flight:
+        # everything that goes through the store's views (the model's own forward / inference, sync_shadow) orders itself;
+        # code that reads parameters directly (p.data, state_dict()) calls trainer.synchronize() first.
+        # optimizer_groups: explicit parameter groups [{"names": [...]}, ...] (exp/trainer.NativeDexboticTrainer: the groups the
+        # exp's OptimizerConfig built); default: engine.FusedAdamW's own name rule.
+        self.opt = FusedAdamW(self.store, self.cfg, exclude=unused, overlap=overlap_optimizer, groups=optimizer_groups)
         self.total_steps, self.warmup_steps, self.grad_accum = total_steps, warmup_steps, grad_accum
         self.global_step = 0
         self.micro = 0
@@ -65,6 +71,22 @@ class NativeTrainer:
         self.store.defer_wgrad = True           # parameters with several consumers per forward: one dW product for all of them
         self.store.invalidate_embed_tracking()
         self._zeroed_unused = False
+        self.store.managed = True               # this object calls begin_step / begin_micro (the model's pre-hook stands down)
+        self.update_due = False
+        self._sumsq, self._reducing = None, False
+        self.last_output = None
+
+    def set_grad_accum(self, n: int) -> None:
+        """change the number of micro-batches per optimizer step (between optimizer steps only)"""
+        assert not self.update_due and self.micro % self.grad_accum == 0, "set_grad_accum() in the middle of an optimizer step"
+        assert n == 1 or not self.store.bf16_grads, "bf16 gradient arena needs one micro-batch per step"
+        self.grad_accum, self.micro = int(n), 0
+        local = self.reducer is None or self.reducer.local_only
+        self.store.epi_sumsq = local and self.norm_tracker is not None and self.grad_accum == 1
+
+    def synchronize(self) -> None:
+        """make the current stream wait for an overlapped optimizer update still in flight"""
+        self.store.wait_pending()
 
     def lr_scale(self) -> float:
         if self.total_steps <= 0:
@@ -73,6 +95,17 @@ class NativeTrainer:
 
     def step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """one micro-batch; the optimizer runs every ``grad_accum`` calls.  Returns the (detached) loss."""
+        loss = self.micro_step(batch)
+        if self.update_due:
+            self.apply_update()
+        return loss
+
+    def micro_step(self, batch: Dict[str, torch.Tensor], loss_scale: Optional[float] = None) -> torch.Tensor:
+        """forward + backward of one micro-batch into the gradient arenas; on the last micro-batch of an optimizer step the
+        data-parallel exchange and the sum of squares are brought to completion and ``update_due`` is set.  Split from
+        ``apply_update`` so that a loop which owns the optimizer call — HF ``Trainer``: ``training_step`` per micro-batch,
+        ``optimizer.step()`` at the boundary (exp/trainer.NativeDexboticTrainer) — drives the same machinery.
+        ``loss_scale``: factor on the loss before backward; default 1 / grad_accum (the mean over micro-batches)."""
         first = self.micro % self.grad_accum == 0
         last = (self.micro + 1) % self.grad_accum == 0
         if first:
@@ -92,7 +125,10 @@ class NativeTrainer:
         with K.f32_gemm_mode(getattr(self.model.config, "fp32_matmul", "exact")):
             out = self.model(**batch)
             loss = out.loss
-            (loss / self.grad_accum if self.grad_accum > 1 else loss).backward()
+            self.store.wait_pending()           # (overlapped optimizer: buckets the forward never touched)
+            scale = (1.0 / self.grad_accum) if loss_scale is None else float(loss_scale)
+            (loss * scale if scale != 1.0 else loss).backward()
+        self.last_output = out
         self.store.flush_wgrads()               # (only when autograd pruned a consumer of a multiply-used parameter)
         self.micro += 1
         if last:
@@ -104,10 +140,19 @@ class NativeTrainer:
             reducing = self.reducer is not None and (self.reducer.world > 1 or self.reducer.force)
             if self.reducer is not None:
                 self.reducer.finish()
-            sumsq = None
+            self._sumsq = None
             if self.norm_tracker is not None:
-                sumsq = self.norm_tracker.finish(fire_unfired=not reducing)
-            # under bf16 data parallelism the averaged gradients live in the bf16 communication copy
-            self.opt.step(self.lr_scale(), sumsq=sumsq, grads=self.reducer.result_arena if reducing else None)
-            self.global_step += 1
+                self._sumsq = self.norm_tracker.finish(fire_unfired=not reducing)
+            self._reducing = reducing
+            self.update_due = True
         return loss.detach()
+
+    def apply_update(self, lr_scale: Optional[float] = None, lrs=None, wds=None) -> None:
+        """global-norm clip + fused AdamW over the arena (+ bf16 shadow refresh).  ``lrs`` / ``wds``: explicit per-group values
+        (an external LR scheduler writing ``param_groups[i]["lr"]``); default: this trainer's cosine schedule."""
+        assert self.update_due, "apply_update() before the last micro-batch of the step"
+        # under bf16 data parallelism the averaged gradients live in the bf16 communication copy
+        self.opt.step(self.lr_scale() if lr_scale is None else lr_scale, sumsq=self._sumsq,
+                      grads=self.reducer.result_arena if self._reducing else None, lrs=lrs, wds=wds)
+        self.update_due = False
+        self.global_step += 1

@@ -69,7 +69,7 @@ class inject_dropout:
         return False
 
 
-def build_reference(cfg, weights, keep_dropout=False):
+def build_reference(cfg, weights, keep_dropout=False, per=None, mem_len=None, group_size=3):
     from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel, Qwen2Config
     from dexbotic.model.memvla.action_model import action_models
     from dexbotic.model.memvla.action_model.dit import DiT
@@ -88,13 +88,13 @@ def build_reference(cfg, weights, keep_dropout=False):
                       num_key_value_heads=cfg.num_key_value_heads, max_position_embeddings=4096,
                       rope_theta=cfg.rope_theta, rms_norm_eps=cfg.rms_norm_eps)
     c = MemVLAConfig(llm_config=llm, mm_vision_tower=d, mm_projector_type="mlp2x_gelu", action_model_type="DiT-T",
-                     action_dim=cfg.action_dim, chunk_size=cfg.chunk_size, per_token_size=PER, dataloader_type="group",
-                     group_size=3, mem_length=MEM_LEN, retrieval_layers=2, use_timestep_pe=True, fusion_type="gate",
+                     action_dim=cfg.action_dim, chunk_size=cfg.chunk_size, per_token_size=per or PER, dataloader_type="group",
+                     group_size=group_size, mem_length=mem_len or MEM_LEN, retrieval_layers=2, use_timestep_pe=True, fusion_type="gate",
                      consolidate_type="tome")
     m = MemVLAForCausalLM(c)
     from oracle.memvla_oracle import memvla_shapes
     ref_shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
-    mine = memvla_shapes(cfg, PER)
+    mine = memvla_shapes(cfg, per or PER)
     assert ref_shapes == mine, (set(ref_shapes) ^ set(mine))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
     for mod in m.modules():                                  # deterministic retrieval: no dropout anywhere

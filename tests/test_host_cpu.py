@@ -144,6 +144,29 @@ def test_registry_and_config_roundtrip(tmp_path):
     assert type(c3) is type(c) and c3.llm_config.to_dict() == c.llm_config.to_dict()
 
 
+def test_pi0_and_memvla_configs_resolve_through_autoconfig(tmp_path):
+    """``AutoConfig.from_pretrained`` on a directory whose config.json carries the reference's model_type strings
+    ("dexbotic_pi0": pi0_arch.py:54, "dexbotic_memvla": memvla_arch.py:21) yields the native PretrainedConfig subclasses with
+    their nested configs intact"""
+    from transformers import AutoConfig, PretrainedConfig
+    from dexbotic_amd.model.memvla.memvla_arch import MemVLAConfig
+    from dexbotic_amd.model.pi0.pi0_arch import Pi0Config
+    gem = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, head_dim=32,
+               intermediate_size=192, vocab_size=300)
+    c = Pi0Config(llm_config=gem, action_config=dict(gem, hidden_size=64, intermediate_size=96),
+                  vision_config=dict(hidden_size=64, num_hidden_layers=2), chunk_size=6, compute_dtype="bfloat16")
+    assert isinstance(c, PretrainedConfig) and c.hidden_size == 128 and c.vocab_size == 300
+    c.save_pretrained(str(tmp_path / "pi0"))
+    c2 = AutoConfig.from_pretrained(str(tmp_path / "pi0"))
+    assert type(c2) is Pi0Config and c2.to_dict() == c.to_dict()
+    assert c2.action_config.hidden_size == 64 and c2.chunk_size == 6 and c2.compute_dtype == "bfloat16"
+    m = MemVLAConfig(llm_config=product_config(CFGS["t1"]).llm_config, per_token_size=32, mem_length=4)
+    assert m.retrieval_dropout == 0.1                      # the reference hard-codes dropout 0.1 in its retrieval blocks
+    m.save_pretrained(str(tmp_path / "mem"))
+    m2 = AutoConfig.from_pretrained(str(tmp_path / "mem"))
+    assert type(m2) is MemVLAConfig and m2.per_token_size == 32 and m2.mem_length == 4 and m2.retrieval_dropout == 0.1
+
+
 def test_action_norm_and_2string_bit_exact(golden_dir):
     """row A9, encode direction, in the PRODUCT (dexbotic_amd/data/dataset/transform/action.py) against the integer rows the
     reference's ActionNormAnd2String produced (tests/golden/action_bins.npz): normalised values, bins (round-half-even on

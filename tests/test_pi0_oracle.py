@@ -48,3 +48,36 @@ def test_pi0_inference_matches_reference(golden_dir):
         acts = P.pi0_inference_action(sd, cfg, t(g["input_ids"]), t(g["attention_mask"]), t(g["states"]), t(g["images"]),
                                       t(g["image_masks"]), t(g["init_noise"]), 10)
     assert rel(acts.numpy(), g["infer_actions"]) < 2e-5
+
+
+def test_pi0_oracle_matches_reference_classes_at_real_width(golden_dir):
+    """tests/golden/pi0_real_ref.npz: the reference Pi0ForCausalLM at Gemma-2B / SigLIP-So400m widths, 2 layers, chunk 50
+    (oracle/gen_golden_pi0_real.py) — training step (fp32) and 10-step fp32 inference"""
+    import os
+    import zlib
+
+    import numpy as np
+    import torch
+
+    from oracle import gen_golden_pi0_real as PR
+    from oracle import pi0_oracle as P
+    from oracle.weights import make_weights, weights_crc
+    g = np.load(os.path.join(golden_dir, "pi0_real_ref.npz"), allow_pickle=False)
+    x = PR.inputs()
+    assert zlib.crc32(x["images"].tobytes()) == int(g["images_crc"])
+    w = make_weights(P.pi0_shapes(PR.REAL), int(g["seed"]))
+    assert weights_crc(w) == int(g["weights_crc"])
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in w.items()}
+    t = torch.from_numpy
+    o = P.pi0_forward(sd, PR.REAL, t(x["input_ids"]), t(x["attention_mask"]), t(x["images"]), t(x["image_masks"]),
+                      t(x["states"]), t(x["actions"]), t(x["noise"]), t(x["time"]))
+    o["loss"].backward()
+    got = PR.summarize({n: p.grad for n, p in sd.items()}, o["loss"].item(), o["v_t"].detach().numpy())
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() /
+                             (np.abs(np.asarray(b, np.float64)).max() + 1e-12))
+    for k, v in got.items():
+        assert rel(v, g["fp32/" + k]) < 5e-5, (k, rel(v, g["fp32/" + k]))
+    with torch.no_grad():
+        acts = P.pi0_inference_action(sd, PR.REAL, t(x["input_ids"]), t(x["attention_mask"]), t(x["states"]), t(x["images"]),
+                                      t(x["image_masks"]), t(x["init_noise"]), 10)
+    assert rel(acts.numpy(), g["fp32/infer_actions"]) < 5e-5

@@ -157,3 +157,82 @@ def test_bf16_gradient_arena_step_tracks_fp32_gradient_step(golden_dir):
     assert (res["bf16"][2] - res["f32"][2]).abs().max().item() <= 2.5e-3      # lr 1e-3: at most ~2 AdamW steps apart
     assert res["bf16_again"][0] == res["bf16"][0] and res["bf16_again"][1] == res["bf16"][1]
     assert torch.equal(res["bf16_again"][2], res["bf16"][2])
+
+
+def test_overlapped_optimizer_is_bit_identical_to_the_serial_step(golden_dir):
+    """NativeTrainer(overlap_optimizer=True): AdamW runs segment by segment in forward order on a side stream and the next
+    step's forward waits per bucket (engine.FusedAdamW / ParamStore.wait_pending).  Same arithmetic, other schedule: losses,
+    clip norm, masters, shadows and moments after three steps are bit-identical to the serial step — fp32 and bf16 compute,
+    tiny segments so that every block is its own segment, followed by an inference request (the persistent DiT kernel reads
+    the masters through raw pointers) and a state_dict() read."""
+    g, cfg, w = load_golden(golden_dir, "t1")
+    for dtype in ("float32", "bfloat16"):
+        res = {}
+        for tag, ov in (("serial", False), ("overlap", True)):
+            m = build_product(cfg, w, dtype, DEV, train=True)
+            m.train()
+            from dexbotic_amd.engine import FusedAdamW
+            tr = _trainer(m, min_bucket_bytes=1 << 14, overlap_optimizer=ov)
+            if ov:
+                tr.opt = FusedAdamW(m.store, tr.cfg, exclude=m.unused_parameter_names(), overlap=True, segment_elems=1)
+                assert len(tr.opt.segments) > 8
+            losses = [tr.step(_batch(g)).item() for _ in range(3)]
+            if ov:
+                assert m.store._pending, "the update of the last step should still be pending"
+            m.eval()
+            acts = m.inference_action(torch.from_numpy(g["infer_ids"]).to(DEV), torch.from_numpy(g["images"][:1]).to(DEV),
+                                      {"cfg_scale": 1.5, "num_ddim_steps": 10,
+                                       "action_norms": {"min": g["norm_min"].tolist(), "max": g["norm_max"].tolist()}},
+                                      noise=torch.from_numpy(g["init_noise"]).to(DEV))
+            tr.synchronize()
+            sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            torch.cuda.synchronize()
+            res[tag] = (losses, tr.opt.norm.clone(), m.store.master.clone(), tr.opt.m.clone(), tr.opt.v.clone(),
+                        None if m.store.shadow is None else m.store.shadow.clone(), np.asarray(acts), sd)
+        a, b = res["serial"], res["overlap"]
+        assert a[0] == b[0], (dtype, a[0], b[0])
+        for i in (1, 2, 3, 4):
+            assert torch.equal(a[i], b[i]), (dtype, i)
+        if a[5] is not None:
+            assert torch.equal(a[5], b[5])
+        assert np.array_equal(a[6], b[6])
+        assert all(torch.equal(a[7][k], b[7][k]) for k in a[7])
+
+
+def test_native_avg_reduce_scatter_all_gather_in_place_at_world_one():
+    """the call sequence every N > 1 RCCL run takes — reduce_scatter_tensor(op=AVG) into this rank's shard of the SAME
+    buffer, all_gather_into_tensor back, 32-byte shard alignment, all-reduced tail — executed on hardware with one GPU
+    (GradReducer(native_avg_world1=True); world size 1 otherwise swaps AVG for SUM).  The mean over one rank is the identity:
+    bf16 and fp32 slices, lengths that do and do not divide, both algorithms, must come back bit-identical."""
+    import torch.distributed as dist
+    from dexbotic_amd.engine import GradReducer, ParamStore
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for comm in (torch.bfloat16, torch.float32):
+            for algo in ("rs_ag", "allreduce"):
+                st = ParamStore(DEV, torch.float32)
+                for i, n in enumerate((4096, 1000, 77, 12345)):
+                    st.new_bucket()
+                    st.register([(f"p{i}", (n,))])
+                st.finalize(train=True)
+                red = GradReducer(st, min_bucket_bytes=1 << 10, force=True, comm_dtype=comm, algo=algo, native_avg_world1=True)
+                gen = torch.Generator(device=DEV).manual_seed(5)
+                st.grad.copy_(torch.randn(st.total, device=DEV, generator=gen))
+                want = st.grad.to(comm).clone()
+                st.begin_step()
+                for i in reversed(range(4)):
+                    st.mark_written(f"p{i}")
+                red.finish()
+                torch.cuda.synchronize()
+                got = red.result_arena
+                for i in range(4):
+                    sl = st.slots[f"p{i}"]
+                    assert torch.equal(got[sl.offset:sl.offset + sl.numel], want[sl.offset:sl.offset + sl.numel]), (comm, algo, i)
+                assert red.collectives >= 2 and red.bytes_reduced > 0
+    finally:
+        if created:
+            dist.destroy_process_group()
