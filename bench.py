@@ -294,9 +294,11 @@ def main():
                          "uploads).  Default: 8 distinct host batches rotated, fresh token ids every step, images / actions uploaded "
                          "from pinned host memory on a copy stream one step ahead (dexbotic_amd/data/feeder.py)")
     ap.add_argument("--ragged", action="store_true", help="every fourth rotated batch has right-padded instructions")
-    ap.add_argument("--no-overlap", dest="no_overlap", action="store_true",
-                    help="serial optimizer: one AdamW launch after the backward (default: AdamW segment by segment on a side stream "
-                         "under the next step's forward, NativeTrainer(overlap_optimizer=True))")
+    ap.add_argument("--overlap", dest="overlap", action="store_true",
+                    help="AdamW segment by segment on a side stream under the next step's forward "
+                         "(NativeTrainer(overlap_optimizer=True)).  Off by default: measured 247.8 vs 247.1 ms/step (round 3, "
+                         "gpurun_out/r03_b_ov.json vs r03_b_noov.json) — the forward GEMMs slow from 254 to 363 us per launch while "
+                         "the update streams beside them, which gives the hidden 36 ms back (DESIGN.md section 4)")
     ap.add_argument("--accum", type=int, default=1, help="gradient accumulation steps of the HEADLINE measurement")
     ap.add_argument("--no-recipe", dest="no_recipe", action="store_true",
                     help="skip the second figure: the reference recipe 8 episodes x 2 accumulation steps per GPU "
@@ -341,7 +343,7 @@ def main():
                             total_steps=1000, force_reducer=args.force_reducer,
                             grad_comm_dtype=getattr(torch, args.grad_comm), grad_accum=args.accum,
                             grad_dtype=getattr(torch, args.grad_dtype) if args.dtype == "bfloat16" else torch.float32,
-                            overlap_optimizer=not args.no_overlap)
+                            overlap_optimizer=args.overlap)
     if trainer.reducer is not None:
         trainer.reducer.time_comm = True
     from dexbotic_amd.data.feeder import DeviceFeeder
@@ -430,7 +432,7 @@ def main():
     result["config"]["inputs"] = ("one device-resident batch re-used" if args.static_batch else
                                   "8 host batches rotated, fresh token ids every step, images/actions uploaded from pinned "
                                   "memory on a copy stream one step ahead" + (", every 4th batch right-padded" if args.ragged else ""))
-    result["config"]["optimizer"] = "AdamW serial" if args.no_overlap else "AdamW overlapped with the next forward (side stream, per-bucket events)"
+    result["config"]["optimizer"] = "AdamW serial" if not args.overlap else "AdamW overlapped with the next forward (side stream, per-bucket events)"
     result["config"]["grad_accum"] = args.accum
     if trainer.reducer is not None and not trainer.reducer.local_only:
         red = trainer.reducer

@@ -366,6 +366,50 @@ __global__ __launch_bounds__(256) void attn_ds_k(T* __restrict__ P, const float*
   }
 }
 
+// P[row, :] = softmax(scale * S[row, :]) over the visible keys (dtype T, rounded like the generic kernel: P then P * mask),
+// lse[row] = log-sum-exp; one wave per row of a MATERIALISED score slab (forward of the non-flash path at sizes where the
+// one-wave-per-row kernel would walk hundreds of keys serially: fp32 serving of pi0, retrieval attention with dropout)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_softmax_rows_k(const float* __restrict__ S, T* __restrict__ P, float* __restrict__ lse,
+                                                           int B, int H, int Sq, int Sk, float scale, int causal,
+                                                           const int32_t* __restrict__ kv_start, const int32_t* __restrict__ kv_end,
+                                                           const int32_t* __restrict__ q_limit, const uint8_t* __restrict__ key_valid,
+                                                           const T* __restrict__ drop) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * H * Sq) return;
+  const int i = (int)(row % Sq);
+  const int b = (int)(row / ((int64_t)Sq * H));
+  int j0 = kv_start ? kv_start[b] : 0, j1 = kv_end ? kv_end[b] : Sk;
+  if (causal) j1 = min(j1, i + (Sk - Sq) + 1);
+  if (q_limit) j1 = min(j1, q_limit[(int64_t)b * Sq + i]);
+  j0 = max(j0, 0);
+  j1 = min(j1, Sk);
+  const uint8_t* kvld = key_valid ? key_valid + (int64_t)b * Sk : nullptr;
+  const float* s = S + row * Sk;
+  T* pr = P + row * Sk;
+  float mx = -INFINITY;
+  for (int j = j0 + lane; j < j1; j += 64)
+    if (!kvld || kvld[j]) mx = fmaxf(mx, s[j] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = j0 + lane; j < j1; j += 64)
+    if (!kvld || kvld[j]) sum += expf(s[j] * scale - mx);
+  sum = wave_sum(sum);
+  const bool any = sum > 0.f;
+  const float inv = any ? 1.f / sum : 0.f;
+  const T* dm = drop ? drop + row * Sk : nullptr;
+  for (int j = lane; j < Sk; j += 64) {
+    float pj = 0.f;
+    if (j >= j0 && j < j1 && (!kvld || kvld[j]) && any) {
+      pj = rnd<T>(expf(s[j] * scale - mx) * inv);
+      if (dm) pj = rnd<T>(pj * ldf<T>(dm + j));
+    }
+    stf<T>(pr + j, pj);
+  }
+  if (lane == 0) lse[row] = any ? mx + logf(sum) : 0.f;
+}
+
 // ------------------------------------------------------------------------------ fused flash backward (bf16)
 // 64-row tiles of Q/dO (or K/V) are staged ROW-major in LDS ([row][d], 16-byte chunks XOR-swizzled by row) and
 // feed both MFMA operand shapes:
@@ -726,16 +770,79 @@ int check_common(const dxa_attn_desc* d, const char* who) {
 
 }  // namespace
 
+static bool fwd_flash_ok(const dxa_attn_desc* d) {
+  const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
+                        d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
+                        d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
+  return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && strides8 &&
+         al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
+}
+
+// non-flash forward at sizes where one wave per query row (attn_fwd_generic_k) would walk hundreds of keys serially:
+// materialise S = Q K^T with the batched MFMA GEMM, one masked row softmax, O = P V with the batched GEMM again
+static bool fwd_materialise(const dxa_attn_desc* d) {
+  if (fwd_flash_ok(d) || d->force_generic == 1) return false;          // force_generic 1: the one-wave-per-row kernel
+  const double n = (double)d->B * d->Hq * d->Sq * d->Sk;
+  if (n * 4 > (double)(1ull << 31)) return false;
+  return d->force_generic == 2 || (d->Sq >= 32 && d->Sk >= 128);       // force_generic 2 (tests): this path at any size
+}
+
+extern "C" size_t dxa_attn_fwd_workspace(const dxa_attn_desc* d) {
+  if (!d || d->B <= 0 || d->Sq <= 0 || d->Sk <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->Hq % d->Hkv) return 0;
+  if (!fwd_materialise(d)) return 0;
+  const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
+  return align_up(n * 4, 256) + align_up(n * (d->dtype == DXA_BF16 ? 2 : 4), 256);
+}
+
+extern "C" int dxa_attn_fwd_ws(const dxa_attn_desc* d, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  if (int rc = check_common(d, "dxa_attn_fwd_ws")) return rc;
+  if (d->B == 0 || d->Sq == 0) return DXA_OK;
+  const size_t need = dxa_attn_fwd_workspace(d);
+  if (need == 0 || d->Sk == 0) return dxa_attn_fwd(d, stream);
+  DXA_CHECK_ARG(workspace && workspace_bytes >= need, "dxa_attn_fwd_ws: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const int G = d->Hq / d->Hkv;
+  const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
+  const int64_t SqSk = (int64_t)d->Sq * d->Sk;
+  float* Sf = (float*)workspace;
+  void* P = (char*)workspace + align_up(n * 4, 256);
+  dxa_gemm_desc g;
+  memset(&g, 0, sizeof(g));
+  g.layout = DXA_NT; g.in_dtype = d->dtype; g.out_dtype = DXA_F32; g.act = DXA_ACT_NONE; g.alpha = 1.f;
+  g.nb[0] = d->B; g.nb[1] = d->Hkv; g.nb[2] = G;
+  g.M = d->Sq; g.N = d->Sk; g.K = d->D;
+  g.A = d->q; g.lda = d->q_ss; g.sA[0] = d->q_sb; g.sA[1] = d->q_sh * G; g.sA[2] = d->q_sh;
+  g.B = d->k; g.ldb = d->k_ss; g.sB[0] = d->k_sb; g.sB[1] = d->k_sh; g.sB[2] = 0;
+  g.C = Sf; g.ldc = d->Sk; g.sC[0] = (int64_t)d->Hq * SqSk; g.sC[1] = (int64_t)G * SqSk; g.sC[2] = SqSk;
+  int rc;
+  if ((rc = dxa_gemm(&g, stream))) return rc;
+  {
+    const int64_t rows = (int64_t)d->B * d->Hq * d->Sq;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (d->dtype == DXA_BF16)
+      hipLaunchKernelGGL((attn_softmax_rows_k<bf16_t>), grid, dim3(256), 0, st, Sf, (bf16_t*)P, d->lse, d->B, d->Hq, d->Sq, d->Sk, d->scale,
+                         d->causal, d->kv_start, d->kv_end, d->q_limit, d->key_valid, (const bf16_t*)d->drop_mask);
+    else
+      hipLaunchKernelGGL((attn_softmax_rows_k<float>), grid, dim3(256), 0, st, Sf, (float*)P, d->lse, d->B, d->Hq, d->Sq, d->Sk, d->scale,
+                         d->causal, d->kv_start, d->kv_end, d->q_limit, d->key_valid, (const float*)d->drop_mask);
+    DXA_CHECK_LAUNCH();
+  }
+  memset(&g, 0, sizeof(g));
+  g.layout = DXA_NN; g.in_dtype = d->dtype; g.out_dtype = d->dtype; g.act = DXA_ACT_NONE; g.alpha = 1.f;
+  g.nb[0] = d->B; g.nb[1] = d->Hkv; g.nb[2] = G;
+  g.M = d->Sq; g.N = d->D; g.K = d->Sk;
+  g.A = P; g.lda = d->Sk; g.sA[0] = (int64_t)d->Hq * SqSk; g.sA[1] = (int64_t)G * SqSk; g.sA[2] = SqSk;
+  g.B = d->v; g.ldb = d->v_ss; g.sB[0] = d->v_sb; g.sB[1] = d->v_sh; g.sB[2] = 0;
+  g.C = d->o; g.ldc = d->o_ss; g.sC[0] = d->o_sb; g.sC[1] = d->o_sh * G; g.sC[2] = d->o_sh;
+  return dxa_gemm(&g, stream);
+}
+
 extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
   if (int rc = check_common(d, "dxa_attn_fwd")) return rc;
   if (d->B == 0 || d->Sq == 0) return DXA_OK;
   hipStream_t st = (hipStream_t)stream;
   const AttnP p = make_params(d);
-  const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
-                        d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
-                        d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
-  const bool flash_ok = !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && strides8 &&
-                        al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
+  const bool flash_ok = fwd_flash_ok(d);
   if (flash_ok) {
     dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
     if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256>), grid, dim3(256), 0, st, p);

@@ -128,6 +128,7 @@ class ParamStore:
         self._shadow_version: Optional[int] = None
         self._grad_version: Optional[int] = None
         self._external_fresh = True                     # nothing written since the last begin_step
+        self._external_trained = False                  # a training forward ran under an external loop since the last sync
 
     # ---- layout -------------------------------------------------------------------------------------
     def new_bucket(self) -> int:
@@ -446,13 +447,26 @@ class ParamStore:
         if dropped:
             self.attach_grads()
         if dropped or self._external_fresh or self.grad._version != self._grad_version:
+            if self.shadow is not None and self._external_trained:
+                # a foreign optimizer has (presumably) moved the fp32 masters since the last training forward.  The arena's
+                # version counter does not see every such update — torch.optim.AdamW(fused=True), HF Trainer's default, leaves
+                # it untouched — so the bf16 shadows are re-derived at every optimizer-step boundary of an external loop
+                # (one 48 GB cast pass at the 7 B size: ~8 ms next to the foreach / fused torch AdamW it follows)
+                self.sync_shadow()
             self.begin_step()
             if dropped or self.grad._version != self._grad_version:
                 self.invalidate_embed_tracking()          # somebody else wrote the gradient arena: dense re-zero
         else:
             self.begin_micro()
         self._external_fresh = False
+        self._external_trained = True
         self._grad_version = self.grad._version
+
+    def external_eval(self) -> None:
+        """``model.eval()`` after training under an external loop: the shadows follow the masters once more"""
+        if not self.managed and self._external_trained and self.shadow is not None:
+            self.sync_shadow()
+            self._external_trained = False
 
     def external_zero_grad(self) -> None:
         """``model.zero_grad()`` of an external loop: gradients stay attached (they are views of the arena, overwritten by the

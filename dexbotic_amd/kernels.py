@@ -369,7 +369,13 @@ def attn_fwd(q, k, v, o, *, causal: bool, scale: float, kv_start=None, kv_end=No
     lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32)
     d = _attn_desc(q, k, v, o, lse, causal, scale, kv_start, kv_end, q_limit, key_valid, drop_mask)
     d.force_generic = int(force_generic)
-    L.check(lib.dxa_attn_fwd(C.byref(d), _stream()), "dxa_attn_fwd")
+    nbytes = int(lib.dxa_attn_fwd_workspace(C.byref(d)))
+    if nbytes:
+        # large non-flash problem (fp32, or attention dropout): scores materialised through the batched GEMMs
+        ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+        L.check(lib.dxa_attn_fwd_ws(C.byref(d), _ptr(ws), nbytes, _stream()), "dxa_attn_fwd_ws")
+    else:
+        L.check(lib.dxa_attn_fwd(C.byref(d), _stream()), "dxa_attn_fwd")
     return lse
 
 

@@ -273,6 +273,12 @@ class NativePreTrainedMixin:
         unused = self.unused_parameter_names() if hasattr(self, "unused_parameter_names") else ()
         st.external_prelude(unused)
 
+    def train(self, mode: bool = True):
+        out = nn.Module.train(self, mode)
+        if not mode:
+            self.store.external_eval()
+        return out
+
     def _apply(self, fn, recurse: bool = True):
         """``model.to(device)`` / ``.cuda()`` (HF Trainer moves the model in its constructor) must not rebuild the parameters:
         they are views of the arenas.  A conversion that would change nothing is accepted and ignored, anything else refused."""

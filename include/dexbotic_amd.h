@@ -175,7 +175,8 @@ typedef struct dxa_attn_desc {
   void* dq; int64_t dq_sb, dq_sh, dq_ss;
   void* dk; int64_t dk_sb, dk_sh, dk_ss;
   void* dv; int64_t dv_sb, dv_sh, dv_ss;
-  int32_t force_generic;    /* testing: bypass the MFMA kernel */
+  int32_t force_generic;    /* testing: 1 = bypass the MFMA kernel (one wave per query row); 2 = bypass it and take the
+                               materialised path of dxa_attn_fwd_ws at any size */
   /* block-prefix masks of the pi0 mixture-of-transformers attention (dexbotic/model/pi0/pi0_arch.py:22-33):
    * cumsum(ar_mask) is non-decreasing, so "cumsum[j] <= cumsum[i]" is a per-query key count; input_mask is a
    * per-key validity.  Either may be NULL.  With one of them set the generic kernels run. */
@@ -187,6 +188,13 @@ typedef struct dxa_attn_desc {
   const void* drop_mask;
 } dxa_attn_desc;
 int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream);
+/* Forward with caller-provided scratch.  Problems the fused bf16 flash kernel does not take (fp32 — how the reference serves
+ * pi0: pi0_exp.py:347-353, eager_attention_forward of pi0_arch.py:185-191 — or attention dropout, memvla_arch.py:120-123) and
+ * that are large (Sq >= 32, Sk >= 128) are computed like the reference's eager path: S = Q K^T (batched MFMA GEMM, fp32 scores),
+ * one masked row softmax (+ dropout mask), O = P V (batched GEMM).  dxa_attn_fwd_workspace() = bytes of scratch that path
+ * needs (0: dxa_attn_fwd_ws behaves exactly like dxa_attn_fwd). */
+size_t dxa_attn_fwd_workspace(const dxa_attn_desc* d);
+int dxa_attn_fwd_ws(const dxa_attn_desc* d, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
 size_t dxa_attn_bwd_workspace(const dxa_attn_desc* d);
 int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
 

@@ -37,6 +37,19 @@ def main():
         t_f = timeit(lambda: K.attn_fwd(q, k, v, o, causal=causal, scale=scale))
         t_b = timeit(lambda: K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=causal, scale=scale))
         print(f"{name:18s} fwd {t_f:7.1f} us {flops / t_f / 1e6:6.1f} TF/s | bwd {t_b:7.1f} us {2.5 * flops / t_b / 1e6:6.1f} TF/s", flush=True)
+        if "pi0" in name:
+            # the masks of the pi0 training step: block-prefix limits (prefix 784 | state | actions) and per-key validity
+            lim = torch.full((B, S), S - 17, dtype=torch.int32, device="cuda")
+            lim[:, S - 17] = S - 16
+            lim[:, S - 16:] = S
+            valid = torch.ones(B, S, dtype=torch.uint8, device="cuda")
+            valid[1, 256:512] = 0
+            kw = dict(causal=False, scale=scale, q_limit=lim, key_valid=valid)
+            lse = K.attn_fwd(q, k, v, o, **kw)
+            t_f = timeit(lambda: K.attn_fwd(q, k, v, o, **kw))
+            t_b = timeit(lambda: K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, **kw))
+            print(f"{name + ' masked':18s} fwd {t_f:7.1f} us {flops / t_f / 1e6:6.1f} TF/s | bwd {t_b:7.1f} us "
+                  f"{2.5 * flops / t_b / 1e6:6.1f} TF/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -60,6 +60,30 @@ def main():
         a.cpu()
         lat.append(1e3 * (time.perf_counter() - t0))
     res["p50_action_inference_ms"] = round(float(np.median(lat[2:])), 1)
+    res["inference_config"] = "bf16 compute, chunk 16, 10 Euler steps"
+    # the way the REFERENCE serves pi0: fp32 weights and arithmetic (pi0_exp.py:347-353; matmul precision "highest", :106) and its
+    # default chunk_size 50 (pi0_arch.py:58-59)
+    del tr, m
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    cfg32 = Pi0Config(vision_config=vis, action_config=act, llm_config=gem, mm_projector_type="linear", action_dim=32,
+                      chunk_size=50, compute_dtype="float32")
+    m32 = Pi0ForCausalLM(cfg32, device=dev, train=False)
+    m32.init_random_(seed=0)
+    for n in m32.store.slots:
+        if n.startswith(("model.llm.", "model.action_expert.")) and "norm" in n:
+            m32.store.w32(n).zero_()
+    m32.post_load()
+    m32.eval()
+    lat = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a = m32.inference_action(diffusion_steps=10, **b1)
+        a.cpu()
+        lat.append(1e3 * (time.perf_counter() - t0))
+    res["p50_action_inference_ms_fp32_chunk50"] = round(float(np.median(lat[2:])), 1)
     print(json.dumps(res), flush=True)
 
 

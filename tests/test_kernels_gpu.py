@@ -424,7 +424,8 @@ ATTN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype,force_generic", [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, True)])
+@pytest.mark.parametrize("dtype,force_generic", [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, True),
+                                                 (torch.float32, 2), (torch.bfloat16, 2)])      # 2: the materialised forward
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_attention_fwd_bwd(dtype, force_generic, case):
     B, Hq, Hkv, S, D, causal, padded, head_major = case
@@ -915,6 +916,43 @@ def test_attention_dropout_mask(dtype):
     o2 = torch.empty_like(q)
     K.attn_fwd(q, k, v, o2, causal=False, scale=D ** -0.5, force_generic=True)
     assert_close(o2, torch.softmax(q.double() @ k.double().transpose(-1, -2) * D ** -0.5, dim=-1) @ v.double(), rtol, atol, "no mask")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_materialised_forward_masks_dropout_and_sizes(dtype):
+    """dxa_attn_fwd_ws: the eager-style forward (S = Q K^T by the batched GEMM, masked row softmax, O = P V) that large non-flash
+    problems take — pi0 served in fp32 (MQA, head_dim 256, suffix queries against prefix + suffix keys, block-prefix limits, key
+    validity) and retrieval attention with a dropout mask — against the one-wave-per-row kernel and an explicit reference"""
+    B, Hq, Hkv, Sq, Sk, D = 2, 8, 1, 51, 300, 256
+    q, k, v = rnd(B, Hq, Sq, D, dtype=dtype, seed=150), rnd(B, Hkv, Sk, D, dtype=dtype, seed=151), rnd(B, Hkv, Sk, D, dtype=dtype, seed=152)
+    valid = torch.ones(B, Sk, dtype=torch.bool, device=DEV)
+    valid[0, 40:60] = False
+    q_limit = torch.full((B, Sq), Sk, dtype=torch.int32, device=DEV)
+    q_limit[:, 0] = Sk - 50                                           # the state token does not see the action tokens
+    scale = D ** -0.5
+    o, o1 = torch.empty_like(q), torch.empty_like(q)
+    kw = dict(causal=False, scale=scale, q_limit=q_limit, key_valid=valid.to(torch.uint8))
+    lse = K.attn_fwd(q, k, v, o, **kw)                                # Sq >= 32, Sk >= 128, not flash-eligible in fp32: materialised
+    lse1 = K.attn_fwd(q, k, v, o1, force_generic=True, **kw)
+    mask = (torch.arange(Sk, device=DEV)[None, None, :] < q_limit[:, :, None]) & valid[:, None, :]
+    sc = torch.einsum("bhid,bjd->bhij", q.double(), k.double()[:, 0]) * scale
+    sc = sc.masked_fill(~mask[:, None], float("-inf"))
+    ref = torch.softmax(sc, -1) @ v.double()[:, :1]
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (1.0 / 64, 2e-2)
+    if dtype == torch.float32:
+        assert_close(o, ref, rtol, atol, "materialised fwd")
+        assert_close(lse, torch.logsumexp(sc, -1), 1e-4, 1e-4, "materialised lse")
+    assert_close(o, o1.double(), rtol, atol, "materialised vs one-wave-per-row")
+    assert_close(lse, lse1.double(), 1e-4 if dtype == torch.float32 else 1e-2, 1e-4 if dtype == torch.float32 else 3e-2, "lse")
+    # dropout mask, 4-head retrieval shape (256 queries x 1024 keys, head_dim 64)
+    B, H, Sq, Sk, D = 1, 4, 256, 1024, 64
+    q, k, v = (rnd(B, H, s_, D, dtype=dtype, seed=160 + i) for i, s_ in enumerate((Sq, Sk, Sk)))
+    g = torch.Generator(device="cpu").manual_seed(6)
+    dm = ((torch.rand(B, H, Sq, Sk, generator=g) >= 0.1).float() / 0.9).to(DEV).to(dtype)
+    o = torch.empty_like(q)
+    K.attn_fwd(q, k, v, o, causal=False, scale=D ** -0.5, drop_mask=dm)
+    ref = (torch.softmax(q.double() @ k.double().transpose(-1, -2) * D ** -0.5, -1) * dm.double()) @ v.double()
+    assert_close(o, ref, rtol, atol, "materialised fwd + dropout")
 
 
 @pytest.mark.parametrize("M,Kd,N", [(1, 14336, 3584), (1, 3584, 3584), (3, 3584, 14336), (8, 200, 520), (5, 64, 64), (2, 1030, 72)])
