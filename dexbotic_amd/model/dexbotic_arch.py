@@ -277,6 +277,9 @@ class NativePreTrainedMixin:
         out = nn.Module.train(self, mode)
         if not mode:
             self.store.external_eval()
+        else:
+            # captured inference graphs hold pointers to eval-time caches (e.g. Gemma's 1 + w norm weights): drop them
+            self.__dict__.pop("_sampler_graphs", None)
         return out
 
     def _apply(self, fn, recurse: bool = True):

@@ -380,9 +380,24 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         else:
             model_kwargs = dict(z=cogf)
             sample_fn = head.net.forward
-        model_kwargs["per_token"] = per.float().repeat(2, 1, 1)
-        samples = head.ddim_diffusion.ddim_sample_loop(sample_fn, noise.shape, noise, clip_denoised=False,
-                                                       model_kwargs=model_kwargs, eta=0.0, device=dev)
+        per_token = per.float().repeat(2, 1, 1) if cfg_scale > 1.0 else per.float()
+        cfg = model_kwargs.get("cfg_scale")
+
+        def sample(noise, z, per_token):
+            mk = dict(z=z, per_token=per_token)
+            if cfg is not None:
+                mk["cfg_scale"] = cfg
+            return head.ddim_diffusion.ddim_sample_loop(sample_fn, noise.shape, noise, clip_denoised=False, model_kwargs=mk,
+                                                        eta=0.0, device=dev)
+        from ... import graphs
+        if dev.type == "cuda" and inference_args.get("use_graph", graphs.enabled()):
+            # the sampler (DiT-L with perceptual attention, ~480 launches per DDIM step) is host-bound: captured once per
+            # shape into a HIP graph and replayed (graphs.GraphCache); the stateful memory bank above stays eager host logic
+            cache = self.__dict__.setdefault("_sampler_graphs", graphs.GraphCache(dev))
+            samples = cache.run(("ddim", float(cfg_scale), int(num_ddim_steps)), sample,
+                                dict(noise=noise, z=model_kwargs["z"].contiguous(), per_token=per_token.contiguous()))
+        else:
+            samples = sample(noise, model_kwargs["z"], per_token)
         if cfg_scale > 1.0:
             samples = samples[:B]
         return self._denorm(samples[0].cpu().numpy(), action_norms).tolist()

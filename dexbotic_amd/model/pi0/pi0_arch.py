@@ -186,15 +186,17 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         input_mask = np.concatenate([np.repeat(im, T, axis=1), am], axis=1)
         return tokens, input_mask, np.zeros(tokens.shape[1], dtype=bool)
 
-    def embed_suffix(self, states: torch.Tensor, noisy_actions: torch.Tensor, time: np.ndarray):
-        """-> tokens [B, 1 + chunk, d_a] fp32->compute dtype, input_mask (all True), ar_mask [True, True, False...]"""
+    def embed_suffix(self, states: torch.Tensor, noisy_actions: torch.Tensor, time: Optional[np.ndarray], te: Optional[torch.Tensor] = None):
+        """-> tokens [B, 1 + chunk, d_a] fp32->compute dtype, input_mask (all True), ar_mask [True, True, False...].
+        ``te``: the sin/cos time embedding [B, d_a] already on the device (the sampler precomputes its schedule)."""
         st, c = self.store, self.config
         cdt = st.compute_dtype
         B, da = states.shape[0], c.action_config.hidden_size
         lin = lambda x, n, act=L.ACT_NONE: Fn.LinearFn.apply(x, st.params[f"model.{n}.weight"], st, f"model.{n}.weight",
                                                              f"model.{n}.bias", act, None)
         state_tok = lin(states.to(cdt), "state_proj").view(B, 1, da)
-        te = torch.from_numpy(posemb_sincos(time, da)).to(device=st.device, dtype=cdt)          # [B, da]
+        if te is None:
+            te = torch.from_numpy(posemb_sincos(time, da)).to(device=st.device, dtype=cdt)      # [B, da]
         act_tok = lin(noisy_actions.to(cdt).reshape(B * c.chunk_size, -1), "action_in_proj").view(B, c.chunk_size, da)
         h = torch.cat([act_tok, te[:, None, :].expand(B, c.chunk_size, da)], dim=-1).reshape(B * c.chunk_size, 2 * da)
         h = lin(h.contiguous(), "action_time_mlp_in", L.ACT_SILU)
@@ -215,8 +217,8 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
                 torch.from_numpy(np.ascontiguousarray(k_valid.astype(np.uint8))).to(device))
 
     @torch.no_grad()
-    def _mot_forward(self, xs: List[Optional[torch.Tensor]], positions: np.ndarray, q_limit: torch.Tensor,
-                     key_valid: torch.Tensor, past: Optional[list] = None, collect: bool = False):
+    def _mot_forward(self, xs: List[Optional[torch.Tensor]], positions: Optional[np.ndarray], q_limit: torch.Tensor,
+                     key_valid: torch.Tensor, past: Optional[list] = None, collect: bool = False, pos_parts=None, rope=None):
         """_inner_forward_mot (pi0_arch.py:116-216) without autograd: xs = [llm tokens | None, expert tokens | None],
         positions [B, S_q] int (RoPE), masks over [past keys ; new keys].  Returns ([out per expert], K/V cache)."""
         experts = [self.model.llm, self.model.action_expert]
@@ -227,10 +229,12 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         lens = [x.shape[1] for _, x in live]
         S = sum(lens)
         dev = self.store.device
-        cos_t, sin_t = experts[0].rope_tables(int(positions.max()) + 1, dev)
         offs = np.cumsum([0] + lens)
-        pos_parts = [torch.from_numpy(np.ascontiguousarray(positions[:, offs[i]:offs[i + 1]].astype(np.int32))).to(dev).reshape(-1)
-                     for i in range(len(live))]
+        if pos_parts is None:              # (the sampler hands in device tensors: nothing host-side inside its captured loop)
+            rope = experts[0].rope_tables(int(positions.max()) + 1, dev)
+            pos_parts = [torch.from_numpy(np.ascontiguousarray(positions[:, offs[i]:offs[i + 1]].astype(np.int32))).to(dev).reshape(-1)
+                         for i in range(len(live))]
+        cos_t, sin_t = rope
         hs = [x.reshape(B * n, -1).contiguous() for (_, x), n in zip(live, lens)]
         cache = []
         for li in range(c.num_hidden_layers):
@@ -333,21 +337,44 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         q_limit, key_valid = self._mask_tensors(pcum, pmask, pcum, pmask, dev)
         ppos = np.cumsum(pmask, axis=1) - 1
         _, cache = self._mot_forward([ptok, None], ppos, q_limit, key_valid, collect=True)
-        states_d = states.to(dev).float()
-        P = pmask.shape[1]
-        time = np.float32(1.0)
-        while time > -dt / 2:
-            stok, smask, sar = self.embed_suffix(states_d, x, np.full(B, time, dtype=np.float32))
-            scum = np.broadcast_to(np.cumsum(sar.astype(np.int64)), smask.shape)
-            # keys = [cached prefix (all visible where valid: cumsum 0) ; suffix]; queries = suffix (cumsum >= 1)
-            k_cum = np.concatenate([np.zeros_like(pmask, dtype=np.int64), scum], axis=1)
-            k_valid = np.concatenate([pmask, smask], axis=1)
-            q_limit, key_valid = self._mask_tensors(scum, smask, k_cum, k_valid, dev)
-            fpos = pmask.sum(-1)[:, None] + np.cumsum(smask, axis=-1) - 1
-            (_, suf), _ = self._mot_forward([None, stok], fpos, q_limit, key_valid, past=cache)
-            v_t = Fn.LinearFn.apply(suf[:, -c.chunk_size:].reshape(B * c.chunk_size, -1).contiguous(),
-                                    st.params["model.action_out_proj.weight"], st, "model.action_out_proj.weight",
-                                    "model.action_out_proj.bias", L.ACT_NONE, None).view(B, c.chunk_size, -1).float()
-            x = K.add(x, K.scale_(v_t.contiguous(), dt))                 # Euler step x += v dt
+        states_d = states.to(dev).float().contiguous()
+        # ---- the Euler loop: everything that does not depend on x is prepared once (masks, positions, RoPE tables, the time
+        #      embeddings of the whole schedule), the loop itself is tensors in / tensors out and is replayed as ONE HIP graph
+        #      (graphs.GraphCache): 10 steps x 18 layers x ~14 tiny launches are host-bound when issued from Python
+        smask = np.ones((B, 1 + c.chunk_size), dtype=bool)
+        sar = np.array([True, True] + [False] * (c.chunk_size - 1))
+        scum = np.broadcast_to(np.cumsum(sar.astype(np.int64)), smask.shape)
+        # keys = [cached prefix (all visible where valid: cumsum 0) ; suffix]; queries = suffix (cumsum >= 1)
+        k_cum = np.concatenate([np.zeros_like(pmask, dtype=np.int64), scum], axis=1)
+        k_valid = np.concatenate([pmask, smask], axis=1)
+        q_limit, key_valid = self._mask_tensors(scum, smask, k_cum, k_valid, dev)
+        fpos = pmask.sum(-1)[:, None] + np.cumsum(smask, axis=-1) - 1
+        rope = self.model.llm.rope_tables(int(fpos.max()) + 1, dev)
+        pos = torch.from_numpy(np.ascontiguousarray(fpos.astype(np.int32))).to(dev).reshape(-1)
+        times, time = [], np.float32(1.0)
+        while time > -dt / 2:                                             # the reference's float32 schedule (pi0_arch.py:470-489)
+            times.append(time)
             time = np.float32(time + np.float32(dt))
-        return x
+        da = c.action_config.hidden_size
+        te_table = torch.from_numpy(np.stack([posemb_sincos(np.full(B, t, dtype=np.float32), da) for t in times])
+                                    ).to(device=dev, dtype=st.compute_dtype)                      # [steps, B, da]
+        n_layers = len(cache)
+
+        def euler(x, states_d, te_table, q_limit, key_valid, pos, **kv):
+            past = [(kv[f"k{i}"], kv[f"v{i}"]) for i in range(n_layers)]
+            for s in range(len(times)):
+                stok, _, _ = self.embed_suffix(states_d, x, None, te=te_table[s])
+                (_, suf), _ = self._mot_forward([None, stok], None, q_limit, key_valid, past=past, pos_parts=[pos], rope=rope)
+                v_t = Fn.LinearFn.apply(suf[:, -c.chunk_size:].reshape(B * c.chunk_size, -1).contiguous(),
+                                        st.params["model.action_out_proj.weight"], st, "model.action_out_proj.weight",
+                                        "model.action_out_proj.bias", L.ACT_NONE, None).view(B, c.chunk_size, -1).float()
+                x = K.add(x, K.scale_(v_t.contiguous(), dt))             # Euler step x += v dt
+            return x
+        inputs = dict(x=x, states_d=states_d, te_table=te_table, q_limit=q_limit, key_valid=key_valid, pos=pos)
+        for i, (k_, v_) in enumerate(cache):
+            inputs[f"k{i}"], inputs[f"v{i}"] = k_.contiguous(), v_.contiguous()
+        from ... import graphs
+        if dev.type == "cuda" and kwargs.get("use_graph", graphs.enabled()):
+            gc_ = self.__dict__.setdefault("_sampler_graphs", graphs.GraphCache(dev))
+            return gc_.run(("euler", int(diffusion_steps), int(fpos.max()), rope[0].data_ptr()), euler, inputs).clone()
+        return euler(**inputs)

@@ -111,6 +111,27 @@ def test_fp32_memvla_inference_episode_matches_reference(golden_dir):
         assert rel_err(np.array(acts), g["infer_actions"][f]) < FP32_TOL, f
 
 
+def test_memvla_sampler_graph_replay_equals_eager_launches(golden_dir):
+    """the DDIM loop over the per-attention DiT is replayed as one HIP graph from the third frame on (graphs.GraphCache); an
+    episode sampled that way equals the eagerly launched episode bit for bit (the memory bank itself stays host logic)"""
+    g, cfg, m = build(golden_dir, "float32", False)
+    m.eval()
+    norms = {"min": [-1.0] * cfg.action_dim, "max": [1.0] * cfg.action_dim}
+    runs = {}
+    for use_graph in (False, True):
+        out = []
+        for rep in range(2):                                   # two episodes: the second one replays from its first frame
+            for f in range(g["infer_frames"].shape[0]):
+                out.append(np.array(m.inference_action(
+                    T(g["infer_prompt"]), T(g["infer_frames"][f:f + 1]), "True" if f == 0 else "False",
+                    {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms, "use_graph": use_graph},
+                    noise=T(g["infer_inits"][f]))))
+        runs[use_graph] = np.stack(out)
+    assert np.array_equal(runs[True], runs[False])
+    assert any(e["graph"] is not None for e in m._sampler_graphs.entries.values())
+    assert rel_err(runs[True][:4], g["infer_actions"]) < FP32_TOL
+
+
 def test_bf16_memvla_step_runs_and_tracks(golden_dir):
     g, cfg, m = build(golden_dir, "bfloat16", True)
     m.train()

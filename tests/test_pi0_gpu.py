@@ -53,6 +53,24 @@ def test_fp32_pi0_inference_action_matches_reference(golden_dir):
     assert rel_err(acts.cpu().numpy(), g["infer_actions"]) < FP32_TOL
 
 
+def test_pi0_sampler_graph_replay_equals_eager_launches(golden_dir):
+    """the Euler loop is captured into one HIP graph per shape (graphs.GraphCache: 1st call eager, 2nd captures, then replays);
+    every call gets its own initial noise and must equal the eager (use_graph=False) result bit for bit — fp32 and bf16"""
+    for dtype in ("float32", "bfloat16"):
+        g, m = build(golden_dir, dtype)
+        kw = dict(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), states=T(g["states"]),
+                  images=T(g["images"]), image_masks=T(g["image_masks"]), diffusion_steps=10)
+        for i in range(4):
+            noise = torch.from_numpy(np.random.RandomState(50 + i).standard_normal(g["init_noise"].shape).astype(np.float32)).to(DEV)
+            want = m.inference_action(noise=noise, use_graph=False, **kw)
+            got = m.inference_action(noise=noise, use_graph=True, **kw)
+            assert torch.equal(got, want), (dtype, i)
+        assert any(e["graph"] is not None for e in m._sampler_graphs.entries.values())
+        if dtype == "float32":
+            acts = m.inference_action(noise=T(g["init_noise"]), use_graph=True, **kw)
+            assert rel_err(acts.cpu().numpy(), g["infer_actions"]) < FP32_TOL
+
+
 def test_fp32_pi0_forward_loss_matches_reference(golden_dir):
     g, m = build(golden_dir, "float32")
     with torch.no_grad():
