@@ -114,8 +114,12 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_
 constexpr float LOG2E = 1.4426950408889634f;
 
 // -------------------------------------------------------------------------------------- flash forward
-template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
+// NW waves of 16 queries each share one staged K/V tile: 4 (64 queries per workgroup) or 8 (128 queries: the tile's staging is
+// amortised over twice the MFMA work and every SIMD holds two waves that hide each other's LDS reads and softmax — head_dim 256,
+// whose 64 accumulator + 32 query registers leave room for only one 4-wave workgroup per CU)
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
+  constexpr int NT = 64 * NW;
   constexpr int NCH = D / 8;          // 16-B chunks per K row
   constexpr int KROW = D * 2;         // bytes per K row
   constexpr int KT_BYTES = 64 * KROW; // K tile
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
   const int l16 = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * (16 * NW);
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
   j_hi = min(j_hi, p.Sk);
   const int coff = p.Sk - p.Sq;
   int blk_hi = j_hi;  // exclusive key bound for the whole workgroup
-  if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
+  if (p.causal) blk_hi = min(blk_hi, min(q0 + 16 * NW - 1, p.Sq - 1) + coff + 1);
   int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;  // exclusive bound for this lane's query
   if (p.q_limit) my_hi = min(my_hi, qi < p.Sq ? p.q_limit[(int64_t)b * p.Sq + qi] : 0);   // block-prefix mask (pi0)
   const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
 
   // K / V tiles travel global -> registers -> LDS; the NEXT tile's global loads are issued right after this tile has been
   // written to LDS, so they are in flight under this tile's MFMAs and softmax instead of in front of them
-  constexpr int RPI = 256 / NCH;           // K rows per pass
+  constexpr int RPI = NT / NCH;            // K rows per pass
   constexpr int KPT = 64 / RPI;            // K chunks (16 B) per thread
-  constexpr int VWI = (8 * (D / 4) + 255) / 256;   // V work items (8 keys x 4 d) per thread
+  constexpr int VWI = (8 * (D / 4) + NT - 1) / NT;   // V work items (8 keys x 4 d) per thread
   uint4 kreg[KPT];
   uint2 vreg[VWI][8];
   auto load_tile = [&](int kt) {
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
     }
 #pragma unroll
     for (int w = 0; w < VWI; ++w) {
-      const int wi = tid + 256 * w;
+      const int wi = tid + NT * w;
       const int kc = wi & 7, dg = wi >> 3;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
     // ---- stage V^T tile: work item (kc = key chunk of 8, dg = group of 4 d) transposes 8x4 -> 4x8
 #pragma unroll
     for (int w = 0; w < VWI; ++w) {
-      const int wi = tid + 256 * w;
+      const int wi = tid + NT * w;
       if (wi >= 8 * (D / 4)) break;
       const int kc = wi & 7, dg = wi >> 3;
       const uint2* vv = vreg[w];
@@ -239,13 +243,20 @@ __global__ __launch_bounds__(256) void attn_fwd_flash_k(const AttnP p) {
       }
     }
     // ---- online softmax for this lane's query
+    // key validity of the 64 keys of this tile as one 64-bit wave-uniform mask: lane j reads key_valid[key0 + j] (one coalesced
+    // 64-byte access) and the ballot spreads it, instead of 16 scattered byte loads per lane
+    unsigned long long kmask = ~0ull;
+    if (kvld) {
+      const int kj = key0 + lane;
+      kmask = __ballot(kj < p.Sk && kvld[kj] != 0);
+    }
     float tmax = -INFINITY;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + 16 * n + 4 * lg + r;
-        const bool vis = key >= j_lo && key < my_hi && (!kvld || kvld[key]);     // key < my_hi <= Sk: in bounds
+        const bool vis = key >= j_lo && key < my_hi && ((kmask >> (16 * n + 4 * lg + r)) & 1ull);
         const float s = vis ? sacc[n][r] * sc2 : -INFINITY;          // scores in log2 units
         sacc[n][r] = s;
         tmax = fmaxf(tmax, s);
@@ -425,12 +436,12 @@ __global__ __launch_bounds__(256) void attn_softmax_rows_k(const float* __restri
 //                S^T = K Q^T, dP^T = V dO^T (lane = one query), dS^T = P^T (dP^T - delta) scale, dQ^T += K^T dS^T
 //   dKV kernel : workgroup = 64 keys of one kv head, waves own 16 keys; loops over the G query heads of the
 //                group and over query tiles: S = Q K^T, dP = dO V^T (lane = one key), dV^T += dO^T P, dK^T += Q^T dS
-template <int D> struct FlashTile {
+template <int D, int NT = 256> struct FlashTile {
   static constexpr int NCH = D / 8;             // 16-byte chunks per row
   static constexpr int ROW = D * 2;             // bytes per row
   static constexpr int RM_BYTES = 64 * ROW;
   static constexpr int SWZ = (NCH < 16 ? NCH : 16) - 1;   // chunk ^= row & SWZ (16 rows x 16-byte chunks span the 64 banks)
-  static constexpr int RPI = 256 / NCH;         // rows covered by one pass of the 256 threads
+  static constexpr int RPI = NT / NCH;          // rows covered by one pass of the NT threads
   static constexpr int NPASS = 64 / RPI;        // 16-byte loads per thread per tile
 };
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -438,10 +449,10 @@ typedef uint32_t tile_reg_t __attribute__((ext_vector_type(4)));   // 16 bytes o
 
 // global -> registers: thread (c = tid % NCH, r = tid / NCH + RPI*i) holds chunk c of row r.  Rows past the end
 // are clamped to the last row (finite data; the score mask zeroes whatever they produce) — no divergent loads.
-template <int D>
-__device__ __forceinline__ void tile_gload(tile_reg_t (&reg)[FlashTile<D>::NPASS], const bf16_t* base, int64_t stride, int row0,
+template <int D, int NT = 256>
+__device__ __forceinline__ void tile_gload(tile_reg_t* __restrict__ reg, const bf16_t* base, int64_t stride, int row0,
                                            int nrows, int tid) {
-  using FT = FlashTile<D>;
+  using FT = FlashTile<D, NT>;
   const bf16_t* src = base + (tid % FT::NCH) * 8;
 #pragma unroll
   for (int i = 0; i < FT::NPASS; ++i) {
@@ -449,9 +460,9 @@ __device__ __forceinline__ void tile_gload(tile_reg_t (&reg)[FlashTile<D>::NPASS
     reg[i] = *reinterpret_cast<const tile_reg_t*>(src + (int64_t)r * stride);
   }
 }
-template <int D>
-__device__ __forceinline__ void tile_sstore(char* dst, const tile_reg_t (&reg)[FlashTile<D>::NPASS], int tid) {
-  using FT = FlashTile<D>;
+template <int D, int NT = 256>
+__device__ __forceinline__ void tile_sstore(char* dst, const tile_reg_t* __restrict__ reg, int tid) {
+  using FT = FlashTile<D, NT>;
   const int c = tid % FT::NCH, r0 = tid / FT::NCH;
   // RPI is a multiple of NCH's swizzle period only when RPI >= NCH; the row's low bits are those of r0 then
   char* d0 = dst + r0 * FT::ROW;
@@ -497,10 +508,11 @@ struct AttnBwdP {
   char* dv; int64_t dv_sb, dv_sh, dv_ss;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
-  using FT = FlashTile<D>;
+  constexpr int NT = 64 * NW;                  // NW waves of 16 queries share a staged K/V tile (see attn_fwd_flash_k)
+  using FT = FlashTile<D, NT>;
   __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES];
   char* Ks = smem;
   char* Vs = smem + FT::RM_BYTES;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
   const FragAddr<D> fa(l16, lg);
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * (16 * NW);
   const int qi = q0 + wave * 16 + l16;
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
@@ -548,25 +560,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
   j_hi = min(j_hi, p.Sk);
   const int coff = p.Sk - p.Sq;
   int blk_hi = j_hi;
-  if (p.causal) blk_hi = min(blk_hi, min(q0 + 63, p.Sq - 1) + coff + 1);
+  if (p.causal) blk_hi = min(blk_hi, min(q0 + 16 * NW - 1, p.Sq - 1) + coff + 1);
   int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;
   if (p.q_limit) my_hi = min(my_hi, qi < p.Sq ? p.q_limit[(int64_t)b * p.Sq + qi] : 0);   // block-prefix mask (pi0)
   const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
   const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
   tile_reg_t rk[FT::NPASS], rv[FT::NPASS];
   if (t_lo < t_hi) {
-    tile_gload<D>(rk, kb, p.k_ss, t_lo * 64, p.Sk, tid);
-    tile_gload<D>(rv, vb, p.v_ss, t_lo * 64, p.Sk, tid);
+    tile_gload<D, NT>(rk, kb, p.k_ss, t_lo * 64, p.Sk, tid);
+    tile_gload<D, NT>(rv, vb, p.v_ss, t_lo * 64, p.Sk, tid);
   }
   for (int kt = t_lo; kt < t_hi; ++kt) {
     const int key0 = kt * 64;
     __syncthreads();                       // previous tile fully consumed
-    tile_sstore<D>(Ks, rk, tid);
-    tile_sstore<D>(Vs, rv, tid);
+    tile_sstore<D, NT>(Ks, rk, tid);
+    tile_sstore<D, NT>(Vs, rv, tid);
     __syncthreads();
     if (kt + 1 < t_hi) {                   // next tile's loads fly during this tile's MFMAs
-      tile_gload<D>(rk, kb, p.k_ss, key0 + 64, p.Sk, tid);
-      tile_gload<D>(rv, vb, p.v_ss, key0 + 64, p.Sk, tid);
+      tile_gload<D, NT>(rk, kb, p.k_ss, key0 + 64, p.Sk, tid);
+      tile_gload<D, NT>(rv, vb, p.v_ss, key0 + 64, p.Sk, tid);
+    }
+    unsigned long long kmask = ~0ull;       // validity of this tile's 64 keys: one coalesced byte load per lane + ballot
+    if (kvld) {
+      const int kj = key0 + lane;
+      kmask = __ballot(kj < p.Sk && kvld[kj] != 0);
     }
     uint32_t dsp[8];
 #pragma unroll
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const AttnBwdP bp) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int key = key0 + 16 * n + 4 * lg + rr;
-        const bool vis = key >= j_lo && key < my_hi && (!kvld || kvld[key]);
+        const bool vis = key >= j_lo && key < my_hi && ((kmask >> (16 * n + 4 * lg + rr)) & 1ull);
         const float pr = vis ? __builtin_amdgcn_exp2f(s[rr] * sc2 - lse2) : 0.f;
         dsv[rr] = pr * (dp[rr] - dlt) * p.scale;
       }
@@ -844,10 +861,20 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
   const AttnP p = make_params(d);
   const bool flash_ok = fwd_flash_ok(d);
   if (flash_ok) {
-    dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
-    if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256>), grid, dim3(256), 0, st, p);
-    else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_fwd_flash_k<64>), grid, dim3(256), 0, st, p);
+    // 8-wave workgroups (128 queries per staged K/V tile) for head_dim 256 once there are enough queries to fill the chip that way
+    static const int nw_env = getenv("DXA_ATTN_FWD_NW") ? atoi(getenv("DXA_ATTN_FWD_NW")) : 0;
+    const int64_t wgs8 = (int64_t)((d->Sq + 127) / 128) * d->Hq * d->B;
+    const int nw = nw_env ? nw_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
+    dim3 grid((unsigned)((d->Sq + 16 * nw - 1) / (16 * nw)), (unsigned)d->Hq, (unsigned)d->B);
+    if (nw == 8) {
+      if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 8>), grid, dim3(512), 0, st, p);
+      else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 8>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd_flash_k<64, 8>), grid, dim3(512), 0, st, p);
+    } else {
+      if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 4>), grid, dim3(256), 0, st, p);
+      else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 4>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd_flash_k<64, 4>), grid, dim3(256), 0, st, p);
+    }
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
@@ -905,7 +932,10 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     bp.dq = (char*)d->dq; bp.dq_sb = d->dq_sb; bp.dq_sh = d->dq_sh; bp.dq_ss = d->dq_ss;
     bp.dk = (char*)d->dk; bp.dk_sb = d->dk_sb; bp.dk_sh = d->dk_sh; bp.dk_ss = d->dk_ss;
     bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
-    dim3 gq((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)d->B);
+    static const int nwq_env = getenv("DXA_ATTN_DQ_NW") ? atoi(getenv("DXA_ATTN_DQ_NW")) : 0;
+    const int64_t wgs8 = (int64_t)((d->Sq + 127) / 128) * d->Hq * d->B;
+    const int nwq = nwq_env ? nwq_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
+    dim3 gq((unsigned)((d->Sq + 16 * nwq - 1) / (16 * nwq)), (unsigned)d->Hq, (unsigned)d->B);
     dim3 gk((unsigned)((d->Sk + 63) / 64), (unsigned)d->Hkv, (unsigned)d->B);
 #define LAUNCH_BWD(D_)                                                                                           \
   do {                                                                                                            \
@@ -916,7 +946,8 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                \
       attr_ = true;                                                                                               \
     }                                                                                                             \
-    hipLaunchKernelGGL((attn_bwd_dq_k<D_>), gq, dim3(256), 0, st, bp);                                            \
+    if (nwq == 8) hipLaunchKernelGGL((attn_bwd_dq_k<D_, 8>), gq, dim3(512), 0, st, bp);                           \
+    else hipLaunchKernelGGL((attn_bwd_dq_k<D_, 4>), gq, dim3(256), 0, st, bp);                                    \
     hipLaunchKernelGGL((attn_bwd_dkv_k<D_>), gk, dim3(256), lds_, st, bp);                                        \
   } while (0)
     if (d->D == 256) LAUNCH_BWD(256); else if (d->D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(64);
