@@ -1775,6 +1775,24 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
 
   const size_t es = d->in_dtype == DXA_BF16 ? 2 : 4, os = d->out_dtype == DXA_BF16 ? 2 : 4;
   const int64_t epc = 16 / es;
+  // ---- a contraction length that is not a multiple of 64 (SigLIP-So400m's 4304-wide MLP: fc2 forward, fc1 dX) would send a
+  //      large bf16 NT / NN product to the generic kernel (3x slower): K = K0 + K1 with K0 = K - K % 64 on the MFMA fast path
+  //      (bias / residual epilogue applied there) and the < 64-deep tail accumulated on top by the generic kernel.  With a bf16
+  //      C the partial result is rounded once more than a single pass would (one extra bf16 rounding of the output).
+  static const bool ksplit_off = getenv("DXA_GEMM_NO_KTAIL") != nullptr;
+  if (!ksplit_off && d->in_dtype == DXA_BF16 && nbatch == 1 && d->layout != DXA_TN && d->K % 64 != 0 && d->K >= 1024 &&
+      d->M >= 256 && d->N >= 256 && d->act == DXA_ACT_NONE && !d->aux_out && !d->mulgrad && !d->sumsq && !d->mirror && !d->epi_f32) {
+    const int64_t K0 = d->K - d->K % 64;
+    dxa_gemm_desc head = *d, tail = *d;
+    head.K = K0;
+    tail.K = d->K - K0;
+    tail.accumulate = 1; tail.bias = nullptr; tail.residual = nullptr;
+    tail.A = (const char*)d->A + K0 * (int64_t)es;
+    tail.B = (const char*)d->B + (d->layout == DXA_NT ? K0 : K0 * d->ldb) * (int64_t)es;
+    bool m2 = false, s2 = false;
+    if (int rc = gemm_dispatch(&head, stream, &m2, &s2)) return rc;
+    return gemm_dispatch(&tail, stream, &m2, &s2);
+  }
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.M = d->M; p.N = d->N; p.K = d->K;

@@ -918,6 +918,27 @@ def test_attention_dropout_mask(dtype):
     assert_close(o2, torch.softmax(q.double() @ k.double().transpose(-1, -2) * D ** -0.5, dim=-1) @ v.double(), rtol, atol, "no mask")
 
 
+def test_gemm_contraction_not_multiple_of_64_takes_the_fast_path_plus_tail():
+    """K = 4304 (SigLIP-So400m's MLP width): NT with bias + residual (fc2 forward) and NN (fc1 dX) run as K0 = 4288 on the
+    MFMA fast path + a 16-deep tail accumulated by the generic kernel; against fp64, and against the single generic pass
+    (DXA_GEMM_NO_KTAIL semantics are exercised by the small-M call, which stays on the generic kernel)"""
+    M, N, Kd = 1024, 1152, 4304
+    a = rnd(M, Kd, dtype=torch.bfloat16, seed=170)
+    w = rnd(N, Kd, dtype=torch.bfloat16, seed=171, scale=0.05)
+    bias = rnd(N, dtype=torch.bfloat16, seed=172)
+    res = rnd(M, N, dtype=torch.bfloat16, seed=173)
+    ref = a.double() @ w.double().T + bias.double() + res.double()
+    rtol, atol = tol_for(torch.bfloat16, Kd)
+    assert_close(K.mm_nt(a, w, bias=bias, residual=res), ref, 2 * rtol, 2 * atol, "NT K=4304 bias+residual")
+    small = K.mm_nt(a[:128], w, bias=bias, residual=res[:128])                     # M < 256: one generic pass
+    assert_close(small, ref[:128], 2 * rtol, 2 * atol, "NT K=4304 generic")
+    dy = rnd(M, Kd, dtype=torch.bfloat16, seed=174)
+    w1 = rnd(Kd, N, dtype=torch.bfloat16, seed=175, scale=0.05)
+    assert_close(K.mm_nn(dy, w1), dy.double() @ w1.double(), 2 * rtol, 2 * atol, "NN K=4304")
+    o32 = K.mm_nt(a, w, out_dtype=torch.float32)
+    assert_close(o32, a.double() @ w.double().T, 2e-5, 2e-3 * math.sqrt(Kd / 320), "NT K=4304 fp32 out")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_materialised_forward_masks_dropout_and_sizes(dtype):
     """dxa_attn_fwd_ws: the eager-style forward (S = Q K^T by the batched GEMM, masked row softmax, O = P V) that large non-flash
