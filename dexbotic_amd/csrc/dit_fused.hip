@@ -71,6 +71,9 @@ struct Act {
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 #endif
   }
+  __device__ __forceinline__ float ld1(size_t idx) const {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(idx * 4), 0, SC1));
+  }
   __device__ __forceinline__ void st4(size_t idx, const float4& v) const {
     const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)(idx * 4), 0, SC1);
@@ -324,12 +327,9 @@ __device__ __forceinline__ void attention_phase(const DitP& p, Smem& s, const Ac
   }
 }
 
-__global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
-  __shared__ Smem s;
-  unsigned epoch = 0;
-  const unsigned nblk = gridDim.x;
-  const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I),
-      part(p.part, (size_t)SMAX * p.M * p.H);
+// the `depth` blocks of one denoising call; `base` = blocks walked by this launch before (the split-K tile counters count on)
+__device__ __forceinline__ void walk_blocks(const DitP& p, Smem& s, unsigned& epoch, unsigned nblk, unsigned base, const Act& h,
+                                            const Act& qkv, const Act& o, const Act& a, const Act& part) {
   const bool work = p.dbg != 1, sync = p.dbg != 2;
   for (int blk = 0; blk < p.depth; ++blk) {
     const float* const* w = p.w + blk * 8;
@@ -338,18 +338,18 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
     if (work && p.dbg != 3) attention_phase(p, s, qkv, o);
     if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
     if (work) gemm_phase<false, EPI_RESADD>(p, s, o, p.H, w[2], w[3], h, p.H, p.H, p.H, p.s_proj, p.cnt_proj,
-                                            (unsigned)(blk + 1) * p.s_proj, part);
+                                            (base + (unsigned)blk + 1u) * p.s_proj, part);
     if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
     if (work) gemm_phase<true, EPI_GELU>(p, s, h, p.H, w[4], w[5], a, p.I, p.I, p.H, 1, nullptr, 0, part);
     if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
     if (work) gemm_phase<false, EPI_RESADD>(p, s, a, p.I, w[6], w[7], h, p.H, p.H, p.I, p.s_fc2, p.cnt_fc2,
-                                            (unsigned)(blk + 1) * p.s_fc2, part);
+                                            (base + (unsigned)blk + 1u) * p.s_fc2, part);
     if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
   }
-  // Leave the counters zeroed for the next launch on this stream (like the split-K flags of the ring GEMM): every
-  // workgroup has passed the last barrier when it gets here, so the LAST one out may clear them.  Agent-scope atomic
-  // stores, not a host-side memset: under HIP-graph replay a memset node's zeros were not reliably what the next
-  // kernel's atomics saw (the sampler hung), atomics are performed at the memory side and always are.
+}
+
+// Leave the counters zeroed for the next launch on this stream (see the comment at the end of dit_blocks_fused_k)
+__device__ __forceinline__ void leave_clean(const DitP& p, unsigned nblk) {
   if (threadIdx.x == 0) {
     unsigned* exit_cnt = p.bar + 48;
     const unsigned out = __hip_atomic_fetch_add(exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -363,6 +363,131 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
       __hip_atomic_store(exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The WHOLE sampler in one launch (reference: the loop of GaussianDiffusion.ddim_sample_loop, diffusion.py:714-794, around
+// DiT.forward_with_cfg, dit.py:273-311): per DDIM step
+//   assemble   h = [t_emb + z_emb ; x W_x^T + b_x] + pos          (x_embedder, dit.py:106-135; the conditioning token, :281-286)
+//   blocks     the `depth` DiTBlocks (walk_blocks)
+//   final      eps_hat = LN(h) W_f^T + b_f on the action tokens    (FinalLayer, dit.py:165-178)
+//   update     eps = u + s (c - u);  x <- ddim(x, eps)              (forward_with_cfg :294-311 + ddim_sample :626-673, eta = 0)
+// The embeddings that do not depend on x are precomputed by the caller: z_emb [N, H] (constant over the steps) and t_emb
+// [steps, H] (the schedule is known).  x lives in global memory (sc1 accesses: workgroup 0 writes it, everybody reads it).
+struct DitSampleP {
+  DitP blk;
+  float* x;                  // [nb, T, A] in/out
+  const float* ze;           // [N, H]
+  const float* te;           // [steps, H]
+  const float* pos;          // [T1, H]
+  const float* xw; const float* xb;    // x_embedder: [H, A], [H]
+  const float* fw; const float* fb;    // final linear: [A, H], [A]
+  const float* coef;         // [steps][4]: sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, alphas_cumprod_prev, -
+  float* xpp;                // [2][nb, T, A] scratch: x of the current / previous step
+  float* eps;                // [M][MAXA] scratch: the network output rows of the step
+  int steps, A, nb, use_cfg;
+  float cfg_scale;
+};
+constexpr int MAXA = 8;      // action_dim (7)
+
+__global__ __launch_bounds__(512) void dit_sample_fused_k(const DitSampleP sp) {
+  __shared__ Smem s;
+  __shared__ float xs[MAXM * MAXA];              // this step's x, every workgroup's own copy
+  const DitP& p = sp.blk;
+  unsigned epoch = 0;
+  const unsigned nblk = gridDim.x;
+  const int T = p.T1 - 1, A = sp.A, H = p.H, nx = sp.nb * T * A;
+  const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I),
+      part(p.part, (size_t)SMAX * p.M * p.H), xin(sp.x, (size_t)nx), xpp(sp.xpp, (size_t)2 * nx), epsg(sp.eps, (size_t)p.M * MAXA);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // x of step `step` = ddim(x of step - 1, eps of step - 1): recomputed by EVERY workgroup into its LDS (3 x 112 coherent loads)
+  // instead of one workgroup updating x and everybody waiting for one more device-wide barrier; workgroup 0 also keeps the
+  // global copy (ping-pong: the others still read the previous one in this phase)
+  auto load_x = [&](int step) {
+    if (tid < nx) {
+      float xv;
+      if (step == 0) {
+        xv = xin.ld1(tid);
+      } else {
+        const int k = tid % A, t = (tid / A) % T, n = tid / (A * T);
+        float eps = epsg.ld1((size_t)(n * p.T1 + 1 + t) * MAXA + k);
+        if (sp.use_cfg) {
+          const float eu = epsg.ld1((size_t)((n + sp.nb) * p.T1 + 1 + t) * MAXA + k);
+          eps = eu + sp.cfg_scale * (eps - eu);
+        }
+        const float c_recip = sp.coef[(step - 1) * 4], c_recipm1 = sp.coef[(step - 1) * 4 + 1], ab_prev = sp.coef[(step - 1) * 4 + 2];
+        const float xo = xpp.ld1((size_t)((step - 1) & 1) * nx + tid);
+        const float x0 = c_recip * xo - c_recipm1 * eps;
+        const float eps2 = (c_recip * xo - x0) / c_recipm1;
+        xv = x0 * sqrtf(ab_prev) + sqrtf(1.f - ab_prev - 0.f) * eps2;
+      }
+      xs[tid] = xv;
+      if (blockIdx.x == 0) {
+        if (step < sp.steps) xpp.st1((size_t)(step & 1) * nx + tid, xv);
+        else xin.st1(tid, xv);                                   // the sample
+      }
+    }
+    __syncthreads();
+  };
+  for (int step = 0; step < sp.steps; ++step) {
+    load_x(step);
+    // ---- assemble: every element of h once, spread over the grid
+    for (int idx = blockIdx.x * 512 + tid; idx < p.M * H; idx += gridDim.x * 512) {
+      const int m = idx / H, c = idx - m * H;
+      const int n = m / p.T1, t = m - n * p.T1;
+      float v;
+      if (t == 0) {
+        v = sp.te[(size_t)step * H + c] + sp.ze[(size_t)n * H + c];
+      } else {
+        const float* xr = xs + ((n % sp.nb) * T + (t - 1)) * A;          // CFG: both halves embed the first half of x
+        v = sp.xb[c];
+        for (int k = 0; k < A; ++k) v += xr[k] * sp.xw[(size_t)c * A + k];
+      }
+      h.st1(idx, v + sp.pos[(size_t)t * H + c]);
+    }
+    grid_sync(p.bar, nblk, epoch, true);
+    walk_blocks(p, s, epoch, nblk, (unsigned)step * (unsigned)p.depth, h, qkv, o, a, part);
+    // ---- final layer on the action tokens: one wave per row, rows spread over the workgroups
+    for (int m = blockIdx.x * 8 + wave; m < p.M; m += gridDim.x * 8) {
+      if (m % p.T1 == 0) continue;                                      // the conditioning token is dropped (dit.py:291)
+      float v[16];                                                      // H <= 1024: 16 values per lane
+      float sx = 0.f, sxx = 0.f;
+      const int per = H / 64;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v[j] = 0.f;
+        if (j < per) { v[j] = h.ld1((size_t)m * H + j * 64 + lane); sx += v[j]; sxx += v[j] * v[j]; }
+      }
+      sx = wave_sum(sx); sxx = wave_sum(sxx);
+      const float mu = sx / (float)H;
+      const float rs = rsqrtf(fmaxf(sxx / (float)H - mu * mu, 0.f) + p.eps);
+      for (int k = 0; k < A; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j < per) d += (v[j] - mu) * rs * sp.fw[(size_t)k * H + j * 64 + lane];
+        d = wave_sum(d);
+        if (lane == 0) epsg.st1((size_t)m * MAXA + k, d + sp.fb[k]);
+      }
+    }
+    grid_sync(p.bar, nblk, epoch, true);
+  }
+  if (blockIdx.x == 0) load_x(sp.steps);                                  // the last update, written to x
+  leave_clean(p, nblk);
+}
+
+__global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
+  __shared__ Smem s;
+  unsigned epoch = 0;
+  const unsigned nblk = gridDim.x;
+  const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I),
+      part(p.part, (size_t)SMAX * p.M * p.H);
+  walk_blocks(p, s, epoch, nblk, 0u, h, qkv, o, a, part);
+  // Leave the counters zeroed for the next launch on this stream (like the split-K flags of the ring GEMM): every
+  // workgroup has passed the last barrier when it gets here, so the LAST one out may clear them.  Agent-scope atomic
+  // stores, not a host-side memset: under HIP-graph replay a memset node's zeros were not reliably what the next
+  // kernel's atomics saw (the sampler hung), atomics are performed at the memory side and always are.
+  leave_clean(p, nblk);
 }
 
 // Barrier counter, flag, exit counter and the two per-tile counter arrays (H / 16 <= 64 entries each): one 1 KiB block
@@ -426,25 +551,23 @@ extern "C" size_t dxa_dit_blocks_workspace(int M, int H, int I) {
   return act_bytes_for(M, H, I);
 }
 
-extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I,
-                                  float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
-  DXA_CHECK_ARG(h && weights && workspace, "dxa_dit_blocks_fwd: null buffer");
-  DXA_CHECK_ARG(depth >= 1 && N >= 1 && T1 >= 1 && heads >= 1, "dxa_dit_blocks_fwd: bad sizes");
+namespace {
+// argument checks, workspace carving and launch geometry shared by the two entry points
+int setup_blocks(DitP& p, int* grid_out, float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I,
+                 float eps, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  DXA_CHECK_ARG(h && weights && workspace, "%s: null buffer", who);
+  DXA_CHECK_ARG(depth >= 1 && N >= 1 && T1 >= 1 && heads >= 1, "%s: bad sizes", who);
   const int M = N * T1;
-  DXA_CHECK_ARG(M < MAXM && T1 <= MAXT, "dxa_dit_blocks_fwd: at most %d rows / %d tokens per sample (got %d / %d)", MAXM - 1,
-                MAXT, M, T1);
-  DXA_CHECK_ARG(H % 64 == 0 && I % 64 == 0 && H == heads * HD && H <= 1024,
-                "dxa_dit_blocks_fwd: needs head width 64, H <= 1024 and H, I %% 64 == 0");
-  DXA_CHECK_ARG(workspace_bytes >= dxa_dit_blocks_workspace(M, H, I), "dxa_dit_blocks_fwd: workspace too small");
+  DXA_CHECK_ARG(M < MAXM && T1 <= MAXT, "%s: at most %d rows / %d tokens per sample (got %d / %d)", who, MAXM - 1, MAXT, M, T1);
+  DXA_CHECK_ARG(H % 64 == 0 && I % 64 == 0 && H == heads * HD && H <= 1024, "%s: needs head width 64, H <= 1024 and H, I %% 64 == 0", who);
+  DXA_CHECK_ARG(workspace_bytes >= dxa_dit_blocks_workspace(M, H, I), "%s: workspace too small", who);
   DXA_CHECK_ARG((reinterpret_cast<uintptr_t>(h) % 16) == 0 && (reinterpret_cast<uintptr_t>(workspace) % 16) == 0,
-                "dxa_dit_blocks_fwd: buffers must be 16-byte aligned");
-  DitP p;
+                "%s: buffers must be 16-byte aligned", who);
   p.h = h;
   p.qkv = reinterpret_cast<float*>(workspace);
   p.o = p.qkv + (size_t)M * 3 * H;
   p.a = p.o + (size_t)M * H;
   p.part = p.a + (size_t)M * I;
-  hipStream_t st = (hipStream_t)stream;
   unsigned* tail = nullptr;          // first use on a stream allocates: must not happen under stream capture
   if (int rc = get_sync_block(st, &tail)) return rc;
   p.bar = tail;
@@ -463,13 +586,15 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   // ... and never more than fit on the device at once (registers allow one 512-thread workgroup per CU)
   static int resident = 0;
   if (resident == 0) {
-    int dev = 0, per_cu = 0;
+    int dev = 0, per_cu = 0, per_cu2 = 0;
     hipDeviceProp_t prop;
     DXA_CHECK_HIP(hipGetDevice(&dev));
     DXA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     DXA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dit_blocks_fused_k, 512, 0));
+    DXA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, dit_sample_fused_k, 512, 0));
+    if (per_cu2 < per_cu) per_cu = per_cu2;
     resident = per_cu * prop.multiProcessorCount;
-    DXA_CHECK_ARG(resident >= 1, "dxa_dit_blocks_fwd: the kernel does not fit on this device");
+    DXA_CHECK_ARG(resident >= 1, "%s: the kernel does not fit on this device", who);
   }
   if (grid > resident) grid = resident;
   static const int grid_cap = getenv("DXA_DIT_GRID") ? atoi(getenv("DXA_DIT_GRID")) : 0;   // tuning aid
@@ -477,7 +602,52 @@ extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int dep
   static const int no_slice = getenv("DXA_DIT_NO_SLICE") ? 1 : 0;
   p.s_proj = no_slice ? 1 : pick_slices(H / 16, H / 64, grid);
   p.s_fc2 = no_slice ? 1 : pick_slices(H / 16, I / 64, grid);
+  *grid_out = grid;
+  return DXA_OK;
+}
+}  // namespace
+
+extern "C" int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, int T1, int H, int heads, int I,
+                                  float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  DitP p;
+  int grid = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = setup_blocks(p, &grid, h, weights, depth, N, T1, H, heads, I, eps, workspace, workspace_bytes, st, "dxa_dit_blocks_fwd"))
+    return rc;
   hipLaunchKernelGGL(dit_blocks_fused_k, dim3(grid), dim3(512), 0, st, p);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+constexpr size_t SAMPLE_EXTRA = (3 * MAXM * MAXA * sizeof(float) + 255) / 256 * 256;      // x ping-pong + eps rows
+extern "C" size_t dxa_dit_sample_workspace(int M, int H, int I) {
+  if (M <= 0 || H <= 0 || I <= 0) return 0;
+  return dxa_dit_blocks_workspace(M, H, I) + ((size_t)M * H * sizeof(float) + 255) / 256 * 256 + SAMPLE_EXTRA;   // + h + small scratch
+}
+
+extern "C" int dxa_dit_sample_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w,
+                                  const float* x_b, const float* final_w, const float* final_b, const float* coef, int steps, int A,
+                                  int nb, int use_cfg, float cfg_scale, const float* const* weights, int depth, int N, int T1, int H,
+                                  int heads, int I, float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  DXA_CHECK_ARG(x && z_emb && t_emb && pos && x_w && x_b && final_w && final_b && coef && workspace, "dxa_dit_sample_fwd: null buffer");
+  DXA_CHECK_ARG(steps >= 1 && A >= 1 && A <= MAXA && nb >= 1 && N == (use_cfg ? 2 * nb : nb),
+                "dxa_dit_sample_fwd: needs 1 <= action_dim <= %d and N == nb (or 2 nb with guidance)", MAXA);
+  const int M = N * T1;
+  DXA_CHECK_ARG(workspace_bytes >= dxa_dit_sample_workspace(M, H, I), "dxa_dit_sample_fwd: workspace too small");
+  DitSampleP sp;
+  int grid = 0;
+  hipStream_t st = (hipStream_t)stream;
+  DXA_CHECK_ARG(nb * (T1 - 1) * A <= 512 && nb * (T1 - 1) * A <= MAXM * MAXA, "dxa_dit_sample_fwd: the sample has too many elements");
+  float* h = reinterpret_cast<float*>(workspace);
+  float* extra = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)M * H * sizeof(float) + 255) / 256 * 256);
+  void* ws = reinterpret_cast<char*>(extra) + SAMPLE_EXTRA;
+  if (int rc = setup_blocks(sp.blk, &grid, h, weights, depth, N, T1, H, heads, I, eps, ws, workspace_bytes - ((char*)ws - (char*)workspace),
+                            st, "dxa_dit_sample_fwd"))
+    return rc;
+  sp.x = x; sp.ze = z_emb; sp.te = t_emb; sp.pos = pos; sp.xw = x_w; sp.xb = x_b; sp.fw = final_w; sp.fb = final_b; sp.coef = coef;
+  sp.steps = steps; sp.A = A; sp.nb = nb; sp.use_cfg = use_cfg; sp.cfg_scale = cfg_scale;
+  sp.xpp = extra; sp.eps = extra + 2 * MAXM * MAXA;
+  hipLaunchKernelGGL(dit_sample_fused_k, dim3(grid), dim3(512), 0, st, sp);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

@@ -834,6 +834,24 @@ def dit_blocks_fwd(h: torch.Tensor, weight_table: torch.Tensor, depth: int, N: i
     return h
 
 
+def dit_sample_fwd(x: torch.Tensor, z_emb: torch.Tensor, t_emb: torch.Tensor, pos: torch.Tensor, x_w: torch.Tensor, x_b: torch.Tensor,
+                   final_w: torch.Tensor, final_b: torch.Tensor, coef: torch.Tensor, nb: int, use_cfg: bool, cfg_scale: float,
+                   weight_table: torch.Tensor, depth: int, T1: int, H: int, heads: int, I: int, eps: float) -> torch.Tensor:
+    """the whole DDIM sampler in one persistent launch (dxa_dit_sample_fwd); x [nb, T1-1, A] fp32 is updated in place"""
+    steps, A = t_emb.shape[0], x.shape[-1]
+    N = z_emb.shape[0]
+    for t in (x, z_emb, t_emb, pos, x_w, x_b, final_w, final_b, coef):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    assert x.shape == (nb, T1 - 1, A) and z_emb.shape == (N, H) and t_emb.shape == (steps, H) and coef.shape == (steps, 4)
+    assert pos.shape == (T1, H) and x_w.shape == (H, A) and final_w.shape == (A, H)
+    nbytes = lib.dxa_dit_sample_workspace(N * T1, H, I)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    L.check(lib.dxa_dit_sample_fwd(_ptr(x), _ptr(z_emb), _ptr(t_emb), _ptr(pos), _ptr(x_w), _ptr(x_b), _ptr(final_w), _ptr(final_b),
+                                   _ptr(coef), steps, A, nb, int(use_cfg), float(cfg_scale), _ptr(weight_table), depth, N, T1, H,
+                                   heads, I, float(eps), _ptr(ws), nbytes, _stream()), "dxa_dit_sample_fwd")
+    return x
+
+
 def dit_blocks_timed_out(stream: Optional["torch.cuda.Stream"] = None) -> bool:
     """True if a fused DiT launch on `stream` (default: the current one) gave up at a device-wide barrier since the last
     call (its result is garbage and the request must be re-run unfused).  Synchronises the stream."""

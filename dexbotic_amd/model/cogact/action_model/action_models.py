@@ -24,6 +24,39 @@ def DiT_L(**kw):
     return DiT(depth=24, hidden_size=1024, num_heads=16, **kw)
 
 
+class LinearModel(nn.Module):
+    """the regression head of action_models.py:14-45: Linear(token, 768) -> ReLU -> Linear(768, 768) -> ReLU -> Linear(768, 7),
+    L1 loss against the scaled action.  Parameter names ``linear.{0,2,4}.{weight,bias}`` like the reference's nn.Sequential.
+    The three products run on the fp32 masters (the head sits inside the reference's autocast(float32) region)."""
+
+    def __init__(self, store: ParamStore, prefix: str, token_size: int, model_type: str, in_channels: int,
+                 future_action_window_size: int, past_action_window_size: int, action_scale: float = 1.0):
+        super().__init__()
+        from ....engine import Fp32View
+        self.store, self.p, self.action_scale = Fp32View(store), prefix, action_scale
+        store.new_bucket()
+        for i, (o, k) in zip((0, 2, 4), ((768, token_size), (768, 768), (7, 768))):
+            store.register([(f"{prefix}linear.{i}.weight", (o, k)), (f"{prefix}linear.{i}.bias", (o,))])
+
+    def _mlp(self, z: torch.Tensor) -> torch.Tensor:
+        from .... import _lib as L
+        st, p = self.store, self.p
+        anchor = st.params[p + "linear.4.weight"]
+        h = z.float().contiguous()
+        for i, act in ((0, L.ACT_RELU), (2, L.ACT_RELU), (4, L.ACT_NONE)):
+            h = Fn.LinearFn.apply(h, anchor, st, f"{p}linear.{i}.weight", f"{p}linear.{i}.bias", act, None)
+        return h
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._mlp(x) / self.action_scale
+
+    def loss(self, x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        out = self._mlp(z)
+        assert out.shape == x.shape
+        # (a [N, 1, 7] tensor: the L1 mean is torch glue, like the reference line :43)
+        return torch.abs(out - x.float() * self.action_scale).mean()
+
+
 # model-size registry (action_models.py:60); tests may register tiny sizes the same way
 DiT_models = {"DiT-S": DiT_S, "DiT-B": DiT_B, "DiT-L": DiT_L}
 

@@ -206,6 +206,56 @@ class DiT(nn.Module):
                                 L.ACT_NONE, None)
         return out.view(N, T + 1, A)[:, 1:, :]
 
+    # ---- the whole sampler in one launch ---------------------------------------------------------------------------
+    def fused_sampler_ok(self, N: int, T1: int) -> bool:
+        return (self._use_fused_blocks(N, T1) and not self.use_per_attn and self.in_channels <= 8 and
+                os.environ.get("DXA_DIT_SAMPLER", "1") != "0")
+
+    def _sampler_tables(self, diffusion, device):
+        """per (schedule, device): the timesteps in execution order and the three DDIM coefficients per step, rounded to fp32
+        exactly like the per-step path (diffusion.ddim_sample_loop: float(np.float32(a[i])))"""
+        key = (id(diffusion), str(device))
+        tabs = self.__dict__.setdefault("_samp_tabs", {})
+        if key not in tabs:
+            import numpy as np
+            order = list(reversed(range(diffusion.num_timesteps)))
+            tv = torch.tensor([float(diffusion.timestep_map[i]) for i in order], dtype=torch.float32)
+            coef = np.zeros((len(order), 4), dtype=np.float32)
+            for r, i in enumerate(order):
+                coef[r, 0] = np.float32(diffusion.sqrt_recip_alphas_cumprod[i])
+                coef[r, 1] = np.float32(diffusion.sqrt_recipm1_alphas_cumprod[i])
+                coef[r, 2] = np.float32(diffusion.alphas_cumprod_prev[i])
+            tabs[key] = (tv.to(device), torch.from_numpy(coef).to(device), diffusion)     # (keeps the schedule object alive)
+        return tabs[key][:2]
+
+    @torch.no_grad()
+    def ddim_sample_fused(self, noise: torch.Tensor, z: torch.Tensor, diffusion, cfg_scale: Optional[float]) -> torch.Tensor:
+        """GaussianDiffusion.ddim_sample_loop over forward_with_cfg (diffusion.py:714-794, dit.py:294-311) as ONE persistent
+        launch (csrc/dit_fused.hip dit_sample_fused_k): noise [nb, T, A], z [N, 1, token] (N = 2 nb with guidance: [cond; uncond])
+        -> the sample [nb, T, A].  What does not depend on x is prepared by three small launches: the z embedding and the
+        timestep embeddings of the whole schedule."""
+        from .... import kernels as K
+        st = Fp32View(self.store)
+        p, h = self.p, self.hidden_size
+        N = z.shape[0]
+        nb, T, A = noise.shape
+        anchor = self._anchor()
+        tv, coef = self._sampler_tables(diffusion, noise.device)
+        ze = Fn.LinearFn.apply(z.reshape(N, self.token_size).float().contiguous(), anchor, st, p + "z_embedder.linear.weight",
+                               p + "z_embedder.linear.bias", L.ACT_NONE, None)
+        tf = K.timestep_embedding(tv, self._timestep_freqs(noise.device))
+        te = Fn.MlpFn.apply(tf, anchor, st, p + "t_embedder.mlp.0.weight", p + "t_embedder.mlp.0.bias",
+                            p + "t_embedder.mlp.2.weight", p + "t_embedder.mlp.2.bias", L.ACT_SILU)
+        x = noise.float().contiguous().clone()
+        self.used_fused = True
+        self.store.wait_pending()                  # the kernel reads the masters through raw pointers
+        K.dit_sample_fwd(x, ze.contiguous(), te.contiguous(), st.w(p + "positional_embedding").reshape(T + 1, h),
+                         st.w(p + "x_embedder.linear.weight"), st.w(p + "x_embedder.linear.bias"),
+                         st.w(p + "final_layer.linear.weight"), st.w(p + "final_layer.linear.bias"), coef, nb,
+                         cfg_scale is not None, float(cfg_scale or 0.0), self._weight_table(st), self.depth, T + 1, h,
+                         self.num_heads, self.mlp_hidden, 1e-6)
+        return x
+
     def forward_with_cfg(self, x, t, z, cfg_scale=None, per_token=None):
         """dit.py:294-311: both halves of the batch are the FIRST half of x; returns the RAW network output
         for [cond; uncond] — the guidance mix eps = u + s (c - u) is fused into dxa_ddim_step

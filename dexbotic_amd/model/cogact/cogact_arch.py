@@ -122,6 +122,12 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
         else:
             model_kwargs = dict(z=cognition)
             sample_fn = head.net.forward
+        N_rows = noise.shape[0]
+        if not return_trajectory and hasattr(head.net, "fused_sampler_ok") and \
+                head.net.fused_sampler_ok(N_rows, self.config.chunk_size + 1):
+            # all DDIM steps in ONE persistent launch (embedders, blocks, final layer, guidance and update inside)
+            return head.net.ddim_sample_fused(noise[:B], model_kwargs["z"], head.ddim_diffusion,
+                                              cfg_scale if cfg_scale > 1.0 else None), None
         res = head.ddim_diffusion.ddim_sample_loop(sample_fn, noise.shape, noise, clip_denoised=False,
                                                    model_kwargs=model_kwargs, eta=0.0, device=cognition.device,
                                                    return_trajectory=return_trajectory)
@@ -223,3 +229,8 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             ent["graph"].replay()
         torch.cuda.current_stream().wait_stream(ent["stream"])
         return ent["out"]
+
+
+from ..dexbotic_arch import register_model_with_hf  # noqa: E402
+
+register_model_with_hf(CogACTForCausalLM)

@@ -93,14 +93,19 @@ class DexboticConfig(_hf_config_base()):
     @classmethod
     def from_pretrained(cls, path: str, **kwargs):
         with open(os.path.join(path, "config.json")) as f:
-            return cls.from_dict(json.load(f))
+            return cls.from_dict(json.load(f), **kwargs)
 
     @classmethod
     def from_dict(cls, d: Dict[str, Any], **kwargs):
+        """HF contract: with ``return_unused_kwargs=True`` (AutoModel.from_pretrained asks for it) -> (config, unused kwargs)"""
         d = dict(d)
         for k in ("model_type", "architectures", "transformers_version"):
             d.pop(k, None)
-        return cls(**d)
+        config = cls(**d)
+        if kwargs.pop("return_unused_kwargs", False):
+            unused = {k: v for k, v in kwargs.items() if not k.startswith("_") and k not in ("name_or_path", "trust_remote_code")}
+            return config, unused
+        return config
 
     def save_pretrained(self, path: str, **kwargs) -> None:
         os.makedirs(path, exist_ok=True)
@@ -113,6 +118,16 @@ def register_with_hf(config_cls) -> None:
     from transformers import AutoConfig
     try:
         AutoConfig.register(config_cls.model_type, config_cls)
+    except ValueError:
+        pass                                         # already registered (module re-import)
+
+
+def register_model_with_hf(model_cls) -> None:
+    """AutoModel.register(Config, ForCausalLM), the pattern of dexbotic/model/dm0/__init__.py:12-16 and pi05/__init__.py:6-7:
+    ``AutoModel.from_pretrained(ckpt)`` on a reference checkpoint directory builds the native class"""
+    from transformers import AutoModel
+    try:
+        AutoModel.register(model_cls.config_class, model_cls)
     except ValueError:
         pass                                         # already registered (module re-import)
 
@@ -504,6 +519,9 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         canvas = Image.new(pil_img.mode, (side, side), background_color)
         canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
         return canvas
+
+
+register_model_with_hf(DexboticForCausalLM)
 
 
 @dataclass

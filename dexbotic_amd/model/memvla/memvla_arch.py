@@ -401,3 +401,8 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         if cfg_scale > 1.0:
             samples = samples[:B]
         return self._denorm(samples[0].cpu().numpy(), action_norms).tolist()
+
+
+from ..dexbotic_arch import register_model_with_hf  # noqa: E402
+
+register_model_with_hf(MemVLAForCausalLM)

@@ -77,14 +77,18 @@ class Pi0Config(_hf_config_base()):
         d = dict(d)
         for k in ("model_type", "architectures", "transformers_version"):
             d.pop(k, None)
-        return cls(**d)
+        config = cls(**d)
+        if kwargs.pop("return_unused_kwargs", False):
+            unused = {k: v for k, v in kwargs.items() if not k.startswith("_") and k not in ("name_or_path", "trust_remote_code")}
+            return config, unused
+        return config
 
     @classmethod
     def from_pretrained(cls, path: str, **kwargs):
         import json
         import os
         with open(os.path.join(path, "config.json")) as f:
-            return cls.from_dict(json.load(f))
+            return cls.from_dict(json.load(f), **kwargs)
 
     def save_pretrained(self, path: str, **kwargs) -> None:
         import json
@@ -378,3 +382,8 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
             gc_ = self.__dict__.setdefault("_sampler_graphs", graphs.GraphCache(dev))
             return gc_.run(("euler", int(diffusion_steps), int(fpos.max()), rope[0].data_ptr()), euler, inputs).clone()
         return euler(**inputs)
+
+
+from ..dexbotic_arch import register_model_with_hf  # noqa: E402
+
+register_model_with_hf(Pi0ForCausalLM)

@@ -409,6 +409,18 @@ int dxa_dit_blocks_fwd(float* h, const float* const* weights, int depth, int N, 
 /* The fused launch spins on device-wide barriers and therefore needs all its workgroups resident at once; the spin is
  * bounded (~2 s).  *timed_out = 1 if a launch on this stream gave up since the last call (its output is garbage: re-run
  * the request unfused); the barrier state is re-armed.  Synchronises the stream. */
+/* The WHOLE DDIM sampler of a single request in one persistent launch (the loop of GaussianDiffusion.ddim_sample_loop,
+ * diffusion.py:714-794, over DiT.forward_with_cfg, dit.py:273-311; eta = 0, epsilon prediction, clip_denoised = False): per step
+ * x_embedder + conditioning token + positions, the `depth` DiTBlocks, FinalLayer on the action tokens, classifier-free guidance
+ * eps = u + s (c - u) and the DDIM update, `steps` times, device-wide barriers in between (same co-residency contract and
+ * watchdog as dxa_dit_blocks_fwd).  x [nb, T1-1, A] fp32 in/out; z_emb [N, H] = z_embedder output (N = 2 nb with guidance:
+ * [cond; uncond]); t_emb [steps, H] = t_embedder output per step in execution order; coef [steps][4] = sqrt_recip_alphas_cumprod,
+ * sqrt_recipm1_alphas_cumprod, alphas_cumprod_prev, 0 per step in execution order; weights as for dxa_dit_blocks_fwd. */
+size_t dxa_dit_sample_workspace(int M, int H, int I);
+int dxa_dit_sample_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w, const float* x_b,
+                       const float* final_w, const float* final_b, const float* coef, int steps, int A, int nb, int use_cfg,
+                       float cfg_scale, const float* const* weights, int depth, int N, int T1, int H, int heads, int I, float eps,
+                       void* workspace, size_t workspace_bytes, dxa_stream_t stream);
 int dxa_dit_blocks_status(dxa_stream_t stream, int* timed_out);
 
 #ifdef __cplusplus

@@ -167,6 +167,22 @@ def test_pi0_and_memvla_configs_resolve_through_autoconfig(tmp_path):
     assert type(m2) is MemVLAConfig and m2.per_token_size == 32 and m2.mem_length == 4 and m2.retrieval_dropout == 0.1
 
 
+def test_automodel_from_pretrained_builds_the_native_class(golden_dir, tmp_path):
+    """AutoModel.register(Config, ForCausalLM) (the reference's dm0 / pi05 registration pattern): a checkpoint directory written
+    by save_pretrained resolves to the native class with identical tensors; construction and load need no GPU"""
+    import torch
+    from transformers import AutoModel
+    from dexbotic_amd.model.cogact.cogact_arch import CogACTForCausalLM
+    from tests.helpers import build_product, load_golden
+    g, cfg, w = load_golden(golden_dir, "t1")
+    m = build_product(cfg, w, "float32", "cpu", train=False)
+    m.save_pretrained(str(tmp_path))
+    m2 = AutoModel.from_pretrained(str(tmp_path), device="cpu")
+    assert type(m2) is CogACTForCausalLM
+    sd, sd2 = m.state_dict(), m2.state_dict()
+    assert sd.keys() == sd2.keys() and all(torch.equal(sd[k], sd2[k]) for k in sd)
+
+
 def test_action_norm_and_2string_bit_exact(golden_dir):
     """row A9, encode direction, in the PRODUCT (dexbotic_amd/data/dataset/transform/action.py) against the integer rows the
     reference's ActionNormAnd2String produced (tests/golden/action_bins.npz): normalised values, bins (round-half-even on

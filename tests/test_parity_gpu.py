@@ -179,3 +179,27 @@ def test_gradient_accumulation_equals_big_batch(golden_dir):
                   timesteps=b["timesteps"][sel], drop_ids=b["drop_ids"][sel])
         tr.step(mb)
     assert rel_err(m2.store.grad.cpu().numpy(), g_full.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("cfg_scale", [1.5, 1.0])
+def test_whole_sampler_in_one_launch_equals_the_per_step_sampler(golden_dir, dtype, cfg_scale, monkeypatch):
+    """dxa_dit_sample_fwd (all DDIM steps — embedders, blocks, final layer, guidance, update — in ONE persistent launch) against
+    the per-step path (DXA_DIT_SAMPLER=0: one persistent block launch + ~14 small launches per step) and, in fp32 with
+    guidance, against the reference's golden action chunk; three requests in a row (the barrier / tile counters are left clean)"""
+    g, cfg, w = load_golden(golden_dir, "t2")            # t2: hidden 192 x 3 heads x 64, 3 DiT blocks: the fused kernels' shapes
+    m = build_product(cfg, w, dtype, DEV, train=False)
+    m.eval()
+    with torch.no_grad():
+        assert m.model.action_head.net.fused_sampler_ok(2 if cfg_scale > 1.0 else 1, cfg.chunk_size + 1)
+    norms = {"min": g["norm_min"].tolist(), "max": g["norm_max"].tolist()}
+    args = {"cfg_scale": cfg_scale, "num_ddim_steps": 10, "action_norms": norms}
+    ids, img, noise = T(g["infer_ids"]), T(g["images"][:1]), T(g["init_noise"])
+    got = [np.asarray(m.inference_action(ids, img, args, noise=noise)) for _ in range(3)]
+    assert m.model.action_head.net.used_fused
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    monkeypatch.setenv("DXA_DIT_SAMPLER", "0")
+    want = np.asarray(m.inference_action(ids, img, args, noise=noise))
+    assert rel_err(got[0], want) < 2e-4, rel_err(got[0], want)
+    if dtype == "float32" and cfg_scale == 1.5:
+        assert rel_err(got[0], g["infer_actions"]) < FP32_TOL
