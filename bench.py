@@ -451,8 +451,8 @@ def main():
         # HBM bytes per launch of that kernel come from the committed rocprofv3 PMC passes over this same command
         # (separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, checked on a known byte count)
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
-        if os.path.exists(pmc_path) and in_dt == L.BF16:
+        pmc_path = next((pth for pth in (os.path.join(ROOT, "profiles", f"r0{r}_pmc.json") for r in (3, 2)) if os.path.exists(pth)), None)
+        if pmc_path and in_dt == L.BF16:
             with open(pmc_path) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         by_layout = {}
@@ -466,7 +466,12 @@ def main():
                                         "256x256x64 ping-pong MFMA kernel = every forward linear, dX and dW product of the step)",
                               "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                              "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, separate passes)",
+                              "traffic_source": (os.path.relpath(pmc_path, ROOT) if pmc_path else "-") +
+                                                " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch, separate "
+                                                "passes, scripts/pmc_passes.sh).  FETCH_SIZE counts what leaves the "
+                                                "XCD L2s, Infinity-Cache hits included: this is L2-miss (fabric-side) traffic, an upper "
+                                                "bound on HBM bytes, not HBM bytes",
+                              "traffic_kind": "l2_miss_bytes_per_launch",
                               "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
                               "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 2),
                               "algorithmic_bytes_per_launch": int(by / max(n, 1)), "by_layout": by_layout}
