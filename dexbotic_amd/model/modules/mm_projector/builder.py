@@ -47,13 +47,13 @@ class LinearProjector(nn.Module):
 
     def __init__(self, store: ParamStore, prefix: str, in_dim: int, out_dim: int, bias: bool = True):
         super().__init__()
-        self.store, self.p, self.bias = store, prefix, bias
+        self.store, self.p, self.has_bias = store, prefix, bias     # ('bias' itself is the parameter's attribute name)
         store.new_bucket()
         store.register([(prefix + "weight", (out_dim, in_dim))] + ([(prefix + "bias", (out_dim,))] if bias else []))
 
     def forward(self, x):
         st, p = self.store, self.p
-        return Fn.LinearFn.apply(x, st.params[p + "weight"], st, p + "weight", p + "bias" if self.bias else None,
+        return Fn.LinearFn.apply(x, st.params[p + "weight"], st, p + "weight", p + "bias" if self.has_bias else None,
                                  L.ACT_NONE, None)
 
 

@@ -22,12 +22,12 @@ infer)   # per-request kernel table of action inference: difference of traces wi
   python profiles/rocpd_stats.py --per-step gpurun_out/prof/in10_results.db 10 gpurun_out/prof/in30_results.db 30 > gpurun_out/r03_infer_kernel_stats.txt
   tail -1 gpurun_out/r03_infer_30.log; head -16 gpurun_out/r03_infer_kernel_stats.txt | cut -c1-170 ;;
 smi)     # clocks / power / power cap while the timed steps run
-  ( echo "# rocm-smi --showmaxpower --showperflevel (once), then --showclocks --showpower once per second while 'python bench.py --steps 50 --warmup 2 --no-cpu-baseline --no-latency --no-secondary --no-recipe' runs"
+  ( echo "# rocm-smi --showmaxpower --showperflevel (once), then --showclocks --showpower once per second from second 5 on while 'python bench.py --steps 50 --warmup 2 --no-cpu-baseline --no-latency --no-secondary --no-recipe' runs"
     rocm-smi --showmaxpower --showperflevel 2>&1 | grep -v "^$" ) > gpurun_out/r03_smi_during_bench.txt
   python bench.py --steps 50 --warmup 2 --no-cpu-baseline --no-latency --no-secondary --no-recipe > gpurun_out/r03_smi_bench.json 2>/dev/null &
   BP=$!
-  sleep 45
-  for i in $(seq 1 14); do
+  sleep 5
+  for i in $(seq 1 24); do
     rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket Graphics|Package Power" | sed -e 's/.*sclk clock level[^(]*//' -e 's/.*(W): //' | tr '\n' ' ' >> gpurun_out/r03_smi_during_bench.txt
     echo >> gpurun_out/r03_smi_during_bench.txt; sleep 1
   done
