@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_k(const AttnBwdP bp) {
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
   using FT = FlashTile<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 tiles + 3 x 64 floats (65 KiB at D = 256)

@@ -394,13 +394,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 // the row tiles that share a weight panel hit the same L2.
 // Requirements: K % 64 == 0, 16-byte aligned A/B rows, no batching, operands < 2 GiB.
 // =====================================================================================================
-template <typename TO, int NS>
-__global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
+// WS (wave-specialised, 8 waves): waves 4-7 do nothing but issue the LDS-DMA of the ring, waves 0-3 nothing but fragment reads
+// and MFMAs.  With one wave per SIMD a K tile costs its wave ~0.4 us of DMA issue (8 instructions at 60-180 issue cycles each)
+// PLUS ~0.36 us of reads and MFMAs, back to back: 0.8 us per K tile measured (qkv at M = 543: 45 us for 56 K tiles).  With a
+// loader wave and a compute wave on every SIMD the two run side by side and a K tile costs the longer of them.
+template <typename TO, int NS, int WS>
+__global__ __launch_bounds__(256 + 64 * WS) void gemm_nt_t128_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 32768, A_ST = 16384;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = WS ? wave_id >= 4 : true;          // issues the DMA
+  const bool worker = WS ? wave_id < 4 : true;           // reads fragments, runs the MFMAs and the epilogue
+  const int wave = wave_id & 3;                           // index of a compute wave
+  constexpr int NLW = WS ? WS : 4;                        // waves that share a K tile's 32 DMA instructions
+  constexpr int DPW = 16 / NLW;                           // ... A and B instructions each per loader wave and K tile
+  const int lw = WS ? (wave_id - 4 < 0 ? 0 : wave_id - 4) : wave_id;
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, lh = lane >> 5;
   const int nt = p.tm * p.tn;
@@ -421,10 +431,10 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, (int)(((p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
   // DMA instruction j of a wave covers tile rows (4 wave + j) * 8 .. + 7: lane -> (row = + lane / 8, LDS chunk slot = lane % 8,
   // source chunk = slot ^ ((row >> 1) & 7))
-  uint32_t voA[4], voB[4];
+  uint32_t voA[DPW], voB[DPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+  for (int j = 0; j < DPW; ++j) {
+    const int row = (lw * DPW + j) * 8 + (lane >> 3);
     const uint32_t ch = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
     const int ga = m0 + row, gb = n0 + row;
     voA[j] = ga < (int)p.M ? (uint32_t)ga * (uint32_t)p.lda * 2u + ch : 0x80000000u;
@@ -435,9 +445,9 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
   const int nk = (split_j + 1) * nk_tot / split_s - k_lo;      // K tiles of this workgroup (>= 1)
 #define T1_DMA(slot, t)                                                                                                  \
   do {                                                                                                                   \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                   \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + (slot) * STAGE + (wave * 4 + j_) * 1024), 16, voA[j_], (k_lo + (t)) * 128, 0, 0); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + (slot) * STAGE + A_ST + (wave * 4 + j_) * 1024), 16, voB[j_], (k_lo + (t)) * 128, 0, 0); \
+    _Pragma("unroll") for (int j_ = 0; j_ < DPW; ++j_) {                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(smem + (slot) * STAGE + (lw * DPW + j_) * 1024), 16, voA[j_], (k_lo + (t)) * 128, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(smem + (slot) * STAGE + A_ST + (lw * DPW + j_) * 1024), 16, voB[j_], (k_lo + (t)) * 128, 0, 0); \
     }                                                                                                                    \
   } while (0)
   f32x16_t acc[2][2];
@@ -454,19 +464,25 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
 #define T1_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 #define T1_SB() __builtin_amdgcn_sched_barrier(0)
   // prologue: three K tiles in flight
+  if (loader) {
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) T1_DMA(s, s);
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) T1_DMA(s, s);
+  }
   for (int t = 0; t < nk; ++t) {
     const int rem = nk - 1 - t;                  // K tiles after this one (up to NS - 2 of them already requested)
-    if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (loader) {
+      // (2 DPW instructions per K tile and loader wave still in flight for each of the tiles after this one)
+      if (NS >= 4 && rem >= 2) { if (DPW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else if (NS >= 3 && rem >= 1) { if (DPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     T1_SB();
     __builtin_amdgcn_s_barrier();                // tile t landed for every wave; every wave is done reading tile t - 1
     T1_SB();
-    if (t + NS - 1 < nk) T1_DMA((t + NS - 1) % NS, t + NS - 1);
+    if (loader && t + NS - 1 < nk) T1_DMA((t + NS - 1) % NS, t + NS - 1);
     T1_SB();
+    if (!worker) continue;
     const uint32_t so = (uint32_t)((t % NS) * STAGE);
     const uint32_t a_s = ya + so, b_s = yb + so;
     u32x4_t af[2][2], bf[2][2];                  // [k-step parity][block]
@@ -497,8 +513,9 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
     constexpr int SC1 = 16;
     constexpr uint32_t SLOT = 128 * 128 * 4;
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(1024u * SLOT), 0x00020000);
-    const uint32_t slot0 = (uint32_t)bid * (uint32_t)(split_s - 1) * SLOT + (uint32_t)tid * 16u;
+    const uint32_t slot0 = (uint32_t)bid * (uint32_t)(split_s - 1) * SLOT + (uint32_t)(tid & 255) * 16u;
     if (split_j < split_s - 1) {
+      if (worker)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -520,6 +537,7 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
       __hip_atomic_store(p.flags + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    if (worker)
     for (int sj = 0; sj < split_s - 1; ++sj) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
           }
     }
   }
+  if (!worker) return;
   // ---- epilogue from the registers: lane (l32, lh) holds, per block (i, j), row 32 i + l32 and columns 32 j + 8 q + 4 lh + {0..3}
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
@@ -559,10 +578,14 @@ __global__ __launch_bounds__(256) void gemm_nt_t128_kernel(const GemmP p) {
     }
 #endif
 }
-template __global__ void gemm_nt_t128_kernel<bf16_t, 2>(const GemmP);
-template __global__ void gemm_nt_t128_kernel<float, 2>(const GemmP);
-template __global__ void gemm_nt_t128_kernel<bf16_t, 4>(const GemmP);
-template __global__ void gemm_nt_t128_kernel<float, 4>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<bf16_t, 2, 0>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 2, 0>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<bf16_t, 4, 0>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 4, 0>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<bf16_t, 4, 4>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 4, 4>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<bf16_t, 4, 8>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 4, 8>(const GemmP);
 
 // =====================================================================================================
 // Few-row NN product (M <= 8): out[M, N] = A[M, K] W[K, N] with W as it lies — the dX of a linear layer applied to a handful
@@ -1877,18 +1900,22 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     // gets one workgroup anyway
     static const int force_ns = getenv("DXA_GEMM_T128_NS") ? atoi(getenv("DXA_GEMM_T128_NS")) : 0;
     const int ns = force_ns ? force_ns : (p.tm * p.tn > NUM_CU ? 2 : 4);
-#define LAUNCH_T128(TO_, NS_)                                                                                        \
+#define LAUNCH_T128(TO_, NS_, WS_)                                                                                   \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_t128_kernel<TO_, NS_>),                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_t128_kernel<TO_, NS_, WS_>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, NS_ * 32768);                            \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL((gemm_nt_t128_kernel<TO_, NS_>), tgrid, dim3(256), NS_ * 32768, st, p);                       \
+    hipLaunchKernelGGL((gemm_nt_t128_kernel<TO_, NS_, WS_>), tgrid, dim3(256 + 64 * WS_), NS_ * 32768, st, p);       \
   } while (0)
-    if (ns == 2) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 2); else LAUNCH_T128(float, 2); }
-    else { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4); else LAUNCH_T128(float, 4); }
+    // wave-specialised build: DXA_GEMM_T128_WS = number of dedicated loader waves (0: every wave loads and computes, 4, 8)
+    static const int t128_ws = getenv("DXA_GEMM_T128_WS") ? atoi(getenv("DXA_GEMM_T128_WS")) : 4;
+    if (ns == 2) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 2, 0); else LAUNCH_T128(float, 2, 0); }
+    else if (t128_ws == 8) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4, 8); else LAUNCH_T128(float, 4, 8); }
+    else if (t128_ws == 4) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4, 4); else LAUNCH_T128(float, 4, 4); }
+    else { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4, 0); else LAUNCH_T128(float, 4, 0); }
 #undef LAUNCH_T128
     DXA_CHECK_LAUNCH();
     return DXA_OK;
