@@ -410,6 +410,20 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
     def dtype(self):
         return self.store.compute_dtype
 
+    # DexboticTrainer.create_optimizer hands the *ForCausalLM to OptimizerConfig._get_optimizer_grouped_parameters, which reads
+    # the prefix properties off it when a module has a learning rate of its own (trainer.py:25-36, base_exp.py:111-160)
+    @property
+    def mm_projector_prefix(self) -> str:
+        return self.model.mm_projector_prefix
+
+    @property
+    def mm_vision_prefix(self) -> str:
+        return self.model.mm_vision_prefix
+
+    @property
+    def action_head_prefix(self) -> str:
+        return self.model.action_head_prefix
+
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
                 return_dict=None, cache_position=None, actions=None, states=None) -> CausalLMOutputDexbotic:

@@ -139,3 +139,38 @@ def test_reference_freeze_and_optimizer_groups_on_native_model(ref_exp, lrs, fre
         assert by_param[id(p)] == (lr_of[lr_key], 0.1 if decayed else 0.0), full
         seen += 1
     assert seen == len(by_param) and seen > 0
+
+
+def test_native_trainer_takes_the_reference_exp_config_objects(ref_exp, tmp_path):
+    """NativeDexboticTrainer (the opt-in replacement of DexboticTrainer) constructed from the REFERENCE's own config objects —
+    dexbotic.exp.base_exp.TrainerConfig with its defaults (deepspeed zero3.json, gradient_checkpointing=True, bf16, 8 x accum 2,
+    cosine) and CogACTOptimizerConfig with per-module learning rates — on the native model: the linked TrainingArguments, and
+    the fused optimizer's groups = the groups the reference's _get_optimizer_grouped_parameters returns for the *ForCausalLM
+    (what DexboticTrainer.create_optimizer passes, trainer.py:25-36).  CPU: construction only, no step."""
+    import types as _t
+    from dexbotic.exp import base_exp
+    from dexbotic_amd.exp.trainer import ArenaAdamW, NativeDexboticTrainer, link_exp_config
+    tc = base_exp.TrainerConfig(output_dir=str(tmp_path))
+    assert tc.gradient_checkpointing and tc.deepspeed and tc.gradient_accumulation_steps == 2
+    oc = ref_exp.CogACTOptimizerConfig(base_lr=2e-5, weight_decay=0.1, mm_projector_lr=1e-4, action_head_lr=5e-5)
+    exp = _t.SimpleNamespace(trainer_config=tc, optimizer_config=oc)
+    args = link_exp_config(exp, use_cpu=True, bf16=False, report_to=[])
+    assert args.gradient_accumulation_steps == 2 and args.per_device_train_batch_size == 8 and args.learning_rate == 2e-5
+    assert args.lr_scheduler_type == "cosine" and args.max_grad_norm == 0.0            # the 1.0 clip runs inside the fused step
+    assert not args.gradient_checkpointing and args.deepspeed is None                  # deliberately not forwarded
+    m = _native_model()
+    tr = NativeDexboticTrainer(model=m, args=args, train_dataset=[0] * 4, exp_config=exp)
+    opt = tr.create_optimizer()
+    assert isinstance(opt, ArenaAdamW) and tr.core.cfg.max_grad_norm == 1.0 and tr.core.grad_accum == 2
+    ref_groups = oc._get_optimizer_grouped_parameters(m)                               # reference code on the *ForCausalLM
+    assert len(opt.param_groups) == len(ref_groups) == len(tr.core.opt.group_keys) == 6
+    name_of = {id(p): n for n, p in m.named_parameters()}
+    unused = set(m.unused_parameter_names())
+    for gi, g in enumerate(ref_groups):
+        assert opt.param_groups[gi]["lr"] == g["lr"] and opt.param_groups[gi]["weight_decay"] == g["weight_decay"]
+        for p in g["params"]:
+            n = name_of[id(p)]
+            if n in unused:
+                assert n not in tr.core.opt.group_of                                   # never gets a gradient: not updated
+            else:
+                assert tr.core.opt.group_of[n] == tr.core.opt.group_keys[gi], n
