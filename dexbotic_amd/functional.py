@@ -409,6 +409,52 @@ class LinearFn(_StoreFn):
         return dx, None, None, None, None, None, None
 
 
+class PackedInProjFn(_StoreFn):
+    """nn.MultiheadAttention's packed in-projection for CROSS attention (torch F._in_projection_packed with k is v):
+    q = x W[:E]^T + b[:E] from the query rows, [k | v] = y W[E:]^T + b[E:] from the key/value rows — the perceptual
+    attention of the MemVLA DiT block (memvla/action_model/dit.py:158-185).  The two products use disjoint row ranges of the
+    one packed parameter: its gradient is written range by range (dW[:E] = dq^T x, dW[E:] = dkv^T y) inside ONE Function, so
+    the slot is announced and marked written once.  (Applying the whole 3E-row projection to both inputs and slicing, as
+    round 2 did, computed a third of the key/value projection — 16384 perceptual rows per block at the MemVLA batch — for
+    nothing.)"""
+
+    @staticmethod
+    def forward(ctx, x, y, anchor, st: ParamStore, wn: str, bn: str, E: int):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y2 = y.reshape(-1, y.shape[-1]).contiguous()
+        W, b = st.w(wn), st.w(bn)
+        q = K.mm_nt(x2, W[:E], bias=b[:E])
+        kv = K.mm_nt(y2, W[E:], bias=b[E:])
+        ctx.st, ctx.wn, ctx.bn, ctx.E = st, wn, bn, E
+        _use(ctx, st, wn, bn)
+        ctx.save_for_backward(x2, y2)
+        return q, kv
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        st, wn, bn, E = ctx.st, ctx.wn, ctx.bn, ctx.E
+        x2, y2 = ctx.saved_tensors
+        W = st.w(wn)
+        dq, dkv = dq.contiguous(), dkv.contiguous()
+        dx = dy = None
+        nt = _f32_nt(dq)
+        if ctx.needs_input_grad[0]:
+            dx = K.mm_nt(dq, K.transpose(W[:E], 1)) if nt else K.mm_nn(dq, W[:E])
+        if ctx.needs_input_grad[1]:
+            dy = K.mm_nt(dkv, K.transpose(W[E:], 1)) if _f32_nt(dkv) else K.mm_nn(dkv, W[E:])
+        if st.trainable(wn):
+            acc = st.accum_flag(wn)
+            g, gb = st.g(wn), st.g(bn)
+            for lo, hi, d2, in2 in ((0, E, dq, x2), (E, W.shape[0], dkv, y2)):
+                if _f32_nt(d2) and in2.dtype == torch.float32:
+                    K.mm_nt(K.transpose(d2, 4), K.transpose(in2, 4), out=g[lo:hi], accumulate=acc)
+                else:
+                    K.mm_tn(d2, in2, out=g[lo:hi], accumulate=acc)
+                K.colsum(d2, out=gb[lo:hi], accumulate=acc)
+            st.mark_written(wn, bn)
+        return dx, dy, None, None, None, None, None
+
+
 class MlpFn(_StoreFn):
     """y = (act(x W1^T + b1)) W2^T + b2 : mm_projector mlp2x_gelu (mm_projector/builder.py:71-79) and the
     TimestepEmbedder MLP (dit.py:27-31)."""

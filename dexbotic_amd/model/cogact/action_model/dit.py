@@ -131,9 +131,10 @@ class DiT(nn.Module):
         hcur = Fn.AddFn.apply(hcur, lin(o, b + "attn.proj.weight", b + "attn.proj.bias"))
         y3 = Fn.NormFn.apply(hcur, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
         P_ = pe.shape[1]
-        qf = lin(y3, b + "per_attn.in_proj_weight", b + "per_attn.in_proj_bias").view(N, T1, 3, H, D)
-        kvf = lin(pe.reshape(N * P_, h), b + "per_attn.in_proj_weight", b + "per_attn.in_proj_bias").view(N, P_, 3, H, D)
-        o2 = Fn.AttnFn.apply(qf[:, :, 0], kvf[:, :, 1], kvf[:, :, 2]).reshape(N * T1, h)
+        qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
+                                          b + "per_attn.in_proj_bias", h)            # q [N*T1, h], [k | v] [N*P, 2h]
+        kvf = kvf.view(N, P_, 2, H, D)
+        o2 = Fn.AttnFn.apply(qf.view(N, T1, H, D), kvf[:, :, 0], kvf[:, :, 1]).reshape(N * T1, h)
         hcur = Fn.AddFn.apply(hcur, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
         y2 = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
         m = Fn.MlpFn.apply(y2, anchor, st, b + "mlp.fc1.weight", b + "mlp.fc1.bias", b + "mlp.fc2.weight",
