@@ -669,6 +669,9 @@ class MseLossFn(Function):
         return K.scale_dev_(dpred.clone(), g.reshape(1).float().contiguous()), None
 
 
+LMHEAD_SLAB_BYTES = (1 << 31) - 4096        # largest output one launch of the MFMA fast path addresses (tests shrink it)
+
+
 class LmHeadLossFn(_StoreFn):
     """logits = lm_head(hidden) and the HF causal-LM cross-entropy over the (already shifted) labels
     (dexbotic_arch.py:483-488; transformers/loss/loss_utils.py ForCausalLMLoss): loss = mean over the non-ignored
@@ -700,7 +703,14 @@ class LmHeadLossFn(_StoreFn):
         W = st.w(wn)
         dz = K.cross_entropy_bwd(logits, labels, lse, g.reshape(1).float().contiguous(), 1.0 / max(ctx.n_valid, 1))
         if st.trainable(wn):
-            K.mm_tn(dz, h2, out=st.g(wn), accumulate=st.accum_flag(wn), mirror=st.mirror_out(wn))
+            # the fp32 dW of the full vocabulary (152064 x 3584 x 4 B = 2.18 GB) is past the 2 GiB the MFMA fast path addresses
+            # in one output: written in row slabs of < 2 GiB (column slices of dZ), each on the fast path
+            g, acc, mir = st.g(wn), st.accum_flag(wn), st.mirror_out(wn)
+            V, d_ = g.shape
+            slab = max(256, min(V, LMHEAD_SLAB_BYTES // (4 * d_) // 256 * 256))
+            for lo in range(0, V, slab):
+                hi = min(V, lo + slab)
+                K.mm_tn(dz[:, lo:hi], h2, out=g[lo:hi], accumulate=acc, mirror=None if mir is None else mir[lo:hi])
             st.mark_written(wn)
         dh = None
         if ctx.needs_input_grad[0]:

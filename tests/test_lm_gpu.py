@@ -36,6 +36,26 @@ def test_fp32_lm_loss_and_grads_match_reference(golden_dir):
     assert rel_err(st.g("model.llm.embed_tokens.weight")[rows].cpu().numpy(), g["grad_embed_rows"]) < FP32_TOL
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_lm_head_weight_gradient_written_in_row_slabs(golden_dir, dtype, monkeypatch):
+    """the fp32 dW of the full 152064-row vocabulary (2.18 GB) exceeds what one launch of the MFMA fast path addresses: it is
+    written in row slabs (column slices of dZ).  With the slab limit shrunk so that the toy vocabulary needs several slabs the
+    gradient must equal the single-launch one bit for bit"""
+    from dexbotic_amd import functional as Fn
+    g, cfg, w = load_lm_golden(golden_dir)
+    grads = []
+    for slab_bytes in (Fn.LMHEAD_SLAB_BYTES, 256 * 4 * cfg.hidden_size):      # one launch | 256-row slabs
+        monkeypatch.setattr(Fn, "LMHEAD_SLAB_BYTES", slab_bytes)
+        m = build_lm_product(cfg, w, dtype, DEV, train=True)
+        m.train()
+        m.store.begin_step()
+        out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), labels=T(g["labels"]), images=T(g["images"]))
+        out.loss.backward()
+        torch.cuda.synchronize()
+        grads.append(m.store.g("lm_head.weight").clone())
+    assert cfg.vocab_size > 256 and torch.equal(grads[0], grads[1])
+
+
 def test_bf16_lm_loss_tracks_reference(golden_dir):
     g, cfg, w = load_lm_golden(golden_dir)
     m = build_lm_product(cfg, w, "bfloat16", DEV, train=True)
