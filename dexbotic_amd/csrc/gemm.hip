@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 // and MFMAs.  With one wave per SIMD a K tile costs its wave ~0.4 us of DMA issue (8 instructions at 60-180 issue cycles each)
 // PLUS ~0.36 us of reads and MFMAs, back to back: 0.8 us per K tile measured (qkv at M = 543: 45 us for 56 K tiles).  With a
 // loader wave and a compute wave on every SIMD the two run side by side and a K tile costs the longer of them.
-template <typename TO, int NS, int WS>
+// TE: element type of bias / residual / mulgrad (float for the split-bf16 fp32 products of the action head, dxa_gemm_desc.epi_f32)
+template <typename TO, int NS, int WS, typename TE = bf16_t>
 __global__ __launch_bounds__(256 + 64 * WS) void gemm_nt_t128_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -556,9 +557,9 @@ __global__ __launch_bounds__(256 + 64 * WS) void gemm_nt_t128_kernel(const GemmP
   // ---- epilogue from the registers: lane (l32, lh) holds, per block (i, j), row 32 i + l32 and columns 32 j + 8 q + 4 lh + {0..3}
   TO* C = reinterpret_cast<TO*>(p.C);
   TO* AUX = p.aux ? reinterpret_cast<TO*>(p.aux) : nullptr;
-  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
-  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.G);
-  const bf16_t* bias = reinterpret_cast<const bf16_t*>(p.bias);
+  const TE* R = reinterpret_cast<const TE*>(p.R);
+  const TE* G = reinterpret_cast<const TE*>(p.G);
+  const TE* bias = reinterpret_cast<const TE*>(p.bias);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -567,13 +568,13 @@ __global__ __launch_bounds__(256 + 64 * WS) void gemm_nt_t128_kernel(const GemmP
       if (n >= p.N) continue;
       const int n_ok = (int)min((int64_t)4, p.N - n);
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) load4<bf16_t>(bv, bias + n, p.vecBias, n_ok);
+      if (bias) load4<TE>(bv, bias + n, p.vecBias, n_ok);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int64_t m = m0 + wm * 64 + 32 * i + l32;
         if (m >= p.M) continue;
         const float a4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        epilogue4<bf16_t, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
+        epilogue4<TE, TO>(p, C, AUX, R, G, bv, m, n, n_ok, a4);
       }
     }
 #endif
@@ -586,6 +587,7 @@ template __global__ void gemm_nt_t128_kernel<bf16_t, 4, 4>(const GemmP);
 template __global__ void gemm_nt_t128_kernel<float, 4, 4>(const GemmP);
 template __global__ void gemm_nt_t128_kernel<bf16_t, 4, 8>(const GemmP);
 template __global__ void gemm_nt_t128_kernel<float, 4, 8>(const GemmP);
+template __global__ void gemm_nt_t128_kernel<float, 4, 4, float>(const GemmP);
 
 // =====================================================================================================
 // Few-row NN product (M <= 8): out[M, N] = A[M, K] W[K, N] with W as it lies — the dX of a linear layer applied to a handful
@@ -1877,10 +1879,14 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   // needs twice as many of them per MFMA as a 256x256 tile
   const int64_t t128_tiles = (int64_t)dxa_cdiv(d->M, 128) * dxa_cdiv(d->N, 128);
   static const bool t128_all = getenv("DXA_GEMM_T128_NS") != nullptr;     // tuning: every admissible shape
-  if (!fast_off && !t128_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && !d->epi_f32 &&
-      d->M >= 64 && d->M <= t128_max_m && d->N >= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB &&
+  // (epi_f32 = the split-bf16 fp32 products of the action head: M = 64 x 17 rows, K' = 3K up to 9216 — their 128x128 tiles fill
+  //  54-216 CUs where the 192-row ring kernel's fill 18-72)
+  // opt-in (DXA_GEMM_T128_F32EPI=1): parity-green, but the step measured the same with it (255.6 vs 256.2 ms on one box)
+  static const bool t128_f32epi = getenv("DXA_GEMM_T128_F32EPI") && atoi(getenv("DXA_GEMM_T128_F32EPI")) != 0;
+  if (!fast_off && !t128_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && (!d->epi_f32 || t128_f32epi) &&
+      d->M >= 64 && d->M <= (d->epi_f32 ? 2048 : t128_max_m) && d->N >= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB &&
       bytesA < (1ll << 31) && bytesB < (1ll << 31) &&
-      (t128_all || (t128_tiles >= 32 && t128_tiles <= NUM_CU && d->K <= 4096))) {
+      (t128_all || (t128_tiles >= 32 && t128_tiles <= NUM_CU && (d->K <= 4096 || d->epi_f32)))) {
     p.tm = dxa_cdiv(d->M, 128);
     p.tn = dxa_cdiv(d->N, 128);
     // few tiles over a deep K: cut K so that every CU gets a workgroup (>= 8 K tiles of 64 per slice, <= 4 slices)
@@ -1912,6 +1918,15 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   } while (0)
     // wave-specialised build: DXA_GEMM_T128_WS = number of dedicated loader waves (0: every wave loads and computes, 4, 8)
     static const int t128_ws = getenv("DXA_GEMM_T128_WS") ? atoi(getenv("DXA_GEMM_T128_WS")) : 4;
+    if (d->epi_f32) {
+      static bool attr_f32 = false;
+      if (!attr_f32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_t128_kernel<float, 4, 4, float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        attr_f32 = true;
+      }
+      hipLaunchKernelGGL((gemm_nt_t128_kernel<float, 4, 4, float>), tgrid, dim3(512), 4 * 32768, st, p);
+    } else
     if (ns == 2) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 2, 0); else LAUNCH_T128(float, 2, 0); }
     else if (t128_ws == 8) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4, 8); else LAUNCH_T128(float, 4, 8); }
     else if (t128_ws == 4) { if (d->out_dtype == DXA_BF16) LAUNCH_T128(bf16_t, 4, 4); else LAUNCH_T128(float, 4, 4); }
