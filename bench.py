@@ -380,6 +380,18 @@ def main():
     sync()                                  # device-wide: also covers the optimizer update still in flight on its side stream
     dt = time.perf_counter() - t0
     K.GEMM_PROFILE = None
+    comm_stats = None
+    if trainer.reducer is not None and not trainer.reducer.local_only:
+        # (before the recipe figure below runs more optimizer steps through the same reducer)
+        red = trainer.reducer
+        n_opt = max(trainer.global_step, 1)
+        win = red.comm_window_ms()[-args.steps:]
+        comm_stats = {"grad_comm_dtype": args.grad_comm, "grad_sync": red.algo,
+                      "allreduce_gb_per_step": round(red.bytes_reduced / n_opt / 1e9, 3),
+                      "collectives_per_step": round(red.collectives / n_opt, 1),
+                      # first collective's start -> last collective's end on the communication stream (it runs under the
+                      # backward: the part of it that is NOT hidden is what ms_per_step grows by against the 1-GPU line)
+                      "comm_window_ms_per_step": round(float(np.mean(win)), 2) if win else None}
     recipe = None
     if not args.no_recipe and args.accum == 1 and args.batch % 2 == 0 and not args.static_batch:
         # second figure: the reference recipe, 8 episodes x 2 accumulation steps per GPU per optimizer
@@ -434,17 +446,8 @@ def main():
                                   "memory on a copy stream one step ahead" + (", every 4th batch right-padded" if args.ragged else ""))
     result["config"]["optimizer"] = "AdamW serial" if not args.overlap else "AdamW overlapped with the next forward (side stream, per-bucket events)"
     result["config"]["grad_accum"] = args.accum
-    if trainer.reducer is not None and not trainer.reducer.local_only:
-        red = trainer.reducer
-        n_opt = args.steps + args.warmup
-        result["grad_comm_dtype"] = args.grad_comm
-        result["grad_sync"] = red.algo
-        result["allreduce_gb_per_step"] = round(red.bytes_reduced / n_opt / 1e9, 3)
-        result["collectives_per_step"] = round(red.collectives / n_opt, 1)
-        win = red.comm_window_ms()[-args.steps:]
-        # first collective's start -> last collective's end on the communication stream (it runs under the backward: the part
-        # of it that is NOT hidden is what ms_per_step grows by against the 1-GPU line)
-        result["comm_window_ms_per_step"] = round(float(np.mean(win)), 2) if win else None
+    if comm_stats is not None:
+        result.update(comm_stats)
     if rank == 0:
         n, ms, fl, by = prof.summary()
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
