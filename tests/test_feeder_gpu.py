@@ -32,10 +32,11 @@ def test_feeder_delivers_intact_batches_one_step_ahead(golden_dir):
     from dexbotic_amd.data.feeder import DeviceFeeder
     g, cfg, w = load_golden(golden_dir, "t1")
     host = _host_batches(g, 7)
-    busy = torch.randn(4096, 4096, device=DEV)
+    busy = torch.randn(64 << 20, device=DEV)
     got = []
     for b in DeviceFeeder(iter(host), DEV):
-        busy = busy @ busy * 1e-3                                          # keep the compute stream busy while the next upload runs
+        for _ in range(20):
+            busy.mul_(1.0001)                                              # keep the compute stream busy while the next upload runs
         got.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
     assert len(got) == len(host)
     for h, d in zip(host, got):
