@@ -106,6 +106,105 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_k(const AttnP p) {
   if (lane == 0 && p.lse) p.lse[row] = any ? mx + logf(sum) : 0.f;
 }
 
+// ------------------------------------------------------------------------------- small fp32 forward
+// The fp32 attentions of the diffusion heads are tiny (DiT: 17-18 tokens over 16 heads; MemVLA's perceptual cross attention:
+// 17 queries over 256 keys) and run hundreds of times per sampled action; one wave per query row (attn_fwd_generic_k) walks
+// the keys and then the values serially — 60 us a call at those sizes.  Here a workgroup owns 16 queries of one (b, head):
+// S = Q K^T by exact fp32 MFMA (v_mfma_f32_16x16x4_f32; the four waves take the 16-key tiles round robin) into LDS, a masked
+// row softmax in LDS (same formulas as the generic kernel), O = P V by MFMA again with the waves taking the 16-column tiles
+// of the head.  K rows and Q rows are read as 16-byte vectors (k permutation shared by both operands, as in gemm.hip's
+// mma_step<float>); V is d-contiguous while MFMA wants the contraction index per lane, so V is read as dwords, 64-byte runs
+// per 16 lanes.  Requirements: fp32, D % 16 == 0 (instantiated 32/64/96/128), no dropout mask, 16-byte aligned q/k/o rows.
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_small_f32_k(const AttnP p, const int srow) {
+  extern __shared__ __attribute__((aligned(16))) float S[];             // [16][srow], srow = 16 * ceil(Sk / 16) + 4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
+  const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.Hq / p.Hkv);
+  const float* qb = reinterpret_cast<const float*>(p.q) + b * p.q_sb + h * p.q_sh;
+  const float* kb = reinterpret_cast<const float*>(p.k) + b * p.k_sb + hk * p.k_sh;
+  const float* vb = reinterpret_cast<const float*>(p.v) + b * p.v_sb + hk * p.v_sh;
+  float* ob = reinterpret_cast<float*>(p.o) + b * p.o_sb + h * p.o_sh;
+  const int nkt = (p.Sk + 15) / 16;
+  {
+    const float* qr = qb + (int64_t)min(q0 + l16, p.Sq - 1) * p.q_ss + 4 * lg;
+    float4 qf[D / 16];
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) qf[t] = *reinterpret_cast<const float4*>(qr + 16 * t);
+    for (int kt = wave; kt < nkt; kt += 4) {
+      const float* kr = kb + (int64_t)min(kt * 16 + l16, p.Sk - 1) * p.k_ss + 4 * lg;
+      float4 kf[D / 16];
+#pragma unroll
+      for (int t = 0; t < D / 16; ++t) kf[t] = *reinterpret_cast<const float4*>(kr + 16 * t);
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < D / 16; ++t) {
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].x, qf[t].x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].y, qf[t].y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].z, qf[t].z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].w, qf[t].w, s, 0, 0, 0);
+      }
+      // lane holds S[query l16][key 16 kt + 4 lg + {0..3}]
+      *reinterpret_cast<float4*>(&S[l16 * srow + kt * 16 + 4 * lg]) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+  }
+  __syncthreads();
+  const int npad = nkt * 16;
+  for (int r = wave * 4; r < wave * 4 + 4; ++r) {            // wave w: the softmax of query rows 4w .. 4w+3
+    const int i = q0 + r;
+    float* ps = S + r * srow;
+    if (i >= p.Sq) {
+      for (int j = lane; j < npad; j += 64) ps[j] = 0.f;
+      continue;
+    }
+    int j0 = p.kv_start ? p.kv_start[b] : 0;
+    int j1 = p.kv_end ? p.kv_end[b] : p.Sk;
+    if (p.causal) j1 = min(j1, i + (p.Sk - p.Sq) + 1);
+    if (p.q_limit) j1 = min(j1, p.q_limit[(int64_t)b * p.Sq + i]);
+    const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
+    j0 = max(j0, 0);
+    j1 = min(j1, p.Sk);
+    float mx = -INFINITY;
+    for (int j = j0 + lane; j < j1; j += 64) {
+      const float a = (kvld && !kvld[j]) ? -INFINITY : ps[j] * p.scale;
+      ps[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = j0 + lane; j < j1; j += 64) {
+      const float e = mx == -INFINITY ? 0.f : expf(ps[j] - mx);
+      ps[j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const bool any = sum > 0.f;
+    const float inv = any ? 1.f / sum : 0.f;
+    for (int j = lane; j < npad; j += 64) ps[j] = (j >= j0 && j < j1) ? ps[j] * inv : 0.f;
+    if (lane == 0 && p.lse) p.lse[((int64_t)b * p.Hq + h) * p.Sq + i] = any ? mx + logf(sum) : 0.f;
+  }
+  __syncthreads();
+  for (int dt = wave; dt < D / 16; dt += 4) {                // wave w: head columns 16 dt .. 16 dt + 15
+    const float* vc = vb + dt * 16 + l16;
+    f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nkt; ++t) {
+      const float4 pf = *reinterpret_cast<const float4*>(&S[l16 * srow + 16 * t + 4 * lg]);
+      const int kbase = 16 * t + 4 * lg;                     // this lane's four keys of the 16-key block
+      const float v0 = kbase + 0 < p.Sk ? vc[(int64_t)(kbase + 0) * p.v_ss] : 0.f;
+      const float v1 = kbase + 1 < p.Sk ? vc[(int64_t)(kbase + 1) * p.v_ss] : 0.f;
+      const float v2 = kbase + 2 < p.Sk ? vc[(int64_t)(kbase + 2) * p.v_ss] : 0.f;
+      const float v3 = kbase + 3 < p.Sk ? vc[(int64_t)(kbase + 3) * p.v_ss] : 0.f;
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, pf.x, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, pf.y, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, pf.z, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, pf.w, o, 0, 0, 0);
+    }
+    // lane holds O[query l16][column 16 dt + 4 lg + {0..3}]
+    if (q0 + l16 < p.Sq)
+      *reinterpret_cast<float4*>(ob + (int64_t)(q0 + l16) * p.o_ss + dt * 16 + 4 * lg) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -795,6 +894,15 @@ static bool fwd_flash_ok(const dxa_attn_desc* d) {
          al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
 }
 
+// fp32 head-sized attention (attn_fwd_small_f32_k): the [16][Sk] score slab of a workgroup has to fit the LDS
+static bool fwd_small_f32_ok(const dxa_attn_desc* d) {
+  static const bool off = getenv("DXA_ATTN_NO_SMALL") != nullptr;
+  auto s4 = [](int64_t a, int64_t b, int64_t c) { return a % 4 == 0 && b % 4 == 0 && c % 4 == 0; };
+  return !off && !d->force_generic && !d->drop_mask && d->dtype == DXA_F32 && (d->D == 32 || d->D == 64 || d->D == 96 || d->D == 128) &&
+         d->Sk <= 2048 && d->B <= 65535 && d->Hq <= 65535 && s4(d->q_sb, d->q_sh, d->q_ss) && s4(d->k_sb, d->k_sh, d->k_ss) &&
+         s4(d->o_sb, d->o_sh, d->o_ss) && al(d->q, 16) && al(d->k, 16) && al(d->o, 16);
+}
+
 // non-flash forward at sizes where one wave per query row (attn_fwd_generic_k) would walk hundreds of keys serially:
 // materialise S = Q K^T with the batched MFMA GEMM, one masked row softmax, O = P V with the batched GEMM again
 static bool fwd_materialise(const dxa_attn_desc* d) {
@@ -875,6 +983,25 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
       else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 4>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((attn_fwd_flash_k<64, 4>), grid, dim3(256), 0, st, p);
     }
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
+  if (fwd_small_f32_ok(d)) {
+    const int srow = 16 * ((d->Sk + 15) / 16) + 4;
+    const size_t lds_s = (size_t)16 * srow * sizeof(float);
+    dim3 grid((unsigned)((d->Sq + 15) / 16), (unsigned)d->Hq, (unsigned)d->B);
+#define LAUNCH_SMALL(D_)                                                                                          \
+  do {                                                                                                            \
+    static size_t attr_ = 48 * 1024;                                                                              \
+    if (lds_s > attr_) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_small_f32_k<D_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (2048 + 4) * 4);                 \
+      attr_ = 16 * (2048 + 4) * 4;                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL((attn_fwd_small_f32_k<D_>), grid, dim3(256), lds_s, st, p, srow);                          \
+  } while (0)
+    if (d->D == 32) LAUNCH_SMALL(32); else if (d->D == 64) LAUNCH_SMALL(64); else if (d->D == 96) LAUNCH_SMALL(96); else LAUNCH_SMALL(128);
+#undef LAUNCH_SMALL
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }

@@ -118,7 +118,8 @@ class DiT(nn.Module):
             self._freqs[key] = f.to(device)
         return self._freqs[key]
 
-    def _block_with_per_attn(self, st, k: int, hcur: torch.Tensor, pe: torch.Tensor, N: int, T1: int) -> torch.Tensor:
+    def _block_with_per_attn(self, st, k: int, hcur: torch.Tensor, pe: torch.Tensor, N: int, T1: int,
+                             kv: Optional[torch.Tensor] = None) -> torch.Tensor:
         """memvla DiTBlock (memvla/action_model/dit.py:175-187): x + attn(norm1 x); x + MHA(norm3 x, per, per);
         x + mlp(norm2 x) — composed from the small autograd pieces (the fused VitBlockFn has no slot for the middle
         term).  nn.MultiheadAttention's packed in_proj is applied whole to both inputs and sliced [q | k | v]."""
@@ -130,16 +131,37 @@ class DiT(nn.Module):
         o = Fn.AttnFn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).reshape(N * T1, h)
         hcur = Fn.AddFn.apply(hcur, lin(o, b + "attn.proj.weight", b + "attn.proj.bias"))
         y3 = Fn.NormFn.apply(hcur, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
-        P_ = pe.shape[1]
-        qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
-                                          b + "per_attn.in_proj_bias", h)            # q [N*T1, h], [k | v] [N*P, 2h]
-        kvf = kvf.view(N, P_, 2, H, D)
+        if kv is not None:                       # sampler: [k | v] of this block came from precompute_per_kv
+            from .... import kernels as K
+            qf = K.mm_nt(y3, st.w(b + "per_attn.in_proj_weight")[:h], bias=st.w(b + "per_attn.in_proj_bias")[:h])
+            kvf = kv
+        else:
+            P_ = pe.shape[1]
+            qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
+                                              b + "per_attn.in_proj_bias", h)        # q [N*T1, h], [k | v] [N*P, 2h]
+            kvf = kvf.view(N, P_, 2, H, D)
         o2 = Fn.AttnFn.apply(qf.view(N, T1, H, D), kvf[:, :, 0], kvf[:, :, 1]).reshape(N * T1, h)
         hcur = Fn.AddFn.apply(hcur, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
         y2 = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
         m = Fn.MlpFn.apply(y2, anchor, st, b + "mlp.fc1.weight", b + "mlp.fc1.bias", b + "mlp.fc2.weight",
                            b + "mlp.fc2.bias", L.ACT_GELU_TANH)
         return Fn.AddFn.apply(hcur, m)
+
+    @torch.no_grad()
+    def precompute_per_kv(self, per_token: torch.Tensor) -> list:
+        """inference: the perceptual-token embedding and every block's key/value projection of it depend on the request, not on
+        the DDIM step — the sampler computes them once ([N, P, 2, H, D] per block; DiT-L: 24 x [N*P, 1024] x [2048, 1024]^T
+        products a step otherwise) and hands them to forward(per_kv=...).  Same kernels on the same operands as the per-step
+        path: the samples are bit-identical."""
+        from .... import kernels as K
+        st = Fp32View(self.store)
+        p, h, H = self.p, self.hidden_size, self.num_heads
+        N, P_ = per_token.shape[:2]
+        pe = K.mm_nt(per_token.float().reshape(N * P_, -1).contiguous(), st.w(p + "per_token_embedder.linear.weight"),
+                     bias=st.w(p + "per_token_embedder.linear.bias"))
+        return [K.mm_nt(pe, st.w(f"{p}blocks.{k}.per_attn.in_proj_weight")[h:],
+                        bias=st.w(f"{p}blocks.{k}.per_attn.in_proj_bias")[h:]).view(N, P_, 2, H, h // H)
+                for k in range(self.depth)]
 
     def _use_fused_blocks(self, N: int, T1: int) -> bool:
         from .... import kernels as K
@@ -164,7 +186,7 @@ class DiT(nn.Module):
         return self._wtab
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor, drop_ids: Optional[torch.Tensor] = None,
-                train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None):
+                train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None, per_kv: Optional[list] = None):
         """x (N,T,A) noisy actions, t (N,) timesteps, z (N,1,token) conditions -> eps_hat (N,T,A).
         ``drop_ids`` (N,) bool/uint8: classifier-free-guidance token drop (drawn by the caller in train mode)."""
         from .... import kernels as K
@@ -186,12 +208,13 @@ class DiT(nn.Module):
                                L.ACT_NONE, None)                                        # (N,h)
         hcur = Fn.DitAssembleFn.apply(xe, te, ze, anchor, st, p + "positional_embedding")   # (N,T+1,h)
         if self.use_per_attn:
-            assert per_token is not None
-            pe = Fn.LinearFn.apply(per_token.float().contiguous(), anchor, st, p + "per_token_embedder.linear.weight",
-                                   p + "per_token_embedder.linear.bias", L.ACT_NONE, None)      # (N,P,h)
+            assert per_token is not None or per_kv is not None
+            pe = None if per_kv is not None else Fn.LinearFn.apply(
+                per_token.float().contiguous(), anchor, st, p + "per_token_embedder.linear.weight",
+                p + "per_token_embedder.linear.bias", L.ACT_NONE, None)                         # (N,P,h)
             hcur = hcur.reshape(N * (T + 1), h)
             for k in range(self.depth):
-                hcur = self._block_with_per_attn(st, k, hcur, pe, N, T + 1)
+                hcur = self._block_with_per_attn(st, k, hcur, pe, N, T + 1, None if per_kv is None else per_kv[k])
         elif self._use_fused_blocks(N, T + 1):
             # inference, one request: every block in ONE persistent launch (csrc/dit_fused.hip)
             self.used_fused = True
@@ -257,9 +280,9 @@ class DiT(nn.Module):
                          self.num_heads, self.mlp_hidden, 1e-6)
         return x
 
-    def forward_with_cfg(self, x, t, z, cfg_scale=None, per_token=None):
+    def forward_with_cfg(self, x, t, z, cfg_scale=None, per_token=None, per_kv=None):
         """dit.py:294-311: both halves of the batch are the FIRST half of x; returns the RAW network output
         for [cond; uncond] — the guidance mix eps = u + s (c - u) is fused into dxa_ddim_step
         (diffusion.SpacedDiffusion.ddim_sample_loop receives cfg_scale)."""
         half = x[: len(x) // 2]
-        return self.forward(torch.cat([half, half], dim=0), t, z, per_token=per_token)
+        return self.forward(torch.cat([half, half], dim=0), t, z, per_token=per_token, per_kv=per_kv)

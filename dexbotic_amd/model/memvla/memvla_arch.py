@@ -384,7 +384,9 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         cfg = model_kwargs.get("cfg_scale")
 
         def sample(noise, z, per_token):
-            mk = dict(z=z, per_token=per_token)
+            # the perceptual keys/values of the 24 blocks do not depend on the DDIM step: projected once per request
+            mk = dict(z=z, per_kv=head.net.precompute_per_kv(per_token)) if inference_args.get("cache_per_kv", True) \
+                else dict(z=z, per_token=per_token)
             if cfg is not None:
                 mk["cfg_scale"] = cfg
             return head.ddim_diffusion.ddim_sample_loop(sample_fn, noise.shape, noise, clip_denoised=False, model_kwargs=mk,

@@ -30,6 +30,8 @@ def main():
     m = MemVLAForCausalLM(cfg, device=dev, train=True)
     m.init_random_(seed=0)
     m.train()
+    if os.environ.get("SKIP_TRAIN"):
+        return infer(m, dev, {"params_billion": round(m.store.total / 1e9, 3)})
     tr = NativeTrainer(m, OptimConfig(base_lr=2e-5, weight_decay=0.0, max_grad_norm=1.0), total_steps=1000)
     batch = bench.synthetic_batch(B, 1, 32, dev, seed=5)
     batch.pop("labels")
@@ -47,15 +49,20 @@ def main():
     if os.environ.get("SKIP_INFER"):
         print(json.dumps(res), flush=True)
         return
+    infer(m, dev, res)
+
+
+def infer(m, dev, res):
     m.eval()
     b1 = bench.synthetic_batch(1, 1, 32, dev, seed=7)
     norms = {"min": [-1.0] * 7, "max": [1.0] * 7}
     lat = []
-    for f in range(12):
+    extra = {"cache_per_kv": False} if os.environ.get("NO_KV_CACHE") else {}
+    for f in range(int(os.environ.get("FRAMES", "12"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         m.inference_action(b1["input_ids"], b1["images"], "True" if f == 0 else "False",
-                           {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms})
+                           {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms, **extra})
         lat.append(1e3 * (time.perf_counter() - t0))
     res["p50_frame_inference_ms"] = round(float(np.median(lat[4:])), 1)
     print(json.dumps(res), flush=True)

@@ -939,6 +939,75 @@ def test_gemm_contraction_not_multiple_of_64_takes_the_fast_path_plus_tail():
     assert_close(o32, a.double() @ w.double().T, 2e-5, 2e-3 * math.sqrt(Kd / 320), "NT K=4304 fp32 out")
 
 
+SMALL_F32_CASES = [
+    # B, Hq, Hkv, Sq, Sk, D, causal, masks
+    (2, 16, 16, 17, 17, 64, False, ""),            # DiT-L self attention of a sampler step
+    (2, 16, 16, 17, 256, 64, False, ""),           # MemVLA perceptual cross attention
+    (3, 4, 4, 18, 18, 96, False, ""),              # DiT-S heads (384 / 4)
+    (2, 12, 12, 18, 18, 64, False, "range"),
+    (2, 8, 2, 33, 70, 128, True, "valid"),         # GQA, causal with Sk != Sq, key validity
+    (1, 4, 1, 5, 300, 32, False, "limit,valid"),
+    (2, 2, 2, 16, 1, 64, False, ""),               # one key
+    (1, 2, 2, 20, 2048, 64, True, "range"),        # the largest score slab (16 x 2052 floats of LDS)
+    (2, 3, 3, 40, 40, 64, True, "allmasked"),      # a batch row with no visible key at all
+]
+
+
+@pytest.mark.parametrize("case", SMALL_F32_CASES)
+def test_attention_small_fp32_forward(case):
+    """attn_fwd_small_f32_k (fp32 heads of the diffusion samplers: 16 queries of one head per workgroup, exact fp32 MFMA for
+    Q K^T and P V, softmax in LDS) against fp64 and against the one-wave-per-row kernel, over every mask the descriptor has,
+    token-major (fused qkv) strides, GQA, and the head sizes it is instantiated for"""
+    B, Hq, Hkv, Sq, Sk, D, causal, masks = case
+    scale = D ** -0.5
+    if Sq == Sk and Hq == Hkv:
+        qkv = rnd(B, Sq, 3, Hq, D, dtype=torch.float32, seed=170)          # token-major fused projection output
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    else:
+        q = rnd(B, Hq, Sq, D, dtype=torch.float32, seed=171)
+        kv = rnd(B, Sk, 2, Hkv, D, dtype=torch.float32, seed=172)           # [k | v] of a packed in-projection
+        k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+    o_store = torch.empty(B, Sq, Hq, D, device=DEV, dtype=torch.float32)
+    o = o_store.permute(0, 2, 1, 3)
+    o1 = torch.empty(B, Hq, Sq, D, device=DEV, dtype=torch.float32)
+    kw = dict(causal=causal, scale=scale)
+    vis = torch.ones(B, Sq, Sk, dtype=torch.bool, device=DEV)
+    j = torch.arange(Sk, device=DEV)[None, None, :]
+    i = torch.arange(Sq, device=DEV)[None, :, None]
+    if "range" in masks:
+        kw["kv_start"] = torch.tensor([b % 3 for b in range(B)], dtype=torch.int32, device=DEV)
+        kw["kv_end"] = torch.tensor([Sk - 2 * b for b in range(B)], dtype=torch.int32, device=DEV)
+        vis &= (j >= kw["kv_start"].view(B, 1, 1)) & (j < kw["kv_end"].view(B, 1, 1))
+    if "allmasked" in masks:
+        kw["kv_end"] = torch.tensor([Sk, 0][:B], dtype=torch.int32, device=DEV)
+        vis &= j < kw["kv_end"].view(B, 1, 1)
+    if "valid" in masks:
+        g = torch.Generator(device="cpu").manual_seed(9)
+        valid = (torch.rand(B, Sk, generator=g) > 0.3).to(DEV)
+        kw["key_valid"] = valid.to(torch.uint8)
+        vis &= valid[:, None, :]
+    if "limit" in masks:
+        kw["q_limit"] = torch.tensor([[Sk - 7 * (r % 4) for r in range(Sq)]] * B, dtype=torch.int32, device=DEV)
+        vis &= j < kw["q_limit"][:, :, None]
+    if causal:
+        vis &= j <= i + (Sk - Sq)
+    lse = K.attn_fwd(q, k, v, o, **kw)
+    lse1 = K.attn_fwd(q, k, v, o1, force_generic=True, **kw)
+    G = Hq // Hkv
+    sc = q.double() @ k.double().repeat_interleave(G, 1).transpose(-1, -2) * scale
+    sc = sc.masked_fill(~vis[:, None], float("-inf"))
+    ref = torch.nan_to_num(torch.softmax(sc, -1), nan=0.0) @ v.double().repeat_interleave(G, 1)
+    assert_close(o, ref, 2e-5, 2e-5, "small fp32 fwd")
+    assert_close(o, o1.double(), 2e-5, 2e-5, "small vs one-wave-per-row")
+    live = vis.any(-1)[:, None, :].expand(B, Hq, Sq)
+    assert_close(lse[live], torch.logsumexp(sc, -1)[live], 1e-4, 1e-4, "small fp32 lse")
+    assert bool(torch.all(lse[~live] == 0))                                # rows with no visible key: o = 0, lse = 0
+    assert_close(lse, lse1.double(), 1e-5, 1e-5, "small vs one-wave-per-row lse")
+    o2 = torch.empty_like(o1)
+    K.attn_fwd(q, k, v, o2, **kw)
+    assert torch.equal(o2, o.contiguous())                                 # run to run bit-identical
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_materialised_forward_masks_dropout_and_sizes(dtype):
     """dxa_attn_fwd_ws: the eager-style forward (S = Q K^T by the batched GEMM, masked row softmax, O = P V) that large non-flash

@@ -132,6 +132,21 @@ def test_memvla_sampler_graph_replay_equals_eager_launches(golden_dir):
     assert rel_err(runs[True][:4], g["infer_actions"]) < FP32_TOL
 
 
+def test_memvla_sampler_cached_perceptual_kv_is_bit_identical(golden_dir):
+    """the perceptual-token embedding and the 24 key/value projections are computed once per request (DiT.precompute_per_kv)
+    instead of once per DDIM step: same kernels on the same operands, so the episode is bit-identical"""
+    g, cfg, m = build(golden_dir, "float32", False)
+    m.eval()
+    norms = {"min": [-1.0] * cfg.action_dim, "max": [1.0] * cfg.action_dim}
+    runs = {}
+    for cache in (False, True):
+        runs[cache] = np.stack([np.array(m.inference_action(
+            T(g["infer_prompt"]), T(g["infer_frames"][f:f + 1]), "True" if f == 0 else "False",
+            {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms, "use_graph": False, "cache_per_kv": cache},
+            noise=T(g["infer_inits"][f]))) for f in range(g["infer_frames"].shape[0])])
+    assert np.array_equal(runs[True], runs[False])
+
+
 def test_bf16_memvla_step_runs_and_tracks(golden_dir):
     g, cfg, m = build(golden_dir, "bfloat16", True)
     m.train()
