@@ -675,7 +675,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(const GemmP p) {
   __shared__ float red[8][MB][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
-  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  // workgroup = (16-column tile, K range): split_s ranges per tile when few tiles meet a deep K (a DiT-L fc2 is 64 tiles
+  // of K 4096: 64 CUs would each walk 8 dependent load rounds, 30 us); ranges of one tile have ascending block ids
+  const int split_s = p.split_s > 1 ? p.split_s : 1;
+  const int ntile = (int)gridDim.x / split_s;
+  const int tile = (int)blockIdx.x % ntile, split_j = (int)blockIdx.x / ntile;
+  const int64_t n0 = (int64_t)tile * 16;
   const float* W = reinterpret_cast<const float*>(p.B) + min(n0 + l16, p.N - 1) * p.ldb + 4 * lg;
   const float* A[MB];
 #pragma unroll
@@ -685,15 +690,17 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(const GemmP p) {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkb = (int)(p.K / 64);
-  for (int kb = wave; kb < nkb; kb += 8) {
+  const int kb_lo = split_j * nkb / split_s, kb_hi = (split_j + 1) * nkb / split_s;
+  auto ld = [&](int kb, float4 (&wv)[4], float4 (&av)[MB][4]) {
     const int k0 = kb * 64;
-    float4 wv[4], av[MB][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wv[j] = *reinterpret_cast<const float4*>(W + k0 + 16 * j);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) av[mb][j] = *reinterpret_cast<const float4*>(A[mb] + k0 + 16 * j);
+  };
+  auto mma = [&](const float4 (&wv)[4], const float4 (&av)[MB][4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -703,19 +710,63 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(const GemmP p) {
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j].z, av[mb][j].z, acc[mb], 0, 0, 0);
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j].w, av[mb][j].w, acc[mb], 0, 0, 0);
       }
+  };
+  // the wave's 64-k blocks: every 8th of the range (two blocks' loads in flight at once measured the same: the rounds are
+  // bound by the 32-cycle fp32 MFMAs and the A re-reads, not by the round trip)
+  for (int kb = kb_lo + wave; kb < kb_hi; kb += 8) {
+    float4 w0[4], a0[MB][4];
+    ld(kb, w0, a0);
+    mma(w0, a0);
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
     *reinterpret_cast<float4*>(red[wave][mb][lane]) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
-  if (wave >= MB) return;
   // wave mb folds the 8 partials of row block mb: lane holds out[m = 16 mb + l16][n0 + 4 lg + {0..3}]
+  const bool worker = wave < MB;
   float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (worker) {
 #pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    const float4 v = *reinterpret_cast<const float4*>(red[w][wave][lane]);
-    a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
+    for (int w = 0; w < 8; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(red[w][wave][lane]);
+      a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
+    }
   }
+  if (split_s > 1) {
+    // split-K protocol of the ring kernel: ranges 0 .. S-2 leave their partial tile in the scratch (write-through stores) and
+    // count themselves in; the last range — dispatched after its partners — waits for the count, adds the partials in range
+    // order (deterministic) and runs the epilogue
+    constexpr int SC1 = 16;
+    constexpr uint32_t SLOT = MB * 64 * 16;                  // bytes per partial tile
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(256u * 7u * 4u * 64u * 16u), 0x00020000);
+    const uint32_t slot0 = (uint32_t)tile * (uint32_t)(split_s - 1) * SLOT + (uint32_t)(wave * 64 + lane) * 16u;
+    if (split_j < split_s - 1) {
+      if (worker) {
+        const f32x4_t v = {a4[0], a4[1], a4[2], a4[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rW, slot0 + (uint32_t)split_j * SLOT, 0, SC1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(p.flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_s - 1)
+        __builtin_amdgcn_s_sleep(2);
+      __hip_atomic_store(p.flags + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (worker) {
+      float own[4] = {a4[0], a4[1], a4[2], a4[3]};
+      a4[0] = a4[1] = a4[2] = a4[3] = 0.f;
+      for (int sj = 0; sj < split_s - 1; ++sj) {            // K ranges in ascending order, this workgroup's (the last) at the end
+        const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, slot0 + (uint32_t)sj * SLOT, 0, SC1));
+        a4[0] += v[0]; a4[1] += v[1]; a4[2] += v[2]; a4[3] += v[3];
+      }
+      a4[0] += own[0]; a4[1] += own[1]; a4[2] += own[2]; a4[3] += own[3];
+    }
+  }
+  if (!worker) return;
   const int64_t m = (int64_t)wave * 16 + l16, n = n0 + 4 * lg;
   if (m >= p.M || n >= p.N) return;
   const int n_ok = (int)min((int64_t)4, p.N - n);
@@ -2061,7 +2112,22 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   // ---- skinny fp32 path: M <= 64 (DiT head at inference), weights streamed by N/16 workgroups of 8 K-splitting waves
   if (!skinny_off_g() && d->layout == DXA_NT && d->in_dtype == DXA_F32 && d->out_dtype == DXA_F32 && nbatch == 1 &&
       d->M <= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB) {
-    dim3 sgrid((unsigned)dxa_cdiv(d->N, 16));
+    // few column tiles (<= 128) over a deep K: cut K so that ~256 workgroups share the exact-fp32 MFMAs (32 cycles apiece: 64
+    // workgroups walking K 4096 are MFMA-bound, DiT-L fc2 33 -> 19 us cut in four); each of a range's 8 waves keeps >= 1 block of
+    // 64 k.  192+ tiles measured slower cut (15.1 vs 12.1 us)
+    static const int sk_target = getenv("DXA_SKINNY_TARGET") ? atoi(getenv("DXA_SKINNY_TARGET")) : 256;
+    static const int sk_minkb = getenv("DXA_SKINNY_MINKB") ? std::max(1, atoi(getenv("DXA_SKINNY_MINKB"))) : 8;
+    const int64_t sk_tiles = dxa_cdiv(d->N, 16);
+    int sk_split = 1;
+    if (sk_target > 0 && sk_tiles <= NUM_CU / 2)
+      sk_split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, (d->K / 64) / sk_minkb), dxa_cdiv(sk_target, sk_tiles)));
+    p.split_s = 1;
+    if (sk_split >= 2) {
+      SplitWs w;
+      if (int rc = get_split_ws(st, &w)) return rc;
+      p.split_s = sk_split; p.ws = w.ws; p.flags = w.flags;
+    }
+    dim3 sgrid((unsigned)(sk_tiles * p.split_s));
     switch (dxa_cdiv(d->M, 16)) {
       case 1: hipLaunchKernelGGL((gemm_skinny_f32_kernel<1>), sgrid, dim3(512), 0, st, p); break;
       case 2: hipLaunchKernelGGL((gemm_skinny_f32_kernel<2>), sgrid, dim3(512), 0, st, p); break;

@@ -125,6 +125,8 @@ class DiT(nn.Module):
         term).  nn.MultiheadAttention's packed in_proj is applied whole to both inputs and sliced [q | k | v]."""
         b, h, H = f"{self.p}blocks.{k}.", self.hidden_size, self.num_heads
         D, anchor = h // H, self._anchor()
+        if kv is not None and not torch.is_grad_enabled():
+            return self._block_with_per_attn_sampler(st, b, hcur, kv, N, T1)
         lin = lambda x, wn, bn: Fn.LinearFn.apply(x, anchor, st, wn, bn, L.ACT_NONE, None)
         y = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
         qkv = lin(y, b + "attn.qkv.weight", b + "attn.qkv.bias").view(N, T1, 3, H, D)
@@ -146,6 +148,33 @@ class DiT(nn.Module):
         m = Fn.MlpFn.apply(y2, anchor, st, b + "mlp.fc1.weight", b + "mlp.fc1.bias", b + "mlp.fc2.weight",
                            b + "mlp.fc2.bias", L.ACT_GELU_TANH)
         return Fn.AddFn.apply(hcur, m)
+
+    def _block_with_per_attn_sampler(self, st, b: str, hcur: torch.Tensor, kv: torch.Tensor, N: int, T1: int) -> torch.Tensor:
+        """the same block for the sampler (no autograd graph, cached perceptual [k | v]): 11 launches instead of 14 — the three
+        residual additions ride in the epilogues of the projections that produce the addend (same two fp32 additions in the
+        same order as the stand-alone add).  A launch costs >= 4.5 us on this part however small the kernel; the sampler is
+        240 such blocks a frame."""
+        from .... import kernels as K
+        h, H = self.hidden_size, self.num_heads
+        D = h // H
+        W = lambda n: st.w(b + n)
+
+        def attend(q, k, v):
+            o = torch.empty((N, T1, H, D), device=hcur.device, dtype=hcur.dtype)
+            P = lambda t: t.permute(0, 2, 1, 3)
+            K.attn_fwd(P(q), P(k), P(v), P(o), causal=False, scale=D ** -0.5)
+            return o.view(N * T1, h)
+        y = K.layernorm_fwd(hcur, None, None, 1e-6)[0]
+        qkv = K.mm_nt(y, W("attn.qkv.weight"), bias=W("attn.qkv.bias")).view(N, T1, 3, H, D)
+        hcur = K.mm_nt(attend(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]), W("attn.proj.weight"), bias=W("attn.proj.bias"),
+                       residual=hcur)
+        y3 = K.layernorm_fwd(hcur, W("norm3.weight"), W("norm3.bias"), 1e-6)[0]
+        q = K.mm_nt(y3, W("per_attn.in_proj_weight")[:h], bias=W("per_attn.in_proj_bias")[:h]).view(N, T1, H, D)
+        hcur = K.mm_nt(attend(q, kv[:, :, 0], kv[:, :, 1]), W("per_attn.out_proj.weight"), bias=W("per_attn.out_proj.bias"),
+                       residual=hcur)
+        y2 = K.layernorm_fwd(hcur, None, None, 1e-6)[0]
+        a = K.mm_nt(y2, W("mlp.fc1.weight"), bias=W("mlp.fc1.bias"), act=L.ACT_GELU_TANH)
+        return K.mm_nt(a, W("mlp.fc2.weight"), bias=W("mlp.fc2.bias"), residual=hcur)
 
     @torch.no_grad()
     def precompute_per_kv(self, per_token: torch.Tensor) -> list:
