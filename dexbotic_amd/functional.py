@@ -32,7 +32,30 @@ _OUTER_GRAD = [True]     # grad mode at the apply() call site (inside Function.f
 
 
 class _StoreFn(Function):
-    """autograd Function that writes parameter gradients into the ParamStore arenas"""
+    """autograd Function that writes parameter gradients into the ParamStore arenas.  Its backward runs the fp32 products in the
+    mode its forward ran in (kernels.F32_GEMM_MODE: exact fp32 MFMA or the split-bf16 product): a training loop this package does
+    not manage calls ``loss.backward()`` long after the model's forward — and whatever scoped the mode — has returned."""
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        fwd, bwd = cls.__dict__.get("forward"), cls.__dict__.get("backward")
+        if fwd is None or bwd is None:
+            return
+        f0 = fwd.__func__ if isinstance(fwd, staticmethod) else fwd
+        b0 = bwd.__func__ if isinstance(bwd, staticmethod) else bwd
+
+        def forward(ctx, *args, **kwargs):
+            ctx._f32_mode = K.F32_GEMM_MODE
+            return f0(ctx, *args, **kwargs)
+
+        def backward(ctx, *grads):
+            mode = getattr(ctx, "_f32_mode", None)
+            if mode is None or mode == K.F32_GEMM_MODE:
+                return b0(ctx, *grads)
+            with K.f32_gemm_mode(mode):
+                return b0(ctx, *grads)
+        forward.__doc__, backward.__doc__ = f0.__doc__, b0.__doc__
+        cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
 
     @classmethod
     def apply(cls, *args, **kwargs):

@@ -276,6 +276,7 @@ class NativePreTrainedMixin:
         self.store.finalize(train=train)
         attach_parameters(self, self.store)
         self.register_forward_pre_hook(NativePreTrainedMixin._external_loop_prelude)
+        self.register_forward_hook(NativePreTrainedMixin._external_loop_epilogue)
         self.register_state_dict_pre_hook(lambda *a, **k: self.store.wait_pending())
 
     @staticmethod
@@ -287,6 +288,19 @@ class NativePreTrainedMixin:
             return
         unused = self.unused_parameter_names() if hasattr(self, "unused_parameter_names") else ()
         st.external_prelude(unused)
+        # the fp32 head products run as the model's config says (bf16x3 under bf16 compute; NativeTrainer.micro_step scopes its
+        # forward and backward the same way).  Scoped to this forward (_external_loop_epilogue); the backward of every Function
+        # re-enters the mode its forward ran in (functional._StoreFn)
+        from .. import kernels as K
+        self.__dict__["_f32_mode_prev"] = K.F32_GEMM_MODE
+        K.F32_GEMM_MODE = getattr(self.config, "fp32_matmul", "exact")
+
+    @staticmethod
+    def _external_loop_epilogue(self, args, output) -> None:
+        prev = self.__dict__.pop("_f32_mode_prev", None)
+        if prev is not None:
+            from .. import kernels as K
+            K.F32_GEMM_MODE = prev
 
     def train(self, mode: bool = True):
         out = nn.Module.train(self, mode)
