@@ -131,21 +131,31 @@ __global__ __launch_bounds__(256) void attn_fwd_small_f32_k(const AttnP p, const
     float4 qf[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) qf[t] = *reinterpret_cast<const float4*>(qr + 16 * t);
-    for (int kt = wave; kt < nkt; kt += 4) {
-      const float* kr = kb + (int64_t)min(kt * 16 + l16, p.Sk - 1) * p.k_ss + 4 * lg;
-      float4 kf[D / 16];
+    // four key tiles a round: their 4 x D/16 loads are all in flight before the first MFMA
+    for (int kt0 = wave; kt0 < nkt; kt0 += 16) {
+      float4 kf[4][D / 16];
 #pragma unroll
-      for (int t = 0; t < D / 16; ++t) kf[t] = *reinterpret_cast<const float4*>(kr + 16 * t);
-      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 4; ++u) {
+        const float* kr = kb + (int64_t)min((kt0 + 4 * u) * 16 + l16, p.Sk - 1) * p.k_ss + 4 * lg;
 #pragma unroll
-      for (int t = 0; t < D / 16; ++t) {
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].x, qf[t].x, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].y, qf[t].y, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].z, qf[t].z, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t].w, qf[t].w, s, 0, 0, 0);
+        for (int t = 0; t < D / 16; ++t) kf[u][t] = *reinterpret_cast<const float4*>(kr + 16 * t);
       }
-      // lane holds S[query l16][key 16 kt + 4 lg + {0..3}]
-      *reinterpret_cast<float4*>(&S[l16 * srow + kt * 16 + 4 * lg]) = make_float4(s[0], s[1], s[2], s[3]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kt = kt0 + 4 * u;
+        if (kt < nkt) {
+          f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < D / 16; ++t) {
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][t].x, qf[t].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][t].y, qf[t].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][t].z, qf[t].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][t].w, qf[t].w, s, 0, 0, 0);
+          }
+          // lane holds S[query l16][key 16 kt + 4 lg + {0..3}]
+          *reinterpret_cast<float4*>(&S[l16 * srow + kt * 16 + 4 * lg]) = make_float4(s[0], s[1], s[2], s[3]);
+        }
+      }
     }
   }
   __syncthreads();
@@ -187,17 +197,24 @@ __global__ __launch_bounds__(256) void attn_fwd_small_f32_k(const AttnP p, const
   for (int dt = wave; dt < D / 16; dt += 4) {                // wave w: head columns 16 dt .. 16 dt + 15
     const float* vc = vb + dt * 16 + l16;
     f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nkt; ++t) {
-      const float4 pf = *reinterpret_cast<const float4*>(&S[l16 * srow + 16 * t + 4 * lg]);
-      const int kbase = 16 * t + 4 * lg;                     // this lane's four keys of the 16-key block
-      const float v0 = kbase + 0 < p.Sk ? vc[(int64_t)(kbase + 0) * p.v_ss] : 0.f;
-      const float v1 = kbase + 1 < p.Sk ? vc[(int64_t)(kbase + 1) * p.v_ss] : 0.f;
-      const float v2 = kbase + 2 < p.Sk ? vc[(int64_t)(kbase + 2) * p.v_ss] : 0.f;
-      const float v3 = kbase + 3 < p.Sk ? vc[(int64_t)(kbase + 3) * p.v_ss] : 0.f;
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, pf.x, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, pf.y, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, pf.z, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, pf.w, o, 0, 0, 0);
+    for (int t0 = 0; t0 < nkt; t0 += 4) {                    // four 16-key blocks a round: 16 value loads in flight
+      float4 pf[4];
+      float vv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = min(t0 + u, nkt - 1);
+        const int kbase = 16 * t + 4 * lg;                   // this lane's four keys of the 16-key block
+        pf[u] = t0 + u < nkt ? *reinterpret_cast<const float4*>(&S[l16 * srow + 16 * t + 4 * lg]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[u][e] = kbase + e < p.Sk ? vc[(int64_t)(kbase + e) * p.v_ss] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[u][0], pf[u].x, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[u][1], pf[u].y, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[u][2], pf[u].z, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[u][3], pf[u].w, o, 0, 0, 0);
+      }
     }
     // lane holds O[query l16][column 16 dt + 4 lg + {0..3}]
     if (q0 + l16 < p.Sq)
