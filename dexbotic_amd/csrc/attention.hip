@@ -33,6 +33,10 @@ struct AttnP {
   const int32_t* q_limit;      // [B,Sq] or NULL: query i sees keys j < q_limit[b,i] (block-prefix masks, pi0)
   const uint8_t* key_valid;    // [B,Sk] or NULL: key j takes part at all (padding / missing camera)
   const void* drop_mask;       // [B,Hq,Sq,Sk] or NULL: attention dropout, P <- P * mask (0 or 1 / (1 - p)) after the softmax
+  // flash forward over key ranges (few queries against a long cache): grid z = B * nsplit, workgroup (b, sp) sees keys
+  // [sp * split_len, (sp + 1) * split_len) only and writes the softmax-normalised partial of its range + its log-sum-exp to
+  // o / lse AS IF the batch were B * nsplit (strides of a [B * nsplit, Hq, Sq, D] buffer); attn_split_combine_k folds them
+  int nsplit, split_len;
 };
 
 // ------------------------------------------------------------------------------------ generic forward
@@ -245,7 +249,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
   char* Vs = smem + KT_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int bz = blockIdx.z, h = blockIdx.y;
+  const int b = p.nsplit > 1 ? bz / p.nsplit : bz;             // key-range splits: (batch, range) on grid z
+  const int sp = bz - b * p.nsplit;
   const int hk = h / (p.Hq / p.Hkv);
   const int q0 = blockIdx.x * (16 * NW);
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -270,6 +276,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
   int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
   j_lo = max(j_lo, 0);
   j_hi = min(j_hi, p.Sk);
+  if (p.nsplit > 1) {
+    j_lo = max(j_lo, sp * p.split_len);
+    j_hi = min(j_hi, (sp + 1) * p.split_len);
+  }
   const int coff = p.Sk - p.Sq;
   int blk_hi = j_hi;  // exclusive key bound for the whole workgroup
   if (p.causal) blk_hi = min(blk_hi, min(q0 + 16 * NW - 1, p.Sq - 1) + coff + 1);
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
   l_tot += __shfl_xor(l_tot, 32, 64);
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   if (qi < p.Sq) {
-    bf16_t* orow = reinterpret_cast<bf16_t*>(p.o) + b * p.o_sb + h * p.o_sh + (int64_t)qi * p.o_ss;
+    bf16_t* orow = reinterpret_cast<bf16_t*>(p.o) + bz * p.o_sb + h * p.o_sh + (int64_t)qi * p.o_ss;
 #pragma unroll
     for (int di = 0; di < D / 16; ++di) {
       uint2 ov;
@@ -433,9 +443,44 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
       ov.y = pack_bf16(oacc[di][2] * inv, oacc[di][3] * inv);
       *reinterpret_cast<uint2*>(orow + di * 16 + 4 * lg) = ov;
     }
+    // (a key range in which this query sees nothing: -inf, so that the fold gives it no weight; unsplit: 0 like the other kernels)
     if (lg == 0 && p.lse)
-      p.lse[((int64_t)b * p.Hq + h) * p.Sq + qi] = l_tot > 0.f ? m_run * 0.6931471805599453f + logf(l_tot) : 0.f;
+      p.lse[((int64_t)bz * p.Hq + h) * p.Sq + qi] = l_tot > 0.f ? m_run * 0.6931471805599453f + logf(l_tot)
+                                                                : (p.nsplit > 1 ? -INFINITY : 0.f);
   }
+}
+
+// fold of the key-range partials: o = sum_s w_s o_s / sum_s w_s with w_s = exp(lse_s - max lse), lse = max + log sum w_s.
+// One wave per (b, h, query) row; partial o rows are bf16 [B * nsplit, Hq, Sq, D] contiguous, partial lse fp32 [B * nsplit, Hq, Sq].
+template <int D>
+__global__ __launch_bounds__(256) void attn_split_combine_k(const bf16_t* __restrict__ op, const float* __restrict__ lp, char* o,
+                                                            int64_t o_sb, int64_t o_sh, int64_t o_ss, float* __restrict__ lse,
+                                                            int B, int Hq, int Sq, int nsplit) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Hq * Sq) return;
+  const int i = (int)(row % Sq), h = (int)((row / Sq) % Hq), b = (int)(row / ((int64_t)Sq * Hq));
+  constexpr int EPL = D / 64;                                 // elements per lane
+  float mx = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lp[(((int64_t)b * nsplit + s) * Hq + h) * Sq + i]);
+  float acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+  float wsum = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const int64_t pr = (((int64_t)b * nsplit + s) * Hq + h) * Sq + i;
+    const float w = mx == -INFINITY ? 0.f : expf(lp[pr] - mx);
+    if (w == 0.f) continue;
+    wsum += w;
+    const bf16_t* src = op + pr * D + lane * EPL;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] += w * bf2f(src[e]);
+  }
+  const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+  bf16_t* dst = reinterpret_cast<bf16_t*>(o) + b * o_sb + h * o_sh + (int64_t)i * o_ss + lane * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) dst[e] = f2bf(acc[e] * inv);
+  if (lane == 0) lse[row] = wsum > 0.f ? mx + logf(wsum) : 0.f;
 }
 
 // -------------------------------------------------------------------------------- backward helpers
@@ -887,6 +932,7 @@ AttnP make_params(const dxa_attn_desc* d) {
   p.o = (char*)d->o; p.o_sb = d->o_sb; p.o_sh = d->o_sh; p.o_ss = d->o_ss;
   p.lse = d->lse; p.kv_start = d->kv_start; p.kv_end = d->kv_end;
   p.q_limit = d->q_limit; p.key_valid = d->key_valid; p.drop_mask = d->drop_mask;
+  p.nsplit = 1; p.split_len = 0;
   return p;
 }
 
@@ -929,8 +975,27 @@ static bool fwd_materialise(const dxa_attn_desc* d) {
   return d->force_generic == 2 || (d->Sq >= 32 && d->Sk >= 128);       // force_generic 2 (tests): this path at any size
 }
 
+// Few queries against a long key cache (a KV-cached denoising or decode step: pi0's 17 suffix queries x 8 heads over 833 keys are
+// EIGHT workgroups of the flash kernel, each walking 13 key tiles in sequence — 70 us): the keys are cut into ranges, one
+// workgroup per (query tile, head, batch, range), and the ranges' normalised partials are folded by their log-sum-exps.
+static int fwd_flash_splits(const dxa_attn_desc* d) {
+  static const int off = getenv("DXA_ATTN_NO_KSPLIT") != nullptr;
+  if (off || !fwd_flash_ok(d) || d->Sk < 256) return 1;
+  const int64_t wgs = (int64_t)((d->Sq + 63) / 64) * d->Hq * d->B;
+  if (wgs > 64) return 1;
+  const int tiles = (d->Sk + 63) / 64;
+  const int want = (int)std::min<int64_t>(tiles, std::max<int64_t>(1, 256 / wgs));
+  const int len = ((tiles + want - 1) / want) * 64;            // keys per range, whole tiles
+  const int n = (d->Sk + len - 1) / len;
+  return n >= 2 && (int64_t)d->B * n <= 65535 ? n : 1;
+}
+
 extern "C" size_t dxa_attn_fwd_workspace(const dxa_attn_desc* d) {
   if (!d || d->B <= 0 || d->Sq <= 0 || d->Sk <= 0 || d->Hq <= 0 || d->Hkv <= 0 || d->Hq % d->Hkv) return 0;
+  if (const int ns = fwd_flash_splits(d); ns > 1) {
+    const size_t rows = (size_t)d->B * ns * d->Hq * d->Sq;
+    return align_up(rows * d->D * 2, 256) + align_up(rows * 4, 256);
+  }
   if (!fwd_materialise(d)) return 0;
   const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
   return align_up(n * 4, 256) + align_up(n * (d->dtype == DXA_BF16 ? 2 : 4), 256);
@@ -943,6 +1008,27 @@ extern "C" int dxa_attn_fwd_ws(const dxa_attn_desc* d, void* workspace, size_t w
   if (need == 0 || d->Sk == 0) return dxa_attn_fwd(d, stream);
   DXA_CHECK_ARG(workspace && workspace_bytes >= need, "dxa_attn_fwd_ws: workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
+  if (const int ns = fwd_flash_splits(d); ns > 1) {
+    const size_t rows = (size_t)d->B * ns * d->Hq * d->Sq;
+    bf16_t* op = (bf16_t*)workspace;
+    float* lp = (float*)((char*)workspace + align_up(rows * d->D * 2, 256));
+    AttnP p = make_params(d);
+    const int tiles = (d->Sk + 63) / 64;
+    p.nsplit = ns;
+    p.split_len = ((tiles + ns - 1) / ns) * 64;
+    p.o = (char*)op; p.o_sb = (int64_t)d->Hq * d->Sq * d->D; p.o_sh = (int64_t)d->Sq * d->D; p.o_ss = d->D;
+    p.lse = lp;
+    dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)(d->B * ns));
+    if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 4>), grid, dim3(256), 0, st, p);
+    else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_flash_k<64, 4>), grid, dim3(256), 0, st, p);
+    dim3 cgrid((unsigned)(((int64_t)d->B * d->Hq * d->Sq + 3) / 4));
+    if (d->D == 256) hipLaunchKernelGGL((attn_split_combine_k<256>), cgrid, dim3(256), 0, st, op, lp, (char*)d->o, d->o_sb, d->o_sh, d->o_ss, d->lse, d->B, d->Hq, d->Sq, ns);
+    else if (d->D == 128) hipLaunchKernelGGL((attn_split_combine_k<128>), cgrid, dim3(256), 0, st, op, lp, (char*)d->o, d->o_sb, d->o_sh, d->o_ss, d->lse, d->B, d->Hq, d->Sq, ns);
+    else hipLaunchKernelGGL((attn_split_combine_k<64>), cgrid, dim3(256), 0, st, op, lp, (char*)d->o, d->o_sb, d->o_sh, d->o_ss, d->lse, d->B, d->Hq, d->Sq, ns);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   const int G = d->Hq / d->Hkv;
   const size_t n = (size_t)d->B * d->Hq * d->Sq * d->Sk;
   const int64_t SqSk = (int64_t)d->Sq * d->Sk;

@@ -40,23 +40,26 @@ def main():
                  images=torch.randn(B, 3, 3, 224, 224, generator=g).clamp_(-2.5, 2.5).to(dev),
                  image_masks=torch.ones(B, 3, dtype=torch.bool), states=torch.randn(B, 32, generator=g).to(dev),
                  actions=torch.randn(B, chunk, 32, generator=g).to(dev))
-    for _ in range(2):
-        loss = tr.step(batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.step(batch)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    res = {"metric": "samples/sec DB-pi0 fine-tune", "value": round(B / dt, 2), "ms_per_step": round(1e3 * dt, 1),
-           "batch": B, "loss": round(float(loss), 4), "params_billion": round(m.store.total / 1e9, 3)}
+    infer_only = os.environ.get("INFER_ONLY")                                   # per-request kernel tables: REQS requests, nothing else
+    res = {"params_billion": round(m.store.total / 1e9, 3)}
+    if not infer_only:
+        for _ in range(2):
+            loss = tr.step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = {"metric": "samples/sec DB-pi0 fine-tune", "value": round(B / dt, 2), "ms_per_step": round(1e3 * dt, 1),
+               "batch": B, "loss": round(float(loss), 4), "params_billion": round(m.store.total / 1e9, 3)}
     if os.environ.get("SKIP_INFER"):
         print(json.dumps(res), flush=True)
         return
     m.eval()
     b1 = {k: v[:1] for k, v in batch.items() if k != "actions"}
     lat = []
-    for _ in range(8):
+    for _ in range(int(os.environ.get("REQS", "8"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         a = m.inference_action(diffusion_steps=10, **b1)
@@ -64,6 +67,9 @@ def main():
         lat.append(1e3 * (time.perf_counter() - t0))
     res["p50_action_inference_ms"] = round(float(np.median(lat[2:])), 1)
     res["inference_config"] = "bf16 compute, chunk 16, 10 Euler steps"
+    if infer_only:
+        print(json.dumps(res), flush=True)
+        return
     # the way the REFERENCE serves pi0: fp32 weights and arithmetic (pi0_exp.py:347-353; matmul precision "highest", :106) and its
     # default chunk_size 50 (pi0_arch.py:58-59)
     del tr, m

@@ -1008,6 +1008,42 @@ def test_attention_small_fp32_forward(case):
     assert torch.equal(o2, o.contiguous())                                 # run to run bit-identical
 
 
+@pytest.mark.parametrize("case", [(1, 8, 1, 17, 833, 256), (2, 8, 1, 17, 833, 256), (1, 28, 4, 1, 700, 128), (3, 4, 4, 40, 1000, 64),
+                                  (1, 8, 1, 17, 300, 256)])
+def test_attention_flash_key_range_split(case):
+    """few queries against a long key cache (pi0's KV-cached denoising step: 17 suffix queries x 8 heads over prefix + suffix
+    keys; a decode step): the flash forward runs one workgroup per KEY RANGE and attn_split_combine_k folds the normalised
+    partials by their log-sum-exps.  Block-prefix limits, key validity, a batch row whose cache ends early (whole ranges empty)
+    and — in the last batch row of the multi-row cases — no visible key at all; o and lse against fp64, repetitions bitwise"""
+    B, Hq, Hkv, Sq, Sk, D = case
+    dtype = torch.bfloat16
+    q, k, v = rnd(B, Hq, Sq, D, dtype=dtype, seed=210), rnd(B, Hkv, Sk, D, dtype=dtype, seed=211), rnd(B, Hkv, Sk, D, dtype=dtype, seed=212)
+    g = torch.Generator(device="cpu").manual_seed(12)
+    valid = (torch.rand(B, Sk, generator=g) > 0.1).to(DEV)
+    kv_end = torch.tensor([Sk if b == 0 else (130 if b == 1 else Sk) for b in range(B)], dtype=torch.int32, device=DEV)
+    if B >= 3:
+        valid[B - 1] = False                                               # nothing visible: o = 0, lse = 0
+    q_limit = torch.full((B, Sq), Sk, dtype=torch.int32, device=DEV)
+    q_limit[:, 0] = Sk - Sq + 1                                            # the first query does not see the other new keys
+    scale = D ** -0.5
+    o = torch.empty(B, Sq, Hq, D, device=DEV, dtype=dtype).permute(0, 2, 1, 3)
+    kw = dict(causal=False, scale=scale, kv_end=kv_end, q_limit=q_limit, key_valid=valid.to(torch.uint8))
+    lse = K.attn_fwd(q, k, v, o, **kw)
+    j = torch.arange(Sk, device=DEV)[None, None, :]
+    vis = (j < kv_end.view(B, 1, 1)) & (j < q_limit[:, :, None]) & valid[:, None, :]
+    G = Hq // Hkv
+    sc = q.double() @ k.double().repeat_interleave(G, 1).transpose(-1, -2) * scale
+    sc = sc.masked_fill(~vis[:, None], float("-inf"))
+    ref = torch.nan_to_num(torch.softmax(sc, -1), nan=0.0) @ v.double().repeat_interleave(G, 1)
+    assert_close(o, ref, 1.0 / 64, 2e-2, "split-range flash o")
+    live = vis.any(-1)[:, None, :].expand(B, Hq, Sq)
+    assert_close(lse[live], torch.logsumexp(sc, -1)[live], 1e-2, 3e-2, "split-range flash lse")
+    assert bool(torch.all(lse[~live] == 0)) and bool(torch.all(o.float()[~live] == 0))
+    o2 = torch.empty_like(o)
+    lse2 = K.attn_fwd(q, k, v, o2, **kw)
+    assert torch.equal(o2, o) and torch.equal(lse2, lse)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_attention_materialised_forward_masks_dropout_and_sizes(dtype):
     """dxa_attn_fwd_ws: the eager-style forward (S = Q K^T by the batched GEMM, masked row softmax, O = P V) that large non-flash
