@@ -315,11 +315,13 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
 
 
 # ------------------------------------------------------------------------------------------------ RoPE
-def rope_split(qkv: torch.Tensor, cos_t, sin_t, pos, B, S, Hq, Hkv, D):
+def rope_split(qkv: torch.Tensor, cos_t, sin_t, pos, B, S, Hq, Hkv, D, k_out=None, v_out=None):
+    """k_out / v_out: contiguous [B, Hkv, S, D] destinations (e.g. the tail of a key/value cache) instead of fresh tensors"""
     assert qkv.is_contiguous() and qkv.shape == (B * S, (Hq + 2 * Hkv) * D)
     q = torch.empty((B, Hq, S, D), device=qkv.device, dtype=qkv.dtype)
-    k = torch.empty((B, Hkv, S, D), device=qkv.device, dtype=qkv.dtype)
-    v = torch.empty((B, Hkv, S, D), device=qkv.device, dtype=qkv.dtype)
+    k = torch.empty((B, Hkv, S, D), device=qkv.device, dtype=qkv.dtype) if k_out is None else k_out
+    v = torch.empty((B, Hkv, S, D), device=qkv.device, dtype=qkv.dtype) if v_out is None else v_out
+    assert k.is_contiguous() and v.is_contiguous() and k.shape == (B, Hkv, S, D) == v.shape and k.dtype == qkv.dtype == v.dtype
     L.check(lib.dxa_rope_split(_ptr(qkv), _ptr(q), _ptr(k), _ptr(v), _ptr(cos_t), _ptr(sin_t), _ptr(pos), B, S, Hq,
                                Hkv, D, dt(qkv), _stream()), "dxa_rope_split")
     return q, k, v

@@ -222,7 +222,8 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
 
     @torch.no_grad()
     def _mot_forward(self, xs: List[Optional[torch.Tensor]], positions: Optional[np.ndarray], q_limit: torch.Tensor,
-                     key_valid: torch.Tensor, past: Optional[list] = None, collect: bool = False, pos_parts=None, rope=None):
+                     key_valid: torch.Tensor, past: Optional[list] = None, collect: bool = False, pos_parts=None, rope=None,
+                     past_len: Optional[int] = None):
         """_inner_forward_mot (pi0_arch.py:116-216) without autograd: xs = [llm tokens | None, expert tokens | None],
         positions [B, S_q] int (RoPE), masks over [past keys ; new keys].  Returns ([out per expert], K/V cache)."""
         experts = [self.model.llm, self.model.action_expert]
@@ -243,17 +244,28 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         cache = []
         for li in range(c.num_hidden_layers):
             qs, ks, vs = [], [], []
+            # one request, one key/value head, one live expert, a cache with room behind the prefix (the sampler's Euler steps):
+            # the new keys / values are written straight behind the cached ones — no concatenation (36 launches a step)
+            kf, vf = past[li] if past is not None else (None, None)
+            inplace = (past is not None and past_len is not None and len(live) == 1 and B == 1 and Hkv == 1
+                       and kf.shape[2] == past_len + lens[0])
             for (e, _), h, n, pp in zip(live, hs, lens, pos_parts):
-                q, k, v = K.rope_split(e.pre_attention(h, li), cos_t, sin_t, pp, B, n, Hq, Hkv, D)
+                if inplace:
+                    q, k, v = K.rope_split(e.pre_attention(h, li), cos_t, sin_t, pp, B, n, Hq, Hkv, D,
+                                           k_out=kf[:, :, past_len:], v_out=vf[:, :, past_len:])
+                else:
+                    q, k, v = K.rope_split(e.pre_attention(h, li), cos_t, sin_t, pp, B, n, Hq, Hkv, D)
                 qs.append(q); ks.append(k); vs.append(v)
             q = qs[0] if len(qs) == 1 else torch.cat(qs, dim=2)
             k = ks[0] if len(ks) == 1 else torch.cat(ks, dim=2)
             v = vs[0] if len(vs) == 1 else torch.cat(vs, dim=2)
             if collect:
                 cache.append((k, v))
-            if past is not None:
-                k = torch.cat([past[li][0], k], dim=2)
-                v = torch.cat([past[li][1], v], dim=2)
+            if inplace:
+                k, v = kf, vf
+            elif past is not None:
+                k = torch.cat([kf[:, :, :past_len], k], dim=2)
+                v = torch.cat([vf[:, :, :past_len], v], dim=2)
             o = torch.empty((B, S, Hq, D), device=dev, dtype=q.dtype)
             K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=False, scale=D ** -0.5, q_limit=q_limit, key_valid=key_valid)
             nxt = []
@@ -364,11 +376,16 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
                                     ).to(device=dev, dtype=st.compute_dtype)                      # [steps, B, da]
         n_layers = len(cache)
 
+        P_len, Sx = int(cache[0][0].shape[2]), int(smask.shape[1])
+
         def euler(x, states_d, te_table, q_limit, key_valid, pos, **kv):
-            past = [(kv[f"k{i}"], kv[f"v{i}"]) for i in range(n_layers)]
+            # per layer ONE buffer [prefix keys ; room for the suffix keys], filled behind the prefix by every step's RoPE kernel
+            past = [tuple(torch.cat([kv[f"{n}{i}"], kv[f"{n}{i}"].new_zeros(B, kv[f"{n}{i}"].shape[1], Sx, kv[f"{n}{i}"].shape[3])], dim=2)
+                          for n in ("k", "v")) for i in range(n_layers)]
             for s in range(len(times)):
                 stok, _, _ = self.embed_suffix(states_d, x, None, te=te_table[s])
-                (_, suf), _ = self._mot_forward([None, stok], None, q_limit, key_valid, past=past, pos_parts=[pos], rope=rope)
+                (_, suf), _ = self._mot_forward([None, stok], None, q_limit, key_valid, past=past, pos_parts=[pos], rope=rope,
+                                                past_len=P_len)
                 v_t = Fn.LinearFn.apply(suf[:, -c.chunk_size:].reshape(B * c.chunk_size, -1).contiguous(),
                                         st.params["model.action_out_proj.weight"], st, "model.action_out_proj.weight",
                                         "model.action_out_proj.bias", L.ACT_NONE, None).view(B, c.chunk_size, -1).float()
