@@ -785,7 +785,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
   __shared__ float red[8][MB][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
-  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  // (16-column tile, K range) per workgroup, as in the fp32 kernel: few tiles over a deep K are cut across workgroups
+  const int split_s = p.split_s > 1 ? p.split_s : 1;
+  const int ntile = (int)gridDim.x / split_s;
+  const int tile = (int)blockIdx.x % ntile, split_j = (int)blockIdx.x / ntile;
+  const int64_t n0 = (int64_t)tile * 16;
   const bf16_t* W = reinterpret_cast<const bf16_t*>(p.B) + min(n0 + l16, p.N - 1) * p.ldb + 8 * lg;
   const bf16_t* A[MB];
 #pragma unroll
@@ -795,8 +799,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkb = (int)(p.K / 64);
+  const int kb_lo = split_j * nkb / split_s, kb_hi = (split_j + 1) * nkb / split_s;
 #pragma unroll 2
-  for (int kb = wave; kb < nkb; kb += 8) {
+  for (int kb = kb_lo + wave; kb < kb_hi; kb += 8) {
     const int k0 = kb * 64;
     u32x4n_t wv[2];
     uint4 av[MB][2];
@@ -817,13 +822,47 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
   for (int mb = 0; mb < MB; ++mb)
     *reinterpret_cast<float4*>(red[wave][mb][lane]) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
   __syncthreads();
-  if (wave >= MB) return;
+  const bool worker = wave < MB;
   float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (worker) {
 #pragma unroll
-  for (int w = 0; w < 8; ++w) {
-    const float4 v = *reinterpret_cast<const float4*>(red[w][wave][lane]);
-    a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
+    for (int w = 0; w < 8; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(red[w][wave][lane]);
+      a4[0] += v.x; a4[1] += v.y; a4[2] += v.z; a4[3] += v.w;
+    }
   }
+  if (split_s > 1) {                                         // the ordered gather of gemm_skinny_f32_kernel
+    constexpr int SC1 = 16;
+    constexpr uint32_t SLOT = MB * 64 * 16;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)(256u * 7u * 4u * 64u * 16u), 0x00020000);
+    const uint32_t slot0 = (uint32_t)tile * (uint32_t)(split_s - 1) * SLOT + (uint32_t)(wave * 64 + lane) * 16u;
+    if (split_j < split_s - 1) {
+      if (worker) {
+        const f32x4_t v = {a4[0], a4[1], a4[2], a4[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rW, slot0 + (uint32_t)split_j * SLOT, 0, SC1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.flags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(p.flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < split_s - 1)
+        __builtin_amdgcn_s_sleep(2);
+      __hip_atomic_store(p.flags + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (worker) {
+      const float own[4] = {a4[0], a4[1], a4[2], a4[3]};
+      a4[0] = a4[1] = a4[2] = a4[3] = 0.f;
+      for (int sj = 0; sj < split_s - 1; ++sj) {
+        const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, slot0 + (uint32_t)sj * SLOT, 0, SC1));
+        a4[0] += v[0]; a4[1] += v[1]; a4[2] += v[2]; a4[3] += v[3];
+      }
+      a4[0] += own[0]; a4[1] += own[1]; a4[2] += own[2]; a4[3] += own[3];
+    }
+  }
+  if (!worker) return;
   const int64_t m = (int64_t)wave * 16 + l16, n = n0 + 4 * lg;
   if (m >= p.M || n >= p.N) return;
   const int n_ok = (int)min((int64_t)4, p.N - n);
@@ -2097,7 +2136,19 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   // ---- skinny bf16 path: M <= 64 (KV-cached decode, few-row products): a stream over the weights
   if (!skinny_off_g() && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && d->M <= 64 && d->K >= 64 &&
       d->K % 64 == 0 && p.vecA && p.vecB) {
-    dim3 sgrid((unsigned)dxa_cdiv(d->N, 16));
+    // few column tiles (<= 128) over a deep K: K cut across workgroups (>= 8 blocks of 64 k per range), as for the fp32 twin
+    static const int skb_target = getenv("DXA_SKINNY_TARGET") ? atoi(getenv("DXA_SKINNY_TARGET")) : 256;
+    const int64_t skb_tiles = dxa_cdiv(d->N, 16);
+    int skb_split = 1;
+    if (skb_target > 0 && skb_tiles <= NUM_CU / 2)
+      skb_split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, (d->K / 64) / 8), dxa_cdiv(skb_target, skb_tiles)));
+    p.split_s = 1;
+    if (skb_split >= 2) {
+      SplitWs w;
+      if (int rc = get_split_ws(st, &w)) return rc;
+      p.split_s = skb_split; p.ws = w.ws; p.flags = w.flags;
+    }
+    dim3 sgrid((unsigned)(skb_tiles * p.split_s));
     const int mb = dxa_cdiv(d->M, 16);
 #define LAUNCH_SK(MB_)                                                                                              \
   do {                                                                                                              \
