@@ -253,3 +253,37 @@ def test_uncovered_ranges_of_the_gradient_arena():
     st.begin_step()
     assert not st._ssq_covered
     assert ALIGN == 64
+
+
+def test_backward_reenters_the_fp32_product_mode_of_its_forward():
+    """functional._StoreFn: a Function's backward runs the fp32 head products in the mode its forward ran in (exact fp32 MFMA or
+    the split-bf16 product) — an external training loop (HF Trainer) calls loss.backward() after the scope that set the mode for
+    the forward has been left"""
+    import torch
+    from dexbotic_amd import functional as Fn
+    from dexbotic_amd import kernels as K
+    seen = {}
+
+    class Probe(Fn._StoreFn):
+        @staticmethod
+        def forward(ctx, x):
+            seen["fwd"] = K.F32_GEMM_MODE
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, dy):
+            seen["bwd"] = K.F32_GEMM_MODE
+            return dy * 2.0
+
+    assert K.F32_GEMM_MODE == "exact"
+    x = torch.ones(3, requires_grad=True)
+    with K.f32_gemm_mode("bf16x3"):
+        y = Probe.apply(x)
+    assert K.F32_GEMM_MODE == "exact"
+    y.sum().backward()
+    assert seen == {"fwd": "bf16x3", "bwd": "bf16x3"} and K.F32_GEMM_MODE == "exact"
+    assert torch.equal(x.grad, torch.full((3,), 2.0))
+    y2 = Probe.apply(x)                                     # and the other way round: forward exact, backward inside a bf16x3 scope
+    with K.f32_gemm_mode("bf16x3"):
+        y2.sum().backward()
+    assert seen == {"fwd": "exact", "bwd": "exact"}
