@@ -1982,7 +1982,10 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     // few tiles over a deep K: cut K so that every CU gets a workgroup (>= 8 K tiles of 64 per slice, <= 4 slices)
     static const bool t128_nosplit = getenv("DXA_GEMM_NO_SPLIT") != nullptr;
     int t_split = 1;
-    if (!t128_nosplit && t128_tiles <= NUM_CU / 4)      // (120 tiles x K 1024 measured slower cut in two: 21.2 vs 18.7 us)
+    // (120 tiles x K 1024 measured slower cut in two: 21.2 vs 18.7 us; up to half the CUs over a deep K it pays: the decoder's
+    //  qkv / o_proj at 287 rows are 108 / 84 tiles of K 3584, each CU's feed rate being the bound)
+    static const int t128_deepk = getenv("DXA_GEMM_T128_DEEPK") ? atoi(getenv("DXA_GEMM_T128_DEEPK")) : 2048;
+    if (!t128_nosplit && (t128_tiles <= NUM_CU / 4 || (t128_tiles <= NUM_CU / 2 && t128_deepk > 0 && d->K >= t128_deepk)))
       t_split = (int)std::min<int64_t>(std::min<int64_t>(4, NUM_CU / t128_tiles), (d->K / 64) / 8);
     if (t_split >= 2) {
       SplitWs w;
