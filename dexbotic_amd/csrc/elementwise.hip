@@ -549,7 +549,8 @@ extern "C" int dxa_glu_fwd(const void* gu, void* out, int64_t rows, int64_t F, i
   if (rows == 0) return DXA_OK;
   const bool vec = F % 4 == 0 && al(gu, 16) && al(out, 16);
   if (dtype == DXA_BF16) {
-    if (vec) hipLaunchKernelGGL((glu_fwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F, act);
+    if (vec && F % 8 == 0) hipLaunchKernelGGL((glu_fwd_k<bf16_t, 8>), dim3(dxa_grid1d(rows * F / 8, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F, act);
+    else if (vec) hipLaunchKernelGGL((glu_fwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F, act);
     else hipLaunchKernelGGL((glu_fwd_k<bf16_t, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (bf16_t*)out, rows, F, act);
   } else {
     if (vec) hipLaunchKernelGGL((glu_fwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (float*)out, rows, F, act);
@@ -564,7 +565,8 @@ extern "C" int dxa_glu_bwd(const void* gu, const void* dout, void* dgu, int64_t 
   if (rows == 0) return DXA_OK;
   const bool vec = F % 4 == 0 && al(gu, 16) && al(dout, 16) && al(dgu, 16);
   if (dtype == DXA_BF16) {
-    if (vec) hipLaunchKernelGGL((glu_bwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F, act);
+    if (vec && F % 8 == 0) hipLaunchKernelGGL((glu_bwd_k<bf16_t, 8>), dim3(dxa_grid1d(rows * F / 8, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F, act);
+    else if (vec) hipLaunchKernelGGL((glu_bwd_k<bf16_t, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F, act);
     else hipLaunchKernelGGL((glu_bwd_k<bf16_t, 1>), dim3(dxa_grid1d(rows * F, TPB)), dim3(TPB), 0, ST, (const bf16_t*)gu, (const bf16_t*)dout, (bf16_t*)dgu, rows, F, act);
   } else {
     if (vec) hipLaunchKernelGGL((glu_bwd_k<float, 4>), dim3(dxa_grid1d(rows * F / 4, TPB)), dim3(TPB), 0, ST, (const float*)gu, (const float*)dout, (float*)dgu, rows, F, act);
