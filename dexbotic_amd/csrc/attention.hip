@@ -461,20 +461,30 @@ __global__ __launch_bounds__(256) void attn_split_combine_k(const bf16_t* __rest
   if (row >= (int64_t)B * Hq * Sq) return;
   const int i = (int)(row % Sq), h = (int)((row / Sq) % Hq), b = (int)(row / ((int64_t)Sq * Hq));
   constexpr int EPL = D / 64;                                 // elements per lane
-  float mx = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lp[(((int64_t)b * nsplit + s) * Hq + h) * Sq + i]);
+  constexpr int NSB = 8;                                      // ranges per batch of loads
   float acc[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+  float mx = -INFINITY;
+  const int64_t pr0 = ((int64_t)b * nsplit * Hq + h) * Sq + i, prs = (int64_t)Hq * Sq;    // partial row of range s: pr0 + s * prs
+  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lp[pr0 + s * prs]);
   float wsum = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const int64_t pr = (((int64_t)b * nsplit + s) * Hq + h) * Sq + i;
-    const float w = mx == -INFINITY ? 0.f : expf(lp[pr] - mx);
-    if (w == 0.f) continue;
-    wsum += w;
-    const bf16_t* src = op + pr * D + lane * EPL;
+  for (int s0 = 0; s0 < nsplit; s0 += NSB) {                  // NSB ranges' rows in flight at once (they are independent loads)
+    float w[NSB], v[NSB][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] += w * bf2f(src[e]);
+    for (int u = 0; u < NSB; ++u) {
+      const int s = min(s0 + u, nsplit - 1);
+      w[u] = (s0 + u < nsplit && mx != -INFINITY) ? expf(lp[pr0 + s * prs] - mx) : 0.f;
+      const bf16_t* src = op + (pr0 + s * prs) * D + lane * EPL;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[u][e] = bf2f(src[e]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSB; ++u) {                           // range order: deterministic
+      wsum += w[u];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] += w[u] * v[u][e];
+    }
   }
   const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
   bf16_t* dst = reinterpret_cast<bf16_t*>(o) + b * o_sb + h * o_sh + (int64_t)i * o_ss + lane * EPL;
