@@ -122,10 +122,14 @@ class DiT(nn.Module):
                              kv: Optional[torch.Tensor] = None) -> torch.Tensor:
         """memvla DiTBlock (memvla/action_model/dit.py:175-187): x + attn(norm1 x); x + MHA(norm3 x, per, per);
         x + mlp(norm2 x) — composed from the small autograd pieces (the fused VitBlockFn has no slot for the middle
-        term).  nn.MultiheadAttention's packed in_proj is applied whole to both inputs and sliced [q | k | v]."""
+        term).  nn.MultiheadAttention's packed in_proj: rows [:h] on the queries, rows [h:] on the perceptual tokens
+        (functional.PackedInProjFn).  ``kv``: the sampler's per-request [k | v] of this block (precompute_per_kv)."""
         b, h, H = f"{self.p}blocks.{k}.", self.hidden_size, self.num_heads
         D, anchor = h // H, self._anchor()
-        if kv is not None and not torch.is_grad_enabled():
+        if kv is not None:
+            if torch.is_grad_enabled():
+                raise RuntimeError("DiT: per_kv (precompute_per_kv) is an inference-time cache: its products are not recorded "
+                                   "for autograd; call forward(per_token=...) when gradients are needed")
             return self._block_with_per_attn_sampler(st, b, hcur, kv, N, T1)
         lin = lambda x, wn, bn: Fn.LinearFn.apply(x, anchor, st, wn, bn, L.ACT_NONE, None)
         y = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
@@ -133,15 +137,10 @@ class DiT(nn.Module):
         o = Fn.AttnFn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).reshape(N * T1, h)
         hcur = Fn.AddFn.apply(hcur, lin(o, b + "attn.proj.weight", b + "attn.proj.bias"))
         y3 = Fn.NormFn.apply(hcur, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
-        if kv is not None:                       # sampler: [k | v] of this block came from precompute_per_kv
-            from .... import kernels as K
-            qf = K.mm_nt(y3, st.w(b + "per_attn.in_proj_weight")[:h], bias=st.w(b + "per_attn.in_proj_bias")[:h])
-            kvf = kv
-        else:
-            P_ = pe.shape[1]
-            qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
-                                              b + "per_attn.in_proj_bias", h)        # q [N*T1, h], [k | v] [N*P, 2h]
-            kvf = kvf.view(N, P_, 2, H, D)
+        P_ = pe.shape[1]
+        qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
+                                          b + "per_attn.in_proj_bias", h)            # q [N*T1, h], [k | v] [N*P, 2h]
+        kvf = kvf.view(N, P_, 2, H, D)
         o2 = Fn.AttnFn.apply(qf.view(N, T1, H, D), kvf[:, :, 0], kvf[:, :, 1]).reshape(N * T1, h)
         hcur = Fn.AddFn.apply(hcur, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
         y2 = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
