@@ -8,7 +8,19 @@ there is no CPU or eager-PyTorch fallback for the compute path.
 mirrors ``dexbotic.model.cogact.cogact_arch`` (same class names, ``forward`` / ``inference_action``
 contracts, ``state_dict`` keys and ``model_type`` registry strings).
 """
-from . import _lib  # noqa: F401  (raises ImportError when the native library is absent)
+import sys as _sys
+
+
+def _is_build_invocation() -> bool:
+    """True only for ``python -m dexbotic_amd.build`` — the one command that must work BEFORE the library exists (the
+    ImportError below names it).  runpy imports this package before it runs the build module, so the library check is
+    skipped for exactly that command line and for nothing else."""
+    oa = list(getattr(_sys, "orig_argv", []))
+    return any(a == "-m" and i + 1 < len(oa) and oa[i + 1] == "dexbotic_amd.build" for i, a in enumerate(oa))
+
+
+if not _is_build_invocation():
+    from . import _lib  # noqa: F401  (raises ImportError when the native library is absent)
 
 __version__ = "0.1.0"
 

@@ -72,3 +72,24 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
     code = "import sys; import dexbotic_amd; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_clean_tree_build_command_runs_without_the_library(tmp_path):
+    """`python -m dexbotic_amd.build` is the command the missing-library ImportError names, so it must start in a tree that
+    has no .so yet; plain `import dexbotic_amd` in the same tree must still fail loudly (no fallback).  hipcc is replaced by a
+    stub that writes empty outputs: the compile itself is __graft_entry__.build()'s check, this one is about the import path."""
+    import shutil
+    scratch = tmp_path / "tree"
+    shutil.copytree(os.path.join(ROOT, "dexbotic_amd"), scratch / "dexbotic_amd",
+                    ignore=shutil.ignore_patterns("*.so", "_obj", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), scratch / "include")
+    assert not (scratch / "dexbotic_amd" / "libdexbotic_amd.so").exists()
+    r = subprocess.run([sys.executable, "-c", "import dexbotic_amd"], cwd=scratch, capture_output=True, text=True)
+    assert r.returncode != 0 and "python -m dexbotic_amd.build" in r.stderr
+    stub = tmp_path / "hipcc_stub.sh"
+    stub.write_text("#!/bin/bash\nwhile [ $# -gt 0 ]; do if [ \"$1\" = \"-o\" ]; then : > \"$2\"; fi; shift; done\n")
+    stub.chmod(0o755)
+    env = dict(os.environ, HIPCC=str(stub))
+    r = subprocess.run([sys.executable, "-m", "dexbotic_amd.build"], cwd=scratch, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert (scratch / "dexbotic_amd" / "libdexbotic_amd.so").exists()
