@@ -29,9 +29,10 @@
 // rows, no batching, operands < 2 GiB, the lean epilogue (C = alpha acc + bias (+ R) (+ C), whole 16-byte accesses).
 #include "gemm_common.h"
 
-#ifndef DXA_W4V
-#define DXA_W4V 0      // tuning builds: 1 no global loads in the loop, 2 no ds_write, 4 no fragment reads, 8 no MFMA,
-#endif                 // 16 no order pinning (the compiler schedules the K tile)
+// Tuning instantiations (NT, bf16 out only; env DXA_GEMM_W4V picks one, results are garbage, timings are not): V bits
+// 1 no global loads in the loop, 2 no ds_write, 4 no fragment reads, 8 no MFMA, 16 no order pinning (the compiler schedules),
+// 32 no s_barrier in the loop, 64 no vmcnt wait before the ds_write (the last two keep the operand statistics: a fair clock).
+// PF = K tiles the global loads run ahead of their ds_write (1: one staging register set, 2: two sets).
 
 namespace {
 
@@ -85,15 +86,18 @@ __device__ __forceinline__ bool w4_split_exchange(const GemmP& p, f32x16_t (&acc
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) {
+            f32x4_t v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4_t v = __builtin_bit_cast(
+            for (int q = 0; q < 4; ++q)
+              v[q] = __builtin_bit_cast(
                   f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, src + ((((h * 4 + i) * 2 + j) * 4 + q) * 4096), 0, SC1));
 #pragma unroll
-              for (int c = 0; c < 4; ++c) acc[h][i][j][4 * q + c] += v[c];
-            }
-          if (i & 1) __builtin_amdgcn_sched_barrier(0);   // at most 16 loads (64 VGPRs) in flight
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[h][i][j][4 * q + c] += v[q][c];
+          }
+          __builtin_amdgcn_sched_barrier(0);   // 8 loads (32 VGPRs) in flight: the accumulators live in the AGPR half
         }
     }
   }
@@ -101,7 +105,7 @@ __device__ __forceinline__ bool w4_split_exchange(const GemmP& p, f32x16_t (&acc
   return true;
 }
 
-template <typename TO, typename TE, bool A_KS, bool B_KS>
+template <typename TO, typename TE, bool A_KS, bool B_KS, int PF, int DXA_W4V>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,8 +133,12 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 
   const uint32_t bytesA = (uint32_t)((A_KS ? (p.K - 1) * p.lda + p.M : (p.M - 1) * p.lda + p.K) * 2);
   const uint32_t bytesB = (uint32_t)((B_KS ? (p.K - 1) * p.ldb + p.N : (p.N - 1) * p.ldb + p.K) * 2);
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
+  // buffer descriptors by hand (raw buffer, stride 0, range = the operand's bytes): the staging loads are inline asm — the
+  // compiler must not count them (its own vmcnt bookkeeping drains a two-tile-deep queue at the loop head), the waits are
+  // placed by hand (W4_VMWAIT) and the queue is drained before the epilogue
+  const uint64_t pa_ = (uint64_t)p.A, pb_ = (uint64_t)p.B;
+  const u32x4_t dA = {(uint32_t)pa_, (uint32_t)(pa_ >> 32) & 0xffffu, bytesA, 0x00020000u};
+  const u32x4_t dB = {(uint32_t)pb_, (uint32_t)(pb_ >> 32) & 0xffffu, bytesB, 0x00020000u};
   const int nk_tot = (int)((p.K + 63) >> 6);
   const int k_lo = split_j * nk_tot / split_s;
   const int nk = (split_j + 1) * nk_tot / split_s - k_lo;   // K tiles of this workgroup (>= 1)
@@ -199,40 +207,46 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
-  u32x4_t sA[8], sB[8];                  // staging registers: one K tile of this wave's pieces
+  u32x4_t sA[PF][8], sB[PF][8];          // staging registers: PF K tiles of this wave's pieces (tile tau in set tau % PF)
   u32x4_t fa[2][4], fb[2][4];            // fragments of two k-steps
 
 #define W4_PIN() do { if (!(DXA_W4V & 16)) __builtin_amdgcn_sched_barrier(0); } while (0)
   // global load of piece j of K tile `tile` (relative to k_lo)
-#define W4_LDA(j, tile)                                                                                              \
+#define W4_LD(dst, vo, desc, so) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(desc), "s"(so) : "memory")
+#define W4_LDA(j, set, tile)                                                                                         \
   do {                                                                                                               \
     if (!(DXA_W4V & 1)) {                                                                                            \
-      if constexpr (A_KS) sA[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[j] + (uint32_t)(tile) * ktileA, 0, 0); \
-      else sA[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA[j], (k_lo + min((tile), nk - 1)) * 128, 0);         \
+      if constexpr (A_KS) W4_LD(sA[set][j], voA[j] + (uint32_t)(tile) * ktileA, dA, 0);                              \
+      else W4_LD(sA[set][j], voA[j], dA, (k_lo + min((tile), nk - 1)) * 128);                                        \
     }                                                                                                                \
   } while (0)
-#define W4_LDB(j, tile)                                                                                              \
+#define W4_LDB(j, set, tile)                                                                                         \
   do {                                                                                                               \
     if (!(DXA_W4V & 1)) {                                                                                            \
-      if constexpr (B_KS) sB[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, voB[j] + (uint32_t)(tile) * ktileB, 0, 0); \
-      else sB[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, voB[j], (k_lo + min((tile), nk - 1)) * 128, 0);         \
+      if constexpr (B_KS) W4_LD(sB[set][j], voB[j] + (uint32_t)(tile) * ktileB, dB, 0);                              \
+      else W4_LD(sB[set][j], voB[j], dB, (k_lo + min((tile), nk - 1)) * 128);                                        \
     }                                                                                                                \
   } while (0)
+  // the oldest outstanding load (the piece about to be written) has landed: 16 PF loads are in flight at that point
+#define W4_VMWAIT() do { if (!(DXA_W4V & (1 | 64))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * PF - 1) : "memory"); } while (0)
   // LDS write of piece j into buffer `buf`
-#define W4_WRA(j, buf)                                                                                               \
+#define W4_WRA(j, set, buf)                                                                                          \
   do {                                                                                                               \
     if (!(DXA_W4V & 2))                                                                                              \
-      *reinterpret_cast<u32x4_t*>(smem + (buf) * W4_BUF + (j) * 1024 + (A_KS ? wrA : (wrA ^ (uint32_t)(((j) & 1) << 6)))) = sA[j]; \
+      *reinterpret_cast<u32x4_t*>(smem + (buf) * W4_BUF + (j) * 1024 + (A_KS ? wrA : (wrA ^ (uint32_t)(((j) & 1) << 6)))) = sA[set][j]; \
   } while (0)
-#define W4_WRB(j, buf)                                                                                               \
+#define W4_WRB(j, set, buf)                                                                                          \
   do {                                                                                                               \
     if (!(DXA_W4V & 2))                                                                                              \
-      *reinterpret_cast<u32x4_t*>(smem + (buf) * W4_BUF + W4_OP + (j) * 1024 + (B_KS ? wrB : (wrB ^ (uint32_t)(((j) & 1) << 6)))) = sB[j]; \
+      *reinterpret_cast<u32x4_t*>(smem + (buf) * W4_BUF + W4_OP + (j) * 1024 + (B_KS ? wrB : (wrB ^ (uint32_t)(((j) & 1) << 6)))) = sB[set][j]; \
   } while (0)
-  // staging op n (0..15) of a K tile: pieces A0..A7, B0..B7 — write the piece of tile t+1, then re-load the register for t+2
-#define W4_STAGE(n, buf, tile)                                                                                       \
+  // staging op n (0..15) of a K tile: pieces A0..A7, B0..B7 — write the piece of tile t+1 (register set `set`), then re-load
+  // that register for tile t+1+PF
+#define W4_STAGE(n, set, buf, tile)                                                                                  \
   do {                                                                                                               \
-    if ((n) < 8) { W4_WRA((n) & 7, buf); W4_LDA((n) & 7, tile); } else { W4_WRB((n) & 7, buf); W4_LDB((n) & 7, tile); } \
+    W4_VMWAIT();                                                                                                     \
+    if ((n) < 8) { W4_WRA((n) & 7, set, buf); W4_LDA((n) & 7, set, tile); }                                          \
+    else { W4_WRB((n) & 7, set, buf); W4_LDB((n) & 7, set, tile); }                                                  \
   } while (0)
   // fragment b of k-step ks from buffer `buf` into register set F
 #define W4_TR(dst, off)                                                                                              \
@@ -258,14 +272,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
   // read op n (0..7) of a k-step: A0 B0 A1 B1 A2 B2 A3 B3
 #define W4_READ(n, ks, buf, F) do { if ((n) & 1) W4_RDB((n) >> 1, ks, buf, F); else W4_RDA((n) >> 1, ks, buf, F); } while (0)
   // MFMA n (0..15) of a k-step from register set F: row block n & 3, column block n >> 2
-#if (DXA_W4V & 8)
-#define W4_MFMA(n, F) asm volatile("" : "+v"(acc[(n) >> 3][(n) & 3][((n) >> 2) & 1]) : "v"(fb[F][(n) >> 2]), "v"(fa[F][(n) & 3]))
-#else
 #define W4_MFMA(n, F)                                                                                                \
-  acc[(n) >> 3][(n) & 3][((n) >> 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
-      __builtin_bit_cast(bf16x8_t, fb[F][(n) >> 2]), __builtin_bit_cast(bf16x8_t, fa[F][(n) & 3]),                    \
-      acc[(n) >> 3][(n) & 3][((n) >> 2) & 1], 0, 0, 0)
-#endif
+  do {                                                                                                               \
+    if constexpr ((DXA_W4V & 8) != 0)                                                                                \
+      asm volatile("" : "+v"(acc[(n) >> 3][(n) & 3][((n) >> 2) & 1]) : "v"(fb[F][(n) >> 2]), "v"(fa[F][(n) & 3]));  \
+    else                                                                                                             \
+      acc[(n) >> 3][(n) & 3][((n) >> 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                              \
+          __builtin_bit_cast(bf16x8_t, fb[F][(n) >> 2]), __builtin_bit_cast(bf16x8_t, fa[F][(n) & 3]),                \
+          acc[(n) >> 3][(n) & 3][((n) >> 2) & 1], 0, 0, 0);                                                          \
+  } while (0)
   // One K tile (buffer cur holds tile t; tile t+1 is in the staging registers, its loads issued one tile ago).
   //   k-steps 0..2: 16 MFMAs; behind MFMA n < 8 the fragment read n of the NEXT k-step; behind MFMAs 8.. the staging ops
   //                 (write piece to the other buffer + re-load the register for tile t+2): 6 / 5 / 5 of the 16 per k-step;
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
     _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                              \
       W4_MFMA(n_, (ks) & 1);                                                                                         \
       if (n_ < 8) W4_READ(n_, (ks) + 1, cur, ((ks) + 1) & 1);                                                        \
-      else if ((s0) + n_ - 8 < (s1)) W4_STAGE((s0) + n_ - 8, (cur) ^ 1, (t) + 2);                                    \
+      else if ((s0) + n_ - 8 < (s1)) W4_STAGE((s0) + n_ - 8, PF == 2 ? (cur) ^ 1 : 0, (cur) ^ 1, (t) + 1 + PF);     \
       W4_PIN();                                                                                                      \
     }                                                                                                                \
   } while (0)
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
       if (n_ == 3) {                                                                                                 \
         W4_PIN();                                                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
-        __builtin_amdgcn_s_barrier();                                                                                \
+        if (!(DXA_W4V & 32)) __builtin_amdgcn_s_barrier();                                                           \
         asm volatile("" ::: "memory");                                                                               \
       }                                                                                                              \
       if (n_ >= 4 && n_ < 12) W4_READ(n_ - 4, 0, (cur) ^ 1, 0);                                                      \
@@ -299,10 +314,20 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
   } while (0)
 
   // ---- prologue: tile 0 through the staging registers into buffer 0, tile 1 into the registers, k-step 0 of tile 0 read
+  // (the loads are issued in the order the loop consumes them — A0..A7, B0..B7 — because W4_VMWAIT counts, it does not name)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { W4_LDA(j, 0); W4_LDB(j, 0); }
+  for (int s_ = 0; s_ < PF; ++s_) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { W4_WRA(j, 0); W4_LDA(j, 1); W4_WRB(j, 0); W4_LDB(j, 1); }
+    for (int j = 0; j < 8; ++j) W4_LDA(j, s_, s_);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) W4_LDB(j, s_, s_);
+  }
+  W4_PIN();
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {           // 16 PF loads in flight before each write, as in the loop
+    W4_STAGE(n, 0, 0, PF);
+    W4_PIN();
+  }
   W4_PIN();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -326,9 +351,14 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #undef W4_WRA
 #undef W4_WRB
 #undef W4_LDA
+#undef W4_LD
+#undef W4_VMWAIT
 #undef W4_LDB
 #undef W4_PIN
-  // every wave is past its last fragment read and staging write before the buffers become epilogue slabs
+  // the staging loads still in flight (re-reads of the last tile / out-of-range zeros) land in registers the compiler does
+  // not know are pending: drain them; every wave is past its last fragment read and staging write before the buffers
+  // become epilogue slabs
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!w4_split_exchange(p, acc, tid, split_j, split_s, tail_i)) return;
   __builtin_amdgcn_sched_barrier(0);
@@ -347,15 +377,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <typename TO, typename TE, bool A_KS, bool B_KS>
+template <typename TO, typename TE, bool A_KS, bool B_KS, int PF = 1, int V = 0>
 int w4_launch_one(const GemmP& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<TO, TE, A_KS, B_KS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<TO, TE, A_KS, B_KS, PF, V>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<TO, TE, A_KS, B_KS>), grid, dim3(256), W4_LDS, st, p);
+  hipLaunchKernelGGL((gemm_w4_kernel<TO, TE, A_KS, B_KS, PF, V>), grid, dim3(256), W4_LDS, st, p);
   return 0;
 }
 
@@ -368,6 +398,19 @@ int gemm_w4_launch(const GemmP& p, int layout, bool out_f32, bool epi_f32, hipSt
   const dim3 grid((unsigned)(p.full + p.tail_r * p.split_s));
   if (layout == DXA_NT) {
     if (epi_f32) return w4_launch_one<float, float, false, false>(p, grid, st);
+    if (!out_f32) {                      // tuning instantiations
+      const char* e = getenv("DXA_GEMM_W4V");
+      const int v = e ? atoi(e) : 0;
+      switch (v) {
+        case 0: break;
+        case 16: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 16>(p, grid, st);
+        case 32: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 32>(p, grid, st);
+        case 64: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 64>(p, grid, st);
+        case 96: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 96>(p, grid, st);
+        case 100: return w4_launch_one<bf16_t, bf16_t, false, false, 2, 0>(p, grid, st);     // two K tiles of loads in flight
+        default: break;
+      }
+    }
     return out_f32 ? w4_launch_one<float, bf16_t, false, false>(p, grid, st) : w4_launch_one<bf16_t, bf16_t, false, false>(p, grid, st);
   }
   if (layout == DXA_NN)

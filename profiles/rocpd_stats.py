@@ -5,6 +5,7 @@
     python profiles/rocpd_stats.py gpurun_out/prof/NAME_results.db > profiles/NAME_kernel_stats.txt
     python profiles/rocpd_stats.py --per-step A_results.db 3 B_results.db 9      # exact per-step table from two traces
     python profiles/rocpd_stats.py --pmc PMC_results.db [kernel-substring,...]    # hardware counters per kernel
+    python profiles/rocpd_stats.py --names NAME_results.db                         # full (untruncated) kernel names
 """
 import re
 import sqlite3
@@ -28,6 +29,14 @@ def main(path):
     print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
     for n, c, s, a, mn, mx in rows[:45]:
         print(f"{short(n):110s} {c:7d} {s/1e6:10.2f} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f} {100*s/total:6.2f}")
+
+
+def names(path):
+    """full kernel names (Tensile encodes macro tile, wave tiling, prefetch depths ... in them) with calls and average time"""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, count(*), avg(end-start) from kernels group by name order by sum(end-start) desc").fetchall()
+    for n, c, a in rows[:40]:
+        print(f"{c:6d} calls  {a/1e3:9.1f} us avg  {n}")
 
 
 def per_step(path_a, steps_a, path_b, steps_b):
@@ -73,6 +82,8 @@ if __name__ == "__main__":
     if "--per-step" in sys.argv:
         r = [a for a in sys.argv[1:] if a != "--per-step"]
         per_step(r[0], int(r[1]), r[2], int(r[3]))
+    elif "--names" in sys.argv:
+        names([a for a in sys.argv[1:] if a != "--names"][0])
     elif "--pmc" in sys.argv:
         rest = [a for a in sys.argv[1:] if a != "--pmc"]
         pmc(rest[0], rest[1] if len(rest) > 1 else None)
