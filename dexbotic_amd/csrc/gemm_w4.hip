@@ -30,18 +30,15 @@
 #include "gemm_common.h"
 
 // Tuning instantiations (NT, bf16 out only; env DXA_GEMM_W4V picks one, results are garbage, timings are not): V bits
-// 1 no global loads in the loop, 2 no ds_write, 4 no fragment reads, 8 no MFMA, 16 no order pinning (the compiler schedules),
-// 32 no s_barrier in the loop, 64 no vmcnt wait before the ds_write (the last two keep the operand statistics: a fair clock).
-// PF = K tiles the global loads run ahead of their ds_write (1: one staging register set, 2: two sets).
+// 1 no LDS-DMA in the loop, 4 no fragment reads, 32 no s_barrier in the loop (keeps the operand statistics: a fair clock).
 
 namespace {
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
-constexpr int W4_OP = 32768;          // one operand of one K tile
-constexpr int W4_BUF = 2 * W4_OP;     // A | B
-constexpr int W4_LDS = 2 * W4_BUF;    // two buffers (the epilogue slabs reuse them)
+constexpr int W4_OP = 32768;          // one operand of one K tile = one ring slot
+constexpr int W4_LDS = 5 * W4_OP;     // ring of five slots = all 160 KiB (the epilogue slabs reuse them)
 
 // Split-K hand-off of a tail tile (same protocol and slot size as tile_split_exchange in gemm_common.h; 256 threads, 16
 // accumulator blocks per lane): every piece but the last stores its fp32 partial with write-through (sc1) 16-byte stores and
@@ -105,7 +102,7 @@ __device__ __forceinline__ bool w4_split_exchange(const GemmP& p, f32x16_t (&acc
   return true;
 }
 
-template <typename TO, typename TE, bool A_KS, bool B_KS, int PF, int DXA_W4V>
+template <typename TO, typename TE, bool A_KS, bool B_KS, int DXA_W4V>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,70 +130,68 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 
   const uint32_t bytesA = (uint32_t)((A_KS ? (p.K - 1) * p.lda + p.M : (p.M - 1) * p.lda + p.K) * 2);
   const uint32_t bytesB = (uint32_t)((B_KS ? (p.K - 1) * p.ldb + p.N : (p.N - 1) * p.ldb + p.K) * 2);
-  // buffer descriptors by hand (raw buffer, stride 0, range = the operand's bytes): the staging loads are inline asm — the
-  // compiler must not count them (its own vmcnt bookkeeping drains a two-tile-deep queue at the loop head), the waits are
-  // placed by hand (W4_VMWAIT) and the queue is drained before the epilogue
-  const uint64_t pa_ = (uint64_t)p.A, pb_ = (uint64_t)p.B;
-  const u32x4_t dA = {(uint32_t)pa_, (uint32_t)(pa_ >> 32) & 0xffffu, bytesA, 0x00020000u};
-  const u32x4_t dB = {(uint32_t)pb_, (uint32_t)(pb_ >> 32) & 0xffffu, bytesB, 0x00020000u};
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
   const int nk_tot = (int)((p.K + 63) >> 6);
   const int k_lo = split_j * nk_tot / split_s;
   const int nk = (split_j + 1) * nk_tot / split_s - k_lo;   // K tiles of this workgroup (>= 1)
 
-  // ---- staging: a wave loads 8 + 8 of the 32 + 32 sixteen-byte-per-lane pieces (1 KiB each) of a K tile
-  //   K-contiguous: piece j of wave w = tile rows 64 w + 8 j .. + 7, lane -> (row + lane / 8, chunk lane % 8)
-  //   K-strided   : piece j of wave w = k-rows 32 (w & 1) + 4 j .. + 3 of LDS piece (w >> 1), lane -> (k-row + lane / 16,
-  //                 16-byte slot lane % 16 = tile rows 8 slot .. + 7 of the piece)
+  // ---- feed: LDS-DMA (buffer_load ... lds), 1 KiB per wave instruction written lane-linearly, so the LDS swizzle is applied
+  //      to the per-lane SOURCE address.  A wave issues 8 + 8 of the 32 + 32 pieces of a K tile:
+  //   K-contiguous: piece j of wave w = tile rows 64 w + 8 j .. + 7; lane -> (row + lane / 8, LDS chunk slot lane % 8, source
+  //                 chunk = slot ^ ((row >> 1) & 7)): every row is still fetched as one whole 128-byte line
+  //   K-strided   : piece j of wave w = k-rows 32 (w & 1) + 4 j .. + 3 of LDS piece (w >> 1); lane -> (k-row + lane / 16, LDS
+  //                 16-byte slot s = lane % 16, source slot = s ^ ((k-row & 3) << 2) = tile rows 8 slot .. + 7 of the piece)
   // rows / columns outside the matrix: offset 0x80000000 (outside the descriptor's range: zeros); the K tile goes into the
   // scalar offset for a K-contiguous operand and into the VECTOR offset for a K-strided one (so that k-rows past K are
   // range-checked: the scalar offset is not)
   uint32_t voA[8], voB[8];
-  uint32_t wrA, wrB;                                  // LDS byte offset of piece 0 inside the operand's 32 KiB
   {
     const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u;
-    const int slot = lane & 15, kq = lane >> 4;
+    const int kq = lane >> 4, sig = (lane & 15) ^ (kq << 2);
     if constexpr (A_KS) {
-      const int ga = m0i + (wave >> 1) * 128 + 8 * slot;
+      const int ga = m0i + (wave >> 1) * 128 + 8 * sig;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         voA[j] = ga < (int)p.M ? (uint32_t)(k_lo * 64 + (wave & 1) * 32 + 4 * j + kq) * lda2 + (uint32_t)ga * 2u : 0x80000000u;
-      wrA = (uint32_t)((wave >> 1) * 16384 + ((wave & 1) * 32 + kq) * 256 + (((slot >> 2) ^ kq) << 6) + (slot & 3) * 16);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ga = m0i + 64 * wave + 8 * j + (lane >> 3);
-        voA[j] = ga < (int)p.M ? (uint32_t)ga * lda2 + (uint32_t)((lane & 7) << 4) : 0x80000000u;
+        voA[j] = ga < (int)p.M ? (uint32_t)ga * lda2 + (uint32_t)(((lane & 7) ^ (kq | ((j & 1) << 2))) << 4) : 0x80000000u;
       }
-      wrA = (uint32_t)((64 * wave + (lane >> 3)) * 128 + (((lane & 7) ^ (lane >> 4)) << 4));
     }
     if constexpr (B_KS) {
-      const int gb = n0i + (wave >> 1) * 128 + 8 * slot;
+      const int gb = n0i + (wave >> 1) * 128 + 8 * sig;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         voB[j] = gb < (int)p.N ? (uint32_t)(k_lo * 64 + (wave & 1) * 32 + 4 * j + kq) * ldb2 + (uint32_t)gb * 2u : 0x80000000u;
-      wrB = (uint32_t)((wave >> 1) * 16384 + ((wave & 1) * 32 + kq) * 256 + (((slot >> 2) ^ kq) << 6) + (slot & 3) * 16);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int gb = n0i + 64 * wave + 8 * j + (lane >> 3);
-        voB[j] = gb < (int)p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lane & 7) << 4) : 0x80000000u;
+        voB[j] = gb < (int)p.N ? (uint32_t)gb * ldb2 + (uint32_t)(((lane & 7) ^ (kq | ((j & 1) << 2))) << 4) : 0x80000000u;
       }
-      wrB = (uint32_t)((64 * wave + (lane >> 3)) * 128 + (((lane & 7) ^ (lane >> 4)) << 4));
     }
   }
   const uint32_t ktileA = A_KS ? 64u * (uint32_t)p.lda * 2u : 0u, ktileB = B_KS ? 64u * (uint32_t)p.ldb * 2u : 0u;
+  // piece j of this wave inside the operand's 32 KiB: K-contiguous rows 64 w + 8 j (128 B each); K-strided LDS piece w >> 1,
+  // k-rows 32 (w & 1) + 4 j (256 B each)
+  const int pieceA0 = A_KS ? (wave >> 1) * 16384 + (wave & 1) * 8192 : wave * 8192;
+  const int pieceB0 = B_KS ? (wave >> 1) * 16384 + (wave & 1) * 8192 : wave * 8192;
 
-  // ---- fragment read offsets (inside the operand's 32 KiB)
+  // ---- fragment read addresses
   //   K-contiguous: block b (32 rows) of k-step ks: row = 128 w_ + 32 b + l32, chunk 2 ks + lh at slot ^ sw:
   //                 (ya ^ (ks << 5)) + 4096 b with ya = row base | ((lh ^ sw) << 4)
   //   K-strided   : lane (i = lane % 16, half-group (lane >> 4) & 1, lh) passes the address of 4 consecutive tile rows (8 bytes)
   //                 of k-row 8 lh + (i >> 2) [+ 16 ks + 4 r as immediate] and receives row i's 4 k; the block's 64-byte chunk b
   //                 sits at b ^ (k-row & 3): (yb ^ (b << 6)) + 4096 ks + 1024 r
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int sw = (l32 >> 1) & 7;
   const int i16 = lane & 15;
   const uint32_t ks_lane = (uint32_t)((8 * lh + (i16 >> 2)) * 256 + (((i16 >> 2) & 3) << 6) + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8);
-  const uint32_t ya = A_KS ? (uint32_t)(wm * 16384) + ks_lane : (uint32_t)((wm * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4);
-  const uint32_t yb = W4_OP + (B_KS ? (uint32_t)(wn * 16384) + ks_lane : (uint32_t)((wn * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4));
+  const uint32_t ya = lds0 + (A_KS ? (uint32_t)(wm * 16384) + ks_lane : (uint32_t)((wm * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4));
+  const uint32_t yb = lds0 + (B_KS ? (uint32_t)(wn * 16384) + ks_lane : (uint32_t)((wn * 128 + l32) * 128) | (uint32_t)((lh ^ sw) << 4));
 
   f32x16_t acc[2][4][2];                 // [64-column half][32-row block][32-column block of the half]
 #pragma unroll
@@ -207,158 +202,150 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
-  u32x4_t sA[PF][8], sB[PF][8];          // staging registers: PF K tiles of this wave's pieces (tile tau in set tau % PF)
   u32x4_t fa[2][4], fb[2][4];            // fragments of two k-steps
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-#define W4_PIN() do { if (!(DXA_W4V & 16)) __builtin_amdgcn_sched_barrier(0); } while (0)
-  // global load of piece j of K tile `tile` (relative to k_lo)
-#define W4_LD(dst, vo, desc, so) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(desc), "s"(so) : "memory")
-#define W4_LDA(j, set, tile)                                                                                         \
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+  // LDS-DMA of piece j of K tile `tile` (relative to k_lo) into ring slot `slot`
+#define W4_DMA(rsrc, vo, so, ldsoff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(smem + (ldsoff)), 16, vo, so, 0, 0)
+#define W4_DMA_A(j, slot, tile)                                                                                      \
   do {                                                                                                               \
     if (!(DXA_W4V & 1)) {                                                                                            \
-      if constexpr (A_KS) W4_LD(sA[set][j], voA[j] + (uint32_t)(tile) * ktileA, dA, 0);                              \
-      else W4_LD(sA[set][j], voA[j], dA, (k_lo + min((tile), nk - 1)) * 128);                                        \
+      if constexpr (A_KS) W4_DMA(rA, voA[j] + (uint32_t)(tile) * ktileA, 0, (slot) * W4_OP + pieceA0 + (j) * 1024);  \
+      else W4_DMA(rA, voA[j], (k_lo + min((tile), nk - 1)) * 128, (slot) * W4_OP + pieceA0 + (j) * 1024);            \
     }                                                                                                                \
   } while (0)
-#define W4_LDB(j, set, tile)                                                                                         \
+#define W4_DMA_B(j, slot, tile)                                                                                      \
   do {                                                                                                               \
     if (!(DXA_W4V & 1)) {                                                                                            \
-      if constexpr (B_KS) W4_LD(sB[set][j], voB[j] + (uint32_t)(tile) * ktileB, dB, 0);                              \
-      else W4_LD(sB[set][j], voB[j], dB, (k_lo + min((tile), nk - 1)) * 128);                                        \
+      if constexpr (B_KS) W4_DMA(rB, voB[j] + (uint32_t)(tile) * ktileB, 0, (slot) * W4_OP + pieceB0 + (j) * 1024);  \
+      else W4_DMA(rB, voB[j], (k_lo + min((tile), nk - 1)) * 128, (slot) * W4_OP + pieceB0 + (j) * 1024);            \
     }                                                                                                                \
   } while (0)
-  // the oldest outstanding load (the piece about to be written) has landed: 16 PF loads are in flight at that point
-#define W4_VMWAIT() do { if (!(DXA_W4V & (1 | 64))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * PF - 1) : "memory"); } while (0)
-  // LDS write of piece j into buffer `buf`
-#define W4_WRA(j, set, buf)                                                                                          \
+  // fragment reads (inline asm: the compiler must not order them against the DMA it tracks; waits are placed by hand)
+#define W4_RD128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define W4_RDTR(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define W4_TR(dst, addr, imm)                                                                                        \
   do {                                                                                                               \
-    if (!(DXA_W4V & 2))                                                                                              \
-      *reinterpret_cast<u32x4_t*>(smem + (buf) * W4_BUF + (j) * 1024 + (A_KS ? wrA : (wrA ^ (uint32_t)(((j) & 1) << 6)))) = sA[set][j]; \
-  } while (0)
-#define W4_WRB(j, set, buf)                                                                                          \
-  do {                                                                                                               \
-    if (!(DXA_W4V & 2))                                                                                              \
-      *reinterpret_cast<u32x4_t*>(smem + (buf) * W4_BUF + W4_OP + (j) * 1024 + (B_KS ? wrB : (wrB ^ (uint32_t)(((j) & 1) << 6)))) = sB[set][j]; \
-  } while (0)
-  // staging op n (0..15) of a K tile: pieces A0..A7, B0..B7 — write the piece of tile t+1 (register set `set`), then re-load
-  // that register for tile t+1+PF
-#define W4_STAGE(n, set, buf, tile)                                                                                  \
-  do {                                                                                                               \
-    W4_VMWAIT();                                                                                                     \
-    if ((n) < 8) { W4_WRA((n) & 7, set, buf); W4_LDA((n) & 7, set, tile); }                                          \
-    else { W4_WRB((n) & 7, set, buf); W4_LDB((n) & 7, set, tile); }                                                  \
-  } while (0)
-  // fragment b of k-step ks from buffer `buf` into register set F
-#define W4_TR(dst, off)                                                                                              \
-  do {                                                                                                               \
-    const s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(smem + (off)));                      \
-    const s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(smem + (off) + 1024));               \
-    dst = __builtin_bit_cast(u32x4_t, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));                   \
+    u32x2_t lo_ = {0u, 0u}, hi_ = {0u, 0u};                                                                          \
+    W4_RDTR(lo_, addr, imm); W4_RDTR(hi_, addr, (imm) + 1024);                                                       \
+    dst = (u32x4_t){lo_[0], lo_[1], hi_[0], hi_[1]};                                                                 \
   } while (0)
 #define W4_RDA(b, ks, buf, F)                                                                                        \
   do {                                                                                                               \
     if (!(DXA_W4V & 4)) {                                                                                            \
-      if constexpr (A_KS) W4_TR(fa[F][b], (buf) * W4_BUF + (ks) * 4096 + (ya ^ (uint32_t)((b) << 6)));              \
-      else fa[F][b] = *reinterpret_cast<const u32x4_t*>(smem + (buf) * W4_BUF + (b) * 4096 + (ya ^ (uint32_t)((ks) << 5))); \
+      if constexpr (A_KS) W4_TR(fa[F][b], (ya ^ (uint32_t)((b) << 6)) + (uint32_t)((buf) * W4_OP), (ks) * 4096);     \
+      else W4_RD128(fa[F][b], (ya ^ (uint32_t)((ks) << 5)) + (uint32_t)((buf) * W4_OP), (b) * 4096);                 \
     }                                                                                                                \
   } while (0)
 #define W4_RDB(b, ks, buf, F)                                                                                        \
   do {                                                                                                               \
     if (!(DXA_W4V & 4)) {                                                                                            \
-      if constexpr (B_KS) W4_TR(fb[F][b], (buf) * W4_BUF + (ks) * 4096 + (yb ^ (uint32_t)((b) << 6)));              \
-      else fb[F][b] = *reinterpret_cast<const u32x4_t*>(smem + (buf) * W4_BUF + (b) * 4096 + (yb ^ (uint32_t)((ks) << 5))); \
+      if constexpr (B_KS) W4_TR(fb[F][b], (yb ^ (uint32_t)((b) << 6)) + (uint32_t)((buf) * W4_OP), (ks) * 4096);     \
+      else W4_RD128(fb[F][b], (yb ^ (uint32_t)((ks) << 5)) + (uint32_t)((buf) * W4_OP), (b) * 4096);                 \
     }                                                                                                                \
   } while (0)
-  // read op n (0..7) of a k-step: A0 B0 A1 B1 A2 B2 A3 B3
-#define W4_READ(n, ks, buf, F) do { if ((n) & 1) W4_RDB((n) >> 1, ks, buf, F); else W4_RDA((n) >> 1, ks, buf, F); } while (0)
+  // read op n (0..7) of a k-step of K tile number tm (mod 5): A0 B0 A1 B1 A2 B2 A3 B3.  Ring: operand-tile u = 2 t + (0 A | 1 B)
+  // lives in slot u % 5
+#define W4_SA(tm) ((2 * (tm)) % 5)
+#define W4_SB(tm) ((2 * (tm) + 1) % 5)
+#define W4_READ(n, ks, tm, F) do { if ((n) & 1) W4_RDB((n) >> 1, ks, W4_SB(tm), F); else W4_RDA((n) >> 1, ks, W4_SA(tm), F); } while (0)
   // MFMA n (0..15) of a k-step from register set F: row block n & 3, column block n >> 2
 #define W4_MFMA(n, F)                                                                                                \
+  acc[(n) >> 3][(n) & 3][((n) >> 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
+      __builtin_bit_cast(bf16x8_t, fb[F][(n) >> 2]), __builtin_bit_cast(bf16x8_t, fa[F][(n) & 3]),                    \
+      acc[(n) >> 3][(n) & 3][((n) >> 2) & 1], 0, 0, 0)
+#define W4_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W4_PIN(); } while (0)
+  // One K tile t (tm = t % 5; its operands sit in slots SA(tm), SB(tm)).  Ring discipline: the barrier inside k-step 3 of
+  // tile t retires every wave's reads of A(t) and B(t); right behind it B(t+2) is requested into A(t)'s slot and A(t+3) into
+  // B(t)'s — 12 of the 16 pieces in that k-step 3, the last 4 in k-step 0 of tile t+1 — so B runs ONE whole K tile and A TWO
+  // ahead of the barrier that needs them.  In front of the barrier of tile t a wave's outstanding pieces are ... B(t+1) A(t+2):
+  // vmcnt(8) leaves A(t+2) in flight and guarantees B(t+1) (and the older A(t+1)).
+  //   k-steps 0..2: 16 MFMAs; behind MFMA n < 8 the fragment read n of the NEXT k-step; k-step 0 also carries the last 4 DMA
+  //                 pieces of A(t+2), behind MFMAs 8..11;
+  //   k-step 3    : NB MFMAs, vmcnt(8), s_barrier, then behind the next 8 MFMAs the reads of k-step 0 of tile t+1 and behind
+  //                 MFMAs NB..15 the DMA pieces B0..B7, A0..A3.
+  // Every k-step opens with lgkmcnt(0): its fragments were requested >= 8 MFMAs (256 cycles) earlier.
+#define W4_KSTEP(ks, tm, t)                                                                                          \
   do {                                                                                                               \
-    if constexpr ((DXA_W4V & 8) != 0)                                                                                \
-      asm volatile("" : "+v"(acc[(n) >> 3][(n) & 3][((n) >> 2) & 1]) : "v"(fb[F][(n) >> 2]), "v"(fa[F][(n) & 3]));  \
-    else                                                                                                             \
-      acc[(n) >> 3][(n) & 3][((n) >> 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                              \
-          __builtin_bit_cast(bf16x8_t, fb[F][(n) >> 2]), __builtin_bit_cast(bf16x8_t, fa[F][(n) & 3]),                \
-          acc[(n) >> 3][(n) & 3][((n) >> 2) & 1], 0, 0, 0);                                                          \
-  } while (0)
-  // One K tile (buffer cur holds tile t; tile t+1 is in the staging registers, its loads issued one tile ago).
-  //   k-steps 0..2: 16 MFMAs; behind MFMA n < 8 the fragment read n of the NEXT k-step; behind MFMAs 8.. the staging ops
-  //                 (write piece to the other buffer + re-load the register for tile t+2): 6 / 5 / 5 of the 16 per k-step;
-  //   k-step 3    : 4 MFMAs, then lgkmcnt(0) + s_barrier (every wave's reads of buffer cur and writes of buffer cur^1 are
-  //                 done), then behind MFMAs 4..11 the reads of k-step 0 of tile t+1 from the other buffer.
-#define W4_KSTEP(ks, cur, t, s0, s1)                                                                                 \
-  do {                                                                                                               \
+    W4_LGKM0();                                                                                                      \
     _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                              \
       W4_MFMA(n_, (ks) & 1);                                                                                         \
-      if (n_ < 8) W4_READ(n_, (ks) + 1, cur, ((ks) + 1) & 1);                                                        \
-      else if ((s0) + n_ - 8 < (s1)) W4_STAGE((s0) + n_ - 8, PF == 2 ? (cur) ^ 1 : 0, (cur) ^ 1, (t) + 1 + PF);     \
+      if (n_ < 8) W4_READ(n_, (ks) + 1, tm, ((ks) + 1) & 1);                                                         \
+      else if ((ks) == 0 && n_ < 12) W4_DMA_A(n_ - 4, W4_SB(((tm) + 4) % 5), (t) + 2);                               \
       W4_PIN();                                                                                                      \
     }                                                                                                                \
   } while (0)
-#define W4_TILE(cur, t)                                                                                              \
+#define W4_TILE(tm, t)                                                                                               \
   do {                                                                                                               \
-    W4_KSTEP(0, cur, t, 0, 6);                                                                                       \
-    W4_KSTEP(1, cur, t, 6, 11);                                                                                      \
-    W4_KSTEP(2, cur, t, 11, 16);                                                                                     \
+    W4_KSTEP(0, tm, t);                                                                                              \
+    W4_KSTEP(1, tm, t);                                                                                              \
+    W4_KSTEP(2, tm, t);                                                                                              \
+    W4_LGKM0();                                                                                                      \
     _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                              \
       W4_MFMA(n_, 1);                                                                                                \
-      if (n_ == 3) {                                                                                                 \
+      if (n_ == W4_NB - 1) {                                                                                         \
         W4_PIN();                                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                             \
         if (!(DXA_W4V & 32)) __builtin_amdgcn_s_barrier();                                                           \
         asm volatile("" ::: "memory");                                                                               \
       }                                                                                                              \
-      if (n_ >= 4 && n_ < 12) W4_READ(n_ - 4, 0, (cur) ^ 1, 0);                                                      \
+      if (n_ >= W4_NB && n_ < W4_NB + 8) W4_READ(n_ - W4_NB, 0, ((tm) + 1) % 5, 0);                                  \
+      if (n_ >= W4_NB && n_ < W4_NB + 8) W4_DMA_B(n_ - W4_NB, W4_SA(tm), (t) + 2);                                   \
+      if (n_ >= W4_NB + 8) W4_DMA_A(n_ - W4_NB - 8, W4_SB(tm), (t) + 3);                                             \
       W4_PIN();                                                                                                      \
     }                                                                                                                \
   } while (0)
+  constexpr int W4_NB = 4;               // MFMAs of k-step 3 ahead of the barrier (16 - NB - 8 = 4 A pieces fit behind it)
+  static_assert(W4_NB == 4, "the piece split 12 + 4 assumes NB = 4");
 
-  // ---- prologue: tile 0 through the staging registers into buffer 0, tile 1 into the registers, k-step 0 of tile 0 read
-  // (the loads are issued in the order the loop consumes them — A0..A7, B0..B7 — because W4_VMWAIT counts, it does not name)
+  // ---- prologue: A(0) B(0) A(1) B(1) and the first 4 pieces of A(2) requested (36 per wave), A(0) and B(0) landed (vmcnt(20))
+  //      and k-step 0 of tile 0 read; tile 0's k-step 0 requests the other 4 pieces of A(2), as every tile does
 #pragma unroll
-  for (int s_ = 0; s_ < PF; ++s_) {
+  for (int j = 0; j < 8; ++j) W4_DMA_A(j, W4_SA(0), 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) W4_LDA(j, s_, s_);
+  for (int j = 0; j < 8; ++j) W4_DMA_B(j, W4_SB(0), 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) W4_LDB(j, s_, s_);
-  }
+  for (int j = 0; j < 8; ++j) W4_DMA_A(j, W4_SA(1), 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) W4_DMA_B(j, W4_SB(1), 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) W4_DMA_A(j, W4_SA(2), 2);
   W4_PIN();
-#pragma unroll
-  for (int n = 0; n < 16; ++n) {           // 16 PF loads in flight before each write, as in the loop
-    W4_STAGE(n, 0, 0, PF);
-    W4_PIN();
-  }
-  W4_PIN();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   W4_PIN();
 #pragma unroll
   for (int n = 0; n < 8; ++n) W4_READ(n, 0, 0, 0);
   W4_PIN();
-  for (int t = 0; t < nk; t += 2) {
+  for (int t = 0; t < nk; t += 5) {
     W4_TILE(0, t);
     if (t + 1 < nk) W4_TILE(1, t + 1);
+    if (t + 2 < nk) W4_TILE(2, t + 2);
+    if (t + 3 < nk) W4_TILE(3, t + 3);
+    if (t + 4 < nk) W4_TILE(4, t + 4);
   }
+  W4_LGKM0();                            // the (unused) fragments of the tile past the end
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and its DMA pieces, before the slots become epilogue slabs
 #undef W4_TILE
 #undef W4_KSTEP
+#undef W4_LGKM0
 #undef W4_MFMA
 #undef W4_READ
 #undef W4_RDA
 #undef W4_RDB
 #undef W4_TR
-#undef W4_STAGE
-#undef W4_WRA
-#undef W4_WRB
-#undef W4_LDA
-#undef W4_LD
-#undef W4_VMWAIT
-#undef W4_LDB
+#undef W4_RDTR
+#undef W4_RD128
+#undef W4_SA
+#undef W4_SB
+#undef W4_DMA_A
+#undef W4_DMA_B
+#undef W4_DMA
 #undef W4_PIN
-  // the staging loads still in flight (re-reads of the last tile / out-of-range zeros) land in registers the compiler does
-  // not know are pending: drain them; every wave is past its last fragment read and staging write before the buffers
-  // become epilogue slabs
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // every wave is past its last fragment read and its last DMA piece before the slots become epilogue slabs
   __syncthreads();
   if (!w4_split_exchange(p, acc, tid, split_j, split_s, tail_i)) return;
   __builtin_amdgcn_sched_barrier(0);
@@ -377,15 +364,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <typename TO, typename TE, bool A_KS, bool B_KS, int PF = 1, int V = 0>
+template <typename TO, typename TE, bool A_KS, bool B_KS, int V = 0>
 int w4_launch_one(const GemmP& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<TO, TE, A_KS, B_KS, PF, V>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<TO, TE, A_KS, B_KS, V>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<TO, TE, A_KS, B_KS, PF, V>), grid, dim3(256), W4_LDS, st, p);
+  hipLaunchKernelGGL((gemm_w4_kernel<TO, TE, A_KS, B_KS, V>), grid, dim3(256), W4_LDS, st, p);
   return 0;
 }
 
@@ -403,11 +390,9 @@ int gemm_w4_launch(const GemmP& p, int layout, bool out_f32, bool epi_f32, hipSt
       const int v = e ? atoi(e) : 0;
       switch (v) {
         case 0: break;
-        case 16: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 16>(p, grid, st);
-        case 32: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 32>(p, grid, st);
-        case 64: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 64>(p, grid, st);
-        case 96: return w4_launch_one<bf16_t, bf16_t, false, false, 1, 96>(p, grid, st);
-        case 100: return w4_launch_one<bf16_t, bf16_t, false, false, 2, 0>(p, grid, st);     // two K tiles of loads in flight
+        case 1: return w4_launch_one<bf16_t, bf16_t, false, false, 1>(p, grid, st);
+        case 4: return w4_launch_one<bf16_t, bf16_t, false, false, 4>(p, grid, st);
+        case 32: return w4_launch_one<bf16_t, bf16_t, false, false, 32>(p, grid, st);
         default: break;
       }
     }

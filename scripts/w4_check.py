@@ -136,7 +136,7 @@ def bench(lib):
 
 def ablate():
     """NT bf16 tuning instantiations of the w4 kernel (DXA_GEMM_W4V): what each part of the K loop costs"""
-    names = {0: "everything", 100: "two tiles of loads in flight", 32: "no barrier", 64: "no vmcnt wait", 96: "neither"}
+    names = {0: "everything", 32: "no barrier", 1: "no DMA (stale operands)", 4: "no fragment reads"}
     for name, lay, m, n, k in [STEP[1], STEP[2], STEP[3], STEP[13]]:
         a, b, fn = operands(lay, m, n, k)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
