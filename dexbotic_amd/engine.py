@@ -77,7 +77,10 @@ class ParamStore:
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
         self.slots: Dict[str, Slot] = {}
-        self.epi_sumsq = False                  # the trainer turns it on: one GPU, clip enabled, no gradient accumulation
+        self.epi_sumsq = False                  # the trainer turns it on: one GPU, clip enabled
+        # gradient accumulation: only the LAST micro-batch's dW products (accumulate = 1: what they store is the step's final
+        # gradient) leave their share of sum(g^2); the trainer keeps this flag current (True without accumulation)
+        self.last_micro = True
         # weight gradients of a parameter applied k times in one forward (MemVLA's per-sample retrieval blocks): the k
         # (dY, X) pairs are collected and ONE product over all their rows writes dW once (functional._wgrad), instead of k
         # read-modify-write passes over the gradient (k rank-1 updates of a 14336 x 3584 matrix for the one-token cognition
@@ -110,6 +113,7 @@ class ParamStore:
         self.on_bucket_ready: Optional[Callable[[int], None]] = None
         self._bucket_pending: List[int] = []
         self._micro_written: set = set()
+        self._micro_touched: set = set()
         self._uses: Dict[str, int] = {}
         # embedding-gradient rows written since the slice was last all-zero (sparse re-zero, functional.SpliceFn)
         self.sparse_embed_zero = False
@@ -258,6 +262,7 @@ class ParamStore:
         complete on their first write."""
         for nm in names:
             self.grad_written[nm] = True
+            self._micro_touched.add(nm)
             b = self.slots[nm].bucket
             self._bucket_touched[b] = True
             left = self._uses.get(nm, 0)
@@ -301,6 +306,7 @@ class ParamStore:
 
     def begin_micro(self) -> None:
         self._micro_written = set()
+        self._micro_touched = set()                       # slots that received ANY gradient write this micro-batch
         self._mirrored = set()
         self._uses = {}
         self._bucket_pending = list(self._bucket_total)
@@ -328,7 +334,11 @@ class ParamStore:
             return None
         # (first_write: the caller knows — the one deferred product of a multiply-used parameter — that nothing has been
         # written to the slot this step although its consumers were already counted down)
-        written = self.grad_written[names[0]] if first_write is None else not first_write
+        if not self.last_micro:
+            return None                                   # an earlier micro-batch: more contributions follow
+        # written THIS micro-batch (a slot several kernels add into): not final.  Contributions of EARLIER micro-batches are
+        # fine — the product accumulates onto them and the epilogue squares what it stores.
+        written = any(nm in self._micro_touched for nm in names) if first_write is None else not first_write
         if written or any(self._uses.get(nm, 0) > 1 for nm in names):
             return None
         from . import kernels as K
@@ -568,9 +578,13 @@ class FusedAdamW:
         self.group_of: Dict[str, Tuple[str, bool]] = {}      # parameter name -> (lr key, weight-decayed?)
         cs, cl, cg = [], [], []
         explicit = None
+        self._explicit_defaults: Optional[List[Tuple[Optional[float], Optional[float]]]] = None
         if groups is not None:
             explicit = {nm: gi for gi, g in enumerate(groups) for nm in g["names"]}
             self.group_keys = [(f"group{gi}", True) for gi in range(len(groups))]
+            # per-group defaults for callers that step without lrs / wds: an entry may carry "lr" / "weight_decay" (the
+            # reference's groups do, base_exp.py:95-203); a group without them refuses to be stepped on guessed values
+            self._explicit_defaults = [(g.get("lr"), g.get("weight_decay")) for g in groups]
         for s in sorted(store.slots.values(), key=lambda s: s.offset):
             if not store.params[s.name].requires_grad or s.name in exclude:
                 continue
@@ -630,6 +644,13 @@ class FusedAdamW:
 
     def _lrs_wds(self, lr_scale: float):
         c = self.cfg
+        if self._explicit_defaults is not None:
+            if any(lr is None or wd is None for lr, wd in self._explicit_defaults):
+                raise ValueError("FusedAdamW was built from explicit parameter groups without 'lr' / 'weight_decay' entries: "
+                                 "pass lrs= and wds= to step() (exp.trainer.ArenaAdamW does), base_lr / the name rule do not "
+                                 "apply to explicit groups")
+            return ([float(lr) * lr_scale for lr, _ in self._explicit_defaults],
+                    [float(wd) for _, wd in self._explicit_defaults])
         lr_of = {"base": c.base_lr, "mm_projector": c.mm_projector_lr, "mm_vision": c.mm_vision_lr,
                  "action_head": c.action_head_lr}
         lrs = [lr_of.get(k, c.base_lr) * lr_scale for k, _ in self.group_keys]
@@ -656,9 +677,11 @@ class FusedAdamW:
                 sumsq = self.sumsq
             K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef)
             clip = self.coef
-        d_lrs, d_wds = self._lrs_wds(lr_scale)
-        lrs = d_lrs if lrs is None else [float(x) for x in lrs]
-        wds = d_wds if wds is None else [float(x) for x in wds]
+        if lrs is None or wds is None:
+            d_lrs, d_wds = self._lrs_wds(lr_scale)
+            lrs = d_lrs if lrs is None else lrs
+            wds = d_wds if wds is None else wds
+        lrs, wds = [float(x) for x in lrs], [float(x) for x in wds]
         assert len(lrs) == len(wds) == len(self.group_keys)
         if not self.overlap:
             K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,

@@ -96,8 +96,13 @@ class NativeDexboticTrainer(Trainer):
         self._core: Optional[NativeTrainer] = None
         self._core_kw = dict(kwargs.pop("native", None) or {})
         training_args = kwargs.pop("args", None) or link_exp_config(self.exp_config)
+        import types
+        # what the reference keeps beside the TrainingArguments (trainer.py: self.added_args): the adapter-only switch
+        self.added_args = types.SimpleNamespace(
+            tune_mm_mlp_adapter=bool(getattr(self.exp_config.trainer_config, "tune_mm_mlp_adapter", False)))
         super().__init__(*args, args=training_args, **kwargs)
         self.loss_cache: Dict[str, float] = {}
+        self._loss_dev: Dict[str, Any] = {}
 
     # ---- the native machinery behind HF's loop ---------------------------------------------------------------------------
     def _grouped_parameters(self) -> List[dict]:
@@ -113,7 +118,9 @@ class NativeDexboticTrainer(Trainer):
                               adam_beta2=self.args.adam_beta2, adam_epsilon=self.args.adam_epsilon,
                               max_grad_norm=self.MAX_GRAD_NORM)
             name_of = {id(p): n for n, p in self.model.store.params.items()}
-            groups = [{"names": [name_of[id(p)] for p in g["params"] if id(p) in name_of]} for g in self._grouped_parameters()]
+            groups = [{"names": [name_of[id(p)] for p in g["params"] if id(p) in name_of],
+                       "lr": float(g.get("lr", self.args.learning_rate)), "weight_decay": float(g.get("weight_decay", 0.0))}
+                      for g in self._grouped_parameters()]
             self._core = NativeTrainer(self.model, cfg, grad_accum=self.args.gradient_accumulation_steps,
                                        optimizer_groups=groups, **self._core_kw)
         return self._core
@@ -148,13 +155,22 @@ class NativeDexboticTrainer(Trainer):
     def training_step(self, model, inputs, num_items_in_batch=None):
         model.train()
         inputs = self._prepare_inputs(inputs)
+        core = self.core
+        if core.micro % core.grad_accum == 0:
+            # first micro-batch of an accumulation group: HF closes a SHORT group at the end of an epoch whose length does not
+            # divide by gradient_accumulation_steps (Trainer._inner_training_loop: ``remainder``, do_sync_step on the last
+            # batch) and calls optimizer.step() after it — the group's real size is len(batch_samples), published as
+            # current_gradient_accumulation_steps
+            group = int(getattr(self, "current_gradient_accumulation_steps", None) or self.args.gradient_accumulation_steps)
+            if group != core.grad_accum:
+                core.set_grad_accum(group)
         # HF does NOT divide the loss by the accumulation steps for a model whose forward takes **kwargs once it passes
         # num_items_in_batch (Trainer.training_step; true of the reference's forwards under its pinned transformers 4.51): the
         # micro-batch gradients are then summed, not averaged, before the 1.0 clip.  Mirrored here.
         summed = bool(getattr(self, "model_accepts_loss_kwargs", False)) and num_items_in_batch is not None
-        loss = self.core.micro_step(inputs, loss_scale=1.0 if summed else None)
-        self._cache_losses(self.core.last_output)
-        accum = self.args.gradient_accumulation_steps
+        loss = core.micro_step(inputs, loss_scale=1.0 if summed else None)
+        self._cache_losses(core.last_output)
+        accum = core.grad_accum
         return loss if (summed or accum == 1) else loss / accum
 
     def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
@@ -164,13 +180,64 @@ class NativeDexboticTrainer(Trainer):
         return (loss, outputs) if return_outputs else loss
 
     def _cache_losses(self, outputs) -> None:
+        # detached DEVICE scalars: converting here would drain the stream once per micro-batch (the step itself never waits for
+        # the host); log() converts, every logging_steps
         for key in [k for k in outputs.keys() if k.endswith("_loss")]:
             val = outputs[key]
-            if val is None or float(val) == 0.0:
-                self.loss_cache.setdefault(key, 0.0)
-                continue
-            self.loss_cache[key] = float(val.detach())
+            self._loss_dev[key] = None if val is None else (val.detach() if torch.is_tensor(val) else val)
 
     def log(self, logs: Dict[str, float], start_time: Optional[float] = None) -> None:
+        for key, val in self._loss_dev.items():
+            f = 0.0 if val is None else float(val)
+            if f == 0.0:                              # the reference keeps the last non-zero value (trainer.py:126-134)
+                self.loss_cache.setdefault(key, 0.0)
+            else:
+                self.loss_cache[key] = f
         logs.update(self.loss_cache)
         super().log(logs, start_time)
+
+    # ---- checkpoints: HF's cadence, the reference's contents (dexbotic/exp/trainer.py:38-87) -------------------------------
+    def _save(self, output_dir: Optional[str] = None, state_dict=None) -> None:
+        """what ``Trainer._save`` writes for a PreTrainedModel — config.json + model.safetensors + the tokenizer — through the
+        native model's own ``save_pretrained`` (it is not a ``PreTrainedModel``, so HF would write a bare state dict that
+        ``from_pretrained`` cannot read back).  Adapter-only runs save nothing here, like the reference."""
+        if getattr(getattr(self, "added_args", None), "tune_mm_mlp_adapter", False):
+            return
+        import os
+        output_dir = output_dir if output_dir is not None else self.args.output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        self.core.synchronize()                       # an overlapped optimizer update still in flight
+        self.model.save_pretrained(output_dir)
+        tok = getattr(self, "processing_class", None) or getattr(self, "tokenizer", None)
+        if tok is not None and hasattr(tok, "save_pretrained"):
+            tok.save_pretrained(output_dir)
+        torch.save(self.args, os.path.join(output_dir, "training_args.bin"))
+
+    def _save_checkpoint(self, model, trial, metrics=None) -> None:
+        import os
+        from transformers.trainer_utils import PREFIX_CHECKPOINT_DIR
+        output_dir = os.path.join(self._get_output_dir(trial=trial), f"{PREFIX_CHECKPOINT_DIR}-{self.state.global_step}")
+        main = self.args.local_rank in (0, -1)
+        if getattr(getattr(self, "added_args", None), "tune_mm_mlp_adapter", False):
+            # only the projector (trainer.py:41-57): config.json + mm_projector.bin
+            if main:
+                os.makedirs(output_dir, exist_ok=True)
+                self.core.synchronize()
+                self.model.config.save_pretrained(output_dir)
+                weights = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items() if "mm_projector" in k}
+                torch.save(weights, os.path.join(output_dir, "mm_projector.bin"))
+            return
+        try:
+            super()._save_checkpoint(model, trial)
+        except TypeError:
+            super()._save_checkpoint(model, trial, metrics)
+        if main:
+            self._copy_norm_stats_to_checkpoint(output_dir)
+
+    def _copy_norm_stats_to_checkpoint(self, checkpoint_dir: str) -> None:
+        """norm_stats.json travels with every checkpoint (trainer.py:68-82): inference de-normalises with it"""
+        import os
+        import shutil
+        src = os.path.join(self.args.output_dir, "norm_stats.json")
+        if os.path.exists(src) and os.path.isdir(checkpoint_dir):
+            shutil.copy2(src, os.path.join(checkpoint_dir, "norm_stats.json"))

@@ -292,6 +292,9 @@ class NativePreTrainedMixin:
         # forward and backward the same way).  Scoped to this forward (_external_loop_epilogue); the backward of every Function
         # re-enters the mode its forward ran in (functional._StoreFn)
         from .. import kernels as K
+        stale = self.__dict__.pop("_f32_mode_prev", None)
+        if stale is not None:
+            K.F32_GEMM_MODE = stale          # a previous forward raised before its epilogue hook ran: undo its mode first
         self.__dict__["_f32_mode_prev"] = K.F32_GEMM_MODE
         K.F32_GEMM_MODE = getattr(self.config, "fp32_matmul", "exact")
 

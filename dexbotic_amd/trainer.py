@@ -66,8 +66,9 @@ class NativeTrainer:
         # single GPU: nobody but the splice backward writes the dense embedding gradient, so it can be re-zeroed row-wise
         local = self.reducer is None or self.reducer.local_only        # nobody else writes this rank's gradient arenas
         self.store.sparse_embed_zero = local
-        # single GPU, one micro-batch per step: sum(g^2) of the weight gradients comes out of the dW products' epilogues
-        self.store.epi_sumsq = local and self.norm_tracker is not None and grad_accum == 1
+        # single GPU: sum(g^2) of the weight gradients comes out of the dW products' epilogues (under gradient accumulation:
+        # of the LAST micro-batch's, which store the step's final values — micro_step keeps store.last_micro current)
+        self.store.epi_sumsq = local and self.norm_tracker is not None
         self.store.defer_wgrad = True           # parameters with several consumers per forward: one dW product for all of them
         self.store.invalidate_embed_tracking()
         self._zeroed_unused = False
@@ -82,7 +83,7 @@ class NativeTrainer:
         assert n == 1 or not self.store.bf16_grads, "bf16 gradient arena needs one micro-batch per step"
         self.grad_accum, self.micro = int(n), 0
         local = self.reducer is None or self.reducer.local_only
-        self.store.epi_sumsq = local and self.norm_tracker is not None and self.grad_accum == 1
+        self.store.epi_sumsq = local and self.norm_tracker is not None
 
     def synchronize(self) -> None:
         """make the current stream wait for an overlapped optimizer update still in flight"""
@@ -108,6 +109,7 @@ class NativeTrainer:
         ``loss_scale``: factor on the loss before backward; default 1 / grad_accum (the mean over micro-batches)."""
         first = self.micro % self.grad_accum == 0
         last = (self.micro + 1) % self.grad_accum == 0
+        self.store.last_micro = last
         if first:
             self.store.begin_step()
         else:

@@ -146,6 +146,49 @@ def test_native_dexbotic_trainer_steps_and_full_train_loop(golden_dir):
     assert not tr2._prepare_inputs({"input_ids": torch.zeros(2, 4, dtype=torch.long), "images": torch.zeros(2, 3)})["input_ids"].is_cuda
 
 
+def test_native_dexbotic_trainer_short_last_group_and_checkpoints(golden_dir):
+    """(a) an epoch whose length does not divide by gradient_accumulation_steps: HF closes the last group after ONE micro-batch
+    and calls optimizer.step() (the reference's defaults: accumulation 2, drop_last False) — the native core must follow the
+    group HF actually built; (b) save_steps = 1: checkpoint-N holds config.json + model.safetensors (+ norm_stats.json copied
+    from the run directory, dexbotic/exp/trainer.py:38-82) and reloads through from_pretrained with identical weights."""
+    import json
+    from dexbotic_amd.exp.config import ExpConfig, OptimizerConfig, TrainerConfig
+    from dexbotic_amd.exp.trainer import NativeDexboticTrainer, link_exp_config
+    from dexbotic_amd.model.cogact.cogact_arch import CogACTForCausalLM
+    g, cfg, w = load_golden(golden_dir, "t1")
+    out_dir = tempfile.mkdtemp()
+    with open(os.path.join(out_dir, "norm_stats.json"), "w") as f:
+        json.dump({"min": [-1.0] * 7, "max": [1.0] * 7}, f)
+    exp = ExpConfig(TrainerConfig(output_dir=out_dir, num_train_epochs=1, num_train_steps=-1, per_device_train_batch_size=2,
+                                  gradient_accumulation_steps=2, logging_steps=1, dataloader_num_workers=0,
+                                  lr_scheduler_type="constant", save_strategy="steps", save_steps=1, save_total_limit=None,
+                                  save_only_model=True),
+                    OptimizerConfig(base_lr=LR, weight_decay=0.0))
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6                                   # 3 micro-batches of 2: groups of 2 + 1
+
+        def __getitem__(self, i):
+            rs = np.random.RandomState(i)
+            return {"input_ids": torch.from_numpy(g["input_ids"][i % 2]), "attention_mask": torch.from_numpy(g["attention_mask"][i % 2]),
+                    "labels": torch.from_numpy(g["input_ids"][i % 2]), "images": torch.from_numpy(g["images"][i % 2]),
+                    "actions": torch.from_numpy(rs.uniform(-1, 1, size=g["actions"].shape[1:]).astype(np.float32))}
+    m = build_product(cfg, w, "bfloat16", DEV, train=True)
+    tr = NativeDexboticTrainer(model=m, args=link_exp_config(exp, report_to=[]), train_dataset=DS(), exp_config=exp)
+    out = tr.train()
+    torch.cuda.synchronize()
+    assert out.global_step == 2 and tr.core.global_step == 2 and tr.core.opt.step_count == 2
+    assert not tr.core.update_due and tr.core.micro % tr.core.grad_accum == 0
+    assert any(k.endswith("_loss") for k in tr.loss_cache)
+    for step in (1, 2):
+        ck = os.path.join(out_dir, f"checkpoint-{step}")
+        assert os.path.exists(os.path.join(ck, "config.json")) and os.path.exists(os.path.join(ck, "model.safetensors")), os.listdir(ck)
+        assert os.path.exists(os.path.join(ck, "norm_stats.json"))
+    back = CogACTForCausalLM.from_pretrained(os.path.join(out_dir, "checkpoint-2"), torch_dtype=torch.bfloat16, device=DEV, train=False)
+    assert torch.equal(back.store.master, m.store.master)
+
+
 def test_gradient_checkpointing_is_refused_unless_opted_in(golden_dir, monkeypatch):
     g, cfg, w = load_golden(golden_dir, "t1")
     m = build_product(cfg, w, "float32", DEV, train=True)

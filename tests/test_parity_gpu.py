@@ -179,6 +179,11 @@ def test_gradient_accumulation_equals_big_batch(golden_dir):
                   timesteps=b["timesteps"][sel], drop_ids=b["drop_ids"][sel])
         tr.step(mb)
     assert rel_err(m2.store.grad.cpu().numpy(), g_full.cpu().numpy()) < 1e-4
+    # the global norm under accumulation: the LAST micro-batch's dW epilogues square what they store (= the accumulated
+    # gradient), the rest is read back — together exactly sum(g^2) of the arena
+    want = float((m2.store.grad.double() ** 2).sum())
+    assert m2.store.epi_sumsq and m2.store._ssq_cursor > 0, "the epilogue path was not taken on the last micro-batch"
+    assert abs(float(tr._sumsq) - want) < 1e-5 * want, (float(tr._sumsq), want)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
