@@ -282,6 +282,9 @@ def main():
     ap.add_argument("--vit-layers", dest="vit_layers", type=int, default=24)
     ap.add_argument("--force-reducer", action="store_true",
                     help="debug: run the RCCL gradient reducer even at world size 1 (exercises the DP code path)")
+    ap.add_argument("--native-avg", dest="native_avg", action="store_true",
+                    help="with --force-reducer at world size 1: the exact N > 1 collective sequence (in-place reduce_scatter(AVG) + "
+                         "all_gather on the communication stream under the backward) — provokes the RCCL / GEMM CU contention on one GPU")
     ap.add_argument("--grad-comm", dest="grad_comm", default="bfloat16", choices=["bfloat16", "float32"],
                     help="dtype of the data-parallel gradient all-reduce (the reference's DeepSpeed bf16 run reduces bf16)")
     ap.add_argument("--grad-dtype", dest="grad_dtype", default="float32", choices=["bfloat16", "float32"],
@@ -343,7 +346,7 @@ def main():
                             total_steps=1000, force_reducer=args.force_reducer,
                             grad_comm_dtype=getattr(torch, args.grad_comm), grad_accum=args.accum,
                             grad_dtype=getattr(torch, args.grad_dtype) if args.dtype == "bfloat16" else torch.float32,
-                            overlap_optimizer=args.overlap)
+                            overlap_optimizer=args.overlap, native_avg_world1=args.native_avg)
     if trainer.reducer is not None:
         trainer.reducer.time_comm = True
     from dexbotic_amd.data.feeder import DeviceFeeder

@@ -22,7 +22,8 @@ class NativeTrainer:
     def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
                  force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag",
-                 grad_dtype: torch.dtype = torch.float32, overlap_optimizer: bool = False, optimizer_groups=None):
+                 grad_dtype: torch.dtype = torch.float32, overlap_optimizer: bool = False, optimizer_groups=None,
+                 native_avg_world1: bool = False):
         import torch.distributed as dist
         self.model = model
         self.store = model.store
@@ -49,8 +50,10 @@ class NativeTrainer:
             grad_comm_dtype = torch.bfloat16
         self.reducer = None
         if use_dist and (dist.get_world_size() > 1 or force_reducer):
+            # native_avg_world1: at world size 1 take the exact collective sequence of N > 1 (bench.py --native-avg: RCCL kernels
+            # sharing the GPU with the backward's GEMM grids — the contention measurement of DESIGN.md section 6)
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
-                                       comm_dtype=grad_comm_dtype, algo=grad_sync)
+                                       comm_dtype=grad_comm_dtype, algo=grad_sync, native_avg_world1=native_avg_world1)
         elif bf16_grads:
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, comm_dtype=torch.bfloat16,
                                        local_only=True)

@@ -26,5 +26,30 @@ infer)   # per-request kernel table of action inference: difference of traces wi
   cd $R
   python profiles/rocpd_stats.py --per-step gpurun_out/prof/in10_results.db 10 gpurun_out/prof/in30_results.db 30 > gpurun_out/r04_infer_kernel_stats.txt
   tail -1 gpurun_out/r04_infer_30.log; head -24 gpurun_out/r04_infer_kernel_stats.txt | cut -c1-170 ;;
+contention)   # RCCL kernels of the N > 1 collective sequence sharing the GPU with the backward's GEMM grids, on ONE GPU
+  B="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-latency --no-secondary --no-recipe"
+  $B > gpurun_out/r04_cont_plain.json 2>/dev/null
+  $B --force-reducer > gpurun_out/r04_cont_sum.json 2>/dev/null
+  $B --force-reducer --native-avg > gpurun_out/r04_cont_avg_default.json 2>/dev/null
+  NCCL_MAX_NCHANNELS=8 $B --force-reducer --native-avg > gpurun_out/r04_cont_avg_8ch.json 2>/dev/null
+  NCCL_MAX_NCHANNELS=4 $B --force-reducer --native-avg > gpurun_out/r04_cont_avg_4ch.json 2>/dev/null
+  NCCL_MAX_NCHANNELS=4 $B --force-reducer --native-avg --grad-comm float32 > gpurun_out/r04_cont_avg_4ch_f32.json 2>/dev/null
+  python - <<'PY'
+import json, glob
+out = {}
+for f in sorted(glob.glob("gpurun_out/r04_cont_*.json")):
+    try:
+        d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+    except Exception as e:
+        out[f] = str(e); continue
+    bl = d.get("roofline", {}).get("by_layout", {})
+    out[f.split("r04_cont_")[1][:-5]] = {"ms_per_step": d["ms_per_step"], "episodes_per_s": d["value"],
+        "gemm_avg_launch_us": {k: v.get("avg_launch_us") for k, v in bl.items()}, "gemm_tf": {k: v.get("achieved") for k, v in bl.items()},
+        "comm_window_ms_per_step": d.get("comm_window_ms_per_step"), "collectives_per_step": d.get("collectives_per_step"),
+        "allreduce_gb_per_step": d.get("allreduce_gb_per_step")}
+json.dump(out, open("gpurun_out/r04_reducer_contention.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+  ;;
 esac; done
 rm -rf gpurun_out/prof

@@ -180,7 +180,6 @@ def test_native_dexbotic_trainer_short_last_group_and_checkpoints(golden_dir):
     torch.cuda.synchronize()
     assert out.global_step == 2 and tr.core.global_step == 2 and tr.core.opt.step_count == 2
     assert not tr.core.update_due and tr.core.micro % tr.core.grad_accum == 0
-    assert any(k.endswith("_loss") for k in tr.loss_cache)
     for step in (1, 2):
         ck = os.path.join(out_dir, f"checkpoint-{step}")
         assert os.path.exists(os.path.join(ck, "config.json")) and os.path.exists(os.path.join(ck, "model.safetensors")), os.listdir(ck)
