@@ -129,6 +129,10 @@ SIGNATURES = {
     "dxa_dit_assemble_bwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     "dxa_token_drop": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "dxa_token_drop_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dxa_dropout_mask": (_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint64, _int, _vp]),
+    "dxa_bank_consolidate": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _vp, _vp]),
+    "dxa_add_rows": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _int, _vp]),
+    "dxa_token_sum": (_int, [_vp, _vp, _i64, _i64, _i64, _f32, _int, _vp]),
     "dxa_mse_loss": (_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp]),
     "dxa_mse_loss_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "dxa_ddim_step": (_int, [_vp, _vp, _i64, _i64, _int, _f32, _f32, _f32, _f32, _vp]),

@@ -930,6 +930,51 @@ class AddFn(Function):
         return dy, dy
 
 
+class ForkFn(Function):
+    """x -> n aliases of x, one per consumer: the sum of the consumers' gradients is then library launches (dxa_add) instead of
+    the autograd engine's own at::add on a tensor that fans out (the MemVLA retrieval path is built from small Functions)"""
+
+    @staticmethod
+    def forward(ctx, x, n=2):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0].contiguous()
+        for g in gs[1:]:
+            acc = K.add(acc, g.contiguous())
+        return acc, None
+
+
+class CatLastFn(Function):
+    """[R, Da] , [R, Db] -> [R, Da + Db] (torch.cat(dim=-1) of the gate-fusion input, memvla_arch.py:176-180) with the
+    library's 2-D copy; the backward hands the two column blocks back as contiguous tensors"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        R, Da = a.shape
+        Db = b.shape[1]
+        ctx.dims = (Da, Db)
+        out = torch.empty((R, Da + Db), device=a.device, dtype=a.dtype)
+        K.copy2d(a.contiguous(), out[:, :Da], Da, Da)
+        K.copy2d(b.contiguous(), out[:, Da:], Db, Db)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        Da, Db = ctx.dims
+        R = dy.shape[0]
+        da = torch.empty((R, Da), device=dy.device, dtype=dy.dtype)
+        db = torch.empty((R, Db), device=dy.device, dtype=dy.dtype)
+        K.copy2d(dy[:, :Da], da, Da, Da)
+        K.copy2d(dy[:, Da:], db, Db, Db)
+        return da, db
+
+
 class AttnFn(Function):
     """softmax(q k^T / sqrt(D)) v for [B,S,H,D] VIEWS (any strides with D contiguous) -> [B,Sq,H*D]: the cross
     attention of CrossTransformerBlock (memvla_arch.py:84-127) and of the DiT per-attention (nn.MultiheadAttention,
@@ -957,6 +1002,44 @@ class AttnFn(Function):
         K.attn_bwd(P(q), P(k), P(v), P(o), lse, P(do), P(dq), P(dk), P(dv), causal=False, scale=D ** -0.5,
                    drop_mask=ctx.drop_mask)
         return dq, dk, dv, None
+
+
+class AttnPackedFn(Function):
+    """AttnFn on PACKED projections: ``qkv`` [B,S,3,H,D] (self attention, q = None) or ``q`` [B,Sq,H,D] + ``kv`` [B,Sk,2,H,D]
+    (nn.MultiheadAttention's packed in_proj of the DiT's perceptual cross attention, memvla/action_model/dit.py:158-185).  The
+    backward writes dq / dk / dv straight into ONE packed gradient buffer (the attention kernels take strided views), so
+    autograd sees a single tensor with a single consumer: no select_backward zero-fills, no gradient adds."""
+
+    @staticmethod
+    def forward(ctx, q, packed):
+        self_attn = q is None
+        ctx.self_attn = self_attn
+        if self_attn:
+            q, k, v = packed[:, :, 0], packed[:, :, 1], packed[:, :, 2]
+        else:
+            k, v = packed[:, :, 0], packed[:, :, 1]
+        B, Sq, H, D = q.shape
+        o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
+        P = lambda t: t.permute(0, 2, 1, 3)
+        lse = K.attn_fwd(P(q), P(k), P(v), P(o), causal=False, scale=D ** -0.5)
+        ctx.save_for_backward(q if not self_attn else packed, packed, o, lse)
+        return o.view(B, Sq, H * D)
+
+    @staticmethod
+    def backward(ctx, do):
+        qs, packed, o, lse = ctx.saved_tensors
+        dpk = torch.empty(packed.shape, device=packed.device, dtype=packed.dtype)
+        if ctx.self_attn:
+            q, k, v = packed[:, :, 0], packed[:, :, 1], packed[:, :, 2]
+            dq, dk, dv = dpk[:, :, 0], dpk[:, :, 1], dpk[:, :, 2]
+        else:
+            q, k, v = qs, packed[:, :, 0], packed[:, :, 1]
+            dq, dk, dv = torch.empty(q.shape, device=q.device, dtype=q.dtype), dpk[:, :, 0], dpk[:, :, 1]
+        B, Sq, H, D = q.shape
+        do = do.contiguous().view(B, Sq, H, D)
+        P = lambda t: t.permute(0, 2, 1, 3)
+        K.attn_bwd(P(q), P(k), P(v), P(o), lse, P(do), P(dq), P(dk), P(dv), causal=False, scale=D ** -0.5)
+        return (None, dpk) if ctx.self_attn else (dq, dpk)
 
 
 class DropFn(Function):
@@ -999,18 +1082,65 @@ class TokenMeanFn(Function):
     def forward(ctx, x):
         B, N, C_ = x.shape
         ctx.shape = (B, N, C_)
-        x = x.contiguous()
-        out = torch.empty((B, C_), device=x.device, dtype=torch.float32)
-        for b in range(B):
-            K.colsum(x[b], out=out[b])
-        return K.cast(K.scale_(out, 1.0 / N), x.dtype)
+        return K.token_sum(x.contiguous(), 1.0 / N)          # one launch: fp32 sums in token order, scaled, rounded once
 
     @staticmethod
     def backward(ctx, dm):
         B, N, C_ = ctx.shape
-        ones = torch.ones((B, N, C_), device=dm.device, dtype=dm.dtype)     # broadcast of dm / N over the tokens
-        g = K.cast(K.scale_(K.cast(dm.contiguous(), torch.float32), 1.0 / N), dm.dtype)
-        return K.mul_rows(ones, g)
+        return K.add_rows(None, dm.contiguous(), N, 1.0 / N)  # dm / N broadcast over the tokens
+
+
+class AddRowsFn(Function):
+    """x [R, N, C] + g [R, C] broadcast over the tokens: the timestep positional embedding on every token of a memory entry
+    (memvla_arch.py:352-360: pe.unsqueeze(1).expand(-1, N, -1) added to the bank)"""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        ctx.n = x.shape[1]
+        ctx.needs = (x.requires_grad, g.requires_grad)
+        return K.add_rows(x.contiguous(), g.contiguous(), x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return (dy if ctx.needs[0] else None), (K.token_sum(dy) if ctx.needs[1] else None)
+
+
+class UnbindRowsFn(Function):
+    """[B, ...] -> B tensors [1, ...] (the per-sample walk of the memory bank); the backward writes the B gradients side by
+    side with library copies instead of autograd's zero-fill + add per slice"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dt = tuple(x.shape), x.dtype
+        x = x.contiguous()
+        return tuple(x[i:i + 1] for i in range(x.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        out = torch.empty(ctx.shape, device=next(g for g in gs if g is not None).device, dtype=ctx.dt)
+        for i, g in enumerate(gs):
+            if g is None:
+                out[i].zero_()                                   # (a sample whose output nobody used: not on the training path)
+            else:
+                K.cast(g.contiguous(), ctx.dt, out=out[i:i + 1])
+        return out
+
+
+class CatRowsFn(Function):
+    """B tensors [1, ...] -> [B, ...] with library copies (torch.cat of the per-sample outputs)"""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        out = torch.empty((len(xs),) + tuple(xs[0].shape[1:]), device=xs[0].device, dtype=xs[0].dtype)
+        for i, x in enumerate(xs):
+            K.cast(x.contiguous(), out.dtype, out=out[i:i + 1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return tuple(dy[i:i + 1] for i in range(dy.shape[0]))
 
 
 class RowGateFn(Function):
@@ -1027,8 +1157,4 @@ class RowGateFn(Function):
         x, g = ctx.saved_tensors
         dy = dy.contiguous()
         B = x.shape[0]
-        prod = K.mul(dy, x)
-        dg = torch.empty((B, x.shape[2]), device=x.device, dtype=torch.float32)
-        for b in range(B):
-            K.colsum(prod[b], out=dg[b])
-        return K.mul_rows(dy, g), K.cast(dg, x.dtype)
+        return K.mul_rows(dy, g), K.token_sum(K.mul(dy, x))

@@ -213,6 +213,52 @@ def _ld_kwargs(kw: dict, out: torch.Tensor) -> dict:
     return kw
 
 
+# ------------------------------------------------------------------------------------- MemVLA memory path
+_MASK_STATE = {"seed": None, "offset": 0}
+
+
+def dropout_mask(shape, p: float, dtype: torch.dtype, device, seed: Optional[int] = None) -> torch.Tensor:
+    """a dropout mask (0 | 1/(1-p)) drawn on the device in ONE launch; successive masks advance a process-wide counter, the
+    key comes from torch's seed (torch.manual_seed makes runs repeatable)"""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    out = torch.empty(tuple(int(v) for v in shape), device=device, dtype=dtype)
+    if _MASK_STATE["seed"] is None or seed is not None:
+        _MASK_STATE["seed"] = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+    _MASK_STATE["offset"] += 1
+    L.check(lib.dxa_dropout_mask(_ptr(out), n, float(p), _MASK_STATE["seed"], _MASK_STATE["offset"], dt(out), _stream()),
+            "dxa_dropout_mask")
+    return out
+
+
+def bank_consolidate(feat: torch.Tensor, ts: torch.Tensor, length: int, sims: torch.Tensor, fifo: bool = False) -> None:
+    """token-merge of the most similar neighbouring pair (fifo: drop of the oldest entry) among the first ``length`` entries of
+    feat [cap, N, D] / ts [cap] (in place; afterwards the first length - 1 entries are the bank)"""
+    assert feat.is_contiguous() and ts.is_contiguous() and ts.dtype == torch.float32 and sims.dtype == torch.float32
+    assert feat.dim() == 3 and length <= feat.shape[0] and sims.numel() >= length - 1
+    L.check(lib.dxa_bank_consolidate(_ptr(feat), _ptr(ts), int(length), feat.shape[1], feat.shape[2], dt(feat), int(fifo),
+                                     _ptr(sims), _stream()), "dxa_bank_consolidate")
+
+
+def add_rows(x: Optional[torch.Tensor], g: torch.Tensor, Nn: int, alpha: float = 1.0) -> torch.Tensor:
+    """x [R, Nn, C] + alpha * g [R, C] broadcast over the tokens (x None: the broadcast alone)"""
+    R, C_ = g.shape
+    assert g.is_contiguous() and (x is None or (x.is_contiguous() and x.shape == (R, Nn, C_) and x.dtype == g.dtype))
+    out = torch.empty((R, Nn, C_), device=g.device, dtype=g.dtype)
+    L.check(lib.dxa_add_rows(_ptr(x), _ptr(g), _ptr(out), R, Nn, C_, float(alpha), dt(g), _stream()), "dxa_add_rows")
+    return out
+
+
+def token_sum(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """scale * sum over the token axis: [R, Nn, C] -> [R, C] (same dtype, fp32 accumulation)"""
+    R, Nn, C_ = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((R, C_), device=x.device, dtype=x.dtype)
+    L.check(lib.dxa_token_sum(_ptr(x), _ptr(out), R, Nn, C_, float(scale), dt(x), _stream()), "dxa_token_sum")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- norms
 def rmsnorm_fwd(x: torch.Tensor, w: Optional[torch.Tensor], eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     x2 = x.reshape(-1, x.shape[-1])

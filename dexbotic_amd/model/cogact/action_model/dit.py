@@ -132,21 +132,25 @@ class DiT(nn.Module):
                                    "for autograd; call forward(per_token=...) when gradients are needed")
             return self._block_with_per_attn_sampler(st, b, hcur, kv, N, T1)
         lin = lambda x, wn, bn: Fn.LinearFn.apply(x, anchor, st, wn, bn, L.ACT_NONE, None)
-        y = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
+        # every tensor with two consumers is forked explicitly and the packed projections stay packed through the attention
+        # (Fn.ForkFn / Fn.AttnPackedFn): the backward then consists of library launches only
+        hn, hr = Fn.ForkFn.apply(hcur)
+        y = Fn.NormFn.apply(hn, anchor, st, "ln", None, None, 1e-6)
         qkv = lin(y, b + "attn.qkv.weight", b + "attn.qkv.bias").view(N, T1, 3, H, D)
-        o = Fn.AttnFn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).reshape(N * T1, h)
-        hcur = Fn.AddFn.apply(hcur, lin(o, b + "attn.proj.weight", b + "attn.proj.bias"))
-        y3 = Fn.NormFn.apply(hcur, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
+        o = Fn.AttnPackedFn.apply(None, qkv).reshape(N * T1, h)
+        hcur = Fn.AddFn.apply(hr, lin(o, b + "attn.proj.weight", b + "attn.proj.bias"))
+        hn, hr = Fn.ForkFn.apply(hcur)
+        y3 = Fn.NormFn.apply(hn, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
         P_ = pe.shape[1]
         qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
                                           b + "per_attn.in_proj_bias", h)            # q [N*T1, h], [k | v] [N*P, 2h]
-        kvf = kvf.view(N, P_, 2, H, D)
-        o2 = Fn.AttnFn.apply(qf.view(N, T1, H, D), kvf[:, :, 0], kvf[:, :, 1]).reshape(N * T1, h)
-        hcur = Fn.AddFn.apply(hcur, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
-        y2 = Fn.NormFn.apply(hcur, anchor, st, "ln", None, None, 1e-6)
+        o2 = Fn.AttnPackedFn.apply(qf.view(N, T1, H, D), kvf.view(N, P_, 2, H, D)).reshape(N * T1, h)
+        hcur = Fn.AddFn.apply(hr, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
+        hn, hr = Fn.ForkFn.apply(hcur)
+        y2 = Fn.NormFn.apply(hn, anchor, st, "ln", None, None, 1e-6)
         m = Fn.MlpFn.apply(y2, anchor, st, b + "mlp.fc1.weight", b + "mlp.fc1.bias", b + "mlp.fc2.weight",
                            b + "mlp.fc2.bias", L.ACT_GELU_TANH)
-        return Fn.AddFn.apply(hcur, m)
+        return Fn.AddFn.apply(hr, m)
 
     def _block_with_per_attn_sampler(self, st, b: str, hcur: torch.Tensor, kv: torch.Tensor, N: int, T1: int) -> torch.Tensor:
         """the same block for the sampler (no autograd graph, cached perceptual [k | v]): 11 launches instead of 14 — the three
@@ -241,8 +245,10 @@ class DiT(nn.Module):
                 per_token.float().contiguous(), anchor, st, p + "per_token_embedder.linear.weight",
                 p + "per_token_embedder.linear.bias", L.ACT_NONE, None)                         # (N,P,h)
             hcur = hcur.reshape(N * (T + 1), h)
+            pes = [None] * self.depth if pe is None else \
+                (Fn.ForkFn.apply(pe, self.depth) if (torch.is_grad_enabled() and pe.requires_grad) else [pe] * self.depth)
             for k in range(self.depth):
-                hcur = self._block_with_per_attn(st, k, hcur, pe, N, T + 1, None if per_kv is None else per_kv[k])
+                hcur = self._block_with_per_attn(st, k, hcur, pes[k], N, T + 1, None if per_kv is None else per_kv[k])
         elif self._use_fused_blocks(N, T + 1):
             # inference, one request: every block in ONE persistent launch (csrc/dit_fused.hip)
             self.used_fused = True

@@ -106,8 +106,7 @@ class CrossTransformerBlock(nn.Module):
         if self.mask_fn is not None:
             m = self.mask_fn(tuple(shape))
             return torch.as_tensor(m).to(device=like.device, dtype=like.dtype).reshape(shape).contiguous()
-        keep = torch.rand(shape, device=like.device) >= self.dropout
-        return (keep.to(torch.float32) / (1.0 - self.dropout)).to(like.dtype)
+        return K.dropout_mask(shape, self.dropout, like.dtype, like.device)      # one launch (dxa_dropout_mask)
 
     def forward(self, query: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         st, p, D, H = self.store, self.p, self.D, self.H
@@ -115,13 +114,15 @@ class CrossTransformerBlock(nn.Module):
         M = k.shape[1]
         hd = D // H
         drop = self.dropout > 0.0 and self.training
-        q2 = query.reshape(B * N, D)
+        # tensors with two consumers are forked explicitly (Fn.ForkFn): their gradient sums are then library launches
+        q2, q2r = Fn.ForkFn.apply(query.reshape(B * N, D))
         qp = _lin(st, q2, p + "q_proj.weight", p + "q_proj.bias").view(B, N, H, hd)
         kp = _lin(st, k.reshape(B * M, D), p + "k_proj.weight", p + "k_proj.bias").view(B, M, H, hd)
         vp = _lin(st, v.reshape(B * M, D), p + "v_proj.weight", p + "v_proj.bias").view(B, M, H, hd)
         o = Fn.AttnFn.apply(qp, kp, vp, self._mask((B, H, N, M), qp) if drop else None).reshape(B * N, D)
         anchor = st.params[p + "attn_norm.weight"]
-        x = Fn.NormFn.apply(Fn.AddFn.apply(q2, o), anchor, st, "ln", p + "attn_norm.weight", p + "attn_norm.bias", 1e-5)
+        x = Fn.NormFn.apply(Fn.AddFn.apply(q2r, o), anchor, st, "ln", p + "attn_norm.weight", p + "attn_norm.bias", 1e-5)
+        x, xr = Fn.ForkFn.apply(x)
         if drop:
             h = _lin(st, x, p + "ffn.0.weight", p + "ffn.0.bias", L.ACT_GELU_ERF)
             h = Fn.DropFn.apply(h, self._mask((B * N, 4 * D), h))
@@ -130,8 +131,19 @@ class CrossTransformerBlock(nn.Module):
         else:
             f = Fn.MlpFn.apply(x, anchor, st, p + "ffn.0.weight", p + "ffn.0.bias", p + "ffn.3.weight", p + "ffn.3.bias",
                                L.ACT_GELU_ERF)
-        y = Fn.NormFn.apply(Fn.AddFn.apply(x, f), anchor, st, "ln", p + "ffn_norm.weight", p + "ffn_norm.bias", 1e-5)
+        y = Fn.NormFn.apply(Fn.AddFn.apply(xr, f), anchor, st, "ln", p + "ffn_norm.weight", p + "ffn_norm.bias", 1e-5)
         return y.view(B, N, D)
+
+
+class _BankBuf:
+    """one episode's memory of one role: entries oldest first in one device buffer, timesteps beside them, count on the host"""
+    __slots__ = ("feat", "ts", "sims", "n")
+
+    def __init__(self, cap: int, N: int, D: int, dtype, device):
+        self.feat = torch.empty((cap, N, D), device=device, dtype=dtype)
+        self.ts = torch.empty(cap, device=device, dtype=torch.float32)
+        self.sims = torch.empty(max(cap, 2), device=device, dtype=torch.float32)
+        self.n = 0
 
 
 class PerCogMemBank(nn.Module):
@@ -171,7 +183,15 @@ class PerCogMemBank(nn.Module):
         self.reset()
 
     def reset(self):
-        self.banks: Dict[str, Dict[tuple, List[Tuple[torch.Tensor, torch.Tensor]]]] = {r: {} for r in self.roles}
+        # banks[role][episode] = _BankBuf: the entries (oldest first) live side by side in ONE device buffer [mem_length + 1, N, D]
+        # with their timesteps [mem_length + 1] (fp32, device: after a token merge a timestep is the mean of two, chosen on the
+        # device); the host only keeps the COUNT, which evolves without reading anything back
+        self.banks: Dict[str, Dict[tuple, "_BankBuf"]] = {r: {} for r in self.roles}
+
+    def entries(self, role: str, eid=(0, 0)) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        """[(timestep, feat[N, D])] of one bank, oldest first (tests / inspection; the reference's list layout)"""
+        b = self.banks[role].get(tuple(eid))
+        return [] if b is None else [(b.ts[i], b.feat[i]) for i in range(b.n)]
 
     def train(self, mode: bool = True):
         super().train(mode)
@@ -195,32 +215,31 @@ class PerCogMemBank(nn.Module):
         if key not in self._freqs:
             self._freqs[key] = torch.exp(-math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128).to(t.device)
         p = f"{BANK}timestep_embedders.{role}."
-        e = K.timestep_embedding(t.float().contiguous(), self._freqs[key]).to(dtype)
+        e = K.timestep_embedding(t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous(), self._freqs[key])
+        if dtype != torch.float32:
+            e = K.cast(e, dtype)
         return Fn.MlpFn.apply(e, st.params[p + "mlp.0.weight"], st, p + "mlp.0.weight", p + "mlp.0.bias",
                               p + "mlp.2.weight", p + "mlp.2.bias", L.ACT_SILU)
 
     @torch.no_grad()
     def _consolidate(self, role: str, eid, feat: torch.Tensor, timestep: torch.Tensor) -> None:
-        bank = self.banks[role].setdefault(eid, [])
-        bank.append((timestep, feat.detach().clone()))
-        while len(bank) > self.mem_length:
-            if self.consolidate_type == "fifo":
-                del bank[:-self.mem_length]
-                break
-            # token merge (:263-287): fuse the most similar pair of neighbouring entries.  Bookkeeping on detached
-            # features; the similarity decision needs a host value, as in the reference (.item()).
-            sims = []
-            for i in range(len(bank) - 1):
-                f1, f2 = bank[i][1].float(), bank[i + 1][1].float()
-                f1 = f1.flatten(1) if f1.dim() > 1 else f1.unsqueeze(0)
-                f2 = f2.flatten(1) if f2.dim() > 1 else f2.unsqueeze(0)
-                sims.append(F.cosine_similarity(f1, f2, dim=1).mean().item())
-            j = int(np.argmax(np.array(sims)))
-            (ti, fi), (tj, fj) = bank[j], bank[j + 1]
-            bank[j] = (0.5 * (ti + tj), K.axpby(fi.contiguous(), fj.contiguous(), 0.5, 0.5))
-            bank.pop(j + 1)
+        """append (detached copy) + consolidation (_memory_consolidate, memvla_arch.py:289-306): library copies into the bank's
+        buffer, then — once the bank is over mem_length — ONE device-side merge (dxa_bank_consolidate: similarities, arg-max,
+        merge, compaction; 'fifo': drop of the oldest) per surplus entry.  Nothing is read back."""
+        N, D = feat.shape[-2] if feat.dim() > 1 else 1, feat.shape[-1]
+        bank = self.banks[role].get(eid)
+        if bank is None:
+            bank = self.banks[role][eid] = _BankBuf(self.mem_length + 1, N, D, feat.dtype, feat.device)
+        assert bank.n <= self.mem_length
+        K.cast(feat.detach().reshape(1, N, D).contiguous(), bank.feat.dtype, out=bank.feat[bank.n:bank.n + 1])
+        K.cast(timestep.reshape(1), torch.float32, out=bank.ts[bank.n:bank.n + 1])
+        bank.n += 1
+        while bank.n > self.mem_length:
+            K.bank_consolidate(bank.feat, bank.ts, bank.n, bank.sims, fifo=self.consolidate_type == "fifo")
+            bank.n -= 1
 
-    def _process_batch(self, role: str, tokens: torch.Tensor, episode_ids, timesteps) -> torch.Tensor:
+    def _process_batch(self, role: str, tokens: torch.Tensor, episode_ids, timesteps: torch.Tensor) -> torch.Tensor:
+        """``timesteps``: ONE fp32 device tensor [B] (a single upload per batch)"""
         st = self.store
         B, N, D = tokens.shape
         if self.training:
@@ -228,30 +247,41 @@ class PerCogMemBank(nn.Module):
         else:
             episode_ids = [(0, 0) for _ in range(B)]
         gp = f"{BANK}gate_fusion_blocks.{role}."
+        nl = len(self.blocks[role])
+        grad = torch.is_grad_enabled() and tokens.requires_grad
+        rows = Fn.UnbindRowsFn.apply(tokens) if B > 1 else (tokens,)
         outs = []
         for i in range(B):
             eid = tuple(episode_ids[i])
-            working = tokens[i:i + 1].contiguous()                      # (1,N,D)
-            hist = self.banks[role].get(eid, [])
-            if hist:
-                mem = torch.stack([f for _, f in hist], 0).reshape(1, -1, D)
-                ht = torch.stack([t.float() for t, _ in hist], 0).to(tokens.device)
-                pe = self._encode_time(role, ht, tokens.dtype)          # (T,D)
-                pe = pe.unsqueeze(1).expand(-1, N, -1).reshape(1, -1, D)
+            bank = self.banks[role].get(eid)
+            has_hist = bank is not None and bank.n > 0
+            # consumers of this sample's tokens: the query of block 0, the two gate-fusion operands (+ without history: the key
+            # sum and one value per block, the frame retrieving from itself, :345-349)
+            fork = Fn.ForkFn.apply(rows[i], 3 if has_hist else 4 + nl)
+            working, w_cat, w_fuse = fork[0], fork[1].reshape(N, D), fork[2].reshape(N, D)
+            if has_hist:
+                T_ = bank.n
+                # a snapshot: the bank's buffer is overwritten by the next frames while this sample's backward still needs
+                # what it retrieved from (k / v projection inputs)
+                mem = K.cast(bank.feat[:T_], bank.feat.dtype) if grad else bank.feat[:T_]
+                pe = self._encode_time(role, bank.ts[:T_], tokens.dtype)          # (T,D)
+                vals = [mem.reshape(1, T_ * N, D)] * nl
             else:
-                mem = working
-                pe = self._encode_time(role, timesteps[i].reshape(1).to(tokens.device), tokens.dtype)
-                pe = pe.unsqueeze(1).expand(-1, N, -1).reshape(1, -1, D)
-            key = Fn.AddFn.apply(mem.contiguous(), pe.contiguous())
+                T_ = 1
+                mem = fork[3]
+                pe = self._encode_time(role, timesteps[i:i + 1], tokens.dtype)
+                vals = [fork[4 + l] for l in range(nl)]
+            key = Fn.AddRowsFn.apply(mem.reshape(T_, N, D), pe).reshape(1, T_ * N, D)
+            keys = Fn.ForkFn.apply(key, nl) if nl > 1 else (key,)
             q = working
-            for blk in self.blocks[role]:
-                q = blk(q, key, mem)
-            w2, q2 = working.reshape(N, D), q.reshape(N, D)
-            scale = _lin(st, torch.cat([w2, q2], dim=-1), gp + "proj.weight", gp + "proj.bias", L.ACT_SIGMOID)
-            fused = Fn.GateFuseFn.apply(scale, w2, q2).view(1, N, D)
+            for l, blk in enumerate(self.blocks[role]):
+                q = blk(q, keys[l], vals[l])
+            q_cat, q_fuse = Fn.ForkFn.apply(q.reshape(N, D))
+            scale = _lin(st, Fn.CatLastFn.apply(w_cat, q_cat), gp + "proj.weight", gp + "proj.bias", L.ACT_SIGMOID)
+            fused = Fn.GateFuseFn.apply(scale, w_fuse, q_fuse).view(1, N, D)
             outs.append(fused)
-            self._consolidate(role, eid, fused[0] if self.update_fused else tokens[i], timesteps[i])
-        return torch.cat(outs, dim=0)
+            self._consolidate(role, eid, fused[0] if self.update_fused else tokens[i], timesteps[i:i + 1])
+        return Fn.CatRowsFn.apply(*outs) if B > 1 else outs[0]
 
     def process_batch_per(self, per_tokens, episode_ids, timesteps):
         return self._process_batch("per", per_tokens, episode_ids, timesteps)
@@ -331,7 +361,7 @@ class MemVLAForCausalLM(CogACTForCausalLM):
             cog = Fn.GatherRowsFn.apply(hidden.reshape(B * S, d), idx).to(hidden.dtype).view(B, 1, d)
             per = self.model.per_compr(vision_proj.reshape(B, -1, d))
             eids = [tuple(int(v) for v in item[:2]) for item in indexes]
-            ts = [torch.tensor(float(item[2]), device=hidden.device) for item in indexes]
+            ts = torch.tensor([float(item[2]) for item in indexes], dtype=torch.float32).to(hidden.device, non_blocking=True)
             bank = self.model.per_cog_mem_bank
             cog = bank.process_batch_cog(cog, eids, ts)
             per = bank.process_batch_per(per, eids, ts)
@@ -359,7 +389,7 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         B, d = hidden.shape[0], hidden.shape[-1]
         cog = hidden[:, -1, :].unsqueeze(1).contiguous()
         per = self.model.per_compr(vision_proj.reshape(B, -1, d))
-        ts = [torch.tensor(float(self.cur_timestep), device=dev)]
+        ts = torch.tensor([float(self.cur_timestep)], dtype=torch.float32).to(dev)
         self.cur_timestep += 1
         cog = bank.process_batch_cog(cog, [(0, 0)], ts)
         per = bank.process_batch_per(per, [(0, 0)], ts)

@@ -281,6 +281,24 @@ int dxa_token_drop(const float* z, const float* uncond, const uint8_t* drop, flo
 /* dz[n] = drop[n] ? 0 : dout[n] (dz may be NULL); duncond[c] (+)= sum over dropped n of dout[n,c] */
 int dxa_token_drop_bwd(const float* dout, const uint8_t* drop, float* dz, float* duncond, int64_t N,
                        int64_t d, int accumulate, dxa_stream_t stream);
+/* ---- MemVLA memory path, device side (dexbotic/model/memvla/memvla_arch.py) ----------------------------------------
+ * out[i] = u_i >= p ? 1/(1-p) : 0, u_i uniform in [0,1) from Philox4x32-10 keyed by `seed`, counter (i / 4, offset): one
+ * launch per dropout mask of the retrieval blocks (SDPA's dropout_p on the attention weights, memvla_arch.py:120-123, and
+ * the two nn.Dropout of the FFN, :99-105).  Statistically the reference's draw, not bit-for-bit torch's generator. */
+int dxa_dropout_mask(void* out, int64_t n, float p, uint64_t seed, uint64_t offset, int dtype, dxa_stream_t stream);
+/* token-merge consolidation of ONE memory bank on the device (_consolidate_with_token_merge, memvla_arch.py:263-287):
+ * feat [len, N, D] (dtype), ts [len] fp32, len >= 2 entries oldest first.  sims[i] = mean_n cos(feat[i,n,:], feat[i+1,n,:])
+ * (eps 1e-8 per norm), j = first arg-max; feat[j] <- 0.5 (feat[j] + feat[j+1]), ts[j] likewise, the later entries move down:
+ * afterwards the first len - 1 entries are the bank.  `sims`: len - 1 floats of scratch.  No host read-back. */
+int dxa_bank_consolidate(void* feat, float* ts, int len, int64_t N, int64_t D, int dtype, int fifo, float* sims,
+                         dxa_stream_t stream);      /* fifo = 1: drop the oldest entry instead (memvla_arch.py:300-303) */
+/* out[r,n,:] = (x ? x[r,n,:] : 0) + alpha g[r,:]: the timestep embedding added to every token of a bank entry
+ * (memvla_arch.py:352-360); x = NULL: broadcast of a row over the tokens (backward of the token mean, :139-141) */
+int dxa_add_rows(const void* x, const void* g, void* out, int64_t R, int64_t Nn, int64_t C, float alpha, int dtype,
+                 dxa_stream_t stream);
+/* out[r,:] = scale * sum_n x[r,n,:] (fp32 accumulation, token order): AdaptiveAvgPool2d(1) of BottleneckSE
+ * (memvla_arch.py:139-141) and the gradient of a row broadcast over the tokens */
+int dxa_token_sum(const void* x, void* out, int64_t R, int64_t Nn, int64_t C, float scale, int dtype, dxa_stream_t stream);
 /* loss = mean((pred-target)^2) (action_models.py:119-121); dpred = 2 (pred-target) / n * gscale */
 int dxa_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int64_t n,
                  float gscale, dxa_stream_t stream);

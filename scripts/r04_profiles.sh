@@ -26,6 +26,18 @@ infer)   # per-request kernel table of action inference: difference of traces wi
   cd $R
   python profiles/rocpd_stats.py --per-step gpurun_out/prof/in10_results.db 10 gpurun_out/prof/in30_results.db 30 > gpurun_out/r04_infer_kernel_stats.txt
   tail -1 gpurun_out/r04_infer_30.log; head -24 gpurun_out/r04_infer_kernel_stats.txt | cut -c1-170 ;;
+memvla)  # exact per-step kernel table of the MemVLA fine-tune step (1 + 2 warm-up vs 3 + 2 warm-up steps)
+  cd /tmp; export TMPDIR=/tmp
+  for n in 1 3; do SKIP_INFER=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o mem$n -- python $R/scripts/memvla_bench.py $n > $R/gpurun_out/r04_memvla_$n.log 2>&1; done
+  cd $R
+  python profiles/rocpd_stats.py --per-step gpurun_out/prof/mem1_results.db 3 gpurun_out/prof/mem3_results.db 5 > gpurun_out/r04_memvla_train_per_step_kernel_stats.txt 2>&1
+  grep "^{" gpurun_out/r04_memvla_3.log; head -70 gpurun_out/r04_memvla_train_per_step_kernel_stats.txt | cut -c1-160 ;;
+pi0)
+  cd /tmp; export TMPDIR=/tmp
+  for n in 1 3; do SKIP_INFER=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o pi$n -- python $R/scripts/pi0_bench.py $n 16 > $R/gpurun_out/r04_pi0_$n.log 2>&1; done
+  cd $R
+  python profiles/rocpd_stats.py --per-step gpurun_out/prof/pi1_results.db 3 gpurun_out/prof/pi3_results.db 5 > gpurun_out/r04_pi0_train_per_step_kernel_stats.txt 2>&1
+  grep "^{" gpurun_out/r04_pi0_3.log; head -40 gpurun_out/r04_pi0_train_per_step_kernel_stats.txt | cut -c1-160 ;;
 contention)   # RCCL kernels of the N > 1 collective sequence sharing the GPU with the backward's GEMM grids, on ONE GPU
   B="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-latency --no-secondary --no-recipe"
   $B > gpurun_out/r04_cont_plain.json 2>/dev/null
