@@ -88,6 +88,7 @@ SIGNATURES = {
     "dxa_version": (_int, []),
     "dxa_gemm": (_int, [C.POINTER(GemmDesc), _vp]),
     "dxa_split3": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),
+    "dxa_split3_t": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _int, _vp]),
     "dxa_rmsnorm_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
     "dxa_rmsnorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),

@@ -1785,6 +1785,48 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
 }
 }  // namespace
 
+namespace {
+// split3 of the TRANSPOSE in one pass: src [R, C] fp32 -> dst [C, 3 Rp] bf16, dst[c, j Rp + r] = part j of src[r, c] (r < R; the
+// padding columns R .. Rp - 1 are zero).  What transpose_k + split3_k did in two launches through an fp32 intermediate for the
+// dX = dY W and dW = dY^T X products of the fp32 heads (they run as NT products of the transposed operands).  32 x 32 tiles
+// through LDS (33-float rows: no bank conflicts), 256 threads = 32 x 8.
+__global__ __launch_bounds__(256) void split3_t_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst, int64_t R,
+                                                  int64_t C, int64_t Rp, int side) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[r * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < Rp) {
+      const float x = tile[tx][ty + 8 * i];
+      const bf16_t hb = f2bf(x);
+      const bf16_t lb = f2bf(x - bf2f(hb));
+      bf16_t* d = dst + c * 3 * Rp + r;
+      d[0] = hb;
+      d[Rp] = side == 0 ? hb : lb;
+      d[2 * Rp] = side == 0 ? lb : hb;
+    }
+  }
+}
+}  // namespace
+extern "C" int dxa_split3_t(const float* src, int64_t ld, void* dst, int64_t R, int64_t C, int64_t Rp, int side,
+                            dxa_stream_t stream) {
+  DXA_CHECK_ARG(R >= 0 && C >= 0 && Rp >= R && ld >= C && (side == 0 || side == 1), "dxa_split3_t: bad arguments");
+  if (Rp == 0 || C == 0) return DXA_OK;
+  DXA_CHECK_ARG(src && dst, "dxa_split3_t: null buffer");
+  const dim3 grid((unsigned)((C + 31) / 32), (unsigned)((Rp + 31) / 32));
+  DXA_CHECK_ARG(grid.y <= 65535, "dxa_split3_t: too many rows");
+  hipLaunchKernelGGL(split3_t_k, grid, dim3(256), 0, (hipStream_t)stream, src, ld, (bf16_t*)dst, R, C, Rp, side);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
 extern "C" int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t cols, int side, dxa_stream_t stream) {
   DXA_CHECK_ARG(rows >= 0 && cols >= 0 && (side == 0 || side == 1), "dxa_split3: bad arguments");
   if (rows == 0 || cols == 0) return DXA_OK;

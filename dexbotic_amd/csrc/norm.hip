@@ -3,6 +3,12 @@
 // row re-read from L1/L2 for the normalise pass.  The backward keeps one row per wavefront too and
 // accumulates the weight/bias gradient partials of a workgroup's rows in a per-workgroup fp32 slab
 // (L2 resident), reduced afterwards by dxa_colsum: deterministic, no atomics.
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -285,6 +291,66 @@ __global__ void colsum_stage2_k(const float* __restrict__ part, float* __restric
     for (int u = 0; u < 8; ++u) s += v[u];
   }
   for (; i < nsplit; ++i) s += part[(int64_t)i * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// Both stages in ONE launch: every (column tile, row split) workgroup publishes its partial sums with write-through (sc1)
+// stores and bumps the column tile's arrival counter; the LAST workgroup to arrive adds the splits' partials in split order —
+// the same order, hence the same bits, as colsum_stage2_k — and leaves the counter zeroed for the next launch.  Saves one
+// launch (~4.5 us of kernel + a boundary) per bias / norm-weight gradient: ~280 of them in a DB-CogACT step.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_fused_k(const T* __restrict__ x, int64_t ld, float* __restrict__ part,
+                                                      float* __restrict__ out, int64_t rows, int64_t cols, int vec,
+                                                      int accumulate, int* __restrict__ cnt) {
+  __shared__ float red[4][256];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * 256 + lane * 4;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < cols) {
+    const int n_ok = (int)min((int64_t)4, cols - c0);
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      const T* p = x + r * ld + c0;
+      if (vec && n_ok == 4) {
+        float v[4];
+        Vec<T, 4>::ld(v, p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] += v[i];
+      } else {
+        for (int i = 0; i < n_ok; ++i) a[i] += ldf<T>(p + i);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wave][lane * 4 + i] = a[i];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int64_t c = (int64_t)blockIdx.x * 256 + t;
+  if (c < cols)
+    __hip_atomic_store(part + (int64_t)blockIdx.y * cols + c, red[0][t] + red[1][t] + red[2][t] + red[3][t], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-through stores are acknowledged before the ticket
+  __syncthreads();
+  if (t == 0) {
+    const int arrived = __hip_atomic_fetch_add(cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    last = arrived == (int)gridDim.y;
+    if (last) __hip_atomic_store(cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last || c >= cols) return;
+  const int nsplit = (int)gridDim.y;
+  float s = 0.f;
+  int i = 0;
+  for (; i + 8 <= nsplit; i += 8) {                         // fixed order (split 0, 1, 2, ...), eight loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(part + (int64_t)(i + u) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < nsplit; ++i) s += __hip_atomic_load(part + (int64_t)i * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -725,6 +791,34 @@ extern "C" int dxa_layernorm_bwd(const void* dy, const void* x, const void* w, c
   return DXA_OK;
 }
 
+namespace {
+// arrival counters of colsum_fused_k: COLSUM_CNT ints per (device, stream), zeroed once (the kernel leaves them zeroed),
+// allocated on first use — so the first column sum on a stream must not run under stream capture
+constexpr int COLSUM_CNT = 4096;
+int colsum_counters(hipStream_t st, int** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, int*> tab;
+  int dev = 0;
+  DXA_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tab.find({dev, st});
+  if (it == tab.end()) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      *out = nullptr;                      // under capture before the counters exist: the two-launch form needs none
+      return DXA_OK;
+    }
+    int* p = nullptr;
+    DXA_CHECK_HIP(hipMalloc((void**)&p, COLSUM_CNT * sizeof(int)));
+    DXA_CHECK_HIP(hipMemset(p, 0, COLSUM_CNT * sizeof(int)));
+    DXA_CHECK_HIP(hipDeviceSynchronize());
+    it = tab.emplace(std::make_pair(dev, st), p).first;
+  }
+  *out = it->second;
+  return DXA_OK;
+}
+}  // namespace
+
 extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, int64_t cols, int dtype,
                           int accumulate, float* scratch, size_t scratch_bytes, dxa_stream_t stream) {
   DXA_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "dxa_colsum: bad args");
@@ -746,6 +840,19 @@ extern "C" int dxa_colsum(const void* x, int64_t ld, float* out, int64_t rows, i
       hipLaunchKernelGGL((colsum_stage1_k<bf16_t, true>), g1, dim3(256), 0, st, (const bf16_t*)x, ld, out, rows, cols, vec, accumulate);
     else
       hipLaunchKernelGGL((colsum_stage1_k<float, true>), g1, dim3(256), 0, st, (const float*)x, ld, out, rows, cols, vec, accumulate);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
+  static const bool two_stage = getenv("DXA_COLSUM_TWO_STAGE") != nullptr;
+  int* cnt = nullptr;
+  if (!two_stage && grid.x <= COLSUM_CNT) {
+    if (int rc = colsum_counters(st, &cnt)) return rc;
+  }
+  if (cnt != nullptr) {
+    if (dtype == DXA_BF16)
+      hipLaunchKernelGGL((colsum_fused_k<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, ld, scratch, out, rows, cols, vec, accumulate, cnt);
+    else
+      hipLaunchKernelGGL((colsum_fused_k<float>), grid, dim3(256), 0, st, (const float*)x, ld, scratch, out, rows, cols, vec, accumulate, cnt);
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }

@@ -86,7 +86,7 @@ def _dx(st: ParamStore, names, wshape, dy2d: torch.Tensor, **kw) -> torch.Tensor
     names = _names(names)
     W = st.w(*names, shape=tuple(wshape))
     if _f32_nt(dy2d):
-        return K.mm_nt(dy2d, K.transpose(W, 1), **kw)
+        return K.mm_nn_f32(dy2d, W, **kw)
     return K.mm_nn(dy2d, W, **kw)
 
 
@@ -141,7 +141,7 @@ def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, sha
     # AdamW reads, so an fp32 product's share is read back from that copy instead)
     ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 and not st.bf16_grads else None
     if _f32_nt(dy2d) and x2d.dtype == torch.float32:
-        K.mm_nt(K.transpose(dy2d, 4), K.transpose(x2d, 4), out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
+        K.mm_tn_f32(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     else:
         K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     st.mark_written(*names)
@@ -462,15 +462,15 @@ class PackedInProjFn(_StoreFn):
         dx = dy = None
         nt = _f32_nt(dq)
         if ctx.needs_input_grad[0]:
-            dx = K.mm_nt(dq, K.transpose(W[:E], 1)) if nt else K.mm_nn(dq, W[:E])
+            dx = K.mm_nn_f32(dq, W[:E]) if nt else K.mm_nn(dq, W[:E])
         if ctx.needs_input_grad[1]:
-            dy = K.mm_nt(dkv, K.transpose(W[E:], 1)) if _f32_nt(dkv) else K.mm_nn(dkv, W[E:])
+            dy = K.mm_nn_f32(dkv, W[E:]) if _f32_nt(dkv) else K.mm_nn(dkv, W[E:])
         if st.trainable(wn):
             acc = st.accum_flag(wn)
             g, gb = st.g(wn), st.g(bn)
             for lo, hi, d2, in2 in ((0, E, dq, x2), (E, W.shape[0], dkv, y2)):
                 if _f32_nt(d2) and in2.dtype == torch.float32:
-                    K.mm_nt(K.transpose(d2, 4), K.transpose(in2, 4), out=g[lo:hi], accumulate=acc)
+                    K.mm_tn_f32(d2, in2, out=g[lo:hi], accumulate=acc)
                 else:
                     K.mm_tn(d2, in2, out=g[lo:hi], accumulate=acc)
                 K.colsum(d2, out=gb[lo:hi], accumulate=acc)

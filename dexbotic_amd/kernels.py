@@ -77,6 +77,50 @@ def split3(x: torch.Tensor, rows: int, cols: int, ld: int, side: int) -> torch.T
     return out
 
 
+def split3_t(x: torch.Tensor, pad_to: int, side: int) -> torch.Tensor:
+    """fp32 [R, C] -> bf16 [C, 3 * Rp] = split3 of x^T (Rp = R rounded up to ``pad_to``, zero filled) in ONE launch"""
+    R, C_ = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((C_, 3 * Rp), device=x.device, dtype=torch.bfloat16)
+    L.check(lib.dxa_split3_t(_ptr(x), _row_major(x, "x"), _ptr(out), R, C_, Rp, side, _stream()), "dxa_split3_t")
+    return out
+
+
+def _x3_t_ok(M: int, N: int, Kc: int, out: torch.Tensor) -> bool:
+    """the split-bf16 NT product is admissible for these extents (same rule as _x3_eligible; Kc = contraction length)"""
+    return (F32_GEMM_MODE == "bf16x3" and out.dtype == torch.float32 and M >= 128 and N >= 128 and Kc >= 64 and Kc % 32 == 0
+            and 6 * max(M, N) * Kc < (1 << 31))
+
+
+def mm_tn_f32(a: torch.Tensor, b: torch.Tensor, *, out: torch.Tensor, **kw) -> torch.Tensor:
+    """out[M,N] = a[K,M]^T @ b[K,N] for fp32 operands as an NT product of the transposes (the fp32 heads' dW).  bf16x3 mode: the
+    transposed split operands come out of ONE launch each (dxa_split3_t); exact mode: fp32 transposes + the fp32 MFMA kernel."""
+    Kc, M = a.shape
+    N = b.shape[1]
+    if a.dtype == torch.float32 and b.dtype == torch.float32 and _x3_t_ok(M, N, (Kc + 31) // 32 * 32, out):
+        a3, b3 = split3_t(a, 32, 0), split3_t(b, 32, 1)
+        Kp = a3.shape[1] // 3
+        kw = _ld_kwargs(kw, out)
+        return gemm(L.NT, a3, b3, M, N, 3 * Kp, 3 * Kp, 3 * Kp, out, _row_major(out, "out"), epi_f32=True, **kw)
+    return mm_nt(transpose(a, 4), transpose(b, 4), out=out, **kw)
+
+
+def mm_nn_f32(a: torch.Tensor, b: torch.Tensor, **kw) -> torch.Tensor:
+    """a[M,K] @ b[K,N] for fp32 operands as an NT product against b^T (the fp32 heads' dX = dY W)"""
+    M, Kc = a.shape
+    N = b.shape[1]
+    out = kw.get("out")
+    if (a.dtype == torch.float32 and b.dtype == torch.float32 and Kc % 32 == 0 and a.is_contiguous() and a.data_ptr() % 16 == 0
+            and Kc % 4 == 0 and (out is None or out.dtype == torch.float32)):
+        if out is None:
+            out = kw["out"] = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        if _x3_t_ok(M, N, Kc, out):
+            a3, b3 = split3(a, M, Kc, Kc, 0), split3_t(b, 1, 1)
+            kw2 = _ld_kwargs({k: v for k, v in kw.items() if k != "out"}, out)
+            return gemm(L.NT, a3, b3, M, N, 3 * Kc, 3 * Kc, 3 * Kc, out, _row_major(out, "out"), epi_f32=True, **kw2)
+    return mm_nt(a, transpose(b, 1), **kw)
+
+
 def _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb) -> bool:
     return (F32_GEMM_MODE == "bf16x3" and layout == L.NT and a.dtype == torch.float32 and b.dtype == torch.float32
             and out.dtype == torch.float32 and tuple(nb) == (1, 1, 1) and M >= 128 and N >= 128 and K >= 64 and K % 32 == 0

@@ -108,6 +108,10 @@ int64_t dxa_gemm_sumsq_slots(int64_t M, int64_t N);
  * i.e. ONE bf16 NT product with K' = 3K accumulated in fp32 inside the MFMA.  dxa_split3 writes that operand:
  * dst[r, 0:K | K:2K | 2K:3K] = (hi, hi, lo) for side 0 (A) and (hi, lo, hi) for side 1 (B); dst is bf16 [rows, 3*cols]. */
 int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t cols, int side, dxa_stream_t stream);
+/* the same operand of the TRANSPOSE in one pass: src [R, C] fp32 -> dst [C, 3 Rp] bf16 (columns R..Rp-1 of every part zero):
+ * the dX = dY W and dW = dY^T X products of the fp32 heads run as NT products of transposed operands (the backward of the
+ * reference's autocast(float32) head, cogact_arch.py:133 / dit.py) */
+int dxa_split3_t(const float* src, int64_t ld, void* dst, int64_t R, int64_t C, int64_t Rp, int side, dxa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.  w/b are [cols] in w_dtype (NULL = no affine).
