@@ -102,7 +102,7 @@ __device__ __forceinline__ bool w4_split_exchange(const GemmP& p, f32x16_t (&acc
   return true;
 }
 
-template <typename TO, typename TE, bool A_KS, bool B_KS, int DXA_W4V>
+template <typename TO, typename TE, bool A_KS, bool B_KS, int DXA_W4V, int SCH>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -206,21 +206,32 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
   typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 #define W4_PIN() __builtin_amdgcn_sched_barrier(0)
-  // LDS-DMA of piece j of K tile `tile` (relative to k_lo) into ring slot `slot`
+  // Ring of five 32 KiB slots: operand-tile u = 2 t + (0: A | 1: B) lives in slot u % 5.  The slot byte offsets of the current
+  // tile (oA, oB), of the previous one (oAp, oBp) and of the next one (oA1, oB1) are wave-uniform integers rotated once per
+  // tile: ONE loop body serves every tile (no five-fold unrolling), fragment addresses = per-lane base + slot offset.
+  uint32_t oA = 0, oB = W4_OP, oAp = 3 * W4_OP, oBp = 4 * W4_OP, oA1 = 2 * W4_OP, oB1 = 3 * W4_OP;
+  // per-lane fragment bases without the slot: K-contiguous indexed by k-step, K-strided by 32-row block
+  uint32_t yak[4], ybk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    yak[i] = A_KS ? (ya ^ (uint32_t)(i << 6)) : (ya ^ (uint32_t)(i << 5));
+    ybk[i] = B_KS ? (yb ^ (uint32_t)(i << 6)) : (yb ^ (uint32_t)(i << 5));
+  }
+  // LDS-DMA of piece j of K tile `tile` (relative to k_lo) into the slot at byte offset `off`
 #define W4_DMA(rsrc, vo, so, ldsoff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(smem + (ldsoff)), 16, vo, so, 0, 0)
-#define W4_DMA_A(j, slot, tile)                                                                                      \
+#define W4_DMA_A(j, off, tile)                                                                                       \
   do {                                                                                                               \
     if (!(DXA_W4V & 1)) {                                                                                            \
-      if constexpr (A_KS) W4_DMA(rA, voA[j] + (uint32_t)(tile) * ktileA, 0, (slot) * W4_OP + pieceA0 + (j) * 1024);  \
-      else W4_DMA(rA, voA[j], (k_lo + min((tile), nk - 1)) * 128, (slot) * W4_OP + pieceA0 + (j) * 1024);            \
+      if constexpr (A_KS) W4_DMA(rA, voA[j] + (uint32_t)(tile) * ktileA, 0, (off) + pieceA0 + (j) * 1024);           \
+      else W4_DMA(rA, voA[j], (k_lo + min((tile), nk - 1)) * 128, (off) + pieceA0 + (j) * 1024);                     \
     }                                                                                                                \
   } while (0)
-#define W4_DMA_B(j, slot, tile)                                                                                      \
+#define W4_DMA_B(j, off, tile)                                                                                       \
   do {                                                                                                               \
     if (!(DXA_W4V & 1)) {                                                                                            \
-      if constexpr (B_KS) W4_DMA(rB, voB[j] + (uint32_t)(tile) * ktileB, 0, (slot) * W4_OP + pieceB0 + (j) * 1024);  \
-      else W4_DMA(rB, voB[j], (k_lo + min((tile), nk - 1)) * 128, (slot) * W4_OP + pieceB0 + (j) * 1024);            \
+      if constexpr (B_KS) W4_DMA(rB, voB[j] + (uint32_t)(tile) * ktileB, 0, (off) + pieceB0 + (j) * 1024);           \
+      else W4_DMA(rB, voB[j], (k_lo + min((tile), nk - 1)) * 128, (off) + pieceB0 + (j) * 1024);                     \
     }                                                                                                                \
   } while (0)
   // fragment reads (inline asm: the compiler must not order them against the DMA it tracks; waits are placed by hand)
@@ -232,101 +243,113 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
     W4_RDTR(lo_, addr, imm); W4_RDTR(hi_, addr, (imm) + 1024);                                                       \
     dst = (u32x4_t){lo_[0], lo_[1], hi_[0], hi_[1]};                                                                 \
   } while (0)
-#define W4_RDA(b, ks, buf, F)                                                                                        \
+  // block b of k-step ks of the operand whose slot offset is `off` into register set F
+#define W4_RDA(b, ks, off, F)                                                                                        \
   do {                                                                                                               \
     if (!(DXA_W4V & 4)) {                                                                                            \
-      if constexpr (A_KS) W4_TR(fa[F][b], (ya ^ (uint32_t)((b) << 6)) + (uint32_t)((buf) * W4_OP), (ks) * 4096);     \
-      else W4_RD128(fa[F][b], (ya ^ (uint32_t)((ks) << 5)) + (uint32_t)((buf) * W4_OP), (b) * 4096);                 \
+      if constexpr (A_KS) W4_TR(fa[F][b], yak[b] + (off), (ks) * 4096);                                              \
+      else W4_RD128(fa[F][b], yak[ks] + (off), (b) * 4096);                                                          \
     }                                                                                                                \
   } while (0)
-#define W4_RDB(b, ks, buf, F)                                                                                        \
+#define W4_RDB(b, ks, off, F)                                                                                        \
   do {                                                                                                               \
     if (!(DXA_W4V & 4)) {                                                                                            \
-      if constexpr (B_KS) W4_TR(fb[F][b], (yb ^ (uint32_t)((b) << 6)) + (uint32_t)((buf) * W4_OP), (ks) * 4096);     \
-      else W4_RD128(fb[F][b], (yb ^ (uint32_t)((ks) << 5)) + (uint32_t)((buf) * W4_OP), (b) * 4096);                 \
+      if constexpr (B_KS) W4_TR(fb[F][b], ybk[b] + (off), (ks) * 4096);                                              \
+      else W4_RD128(fb[F][b], ybk[ks] + (off), (b) * 4096);                                                          \
     }                                                                                                                \
   } while (0)
-  // read op n (0..7) of a k-step of K tile number tm (mod 5): A0 B0 A1 B1 A2 B2 A3 B3.  Ring: operand-tile u = 2 t + (0 A | 1 B)
-  // lives in slot u % 5
-#define W4_SA(tm) ((2 * (tm)) % 5)
-#define W4_SB(tm) ((2 * (tm) + 1) % 5)
-#define W4_READ(n, ks, tm, F) do { if ((n) & 1) W4_RDB((n) >> 1, ks, W4_SB(tm), F); else W4_RDA((n) >> 1, ks, W4_SA(tm), F); } while (0)
+  // read op n (0..7) of a k-step: A0 B0 A1 B1 A2 B2 A3 B3
+#define W4_READ(n, ks, offa, offb, F) do { if ((n) & 1) W4_RDB((n) >> 1, ks, offb, F); else W4_RDA((n) >> 1, ks, offa, F); } while (0)
   // MFMA n (0..15) of a k-step from register set F: row block n & 3, column block n >> 2
 #define W4_MFMA(n, F)                                                                                                \
   acc[(n) >> 3][(n) & 3][((n) >> 2) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
       __builtin_bit_cast(bf16x8_t, fb[F][(n) >> 2]), __builtin_bit_cast(bf16x8_t, fa[F][(n) & 3]),                    \
       acc[(n) >> 3][(n) & 3][((n) >> 2) & 1], 0, 0, 0)
 #define W4_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W4_PIN(); } while (0)
-  // One K tile t (tm = t % 5; its operands sit in slots SA(tm), SB(tm)).  Ring discipline: the barrier inside k-step 3 of
-  // tile t retires every wave's reads of A(t) and B(t); right behind it B(t+2) is requested into A(t)'s slot and A(t+3) into
-  // B(t)'s — 12 of the 16 pieces in that k-step 3, the last 4 in k-step 0 of tile t+1 — so B runs ONE whole K tile and A TWO
-  // ahead of the barrier that needs them.  In front of the barrier of tile t a wave's outstanding pieces are ... B(t+1) A(t+2):
-  // vmcnt(8) leaves A(t+2) in flight and guarantees B(t+1) (and the older A(t+1)).
-  //   k-steps 0..2: 16 MFMAs; behind MFMA n < 8 the fragment read n of the NEXT k-step; k-step 0 also carries the last 4 DMA
-  //                 pieces of A(t+2), behind MFMAs 8..11;
-  //   k-step 3    : NB MFMAs, vmcnt(8), s_barrier, then behind the next 8 MFMAs the reads of k-step 0 of tile t+1 and behind
-  //                 MFMAs NB..15 the DMA pieces B0..B7, A0..A3.
-  // Every k-step opens with lgkmcnt(0): its fragments were requested >= 8 MFMAs (256 cycles) earlier.
-#define W4_KSTEP(ks, tm, t)                                                                                          \
+  // One K tile t (operands in slots oA, oB).  Every k-step opens with lgkmcnt(0) (its fragments were requested >= 8 MFMAs
+  // earlier) and reads the NEXT k-step's fragments behind its first 8 MFMAs; k-step 3: NB MFMAs, vmcnt(8), s_barrier (every
+  // wave's reads of A(t), B(t) are retired and every wave's pieces of tile t+1 have landed), then the reads of k-step 0 of tile
+  // t+1.  In front of that barrier a wave's outstanding pieces are ... B(t+1) A(t+2): vmcnt(8) leaves A(t+2) in flight.
+  // Where the 16 DMA pieces of a tile go (SCH):
+  //   0: right behind the barrier — B(t+2) into A(t)'s slot with the reads of k-step 3, A(t+3) into B(t)'s slot behind them
+  //      (4 pieces) and in k-step 0 of tile t+1 (4 pieces): B runs one whole tile, A two tiles ahead of its barrier;
+  //   1: away from the fragment reads (an LDS-DMA issued beside ds_reads costs its wave 100-185 cycles, alone 25-60): B(t+1)
+  //      behind MFMAs 8..15 of k-step 0 into A(t-1)'s slot, A(t+2) behind MFMAs 8..15 of k-step 1 into B(t-1)'s slot: B runs
+  //      ~0.7, A ~1.5 tiles ahead.
+#define W4_KSTEP(ks, t)                                                                                              \
   do {                                                                                                               \
     W4_LGKM0();                                                                                                      \
     _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                              \
       W4_MFMA(n_, (ks) & 1);                                                                                         \
-      if (n_ < 8) W4_READ(n_, (ks) + 1, tm, ((ks) + 1) & 1);                                                         \
-      else if ((ks) == 0 && n_ < 12) W4_DMA_A(n_ - 4, W4_SB(((tm) + 4) % 5), (t) + 2);                               \
+      if (n_ < 8) W4_READ(n_, (ks) + 1, oA, oB, ((ks) + 1) & 1);                                                     \
+      else if (SCH == 0 && (ks) == 0 && n_ < 12) W4_DMA_A(n_ - 4, oBp, (t) + 2);                                     \
+      else if (SCH == 1 && (ks) == 0) W4_DMA_B(n_ - 8, oAp, (t) + 1);                                                \
+      else if (SCH == 1 && (ks) == 1) W4_DMA_A(n_ - 8, oBp, (t) + 2);                                                \
       W4_PIN();                                                                                                      \
     }                                                                                                                \
   } while (0)
-#define W4_TILE(tm, t)                                                                                               \
+#define W4_TILE(t)                                                                                                   \
   do {                                                                                                               \
-    W4_KSTEP(0, tm, t);                                                                                              \
-    W4_KSTEP(1, tm, t);                                                                                              \
-    W4_KSTEP(2, tm, t);                                                                                              \
+    W4_KSTEP(0, t);                                                                                                  \
+    W4_KSTEP(1, t);                                                                                                  \
+    W4_KSTEP(2, t);                                                                                                  \
     W4_LGKM0();                                                                                                      \
     _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                              \
       W4_MFMA(n_, 1);                                                                                                \
       if (n_ == W4_NB - 1) {                                                                                         \
         W4_PIN();                                                                                                    \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                             \
+        if (!(DXA_W4V & 64)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
         if (!(DXA_W4V & 32)) __builtin_amdgcn_s_barrier();                                                           \
         asm volatile("" ::: "memory");                                                                               \
       }                                                                                                              \
-      if (n_ >= W4_NB && n_ < W4_NB + 8) W4_READ(n_ - W4_NB, 0, ((tm) + 1) % 5, 0);                                  \
-      if (n_ >= W4_NB && n_ < W4_NB + 8) W4_DMA_B(n_ - W4_NB, W4_SA(tm), (t) + 2);                                   \
-      if (n_ >= W4_NB + 8) W4_DMA_A(n_ - W4_NB - 8, W4_SB(tm), (t) + 3);                                             \
+      if (n_ >= W4_NB && n_ < W4_NB + 8) W4_READ(n_ - W4_NB, 0, oA1, oB1, 0);                                        \
+      if (SCH == 0 && n_ >= W4_NB && n_ < W4_NB + 8) W4_DMA_B(n_ - W4_NB, oA, (t) + 2);                              \
+      if (SCH == 0 && n_ >= W4_NB + 8) W4_DMA_A(n_ - W4_NB - 8, oB, (t) + 3);                                        \
       W4_PIN();                                                                                                      \
     }                                                                                                                \
   } while (0)
   constexpr int W4_NB = 4;               // MFMAs of k-step 3 ahead of the barrier (16 - NB - 8 = 4 A pieces fit behind it)
   static_assert(W4_NB == 4, "the piece split 12 + 4 assumes NB = 4");
 
-  // ---- prologue: A(0) B(0) A(1) B(1) and the first 4 pieces of A(2) requested (36 per wave), A(0) and B(0) landed (vmcnt(20))
-  //      and k-step 0 of tile 0 read; tile 0's k-step 0 requests the other 4 pieces of A(2), as every tile does
+  // ---- prologue.  SCH 0: A(0) B(0) A(1) B(1) and the first 4 pieces of A(2) requested (36 per wave), vmcnt(20): A(0), B(0)
+  //      landed.  SCH 1: A(0) B(0) A(1) (24 per wave), vmcnt(8).  Then k-step 0 of tile 0 is read.
 #pragma unroll
-  for (int j = 0; j < 8; ++j) W4_DMA_A(j, W4_SA(0), 0);
+  for (int j = 0; j < 8; ++j) W4_DMA_A(j, 0 * W4_OP, 0);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) W4_DMA_B(j, W4_SB(0), 0);
+  for (int j = 0; j < 8; ++j) W4_DMA_B(j, 1 * W4_OP, 0);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) W4_DMA_A(j, W4_SA(1), 1);
+  for (int j = 0; j < 8; ++j) W4_DMA_A(j, 2 * W4_OP, 1);
+  if constexpr (SCH == 0) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) W4_DMA_B(j, W4_SB(1), 1);
+    for (int j = 0; j < 8; ++j) W4_DMA_B(j, 3 * W4_OP, 1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) W4_DMA_A(j, W4_SA(2), 2);
+    for (int j = 0; j < 4; ++j) W4_DMA_A(j, 4 * W4_OP, 2);
+  }
   W4_PIN();
-  asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  if constexpr (SCH == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   W4_PIN();
 #pragma unroll
-  for (int n = 0; n < 8; ++n) W4_READ(n, 0, 0, 0);
+  for (int n = 0; n < 8; ++n) W4_READ(n, 0, oA, oB, 0);
   W4_PIN();
-  for (int t = 0; t < nk; t += 5) {
-    W4_TILE(0, t);
-    if (t + 1 < nk) W4_TILE(1, t + 1);
-    if (t + 2 < nk) W4_TILE(2, t + 2);
-    if (t + 3 < nk) W4_TILE(3, t + 3);
-    if (t + 4 < nk) W4_TILE(4, t + 4);
+  // rotate the ring: tile t+1's slots become current; tile t+2 sits two slots further (mod 5)
+#define W4_ROTATE()                                                                                                  \
+  do {                                                                                                               \
+    oAp = oA; oBp = oB; oA = oA1; oB = oB1;                                                                          \
+    oA1 = oA + 2 * W4_OP; if (oA1 >= 5 * W4_OP) oA1 -= 5 * W4_OP;                                                    \
+    oB1 = oB + 2 * W4_OP; if (oB1 >= 5 * W4_OP) oB1 -= 5 * W4_OP;                                                    \
+  } while (0)
+  for (int t = 0; t < nk; t += 2) {      // (two tiles per trip: with one, hipcc permutes the accumulator registers on the back edge)
+    W4_TILE(t);
+    W4_ROTATE();
+    if (t + 1 < nk) {
+      W4_TILE(t + 1);
+      W4_ROTATE();
+    }
   }
+#undef W4_ROTATE
   W4_LGKM0();                            // the (unused) fragments of the tile past the end
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and its DMA pieces, before the slots become epilogue slabs
 #undef W4_TILE
@@ -339,8 +362,6 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #undef W4_TR
 #undef W4_RDTR
 #undef W4_RD128
-#undef W4_SA
-#undef W4_SB
 #undef W4_DMA_A
 #undef W4_DMA_B
 #undef W4_DMA
@@ -364,15 +385,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(const GemmP p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <typename TO, typename TE, bool A_KS, bool B_KS, int V = 0>
+template <typename TO, typename TE, bool A_KS, bool B_KS, int V = 0, int SCH = 0>
 int w4_launch_one(const GemmP& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<TO, TE, A_KS, B_KS, V>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<TO, TE, A_KS, B_KS, V, SCH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<TO, TE, A_KS, B_KS, V>), grid, dim3(256), W4_LDS, st, p);
+  hipLaunchKernelGGL((gemm_w4_kernel<TO, TE, A_KS, B_KS, V, SCH>), grid, dim3(256), W4_LDS, st, p);
   return 0;
 }
 
@@ -393,6 +414,10 @@ int gemm_w4_launch(const GemmP& p, int layout, bool out_f32, bool epi_f32, hipSt
         case 1: return w4_launch_one<bf16_t, bf16_t, false, false, 1>(p, grid, st);
         case 4: return w4_launch_one<bf16_t, bf16_t, false, false, 4>(p, grid, st);
         case 32: return w4_launch_one<bf16_t, bf16_t, false, false, 32>(p, grid, st);
+        case 64: return w4_launch_one<bf16_t, bf16_t, false, false, 64>(p, grid, st);
+        case 96: return w4_launch_one<bf16_t, bf16_t, false, false, 96>(p, grid, st);
+        case 100: return w4_launch_one<bf16_t, bf16_t, false, false, 0, 1>(p, grid, st);      // schedule 1
+        case 132: return w4_launch_one<bf16_t, bf16_t, false, false, 32, 1>(p, grid, st);     // schedule 1, no barrier
         default: break;
       }
     }

@@ -136,7 +136,7 @@ def bench(lib):
 
 def ablate():
     """NT bf16 tuning instantiations of the w4 kernel (DXA_GEMM_W4V): what each part of the K loop costs"""
-    names = {0: "everything", 32: "no barrier", 1: "no DMA (stale operands)", 4: "no fragment reads"}
+    names = {0: "schedule 0", 32: "no barrier", 64: "no vmcnt wait", 100: "schedule 1", 132: "schedule 1 no barrier"}
     for name, lay, m, n, k in [STEP[1], STEP[2], STEP[3], STEP[13]]:
         a, b, fn = operands(lay, m, n, k)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
@@ -165,8 +165,13 @@ def pmc_run():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     rc = 0
+    for w in what:
+        if w.startswith("check") and w != "check":      # check200: the NT bf16 tuning instantiation DXA_GEMM_W4V=200 etc.
+            os.environ["DXA_GEMM_W4V"] = w[5:]
+            rc |= check()
+            os.environ["DXA_GEMM_W4V"] = "0"
     if "check" in what:
-        rc = check()
+        rc |= check()
     if "time" in what:
         bench("lib" in what)
     if "abl" in what:
