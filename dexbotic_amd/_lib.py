@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("alpha", _f32), ("accumulate", _i32), ("nb", _i32 * 3),
         ("sA", _i64 * 3), ("sB", _i64 * 3), ("sC", _i64 * 3), ("sR", _i64 * 3), ("sG", _i64 * 3),
         ("epi_f32", _i32), ("mirror", _vp), ("sumsq", _vp),
+        ("A2", _vp), ("B2", _vp), ("K2", _i64),
     ]
 
 

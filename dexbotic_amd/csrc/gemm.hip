@@ -1071,7 +1071,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
         }
       }
   }
-  const int nk_tot = (int)((p.K + 63) >> 6);
+  // TN with a second segment (p.K2 > 0): K tiles [0, nk1) come from (A, B), tiles [nk1, nk1 + nk2) from (A2, B2); the last
+  // tile of segment 1 is zero-filled past K by its descriptor's range check, like the last tile of any TN product
+  const int nk1 = (int)((p.K + 63) >> 6);
+  const int nk_tot = nk1 + ((A_KS && B_KS) ? (int)((p.K2 + 63) >> 6) : 0);
+  const bool seg2 = (A_KS && B_KS) && p.K2 > 0;
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(seg2 ? p.A2 : p.A), 0, seg2 ? (uint32_t)(((p.K2 - 1) * p.lda + p.M) * 2) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(seg2 ? p.B2 : p.B), 0, seg2 ? (uint32_t)(((p.K2 - 1) * p.ldb + p.N) * 2) : 0u, 0x00020000);
   const int k_lo = split_j * nk_tot / split_s;
   const int nk = (split_j + 1) * nk_tot / split_s - k_lo;   // K tiles of this workgroup (>= 1)
   // K-contiguous operand: the K tile is a byte offset inside the row (scalar offset of the instruction).  K-strided: it is
@@ -1086,7 +1094,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #endif
 #define PP_DMA_A1(h, j, buf, tile)                                                                          \
   do {                                                                                                      \
-    if constexpr (A_KS) {                                                                                   \
+    if constexpr (A_KS && B_KS) {                                                                           \
+      const int kt_ = k_lo + (tile);                                                                        \
+      if (kt_ < nk1) PP_DMA(rA, voA[h][j] + (uint32_t)kt_ * ktileA, (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);          \
+      else PP_DMA(rA2, voA[h][j] + (uint32_t)(kt_ - nk1) * ktileA, (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);           \
+    } else if constexpr (A_KS) {                                                                            \
       const uint32_t kb_ = (uint32_t)(k_lo + (tile)) * ktileA;                                              \
       PP_DMA(rA, voA[h][j] + kb_, (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);                           \
     } else {                                                                                                \
@@ -1095,7 +1107,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   } while (0)
 #define PP_DMA_B1(h, j, buf, tile)                                                                          \
   do {                                                                                                      \
-    if constexpr (B_KS) {                                                                                   \
+    if constexpr (A_KS && B_KS) {                                                                           \
+      const int kt_ = k_lo + (tile);                                                                        \
+      if (kt_ < nk1) PP_DMA(rB, voB[h][j] + (uint32_t)kt_ * ktileB, REG + (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);    \
+      else PP_DMA(rB2, voB[h][j] + (uint32_t)(kt_ - nk1) * ktileB, REG + (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);     \
+    } else if constexpr (B_KS) {                                                                            \
       const uint32_t kb_ = (uint32_t)(k_lo + (tile)) * ktileB;                                              \
       PP_DMA(rB, voB[h][j] + kb_, REG + (h) * 16384 + (wave * 2 + (j)) * 1024, buf, 0);                     \
     } else {                                                                                                \
@@ -1593,6 +1609,25 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
+  // ---- a second (A2, B2) segment (TN: dW over two micro-batches in one pass over C): the ping-pong kernel contracts both;
+  //      every other path runs the two products one after the other, the second accumulating (mirror / sumsq from the second)
+  if (d->K2 > 0) {
+    DXA_CHECK_ARG(d->layout == DXA_TN && d->A2 && d->B2 && nbatch == 1, "dxa_gemm: A2 / B2 / K2 need an unbatched TN product");
+    const int64_t bytesA2 = ((d->K2 - 1) * d->lda + d->M) * 2, bytesB2 = ((d->K2 - 1) * d->ldb + d->N) * 2;
+    const bool seg_fast = !fast_off && d->in_dtype == DXA_BF16 && ks_ok && d->M >= 64 && d->N >= 64 &&
+                          (int64_t)d->M * d->N >= 128 * 128 && bytesA < (1ll << 31) && bytesB < (1ll << 31) &&
+                          bytesA2 < (1ll << 31) && bytesB2 < (1ll << 31) && aligned_to(d->A2, 16) && aligned_to(d->B2, 16);
+    if (!seg_fast) {
+      dxa_gemm_desc first = *d, second = *d;
+      first.A2 = first.B2 = nullptr; first.K2 = 0; first.mirror = nullptr; first.sumsq = nullptr;
+      second.A = d->A2; second.B = d->B2; second.K = d->K2; second.A2 = second.B2 = nullptr; second.K2 = 0;
+      second.accumulate = 1; second.bias = nullptr; second.residual = nullptr;
+      bool m1 = false, s1 = false;
+      if (int rc = gemm_dispatch(&first, stream, &m1, &s1)) return rc;
+      return gemm_dispatch(&second, stream, mirrored, summed);
+    }
+    p.A2 = (const char*)d->A2; p.B2 = (const char*)d->B2; p.K2 = d->K2;
+  }
   if (!fast_off && d->in_dtype == DXA_BF16 && nbatch == 1 &&
       ((d->layout == DXA_NT && d->K >= 32 && d->K % 32 == 0 && p.vecA && p.vecB) || ks_ok) &&
       d->M >= 64 && d->N >= 64 && (int64_t)d->M * d->N >= 128 * 128 && bytesA < (1ll << 31) && bytesB < (1ll << 31)) {
@@ -1602,7 +1637,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     const int ai = ks_layout ? 4 : (force_ai ? force_ai : (pad192 * 27 < pad256 * 25 ? 3 : 4));
     p.tm = dxa_cdiv(d->M, ai * 64);
     p.tn = dxa_cdiv(d->N, 256);
-    const int nt = p.tm * p.tn, nk_tot = (int)((d->K + 31) / 32);
+    const int nt = p.tm * p.tn, nk_tot = (int)((d->K + d->K2 + 31) / 32);
     p.full = nt; p.tail_r = 0; p.split_s = 1;
     static const int group_m = getenv("DXA_GEMM_GROUP_M") ? atoi(getenv("DXA_GEMM_GROUP_M")) : 4;
     p.group_m = group_m;
@@ -1653,7 +1688,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     //      K-strided operands are read two K tiles past the end (range-checked): keep that inside 32-bit offsets.
     const char* w4_env = getenv("DXA_GEMM_W4");          // read per call while the kernel is being tuned (scripts/w4_check.py)
     const int w4_mode = w4_env ? atoi(w4_env) : 0;
-    if (w4_mode && pp && lean && bytesA + 128 * d->lda * 2 < (1ll << 31) && bytesB + 128 * d->ldb * 2 < (1ll << 31)) {
+    if (w4_mode && pp && lean && d->K2 == 0 && bytesA + 128 * d->lda * 2 < (1ll << 31) && bytesB + 128 * d->ldb * 2 < (1ll << 31)) {
       if (int rc = dxa_gemm_detail::gemm_w4_launch(p, d->layout, d->out_dtype == DXA_F32, d->epi_f32 != 0, st)) return rc;
       DXA_CHECK_LAUNCH();
       return DXA_OK;

@@ -28,6 +28,8 @@ struct GemmP {
   float* sumsq; // fp32 output: per-tile sum of squares of the final C values (one float per 256x256 tile), or null
   float* ws;    // fp32 partial accumulators, tail_r * (split_s - 1) slots of 256x256
   int* flags;   // per tail tile arrival counter (self-resetting)
+  // TN with a second (A2, B2) segment of K2 contraction rows (same lda / ldb): C = A^T B + A2^T B2 (ping-pong kernel only)
+  const char* A2; const char* B2; int64_t K2;
 };
 }  // namespace dxa_gemm_detail
 

@@ -81,6 +81,10 @@ class ParamStore:
         # gradient accumulation: only the LAST micro-batch's dW products (accumulate = 1: what they store is the step's final
         # gradient) leave their share of sum(g^2); the trainer keeps this flag current (True without accumulation)
         self.last_micro = True
+        # two micro-batches per optimizer step: the weight gradients of single-use linears are ONE product over both micro-
+        # batches' (dY, X) pairs (functional._wgrad; dxa_gemm_desc.A2 / B2) instead of a read-modify-write of the fp32 gradient
+        self.accum_merge = False
+        self._accum_stash: Dict[tuple, tuple] = {}
         # weight gradients of a parameter applied k times in one forward (MemVLA's per-sample retrieval blocks): the k
         # (dY, X) pairs are collected and ONE product over all their rows writes dW once (functional._wgrad), instead of k
         # read-modify-write passes over the gradient (k rank-1 updates of a 14336 x 3584 matrix for the one-token cognition
@@ -318,6 +322,7 @@ class ParamStore:
         only slots that are accumulated into (embedding rows, never-written slots) need zeroing."""
         for nm in self.grad_written:
             self.grad_written[nm] = False
+        self._accum_stash.clear()
         self.begin_micro()
         for nm in zero_names:
             self.g(nm).zero_()

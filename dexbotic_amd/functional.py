@@ -114,7 +114,27 @@ def _wgrad(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape) 
             return
         _wgrad_flush(st, key)
         return
+    if st.accum_merge and dy2d.dtype == torch.bfloat16 and x2d.dtype == torch.bfloat16 and dy2d.is_contiguous() and x2d.is_contiguous():
+        # gradient accumulation over TWO micro-batches (the reference recipe): the first micro-batch keeps its (dY, X) and
+        # writes nothing; the last one contracts both pairs in ONE product — dW is written once instead of written, read back
+        # and written again (ParamStore.accum_merge; the trainer arms it for grad_accum == 2)
+        if not st.last_micro and key not in st._accum_stash:
+            st._accum_stash[key] = (dy2d, x2d, shape)
+            return
+        held = st._accum_stash.pop(key, None)
+        if held is not None:
+            if st.last_micro and held[0].shape[1] == dy2d.shape[1] and held[1].shape[1] == x2d.shape[1]:
+                _wgrad_now(st, names, dy2d, x2d, shape, st.accum_flag(*names), seg2=held[:2])
+                return
+            _wgrad_now(st, names, held[0], held[1], held[2], st.accum_flag(*names))      # (no partner: written on its own)
     _wgrad_now(st, names, dy2d, x2d, shape, st.accum_flag(*names))
+
+
+def flush_accum(st: ParamStore) -> None:
+    """(dY, X) pairs of the first micro-batch whose parameter the last micro-batch did not use: their dW is written now"""
+    for key in list(st._accum_stash):
+        dy, x, shape = st._accum_stash.pop(key)
+        _wgrad_now(st, key, dy, x, shape, st.accum_flag(*key))
 
 
 def _wgrad_flush(st: ParamStore, key: tuple) -> None:
@@ -125,12 +145,13 @@ def _wgrad_flush(st: ParamStore, key: tuple) -> None:
 
 
 def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape, accumulate: bool,
-               first_write: Optional[bool] = None) -> None:
+               first_write: Optional[bool] = None, seg2=None) -> None:
+    kw2 = {} if seg2 is None else {"a2": seg2[0], "b2": seg2[1]}
     if st.bf16_grads and st.gradc is not None and dy2d.dtype == torch.bfloat16 and x2d.dtype == torch.bfloat16:
         # bf16 gradient arena: the product writes bf16 only (ParamStore.bf16_grads); the slots count as already copied
         out = st.gc(*names, shape=shape)
         ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 else None
-        K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, sumsq=ssq)
+        K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, sumsq=ssq, **kw2)
         st._mirrored.update(names)
         st.mark_written(*names)
         return
@@ -143,7 +164,7 @@ def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, sha
     if _f32_nt(dy2d) and x2d.dtype == torch.float32:
         K.mm_tn_f32(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     else:
-        K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
+        K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq, **kw2)
     st.mark_written(*names)
 
 

@@ -135,8 +135,9 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
          alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = (1, 1, 1),
          sA: Sequence[int] = (0, 0, 0), sB: Sequence[int] = (0, 0, 0), sC: Sequence[int] = (0, 0, 0),
          sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0), epi_f32: bool = False,
-         mirror: Optional[torch.Tensor] = None, sumsq: Optional[torch.Tensor] = None) -> torch.Tensor:
-    if not epi_f32 and _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb):
+         mirror: Optional[torch.Tensor] = None, sumsq: Optional[torch.Tensor] = None,
+         a2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if not epi_f32 and a2 is None and _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb):
         a3, b3 = split3(a, M, K, lda, 0), split3(b, N, K, ldb, 1)
         return gemm(L.NT, a3, b3, M, N, 3 * K, 3 * K, 3 * K, out, ldc, bias=bias, residual=residual, ldr=ldr, act=act,
                     aux_out=aux_out, mulgrad=mulgrad, ldg=ldg, alpha=alpha, accumulate=accumulate, epi_f32=True,
@@ -168,6 +169,13 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
         d.sumsq = _ptr(sumsq)
     for i in range(3):
         d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
+    K_all = K
+    if a2 is not None:                         # TN: a second pair of operands contracted into the same product
+        if layout != L.TN or b2 is None or a2.shape[1] != M or b2.shape[1] != N or a2.shape[0] != b2.shape[0] \
+                or dt(a2) != d.in_dtype or dt(b2) != d.in_dtype or _row_major(a2, "a2") != lda or _row_major(b2, "b2") != ldb:
+            raise L.DxaError("gemm: a2 / b2 are a second [K2, M] / [K2, N] pair of a TN product (same dtypes and leading dimensions)")
+        d.A2, d.B2, d.K2 = _ptr(a2), _ptr(b2), a2.shape[0]
+        K_all = K + a2.shape[0]
     prof = GEMM_PROFILE
     if prof is not None and prof.wants(layout, d.in_dtype, d.out_dtype):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -176,8 +184,8 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
         e1.record()
         batches = nb[0] * nb[1] * nb[2]
         esz = {L.BF16: 2, L.F32: 4}
-        prof.add((layout, d.in_dtype, d.out_dtype), e0, e1, 2.0 * M * N * K * batches,
-                 float((M * K + N * K) * esz.get(d.in_dtype, 2) + M * N * esz.get(d.out_dtype, 2)) * batches)
+        prof.add((layout, d.in_dtype, d.out_dtype), e0, e1, 2.0 * M * N * K_all * batches,
+                 float((M * K_all + N * K_all) * esz.get(d.in_dtype, 2) + M * N * esz.get(d.out_dtype, 2)) * batches)
         return out
     L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm")
     return out

@@ -9,6 +9,8 @@ arena is averaged across ranks by engine.GradReducer, overlapped with the backwa
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import torch
@@ -113,6 +115,9 @@ class NativeTrainer:
         first = self.micro % self.grad_accum == 0
         last = (self.micro + 1) % self.grad_accum == 0
         self.store.last_micro = last
+        # exactly two micro-batches: dW of the linears = one product over both (the pair of micro-batch 1 is held until 2)
+        self.store.accum_merge = self.grad_accum == 2 and self.store.device.type == "cuda" and not self.store.bf16_grads \
+            and os.environ.get("DXA_NO_ACCUM_MERGE") is None
         if first:
             self.store.begin_step()
         else:
@@ -135,6 +140,9 @@ class NativeTrainer:
             (loss * scale if scale != 1.0 else loss).backward()
         self.last_output = out
         self.store.flush_wgrads()               # (only when autograd pruned a consumer of a multiply-used parameter)
+        if last and self.store._accum_stash:
+            from .functional import flush_accum
+            flush_accum(self.store)             # (a parameter the last micro-batch did not use)
         self.micro += 1
         if last:
             if not self._zeroed_unused:

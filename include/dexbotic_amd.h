@@ -97,6 +97,11 @@ typedef struct dxa_gemm_desc {
                          weight gradient's share of the global-norm clip (torch.nn.utils.clip_grad_norm_ in the reference's
                          Trainer, dexbotic/exp/base_exp.py:250 max_grad_norm), produced by the dW product's own epilogue
                          instead of a pass that reads the gradient back; deterministic (fixed fold order per slot) */
+  const void* A2;     /* TN only, or NULL: a SECOND pair of operands A2 [K2, M] (ld = lda), B2 [K2, N] (ld = ldb) contracted into */
+  const void* B2;     /* the same product: C = A^T B + A2^T B2 in ONE pass over C.  The weight gradient of a linear layer under  */
+  int64_t K2;         /* gradient accumulation (the reference recipe: 8 episodes x 2 steps, dexbotic/exp/cogact_exp.py:41-46)    */
+                      /* is dY1^T X1 + dY2^T X2: HF accumulates it with a read-modify-write of the fp32 gradient per micro-      */
+                      /* batch; here the first micro-batch's (dY, X) are kept and the last one writes dW once                     */
 } dxa_gemm_desc;
 int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream);
 int64_t dxa_gemm_sumsq_slots(int64_t M, int64_t N);

@@ -1094,3 +1094,29 @@ def test_gemv_few_row_nn(M, Kd, N):
     o32 = K.mm_nn(dy, w, out_dtype=torch.float32)
     assert_close(o32, ref, 2e-5, 2e-3 * math.sqrt(max(Kd, 320) / 320), "few-row nn f32")
     assert torch.equal(o1, K.mm_nn(dy, w)) and torch.equal(o32, K.mm_nn(dy, w, out_dtype=torch.float32))
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(512, 384, 1000, 1000), (300, 520, 200, 77), (3584, 1024, 2296, 2296), (96, 96, 130, 64)])
+@pytest.mark.parametrize("accum", [False, True])
+def test_tn_two_segments_is_one_product_over_both(M, N, K1, K2, accum):
+    """dxa_gemm_desc.A2 / B2 / K2: C = A^T B + A2^T B2 in one pass over C — the weight gradient over two micro-batches
+    (ping-pong kernel: both segments inside the K loop, segment 1's ragged last tile zero-filled by its own descriptor;
+    small / odd shapes: two products, the second accumulating).  Held to the fp64 product over the concatenated rows, with the
+    mirror and the sum of squares of the final values."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K1)
+    r = lambda *s: (torch.rand(*s, device=DEV, generator=g) * 2 - 1).bfloat16()
+    a, b, a2, b2 = r(K1, M), r(K1, N), r(K2, M), r(K2, N)
+    c0 = torch.rand(M, N, device=DEV, generator=g)
+    out = c0.clone() if accum else torch.empty(M, N, device=DEV)
+    mir = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    part = torch.full((K.gemm_sumsq_slots(M, N),), float("nan"), device=DEV)
+    K.mm_tn(a, b, out=out, accumulate=accum, mirror=mir, sumsq=part, a2=a2, b2=b2)
+    ref = torch.cat([a, a2]).double().t() @ torch.cat([b, b2]).double() + (c0.double() if accum else 0)
+    assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    assert ((mir.double() - ref).abs().max() / ref.abs().max()).item() < 8e-3
+    want = (out.double() ** 2).sum().item()
+    assert abs(part.double().sum().item() - want) < 1e-5 * want
+    # and it equals the two-pass form bit for bit where both run the same kernel in the same K order is NOT promised: the
+    # one-pass form keeps a single fp32 accumulation chain; the bound above is what both satisfy
+    with pytest.raises(L.DxaError):
+        K.mm_nt(r(64, 64), r(64, 64), a2=a2, b2=b2)

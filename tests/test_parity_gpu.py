@@ -208,3 +208,39 @@ def test_whole_sampler_in_one_launch_equals_the_per_step_sampler(golden_dir, dty
     assert rel_err(got[0], want) < 2e-4, rel_err(got[0], want)
     if dtype == "float32" and cfg_scale == 1.5:
         assert rel_err(got[0], g["infer_actions"]) < FP32_TOL
+
+
+def test_two_micro_batches_write_each_weight_gradient_once(golden_dir, monkeypatch):
+    """gradient accumulation over exactly two micro-batches (the reference recipe, cogact_exp.py:41-46): the linears' dW is ONE
+    product over both micro-batches' (dY, X) pairs (ParamStore.accum_merge).  bf16 model: gradients, global norm and the
+    parameters after the update against the read-modify-write form (DXA_NO_ACCUM_MERGE) — two fp32 accumulation chains added
+    vs one chain: equal to fp32 rounding."""
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    g, cfg, w = load_golden(golden_dir, "t2")
+    b = _batch(g)
+    B = b["input_ids"].shape[0]
+    R = b["noise"].shape[0] // B
+    res = {}
+    for tag in ("merge", "rmw"):
+        if tag == "rmw":
+            monkeypatch.setenv("DXA_NO_ACCUM_MERGE", "1")
+        m = build_product(cfg, w, "bfloat16", DEV, train=True)
+        tr = NativeTrainer(m, OptimConfig(base_lr=1e-3), grad_accum=2)
+        half = B // 2
+        for i in range(2):
+            rows = torch.arange(i * half, (i + 1) * half, device=DEV)
+            sel = (torch.arange(R, device=DEV)[:, None] * B + rows[None, :]).reshape(-1)
+            mb = dict(input_ids=b["input_ids"][i * half:(i + 1) * half], attention_mask=b["attention_mask"][i * half:(i + 1) * half],
+                      images=b["images"][i * half:(i + 1) * half], actions=b["actions"][i * half:(i + 1) * half], noise=b["noise"][sel],
+                      timesteps=b["timesteps"][sel], drop_ids=b["drop_ids"][sel])
+            tr.micro_step(mb)
+        assert m.store.accum_merge == (tag == "merge") and not m.store._accum_stash
+        res[tag] = (m.store.grad.clone(), float(tr._sumsq))
+        tr.apply_update()
+        torch.cuda.synchronize()
+        res[tag] += (m.store.master.clone(),)
+    gm, gr = res["merge"][0], res["rmw"][0]
+    assert rel_err(gm.cpu().numpy(), gr.cpu().numpy()) < 1e-5
+    assert abs(res["merge"][1] - res["rmw"][1]) < 1e-5 * res["rmw"][1]
+    assert rel_err(res["merge"][2].cpu().numpy(), res["rmw"][2].cpu().numpy()) < 1e-6
