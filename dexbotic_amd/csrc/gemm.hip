@@ -1207,6 +1207,38 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     PP_MFMA(0, 3, 2 * (h), j); PP_MFMA(1, 3, 2 * (h) + 1, j);                                     \
     PP_SB();                                                                                      \
   } while (0)
+  // k-step ks of A half h / B half j alone (round 4: the fragment reads ride in the gaps of the PREVIOUS compute cluster's MFMAs)
+#define PP_RDK_A(cur, h, ks)                                                                                \
+  do {                                                                                                      \
+    if constexpr (A_KS) {                                                                                   \
+      const uint32_t a0_ = ya ^ (uint32_t)((cur) * BUF + (h) * 16384), a1_ = a0_ ^ 64u;                     \
+      PP_FRAG_TR(af[0][ks], a0_, 4096 * (ks)); PP_FRAG_TR(af[1][ks], a1_, 4096 * (ks));                     \
+    } else {                                                                                                \
+      const uint32_t a_ = ya ^ (uint32_t)((cur) * BUF + 32 * (ks));                                         \
+      PP_READ(af[0][ks], a_, (2 * (h)) * 4096); PP_READ(af[1][ks], a_, (2 * (h) + 1) * 4096);              \
+    }                                                                                                       \
+  } while (0)
+#define PP_RDK_B(cur, j, ks)                                                                                \
+  do {                                                                                                      \
+    if constexpr (B_KS) {                                                                                   \
+      const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF + (j) * 16384);                                      \
+      PP_FRAG_TR(bq[j][ks], b0_, 4096 * (ks));                                                              \
+    } else {                                                                                                \
+      const uint32_t b_ = yb ^ (uint32_t)((cur) * BUF + 32 * (ks));                                         \
+      PP_READ(bq[j][ks], b_, (j) * 4096);                                                                   \
+    }                                                                                                       \
+  } while (0)
+  // compute cluster with the NEXT cluster's fragment reads in its gaps: after the two MFMAs of k-step ks their operand registers are
+  // dead, R(ks) refills them (the data lands tens of cycles after the MFMAs have read their sources)
+#define PP_COMPUTE_R(h, j, R)                                                                     \
+  do {                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+    PP_SB();                                                                                      \
+    PP_MFMA(0, 0, 2 * (h), j); PP_MFMA(1, 0, 2 * (h) + 1, j); PP_SB(); R(0); PP_SB();             \
+    PP_MFMA(0, 1, 2 * (h), j); PP_MFMA(1, 1, 2 * (h) + 1, j); PP_SB(); R(1); PP_SB();             \
+    PP_MFMA(0, 2, 2 * (h), j); PP_MFMA(1, 2, 2 * (h) + 1, j); PP_SB(); R(2); PP_SB();             \
+    PP_MFMA(0, 3, 2 * (h), j); PP_MFMA(1, 3, 2 * (h) + 1, j); PP_SB(); R(3); PP_SB();             \
+  } while (0)
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   // one K tile in buffer `cur = t & 1`.  LDS-DMA runs SIX pieces (96 KiB) ahead of the reads, in the two 64 KiB buffers
   // alone: the B0 fragments stay in registers from phase 0 to phase 3, so every piece is read from LDS in exactly one
@@ -1249,6 +1281,63 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   } while (0)
 #define PP_SLOTS(from, to, cur, t) do { _Pragma("unroll") for (int k_ = (from); k_ < (to); ++k_) PP_SLOT(k_, cur, t); } while (0)
 #define PP_VMCNT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  // tuning variant DXA_PPV & 128: s_memtime after every barrier of a K tile (8 stamps, read once per tile where no LDS read is
+  // outstanding); the eight barrier-to-barrier intervals are summed per wave and stored over the first bytes of C
+#if (DXA_PPV & 128)
+  uint64_t ts_[8];
+  uint32_t iv_[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, ts_last_ = 0u;
+#define PP_STAMP(i) asm volatile("s_memtime %0" : "=s"(ts_[i]))
+#define PP_STAMPS_FOLD()                                                                                    \
+  do {                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    PP_SB();                                                                                                \
+    if (ts_last_ != 0u) iv_[7] += (uint32_t)ts_[0] - ts_last_;                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_) iv_[i_] += (uint32_t)ts_[i_ + 1] - (uint32_t)ts_[i_];  \
+    ts_last_ = (uint32_t)ts_[7];                                                                            \
+    PP_SB();                                                                                                \
+  } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#define PP_STAMPS_FOLD() do { } while (0)
+#endif
+#ifndef DXA_PPR
+#define DXA_PPR 1
+#endif
+#if DXA_PPR
+  // Round 4 schedule (DXA_PPR=1, default): NO fragment read is left in a memory cluster.  The stamp build (DXA_PPV=128,
+  // profiles/r04_pp_stamps_before.txt) showed the two barrier intervals in which a group runs M0 — 12 ds_read_b128 (24
+  // ds_read_b64_tr_b16 when both operands are k-strided) — at 440 cycles (TN 540) against 285 for the other six: the compute
+  // cluster of the other group finishes its 256 cycles of MFMAs and waits.  Now every fragment is read in the gaps of the compute
+  // cluster BEFORE the one that needs it, into the operand registers its MFMAs have just consumed:
+  //   C0 (A0 x B0) reads B1(t);  C1 (A0 x B1) reads A1(t);  C2 (A1 x B1) reads nothing;  C3 (A1 x B0) reads A0(t+1), B0(t+1).
+  // A piece read in C_q by one group is read a barrier interval earlier than the other group's M_q ends, so it is waited for at the
+  // end of M_{q-1} by every wave (vmcnt + the barrier order it before every read), and the LDS-DMA issue moves a phase earlier with
+  // it: M0 A1(t+1) -> other buffer, M1 A0(t+2), M2 B0(t+2), M3 B1(t+2) -> this buffer (the bytes they overwrite were read in
+  // C1(t-1), C3(t-1), C3(t-1), C0(t): at least one full barrier interval before, for both groups).  In-order issue per wave:
+  //   ... A1(t) | A0(t+1) | B0(t+1) | B1(t+1) | A1(t+1) | A0(t+2) | B0(t+2) | B1(t+2) ...   (2 instructions each)
+  // end of M0: A1(t) landed = vmcnt(8);  end of M2: A0(t+1), B0(t+1) = vmcnt(8);  end of M3: B1(t+1) = vmcnt(8)  (4 phases ahead).
+#define PP_R_B1(ks) PP_RDK_B(cur_, 1, ks)
+#define PP_R_A1(ks) PP_RDK_A(cur_, 1, ks)
+#define PP_R_NEXT(ks) do { if (more1) { PP_RDK_A(cur_ ^ 1, 0, ks); PP_RDK_B(cur_ ^ 1, 0, ks); } } while (0)
+#define PP_TILE(cur, t)                                                                                     \
+  do {                                                                                                      \
+    constexpr int cur_ = (cur);                                                                             \
+    const bool more1 = (t) + 1 < nk, more2 = (t) + 2 < nk;                                                  \
+    /* phase 0 */                                                                                           \
+    if (more1) { PP_LOOP(PP_DMA_A(1, cur_ ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(8); } else { PP_VMCNT(0); }     \
+    PP_BAR(); PP_STAMP(0); PP_COMPUTE_R(0, 0, PP_R_B1); PP_BAR(); PP_STAMP(1);                              \
+    /* phase 1 */                                                                                           \
+    if (more2) { PP_LOOP(PP_DMA_A(0, cur_, (t) + 2)); PP_SB(); }                                            \
+    PP_BAR(); PP_STAMP(2); PP_COMPUTE_R(0, 1, PP_R_A1); PP_BAR(); PP_STAMP(3);                              \
+    /* phase 2 */                                                                                           \
+    if (more2) { PP_LOOP(PP_DMA_B(0, cur_, (t) + 2)); PP_SB(); PP_VMCNT(8); } else if (more1) { PP_VMCNT(4); } \
+    PP_BAR(); PP_STAMP(4); PP_COMPUTE(1, 1); PP_BAR(); PP_STAMP(5);                                         \
+    /* phase 3 */                                                                                           \
+    if (more2) { PP_LOOP(PP_DMA_B(1, cur_, (t) + 2)); PP_SB(); PP_VMCNT(8); } else if (more1) { PP_VMCNT(2); } \
+    PP_BAR(); PP_STAMP(6); PP_COMPUTE_R(1, 0, PP_R_NEXT); PP_BAR(); PP_STAMP(7);                            \
+    PP_STAMPS_FOLD();                                                                                       \
+  } while (0)
+#else
 #define PP_TILE(cur, t)                                                                                     \
   do {                                                                                                      \
     const bool more1 = (t) + 1 < nk, more2 = (t) + 2 < nk;                                                  \
@@ -1256,20 +1345,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     PP_M(PP_RD_A(cur, 0); PP_RD_B(cur, 0), PP_SLOTS(0, PPD0, cur, t));                                      \
     /* B1(t) landed: younger = A1(t) (2) + A0, B0 of t+1 (4) + this tile's slots so far */                  \
     if (more1) { PP_VMCNT_N(6 + PPD0); } else { PP_VMCNT(2); }                                              \
-    PP_BAR(); PP_COMPUTE(0, 0); PP_BAR();                                                                   \
+    PP_BAR(); PP_STAMP(0); PP_COMPUTE(0, 0); PP_BAR(); PP_STAMP(1);                                         \
     /* phase 1 */                                                                                           \
     PP_M(PP_RD_B(cur, 1), PP_SLOTS(PPD0, PPD0 + PPD1, cur, t));                                             \
     if (more1) { PP_VMCNT_N(4 + PPD0 + PPD1); } else { PP_VMCNT(0); }     /* A1(t) landed */               \
-    PP_BAR(); PP_COMPUTE(0, 1); PP_BAR();                                                                   \
+    PP_BAR(); PP_STAMP(2); PP_COMPUTE(0, 1); PP_BAR(); PP_STAMP(3);                                         \
     /* phase 2 */                                                                                           \
     PP_M(PP_RD_A(cur, 1), PP_SLOTS(PPD0 + PPD1, PPD0 + PPD1 + PPD2, cur, t));                               \
-    PP_BAR(); PP_COMPUTE(1, 1); PP_BAR();                                                                   \
+    PP_BAR(); PP_STAMP(4); PP_COMPUTE(1, 1); PP_BAR(); PP_STAMP(5);                                         \
     /* phase 3: B0 fragments are still in bq[0] */                                                          \
     PP_M(, PP_SLOTS(PPD0 + PPD1 + PPD2, 8, cur, t));                                                        \
     if (more2) { PP_VMCNT(8); } else if (more1) { PP_VMCNT(4); }      /* A0(t+1), B0(t+1) landed */         \
-    PP_BAR(); PP_COMPUTE(1, 0); PP_BAR();                                                                   \
+    PP_BAR(); PP_STAMP(6); PP_COMPUTE(1, 0); PP_BAR(); PP_STAMP(7);                                         \
+    PP_STAMPS_FOLD();                                                                                       \
   } while (0)
+#endif
 
+#if DXA_PPR
+  // ---- prologue: the four pieces of tile 0 and A0, B0, B1 of tile 1 in the steady state's issue order; A0(0), B0(0), B1(0) landed
+  //      for every wave before the first read; tile 0's A0 / B0 fragments are read here (C3 of "tile -1")
+  PP_DMA_A(0, 0, 0); PP_DMA_B(0, 0, 0); PP_DMA_B(1, 0, 0); PP_DMA_A(1, 0, 0);
+  if (nk > 1) { PP_DMA_A(0, 1, 1); PP_DMA_B(0, 1, 1); PP_DMA_B(1, 1, 1); }
+  PP_SB();
+  if (nk > 1) { PP_VMCNT(8); } else { PP_VMCNT(2); }
+  PP_BAR();
+  PP_RD_A(0, 0); PP_RD_B(0, 0);
+  PP_SB();
+#else
   // ---- prologue: the four pieces of tile 0 and the first two of tile 1; A0(0) and B0(0) landed for every wave before
   //      the first read
   PP_DMA_A(0, 0, 0); PP_DMA_B(0, 0, 0); PP_DMA_B(1, 0, 0); PP_DMA_A(1, 0, 0);
@@ -1277,12 +1379,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   PP_SB();
   if (nk > 1) { PP_VMCNT(8); } else { PP_VMCNT(4); }
   PP_BAR();
+#endif
   if (!(DXA_PPV & 16) && wm == 1) PP_BAR();    // group 1 runs one barrier interval behind group 0
   for (int t = 0; t < nk; t += 2) {
     PP_TILE(0, t);
     if (t + 1 < nk) PP_TILE(1, t + 1);
   }
   if (!(DXA_PPV & 16) && wm == 0) PP_BAR();    // every wave has now passed the same number of barriers
+#if (DXA_PPV & 128)
+  const uint32_t iv0_ = iv_[0], iv1_ = iv_[1], iv2_ = iv_[2], iv3_ = iv_[3], iv4_ = iv_[4], iv5_ = iv_[5], iv6_ = iv_[6], iv7_ = iv_[7];
+#endif
 #undef PP_A_ROW0
 #undef PP_B_ROW0
 #undef PP_DMA
@@ -1306,11 +1412,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #undef PP_DMA_A1
 #undef PP_DMA_B1
 #undef PP_M
+#undef PP_STAMP
+#undef PP_STAMPS_FOLD
+#undef PP_RDK_A
+#undef PP_RDK_B
+#undef PP_COMPUTE_R
+#if DXA_PPR
+#undef PP_R_B1
+#undef PP_R_A1
+#undef PP_R_NEXT
+#endif
 
   if constexpr (LEAN) {
     if (!tile_split_exchange<4>(p, acc, tid, split_j, split_s, tail_i)) return;
     __builtin_amdgcn_sched_barrier(0);
     sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i, reinterpret_cast<float*>(smem + 8 * 4096), bid);
+#if (DXA_PPV & 128)
+    __syncthreads();
+    if (m0i == 0 && n0i == 0 && lane == 0) {          // the first tile's waves: [wave][8 intervals + K tiles] over the head of C
+      uint32_t* o_ = reinterpret_cast<uint32_t*>(p.C) + wave * 16;
+      o_[0] = iv0_; o_[1] = iv1_; o_[2] = iv2_; o_[3] = iv3_; o_[4] = iv4_; o_[5] = iv5_; o_[6] = iv6_; o_[7] = iv7_;
+      o_[8] = (uint32_t)nk;
+    }
+#endif
   } else {
     tile_finish<TO, 4, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
   }

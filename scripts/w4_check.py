@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dexbotic_amd import kernels as K  # noqa: E402
 
-M = 4592
+M = int(os.environ.get("W4_M", "4592"))          # W4_M=2296: the reference recipe's micro-batch (8 episodes)
 STEP = [("qkv fwd", "nt", M, 4608, 3584), ("o_proj fwd", "nt", M, 3584, 3584), ("gate_up fwd", "nt", M, 37888, 3584),
         ("down fwd", "nt", M, 3584, 18944), ("qkv dX", "nn", M, 3584, 4608), ("o_proj dX", "nn", M, 3584, 3584),
         ("gate_up dX", "nn", M, 3584, 37888), ("down dX", "nn", M, 18944, 3584),
@@ -116,7 +116,7 @@ def bench(lib):
         out = torch.empty(m, n, device="cuda", dtype=torch.float32 if lay == "tn" else torch.bfloat16)
         res = {}
         for rnd in range(2):                 # interleaved rounds, best of two
-            for tag in ("pp", "w4") + (("lib",) if lib else ()):
+            for tag in (("pp",) if os.environ.get("W4_PP_ONLY") else ("pp", "w4")) + (("lib",) if lib else ()):
                 if tag == "lib":
                     ta, tb = (a.t() if lay == "tn" else a), (b.t() if lay == "nt" else b)
                     lout = out if out.dtype == torch.bfloat16 else torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
