@@ -39,12 +39,30 @@ struct DitP {
   int dbg;   // tuning aid: 1 = barriers only, 2 = work only (wrong results)
 };
 
-struct Smem {
+struct alignas(16) Smem {
   float red[8][MB][64][4];
   float sx[8][MAXM], sxx[8][MAXM], wsum[16];   // LayerNorm: per-wave row sums / sums of squares, sum_k W[n,k]
-  float q[MAXT][HD], k[MAXT][HD + 1], v[MAXT][HD], p[MAXT][MAXT + 1];
+  float q[MAXT][HD], k[MAXT][HD + 4], v[MAXT][HD], p[MAXT][MAXT + 1];
   int last;
+#if defined(DXA_DIT_STAMPS)
+  unsigned long long stamp[5][8], ts[8];    // tuning build: cycles per segment of each phase type, summed by wave 0 of workgroup DXA_DIT_STAMPS
+#endif
 };
+
+// Tuning build (-DDXA_DIT_STAMPS=<workgroup>): s_memtime at fixed points of every phase, taken by wave 0 of one workgroup and summed
+// per phase type (0 qkv, 1 attention, 2 proj, 3 fc1, 4 fc2) in LDS; dxa_dit_debug_stamps() copies the sums out.  Segments of a product
+// phase: 0 entry -> operands loaded and MFMAs retired, 1 -> partials of all waves in LDS, 2 -> epilogue stores issued,
+// 3 -> stores acknowledged (vmcnt(0)) and the workgroup assembled, 4 -> device-wide barrier left.
+#if defined(DXA_DIT_STAMPS)
+__device__ unsigned long long g_dit_stamps[5][8];
+#define DIT_STAMP(s_, i_) do { if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); (s_).ts[i_] = t_; } } while (0)
+#define DIT_STAMP_AFTER(s_, i_, v_) do { if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x == 0) { unsigned long long t_; const unsigned d_ = __builtin_amdgcn_readfirstlane(__float_as_uint(v_)); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "s"(d_) : "memory"); (s_).ts[i_] = t_; } } while (0)
+#define DIT_STAMP_FOLD(s_, ph_, n_) do { if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x == 0) { for (int i_ = 0; i_ < (n_); ++i_) (s_).stamp[ph_][i_] += (s_).ts[i_ + 1] - (s_).ts[i_]; (s_).stamp[ph_][7] += 1; } } while (0)
+#else
+#define DIT_STAMP(s_, i_) do { } while (0)
+#define DIT_STAMP_AFTER(s_, i_, v_) do { } while (0)
+#define DIT_STAMP_FOLD(s_, ph_, n_) do { } while (0)
+#endif
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -52,6 +70,11 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // activation access is an agent-scope (sc1) buffer access — stores write through, loads miss in the private caches —
 // so the barrier needs no cache-wide write-back / invalidate and the weights stay cached.
 constexpr int SC1 = 16;
+#if defined(DXA_DIT_CACHED_LOADS)
+constexpr int A_AUX = 0;      // tuning build: the A operand through the XCD's L2
+#else
+constexpr int A_AUX = SC1;
+#endif
 struct Act {
   __amdgpu_buffer_rsrc_t r;
   __device__ __forceinline__ Act(float* p, size_t floats)
@@ -59,6 +82,11 @@ struct Act {
   // coherent load: data written by other workgroups since the last device-wide barrier (partials, residual)
   __device__ __forceinline__ float4 ld4(size_t idx) const {
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, SC1);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  }
+  // the same by BYTE offset; an offset beyond the descriptor (0x80000000) reads zeros: branch-free loads of ragged tiles
+  __device__ __forceinline__ float4 ld4_or0(uint32_t byte_off) const {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, SC1);
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
   }
   // cached load: data complete before the last device-wide barrier (whose acquire dropped stale lines); the 20+
@@ -90,9 +118,10 @@ struct Act {
 // microseconds with a garbage result, and dxa_dit_blocks_status() reports it to the host, which re-runs the request on
 // the unfused path (persistent kernel needs a watchdog).
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch, bool sleep) {
+__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch, bool sleep, Smem* sst = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
+  if (sst) DIT_STAMP(*sst, 4);
   if (threadIdx.x == 0) {
     unsigned* abortw = bar + 56;
     epoch += 1;
@@ -125,7 +154,7 @@ __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned
         }
       }
 #endif
-#if defined(DXA_DIT_CACHED_LOADS)
+#if defined(DXA_DIT_CACHED_LOADS) && !defined(DXA_DIT_NOACQ)   /* NOACQ: timing experiment only (stale reads) */
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale activation lines from this CU's L1 / this XCD's L2
 #endif
   }
@@ -142,74 +171,95 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESADD = 2 };
 //  * S > 1 (narrow products): the work items are (16 columns) x (K slice); a slice's partial tile goes to `part`
 //    through write-through stores and the LAST workgroup to arrive at the tile's counter (split-K protocol of the ring
 //    GEMM) adds the S partials in slice order, the bias and the residual: deterministic, no extra device-wide barrier.
-template <bool LN, int EPI>
-__device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A, int lda, const float* __restrict__ W,
+template <bool LN, int EPI, int U>
+__device__ __forceinline__ void gemm_phase_u(const DitP& p, Smem& s, const Act& A, int lda, const float* __restrict__ W,
                                            const float* __restrict__ bias, const Act& C, int ldc, int Nout, int K, int S,
                                            unsigned* cnt, unsigned cnt_target, const Act& part) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform branches
   const int l16 = lane & 15, lg = lane >> 4;
-  size_t arow[MB];
-  int akind[MB];            // 0: real row, 1: the ones row (m == M, LN only), 2: padding
+  // Operand loads are BRANCH-FREE buffer loads (round 4): a row that does not exist (padding of the last 16-row block, the LN
+  // ones row) and a K piece past the end of this wave's share get an offset outside the descriptor, which returns zeros.  The
+  // round-3 form (per-lane `if (row valid) load`) compiled to a branch around every load with an s_waitcnt vmcnt(0) after every
+  // fourth one and flat loads for W: 4-5 serialised memory round trips, 20,000 cycles from the barrier to the last MFMA of a
+  // K = 768 product whose MFMAs need 3,100 (profiles/r04_dit_stamps_before.txt).
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t aoff[MB];        // byte offset of this lane's 16-byte piece in its A row, or OOB
+  bool ones[MB];            // the LN ones row (m == M): sum_k W[n, k] comes out of the product itself
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = mb * 16 + l16;
-    arow[mb] = (size_t)min(m, p.M - 1) * lda + 4 * lg;
-    akind[mb] = m < p.M ? 0 : ((LN && m == p.M) ? 1 : 2);
+    aoff[mb] = m < p.M ? (uint32_t)(((size_t)m * lda + 4 * lg) * sizeof(float)) : OOB;
+    ones[mb] = LN && m == p.M;
   }
-  const int ncb = Nout / 16, nkb = K / 64, per = nkb / S;
+  // descriptors in scalar registers (the pointers come out of the weight table: tell the compiler they are wave-uniform, or every
+  // buffer load is wrapped in a waterfall loop)
+  auto uniform_ptr = [](const float* q) {
+    const uint64_t v = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t Wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(W), 0, (int)((size_t)Nout * K * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(bias), 0, Nout * (int)sizeof(float), 0x00020000);
+  // K is walked in 32-deep pieces: piece hb of a slice goes to wave hb % 8, U pieces per wave and trip (K = 768: 24 pieces, U = 3, one
+  // trip, every wave exactly three — round 3 dealt 64-deep blocks 2,2,2,2,1,1,1,1).  A piece past the end of the slice is loaded as
+  // zeros and multiplied like any other: no branch sits between a load and its use, so nothing tempts the compiler to sink a load
+  // behind the products of the pieces before it (it did, with a wave-uniform `continue` here).  U is picked by the caller from the
+  // slice length so that dead pieces only occur in ragged shapes.
+  const int ncb = Nout / 16, nhb = K / 32, per = nhb / S;
   for (int item = blockIdx.x; item < ncb * S; item += gridDim.x) {
     const int cb = item % ncb, ks = item / ncb, n0 = cb * 16;
-    const int kb_lo = ks * per, kb_hi = kb_lo + per;
-    const float* Wp = W + (size_t)(n0 + l16) * K + 4 * lg;
-    // epilogue operands of the folding waves are requested early
+    const int hb_lo = ks * per, hb_hi = hb_lo + per;
+    const uint32_t woff = (uint32_t)(((size_t)(n0 + l16) * K + 4 * lg) * sizeof(float));
+    // epilogue operands of the folding waves are requested first
     const int em = wave * 16 + l16, en = n0 + 4 * lg;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wave < MB && em < p.M) {
-      b4 = *reinterpret_cast<const float4*>(bias + en);
-      if (EPI == EPI_RESADD && S == 1) c4 = C.ld4((size_t)em * ldc + en);
-    }
+    const bool erow = wave < MB && em < p.M;
+    const u32x4_t b4u = __builtin_amdgcn_raw_buffer_load_b128(Br, en * 4, 0, 0);
+    const float4 b4 = make_float4(__uint_as_float(b4u[0]), __uint_as_float(b4u[1]), __uint_as_float(b4u[2]), __uint_as_float(b4u[3]));
+    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_RESADD && S == 1) c4 = C.ld4_or0(erow ? (uint32_t)(((size_t)em * ldc + en) * sizeof(float)) : OOB);
     f32x4_t acc[MB];
     float sx[MB], sxx[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) { acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sx[mb] = 0.f; sxx[mb] = 0.f; }
-    // two 64-deep K blocks per trip: up to 32 independent 16-byte loads per lane in flight
-    for (int kb = kb_lo + wave; kb < kb_hi; kb += 16) {
-      const bool two = kb + 8 < kb_hi;
-      float4 wv[2][4], av[2][MB][4];
+    for (int base = hb_lo; base < hb_hi; base += 8 * U) {
+      u32x4_t wv[U][2], av[U][MB][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int k0 = (kb + 8 * u) * 64;
-        if (u == 0 || two) {
+      for (int u = 0; u < U; ++u) {
+        const int hb = base + wave + 8 * u;
+        const bool live = hb < hb_hi;
+        const uint32_t koff = (uint32_t)hb * 128u;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wv[u][j] = *reinterpret_cast<const float4*>(Wp + k0 + 16 * j);
+        for (int j = 0; j < 2; ++j) {
+          wv[u][j] = __builtin_amdgcn_raw_buffer_load_b128(Wr, (int)(live ? woff + koff + 64u * j : OOB), 0, 0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            av[u][mb][j] = __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)(live && aoff[mb] != OOB ? aoff[mb] + koff + 64u * j : OOB), 0, A_AUX);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);        // every load of the trip is in flight before the first MFMA (the scheduler otherwise
+                                                // threads the loads through the MFMAs with an s_waitcnt vmcnt(0) behind each group)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float a[MB][4];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (akind[mb] == 0) av[u][mb][j] = A.ld4c(arow[mb] + k0 + 16 * j);
-              else av[u][mb][j] = akind[mb] == 1 ? make_float4(1.f, 1.f, 1.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < 4; ++c) {
+              a[mb][c] = ones[mb] ? 1.f : __uint_as_float(av[u][mb][j][c]);
+              if (LN) { sx[mb] += a[mb][c]; sxx[mb] += a[mb][c] * a[mb][c]; }
             }
+          // the three accumulators alternate: a dependent MFMA is three issues (96 cycles) behind its predecessor, not back to back
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+              acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wv[u][j][c]), a[mb][c], acc[mb], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 1 && !two) break;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            if (LN && akind[mb] == 0) {
-              const float4 t = av[u][mb][j];
-              sx[mb] += (t.x + t.y) + (t.z + t.w);
-              sxx[mb] += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
-            }
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].x, av[u][mb][j].x, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].y, av[u][mb][j].y, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].z, av[u][mb][j].z, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j].w, av[u][mb][j].w, acc[mb], 0, 0, 0);
-          }
-      }
     }
+    DIT_STAMP_AFTER(s, 1, acc[0][0] + acc[1][0] + acc[2][0]);
     if (LN) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {       // the 4 lanes l16 + 16 lg hold disjoint columns of row mb*16 + l16
@@ -223,6 +273,7 @@ __device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A,
     for (int mb = 0; mb < MB; ++mb)
       *reinterpret_cast<float4*>(s.red[wave][mb][lane]) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
     __syncthreads();
+    DIT_STAMP(s, 2);
     // wave mb folds the 8 partials of row block mb: lane holds out[m = 16 mb + l16][n0 + 4 lg + {0..3}]
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave < MB) {
@@ -284,44 +335,74 @@ __device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A,
   }
 }
 
-// one workgroup per (sample, head): 17 x 17 scores from LDS copies of q, k, v
+template <bool LN, int EPI>
+__device__ __forceinline__ void gemm_phase(const DitP& p, Smem& s, const Act& A, int lda, const float* __restrict__ W,
+                                           const float* __restrict__ bias, const Act& C, int ldc, int Nout, int K, int S,
+                                           unsigned* cnt, unsigned cnt_target, const Act& part) {
+  const int per = K / 32 / S;             // 32-deep pieces per slice, dealt to 8 waves
+  if (per <= 8) gemm_phase_u<LN, EPI, 1>(p, s, A, lda, W, bias, C, ldc, Nout, K, S, cnt, cnt_target, part);
+  else if (per <= 16) gemm_phase_u<LN, EPI, 2>(p, s, A, lda, W, bias, C, ldc, Nout, K, S, cnt, cnt_target, part);
+  else gemm_phase_u<LN, EPI, 3>(p, s, A, lda, W, bias, C, ldc, Nout, K, S, cnt, cnt_target, part);
+}
+
+// one workgroup per (sample, head): T1 x T1 scores from LDS copies of q, k, v.  Round 4: every loop over the tokens or the head width
+// is a fixed-length, fully unrolled run of 16-byte LDS reads and the softmax of a row lives in the 32 lanes that computed its
+// scores — the round-3 form (runtime-length scalar loops, 17 threads doing the softmax) took 20,000 cycles per phase, as long as a
+// K = 768 product (profiles/r04_dit_stamps_before.txt).
 __device__ __forceinline__ void attention_phase(const DitP& p, Smem& s, const Act& qkv, const Act& o) {
   const int tid = threadIdx.x, T1 = p.T1, ld = 3 * p.H;
+  constexpr uint32_t OOB = 0x80000000u;
   for (int pr = blockIdx.x; pr < p.N * p.heads; pr += gridDim.x) {
     const int n = pr / p.heads, hd = pr - n * p.heads;
     const size_t base = (size_t)n * T1 * ld + hd * HD;
-    for (int e = tid; e < T1 * (HD / 4); e += 512) {
-      const int i = e / (HD / 4), d = (e - i * (HD / 4)) * 4;
-      const size_t r = base + (size_t)i * ld + d;
-      const float4 q4 = qkv.ld4c(r), k4 = qkv.ld4c(r + p.H), v4 = qkv.ld4c(r + 2 * p.H);
-      *reinterpret_cast<float4*>(&s.q[i][d]) = q4;
-      s.k[i][d] = k4.x; s.k[i][d + 1] = k4.y; s.k[i][d + 2] = k4.z; s.k[i][d + 3] = k4.w;
-      *reinterpret_cast<float4*>(&s.v[i][d]) = v4;
+    // q, k, v rows of this head: 3 x T1 x 16 pieces of 16 bytes, two per thread at most (T1 <= 32: 1536 pieces), all requested
+    // before the first is used; rows T1 .. 31 of v are zero-filled (the P V loop runs over all 32 keys)
+    float4 ld_[3];
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+      const int e = tid + 512 * r3, which = e / (MAXT * 16), rem = e - which * (MAXT * 16), i = rem >> 4, d = (rem & 15) * 4;
+      ld_[r3] = qkv.ld4_or0(i < T1 ? (uint32_t)((base + (size_t)i * ld + (size_t)which * p.H + d) * sizeof(float)) : OOB);
+    }
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+      const int e = tid + 512 * r3, which = e / (MAXT * 16), rem = e - which * (MAXT * 16), i = rem >> 4, d = (rem & 15) * 4;
+      float* dst = which == 0 ? &s.q[i][d] : (which == 1 ? &s.k[i][d] : &s.v[i][d]);
+      *reinterpret_cast<float4*>(dst) = ld_[r3];
     }
     __syncthreads();
-    for (int e = tid; e < T1 * T1; e += 512) {
-      const int i = e / T1, j = e - i * T1;
-      float acc = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < HD; ++d) acc += s.q[i][d] * s.k[j][d];
-      s.p[i][j] = acc * p.scale;
+    // scores + softmax: half-wave h = tid / 32 owns query rows h and h + 16, lane j = tid % 32 the key
+    const int j = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int i = (tid >> 5) + 16 * pass;                      // half-wave uniform
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const float4 q4 = *reinterpret_cast<const float4*>(&s.q[i][d]), k4 = *reinterpret_cast<const float4*>(&s.k[j][d]);
+        sc += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+      }
+      sc = j < T1 ? sc * p.scale : -INFINITY;
+      float mx = sc;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float e = j < T1 ? expf(sc - mx) : 0.f;
+      float sum = e;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      if (i < T1) s.p[i][j] = e / sum;                           // keys T1 .. 31: exact zeros
     }
     __syncthreads();
-    if (tid < T1) {
-      float mx = -INFINITY;
-      for (int j = 0; j < T1; ++j) mx = fmaxf(mx, s.p[tid][j]);
-      float sum = 0.f;
-      for (int j = 0; j < T1; ++j) { const float e = expf(s.p[tid][j] - mx); s.p[tid][j] = e; sum += e; }
-      const float inv = 1.f / sum;
-      for (int j = 0; j < T1; ++j) s.p[tid][j] *= inv;
-    }
-    __syncthreads();
-    const size_t ob = (size_t)n * T1 * p.H + hd * HD;
-    for (int e = tid; e < T1 * HD; e += 512) {
-      const int i = e / HD, d = e - i * HD;
-      float acc = 0.f;
-      for (int j = 0; j < T1; ++j) acc += s.p[i][j] * s.v[j][d];
-      o.st1(ob + (size_t)i * p.H + d, acc);
+    // out[i][d .. d+3] = sum_j p[i][j] v[j][d .. d+3]: one 16-byte piece per thread
+    {
+      const int i = tid >> 4, d = (tid & 15) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int jj = 0; jj < MAXT; ++jj) {
+        const float pj = s.p[i][jj];
+        const float4 v4 = *reinterpret_cast<const float4*>(&s.v[jj][d]);
+        acc.x += pj * v4.x; acc.y += pj * v4.y; acc.z += pj * v4.z; acc.w += pj * v4.w;
+      }
+      if (i < T1) o.st4((size_t)n * T1 * p.H + hd * HD + (size_t)i * p.H + d, acc);
     }
     __syncthreads();
   }
@@ -333,18 +414,33 @@ __device__ __forceinline__ void walk_blocks(const DitP& p, Smem& s, unsigned& ep
   const bool work = p.dbg != 1, sync = p.dbg != 2;
   for (int blk = 0; blk < p.depth; ++blk) {
     const float* const* w = p.w + blk * 8;
+    DIT_STAMP(s, 0);
     if (work) gemm_phase<true, EPI_BIAS>(p, s, h, p.H, w[0], w[1], qkv, 3 * p.H, 3 * p.H, p.H, 1, nullptr, 0, part);
-    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 0, 5);
+    DIT_STAMP(s, 0);
     if (work && p.dbg != 3) attention_phase(p, s, qkv, o);
-    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    DIT_STAMP(s, 1); DIT_STAMP(s, 2); DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 1, 5);
+    DIT_STAMP(s, 0);
     if (work) gemm_phase<false, EPI_RESADD>(p, s, o, p.H, w[2], w[3], h, p.H, p.H, p.H, p.s_proj, p.cnt_proj,
                                             (base + (unsigned)blk + 1u) * p.s_proj, part);
-    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 2, 5);
+    DIT_STAMP(s, 0);
     if (work) gemm_phase<true, EPI_GELU>(p, s, h, p.H, w[4], w[5], a, p.I, p.I, p.H, 1, nullptr, 0, part);
-    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 3, 5);
+    DIT_STAMP(s, 0);
     if (work) gemm_phase<false, EPI_RESADD>(p, s, a, p.I, w[6], w[7], h, p.H, p.H, p.I, p.s_fc2, p.cnt_fc2,
                                             (base + (unsigned)blk + 1u) * p.s_fc2, part);
-    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, p.dbg != 4, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 4, 5);
   }
 }
 
@@ -482,7 +578,15 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
   const unsigned nblk = gridDim.x;
   const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I),
       part(p.part, (size_t)SMAX * p.M * p.H);
+#if defined(DXA_DIT_STAMPS)
+  if (threadIdx.x < 40) s.stamp[threadIdx.x / 8][threadIdx.x % 8] = 0ull;
+  __syncthreads();
+#endif
   walk_blocks(p, s, epoch, nblk, 0u, h, qkv, o, a, part);
+#if defined(DXA_DIT_STAMPS)
+  __syncthreads();
+  if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x < 40) g_dit_stamps[threadIdx.x / 8][threadIdx.x % 8] = s.stamp[threadIdx.x / 8][threadIdx.x % 8];
+#endif
   // Leave the counters zeroed for the next launch on this stream (like the split-K flags of the ring GEMM): every
   // workgroup has passed the last barrier when it gets here, so the LAST one out may clear them.  Agent-scope atomic
   // stores, not a host-side memset: under HIP-graph replay a memset node's zeros were not reliably what the next
@@ -544,6 +648,15 @@ extern "C" int dxa_dit_blocks_status(dxa_stream_t stream, int* timed_out) {
   }
   return DXA_OK;
 }
+
+#if defined(DXA_DIT_STAMPS)
+// tuning build only: the segment sums of the LAST dit_blocks_fwd launch, [5 phase types][8] (entry 7 = number of phases summed)
+extern "C" int dxa_dit_debug_stamps(unsigned long long* out) {
+  DXA_CHECK_HIP(hipDeviceSynchronize());
+  DXA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dit_stamps), sizeof(unsigned long long) * 40));
+  return DXA_OK;
+}
+#endif
 
 extern "C" size_t dxa_dit_blocks_workspace(int M, int H, int I) {
   // qkv [M,3H] + o [M,H] + a [M,I] + K-slice partials [8][M,H] floats

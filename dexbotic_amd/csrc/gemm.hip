@@ -1190,10 +1190,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
     }                                                                                                       \
   } while (0)
 #if (DXA_PPV & 4)
-#define PP_MFMA(ii, ks, i, j) asm volatile("" : "+v"(acc[i][j]) : "v"(bq[j][ks]), "v"(af[ii][ks]))
+#define PP_MFMA2(ii, ks, i, j, jr) asm volatile("" : "+v"(acc[i][j]) : "v"(bq[jr][ks]), "v"(af[ii][ks]))
 #else
-#define PP_MFMA(ii, ks, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bq[j][ks]), __builtin_bit_cast(bf16x8_t, af[ii][ks]), acc[i][j], 0, 0, 0)
+#define PP_MFMA2(ii, ks, i, j, jr) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bq[jr][ks]), __builtin_bit_cast(bf16x8_t, af[ii][ks]), acc[i][j], 0, 0, 0)
 #endif
+#define PP_MFMA(ii, ks, i, j) PP_MFMA2(ii, ks, i, j, j)
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_BAR() do { PP_SB(); __builtin_amdgcn_s_barrier(); PP_SB(); } while (0)
   // compute cluster of quadrant (A half h, B half j): the two accumulators alternate so dependent MFMAs are 2 apart
@@ -1227,6 +1228,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
       const uint32_t b_ = yb ^ (uint32_t)((cur) * BUF + 32 * (ks));                                         \
       PP_READ(bq[j][ks], b_, (j) * 4096);                                                                   \
     }                                                                                                       \
+  } while (0)
+  // the same with the register set named apart from the B half (DXA_PPR=2: the two sets swap roles every K tile)
+#define PP_RDK_B2(cur, j, jr, ks)                                                                           \
+  do {                                                                                                      \
+    if constexpr (B_KS) {                                                                                   \
+      const uint32_t b0_ = yb ^ (uint32_t)((cur) * BUF + (j) * 16384);                                      \
+      PP_FRAG_TR(bq[jr][ks], b0_, 4096 * (ks));                                                             \
+    } else {                                                                                                \
+      const uint32_t b_ = yb ^ (uint32_t)((cur) * BUF + 32 * (ks));                                         \
+      PP_READ(bq[jr][ks], b_, (j) * 4096);                                                                  \
+    }                                                                                                       \
+  } while (0)
+#define PP_COMPUTE_R2(h, j, jr, R)                                                                \
+  do {                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+    PP_SB();                                                                                      \
+    PP_MFMA2(0, 0, 2 * (h), j, jr); PP_MFMA2(1, 0, 2 * (h) + 1, j, jr); PP_SB(); R(0); PP_SB();   \
+    PP_MFMA2(0, 1, 2 * (h), j, jr); PP_MFMA2(1, 1, 2 * (h) + 1, j, jr); PP_SB(); R(1); PP_SB();   \
+    PP_MFMA2(0, 2, 2 * (h), j, jr); PP_MFMA2(1, 2, 2 * (h) + 1, j, jr); PP_SB(); R(2); PP_SB();   \
+    PP_MFMA2(0, 3, 2 * (h), j, jr); PP_MFMA2(1, 3, 2 * (h) + 1, j, jr); PP_SB(); R(3); PP_SB();   \
   } while (0)
   // compute cluster with the NEXT cluster's fragment reads in its gaps: after the two MFMAs of k-step ks their operand registers are
   // dead, R(ks) refills them (the data lands tens of cycles after the MFMAs have read their sources)
@@ -1303,7 +1324,44 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #ifndef DXA_PPR
 #define DXA_PPR 1
 #endif
-#if DXA_PPR
+#if DXA_PPR == 2
+  // Round 4 schedule, second form (DXA_PPR=2, default).  DXA_PPR=1 below moved every fragment read into the gaps of the compute cluster
+  // BEFORE the one that needs it; its stamps (profiles/r04_pp_stamps_after.txt) then showed the barrier intervals that hold a C3 —
+  // 12 reads in its gaps (24 ds_read_b64_tr_b16 for TN): A0(t+1) and B0(t+1) — at 360 / 410 cycles (TN 427 / 500) against 270-340 for
+  // the others, while C2 carried none: A1 and B0 are both still live in C2, so nothing could be refilled there.  Here the two B
+  // register sets swap roles every K tile (the loop is unrolled by two, so the set index is a compile-time constant): in tile t set
+  // s0 = t & 1 holds B0(t) and set s1 = s0 ^ 1 receives B1(t) in C0; C2 (A1 x B1) consumes s1 k-step by k-step and refills it with
+  // B0(t+1) — which is then already where tile t+1 (s0' = s1) expects it — and C3 (A1 x B0, set s0) refills only the A registers
+  // with A0(t+1).  Reads per compute cluster 4 / 8 / 4 / 8 instead of 4 / 8 / 0 / 12.
+  //   C0 (A0 x B0) reads B1(t);  C1 (A0 x B1) reads A1(t);  C2 (A1 x B1) reads B0(t+1);  C3 (A1 x B0) reads A0(t+1).
+  // B0(t+1) is needed one phase earlier than before, so the LDS-DMA order swaps A0 and B0:  M0 A1(t+1) -> other buffer, M1 B0(t+2),
+  // M2 A0(t+2), M3 B1(t+2) -> this buffer (the bytes they overwrite were read in C1(t-1), C2(t-1), C3(t-1), C0(t): at least one full
+  // barrier interval before, for both groups).  In-order issue per wave (2 instructions each):
+  //   ... A1(t) | B0(t+1) | A0(t+1) | B1(t+1) | A1(t+1) | B0(t+2) | A0(t+2) | B1(t+2) ...
+  // A piece read in C_q is waited for at the end of M_{q-1} by every wave: always the piece issued four phases earlier = vmcnt(8).
+#define PP_R2_B1(ks) PP_RDK_B2(cur_, 1, cur_ ^ 1, ks)
+#define PP_R2_A1(ks) PP_RDK_A(cur_, 1, ks)
+#define PP_R2_B0N(ks) do { if (more1) { PP_RDK_B2(cur_ ^ 1, 0, cur_ ^ 1, ks); } } while (0)
+#define PP_R2_A0N(ks) do { if (more1) { PP_RDK_A(cur_ ^ 1, 0, ks); } } while (0)
+#define PP_TILE(cur, t)                                                                                     \
+  do {                                                                                                      \
+    constexpr int cur_ = (cur);                                                                             \
+    const bool more1 = (t) + 1 < nk, more2 = (t) + 2 < nk;                                                  \
+    /* phase 0 */                                                                                           \
+    if (more1) { PP_LOOP(PP_DMA_A(1, cur_ ^ 1, (t) + 1)); PP_SB(); PP_VMCNT(8); } else { PP_VMCNT(0); }     \
+    PP_BAR(); PP_STAMP(0); PP_COMPUTE_R2(0, 0, cur_, PP_R2_B1); PP_BAR(); PP_STAMP(1);                      \
+    /* phase 1 */                                                                                           \
+    if (more2) { PP_LOOP(PP_DMA_B(0, cur_, (t) + 2)); PP_SB(); PP_VMCNT(8); } else if (more1) { PP_VMCNT(6); } \
+    PP_BAR(); PP_STAMP(2); PP_COMPUTE_R2(0, 1, cur_ ^ 1, PP_R2_A1); PP_BAR(); PP_STAMP(3);                  \
+    /* phase 2 */                                                                                           \
+    if (more2) { PP_LOOP(PP_DMA_A(0, cur_, (t) + 2)); PP_SB(); PP_VMCNT(8); } else if (more1) { PP_VMCNT(4); } \
+    PP_BAR(); PP_STAMP(4); PP_COMPUTE_R2(1, 1, cur_ ^ 1, PP_R2_B0N); PP_BAR(); PP_STAMP(5);                 \
+    /* phase 3 */                                                                                           \
+    if (more2) { PP_LOOP(PP_DMA_B(1, cur_, (t) + 2)); PP_SB(); PP_VMCNT(8); } else if (more1) { PP_VMCNT(2); } \
+    PP_BAR(); PP_STAMP(6); PP_COMPUTE_R2(1, 0, cur_, PP_R2_A0N); PP_BAR(); PP_STAMP(7);                     \
+    PP_STAMPS_FOLD();                                                                                       \
+  } while (0)
+#elif DXA_PPR
   // Round 4 schedule (DXA_PPR=1, default): NO fragment read is left in a memory cluster.  The stamp build (DXA_PPV=128,
   // profiles/r04_pp_stamps_before.txt) showed the two barrier intervals in which a group runs M0 — 12 ds_read_b128 (24
   // ds_read_b64_tr_b16 when both operands are k-strided) — at 440 cycles (TN 540) against 285 for the other six: the compute
@@ -1365,7 +1423,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   // ---- prologue: the four pieces of tile 0 and A0, B0, B1 of tile 1 in the steady state's issue order; A0(0), B0(0), B1(0) landed
   //      for every wave before the first read; tile 0's A0 / B0 fragments are read here (C3 of "tile -1")
   PP_DMA_A(0, 0, 0); PP_DMA_B(0, 0, 0); PP_DMA_B(1, 0, 0); PP_DMA_A(1, 0, 0);
+#if DXA_PPR == 2
+  if (nk > 1) { PP_DMA_B(0, 1, 1); PP_DMA_A(0, 1, 1); PP_DMA_B(1, 1, 1); }
+#else
   if (nk > 1) { PP_DMA_A(0, 1, 1); PP_DMA_B(0, 1, 1); PP_DMA_B(1, 1, 1); }
+#endif
   PP_SB();
   if (nk > 1) { PP_VMCNT(8); } else { PP_VMCNT(2); }
   PP_BAR();
@@ -1417,7 +1479,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #undef PP_RDK_A
 #undef PP_RDK_B
 #undef PP_COMPUTE_R
-#if DXA_PPR
+#undef PP_COMPUTE_R2
+#undef PP_RDK_B2
+#undef PP_MFMA2
+#if DXA_PPR == 2
+#undef PP_R2_B1
+#undef PP_R2_A1
+#undef PP_R2_B0N
+#undef PP_R2_A0N
+#elif DXA_PPR
 #undef PP_R_B1
 #undef PP_R_A1
 #undef PP_R_NEXT
