@@ -36,7 +36,7 @@ struct DitP {
   int M, N, T1, H, heads, I, depth;
   int s_proj, s_fc2;
   float eps, scale;
-  int dbg;   // tuning aid: 1 = barriers only, 2 = work only (wrong results)
+  int dbg;   // tuning aid (wrong results): 1 = barriers only, 2 = work only, 3 = no attention, 5 = no weight loads, 6 = no activation loads
 };
 
 struct alignas(16) Smem {
@@ -230,10 +230,10 @@ __device__ __forceinline__ void gemm_phase_u(const DitP& p, Smem& s, const Act& 
         const uint32_t koff = (uint32_t)hb * 128u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          wv[u][j] = __builtin_amdgcn_raw_buffer_load_b128(Wr, (int)(live ? woff + koff + 64u * j : OOB), 0, 0);
+          wv[u][j] = __builtin_amdgcn_raw_buffer_load_b128(Wr, (int)(live && p.dbg != 5 ? woff + koff + 64u * j : OOB), 0, 0);
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
-            av[u][mb][j] = __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)(live && aoff[mb] != OOB ? aoff[mb] + koff + 64u * j : OOB), 0, A_AUX);
+            av[u][mb][j] = __builtin_amdgcn_raw_buffer_load_b128(A.r, (int)(live && aoff[mb] != OOB && p.dbg != 6 ? aoff[mb] + koff + 64u * j : OOB), 0, A_AUX);
         }
       }
       __builtin_amdgcn_sched_barrier(0);        // every load of the trip is in flight before the first MFMA (the scheduler otherwise
@@ -761,6 +761,582 @@ extern "C" int dxa_dit_sample_fwd(float* x, const float* z_emb, const float* t_e
   sp.steps = steps; sp.A = A; sp.nb = nb; sp.use_cfg = use_cfg; sp.cfg_scale = cfg_scale;
   sp.xpp = extra; sp.eps = extra + 2 * MAXM * MAXA;
   hipLaunchKernelGGL(dit_sample_fused_k, dim3(grid), dim3(512), 0, st, sp);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+// =====================================================================================================================
+// bf16-operand sampler (round 4).  The reference serves action inference with the WHOLE model loaded in bfloat16
+// (dexbotic/exp/cogact_exp.py:134-138: from_pretrained(torch_dtype=torch.bfloat16); inference_action, cogact_arch.py:149-204, runs
+// the DiT on bf16 weights and bf16 activations — the autocast(float32) of :133 wraps the TRAINING head only).  When the product
+// serves in bf16 the sampler above still multiplied in exact fp32: 1,024 MACs per 32-cycle v_mfma_f32_16x16x4_f32, 4,600 cycles of
+// MFMA per SIMD in every K = 768 phase, 340 MB of fp32 weights streamed per denoising step.  This variant keeps everything that
+// decides the accuracy in fp32 — residual stream h, LayerNorm statistics, attention, accumulation, GELU — and hands the MFMAs
+// bf16 operands like the reference's matmuls get:
+//   * weights: a packed bf16 copy (dxa_dit_bf16_pack): for 16 output columns nb and 32-deep K piece pc one contiguous 1 KiB tile
+//     [16 n][32 k], so a wave's 16-byte-per-lane load IS the A operand of v_mfma_f32_16x16x32_bf16 (lane = n + 16 (k / 8)) and is
+//     one contiguous KiB; 170 MB for DiT-B: it stays in the Infinity Cache between the steps.  sum_k W[n, k] (the LayerNorm fold
+//     needs it) is computed once at pack time, from the rounded weights.
+//   * activations that feed a product exist as bf16 tiles [K / 32][Mp rows][32 k] written by their PRODUCER (one 8-byte store per
+//     lane next to the fp32 value): hb = bf16(h), ob = attention output, ab = gelu(fc1).  Consumers load 16 bytes per lane and
+//     (piece, row block): half the bytes, half the load instructions, no conversion in the hot loop.
+//   * LayerNorm statistics travel beside h: its producer leaves (sum, sum of squares) of every (row, 16-column tile) — 13 KB —
+//     and a consumer's folding waves add the 48 tile pairs of their rows while the operands are in flight.  LN itself stays in the
+//     epilogue: rs (acc - mu wsum) + bias.
+// Per K = 768 phase and wave: 12 loads and 9 MFMAs of 16 cycles where the fp32 form has 24 loads and 72 MFMAs of 32 cycles.
+namespace {
+
+typedef uint32_t u32x2b_t __attribute__((ext_vector_type(2)));
+
+struct Buf {                       // an activation / workspace array behind a buffer descriptor, agent-scope accesses by BYTE offset
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ Buf(const void* p, size_t bytes)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+  __device__ __forceinline__ u32x4_t ld16(uint32_t off) const { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, SC1); }
+  __device__ __forceinline__ float4 ld16f(uint32_t off) const {
+    const u32x4_t v = ld16(off);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  }
+  __device__ __forceinline__ float ld4f(uint32_t off) const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, SC1)); }
+  __device__ __forceinline__ void st16(uint32_t off, const float4& v) const {
+    const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)off, 0, SC1);
+  }
+  __device__ __forceinline__ void st8(uint32_t off, uint32_t a, uint32_t b) const {
+    const u32x2b_t u = {a, b};
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)off, 0, SC1);
+  }
+  __device__ __forceinline__ void st4f(uint32_t off, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)off, 0, SC1); }
+};
+
+struct DitBfP {
+  float *h, *qkv, *stats, *part;   // h [M][H] fp32 residual stream; qkv [M][3H] fp32; stats [Mp][H/16][2]; part [S][H/16][Mp][16]
+  bf16_t *hb, *ob, *ab;            // [K/32][Mp][32] bf16 operand tiles: bf16(h), attention output, gelu(fc1)
+  const void* const* w;            // [depth][10]: qkv_wp, qkv_b, proj_wp, proj_b, fc1_wp, fc1_b, fc2_wp, fc2_b, qkv_wsum, fc1_wsum
+  unsigned *bar, *cnt_proj, *cnt_fc2;
+  int M, Mp, N, T1, H, heads, I, depth;
+  int s_proj, s_fc2;
+  float eps, scale;
+  int dbg;
+};
+
+struct BfBufs {
+  Buf h, qkv, stats, part, hb, ob, ab;
+  __device__ __forceinline__ BfBufs(const DitBfP& p)
+      : h(p.h, (size_t)p.M * p.H * 4), qkv(p.qkv, (size_t)p.M * 3 * p.H * 4), stats(p.stats, (size_t)p.Mp * (p.H / 16) * 8),
+        part(p.part, (size_t)SMAX * (p.H / 16) * p.Mp * 64), hb(p.hb, (size_t)(p.H / 32) * p.Mp * 64),
+        ob(p.ob, (size_t)(p.H / 32) * p.Mp * 64), ab(p.ab, (size_t)(p.I / 32) * p.Mp * 64) {}
+};
+
+__device__ __forceinline__ uint32_t tile_off(int Mp, int m, int c) {      // byte offset of element (row m, column c) in a bf16 operand tile array
+  return (uint32_t)((((c >> 5) * Mp + m) * 32 + (c & 31)) * 2);
+}
+
+// four consecutive columns c .. c+3 (c % 4 == 0, inside ONE 16-column tile ct) of row m of the residual stream: the fp32 value, its
+// bf16 operand copy and — from the four lanes that hold the 16 columns of the tile (lanes `lane ^ x1`, `lane ^ x2` are the others) —
+// the tile's (sum, sum of squares) for the LayerNorm of the consumers.  Every lane of the wave calls this (shuffles); `valid` gates the stores.
+__device__ __forceinline__ void write_h(const DitBfP& p, const BfBufs& b, int m, int c, const float4& t, bool valid, bool first_of_tile,
+                                        int x1, int x2) {
+  float sx = (t.x + t.y) + (t.z + t.w), sq = (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+  sx += __shfl_xor(sx, x1, 64); sq += __shfl_xor(sq, x1, 64);
+  sx += __shfl_xor(sx, x2, 64); sq += __shfl_xor(sq, x2, 64);
+  if (valid) {
+    b.h.st16((uint32_t)(((size_t)m * p.H + c) * 4), t);
+    b.hb.st8(tile_off(p.Mp, m, c), pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w));
+    if (first_of_tile) b.stats.st8((uint32_t)((m * (p.H / 16) + (c >> 4)) * 8), __float_as_uint(sx), __float_as_uint(sq));
+  }
+}
+
+enum { BF_QKV = 0, BF_FC1 = 1, BF_RES = 2 };
+
+// out = epi(pro(A) W^T + bias) with bf16 operands.  BF_QKV: A = hb, LayerNorm, out -> qkv fp32 [M][3H];  BF_FC1: A = hb, LayerNorm,
+// gelu, out -> ab tiles;  BF_RES: A = ob / ab, S K-slices folded by the last arrival (as in gemm_phase), out -> h += ..., hb, stats.
+template <int KIND, int U>
+__device__ __forceinline__ void gemm_bf_u(const DitBfP& p, Smem& s, const BfBufs& b, const Buf& A, int K, const bf16_t* Wp,
+                                          const float* bias, const float* wsum, int Nout, int S, unsigned* cnt, unsigned cnt_target) {
+  constexpr bool LN = KIND != BF_RES;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, lg = lane >> 4, Mp = p.Mp;
+  uint32_t aoff[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mb * 16 + l16;
+    aoff[mb] = m < p.M ? (uint32_t)(m * 64 + lg * 16) : OOB;
+  }
+  auto uniform_ptr = [](const void* q) {
+    const uint64_t v = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t Wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(Wp), 0, (int)((size_t)Nout * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t Br = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(bias), 0, Nout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(LN ? (const void*)wsum : (const void*)bias), 0, Nout * 4, 0x00020000);
+  const int ncb = Nout / 16, npc = K / 32, per = npc / S, ntile = K / 16, nq = ntile / 2;
+  for (int item = blockIdx.x; item < ncb * S; item += gridDim.x) {
+    const int cb = item % ncb, ks = item / ncb, n0 = cb * 16;
+    const int pc_lo = ks * per, pc_hi = pc_lo + per;
+    const uint32_t woff = (uint32_t)(((size_t)cb * npc * 16 + l16) * 64 + lg * 16);
+    const int em = wave * 16 + l16, en = n0 + 4 * lg;
+    const bool erow = wave < MB && em < p.M;
+    // epilogue operands first: bias, sum_k W, the row's LayerNorm tile sums, the residual
+    const u32x4_t b4u = __builtin_amdgcn_raw_buffer_load_b128(Br, en * 4, 0, 0);
+    u32x4_t ws4u = {0u, 0u, 0u, 0u};
+    float4 st[8];
+    if (LN) {
+      ws4u = __builtin_amdgcn_raw_buffer_load_b128(Sr, en * 4, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = lg + 4 * i;
+        st[i] = b.stats.ld16f(erow && q < nq ? (uint32_t)(em * ntile * 8 + q * 16) : OOB);
+      }
+    }
+    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KIND == BF_RES && S == 1) c4 = b.h.ld16f(erow ? (uint32_t)(((size_t)em * p.H + en) * 4) : OOB);
+    f32x4_t acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int base = pc_lo; base < pc_hi; base += 8 * U) {
+      u32x4_t wv[U], av[U][MB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pc = base + wave + 8 * u;
+        const bool live = pc < pc_hi;
+        wv[u] = __builtin_amdgcn_raw_buffer_load_b128(Wr, (int)(live && p.dbg != 5 ? woff + (uint32_t)pc * 1024u : OOB), 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          av[u][mb] = A.ld16(live && aoff[mb] != OOB && p.dbg != 6 ? aoff[mb] + (uint32_t)(pc * Mp) * 64u : OOB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u]), __builtin_bit_cast(bf16x8_t, av[u][mb]), acc[mb], 0, 0, 0);
+    }
+    DIT_STAMP_AFTER(s, 1, acc[0][0] + acc[1][0] + acc[2][0]);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      *reinterpret_cast<float4*>(s.red[wave][mb][lane]) = make_float4(acc[mb][0], acc[mb][1], acc[mb][2], acc[mb][3]);
+    __syncthreads();
+    DIT_STAMP(s, 2);
+    const float4 b4 = make_float4(__uint_as_float(b4u[0]), __uint_as_float(b4u[1]), __uint_as_float(b4u[2]), __uint_as_float(b4u[3]));
+    if (wave < MB) {            // wave mb folds the 8 partials of row block mb: lane holds out[m = 16 mb + l16][n0 + 4 lg + {0..3}]
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        const float4 v = *reinterpret_cast<const float4*>(s.red[w8][wave][lane]);
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+      }
+      if (S == 1) {
+        if (LN) {
+          float tx = 0.f, txx = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { tx += st[i].x + st[i].z; txx += st[i].y + st[i].w; }
+          tx += __shfl_xor(tx, 16, 64); txx += __shfl_xor(txx, 16, 64);
+          tx += __shfl_xor(tx, 32, 64); txx += __shfl_xor(txx, 32, 64);
+          const float mu = tx / (float)K;
+          const float rs = rsqrtf(fmaxf(txx / (float)K - mu * mu, 0.f) + p.eps);
+          r.x = rs * (r.x - mu * __uint_as_float(ws4u[0])); r.y = rs * (r.y - mu * __uint_as_float(ws4u[1]));
+          r.z = rs * (r.z - mu * __uint_as_float(ws4u[2])); r.w = rs * (r.w - mu * __uint_as_float(ws4u[3]));
+        }
+        r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+        if (KIND == BF_QKV) {
+          if (em < p.M) b.qkv.st16((uint32_t)(((size_t)em * Nout + en) * 4), r);
+        } else if (KIND == BF_FC1) {
+          r.x = act_fwd(DXA_ACT_GELU_TANH, r.x); r.y = act_fwd(DXA_ACT_GELU_TANH, r.y);
+          r.z = act_fwd(DXA_ACT_GELU_TANH, r.z); r.w = act_fwd(DXA_ACT_GELU_TANH, r.w);
+          if (em < p.M) b.ab.st8(tile_off(Mp, em, en), pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+        } else {
+          r.x += c4.x; r.y += c4.y; r.z += c4.z; r.w += c4.w;
+          write_h(p, b, em, en, r, em < p.M, lg == 0, 16, 32);
+        }
+      } else if (em < p.M) {
+        b.part.st16((uint32_t)((((size_t)ks * ncb + cb) * Mp + em) * 64 + lg * 16), r);
+      }
+    }
+    if (S > 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned arrived = __hip_atomic_fetch_add(cnt + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s.last = arrived == cnt_target;
+      }
+      __syncthreads();
+      if (s.last && wave < MB) {
+        float4 t = b.h.ld16f(em < p.M ? (uint32_t)(((size_t)em * p.H + en) * 4) : OOB);
+        float4 pq[SMAX];
+#pragma unroll
+        for (int q = 0; q < SMAX; ++q)
+          pq[q] = b.part.ld16f(q < S && em < p.M ? (uint32_t)((((size_t)q * ncb + cb) * Mp + em) * 64 + lg * 16) : OOB);
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < SMAX; ++q) { a4.x += pq[q].x; a4.y += pq[q].y; a4.z += pq[q].z; a4.w += pq[q].w; }
+        t.x += b4.x + a4.x; t.y += b4.y + a4.y; t.z += b4.z + a4.z; t.w += b4.w + a4.w;
+        write_h(p, b, em, en, t, em < p.M, lg == 0, 16, 32);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void gemm_bf(const DitBfP& p, Smem& s, const BfBufs& b, const Buf& A, int K, const void* Wp, const void* bias,
+                                        const void* wsum, int Nout, int S, unsigned* cnt, unsigned cnt_target) {
+  const int per = K / 32 / S;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(Wp);
+  const float *bi = reinterpret_cast<const float*>(bias), *ws = reinterpret_cast<const float*>(wsum);
+  if (per <= 8) gemm_bf_u<KIND, 1>(p, s, b, A, K, W, bi, ws, Nout, S, cnt, cnt_target);
+  else if (per <= 16) gemm_bf_u<KIND, 2>(p, s, b, A, K, W, bi, ws, Nout, S, cnt, cnt_target);
+  else gemm_bf_u<KIND, 3>(p, s, b, A, K, W, bi, ws, Nout, S, cnt, cnt_target);
+}
+
+// attention_phase with the output written as bf16 operand tiles (ob): the A operand of the output projection
+__device__ __forceinline__ void attention_bf(const DitBfP& p, Smem& s, const BfBufs& b) {
+  const int tid = threadIdx.x, T1 = p.T1, ld = 3 * p.H;
+  constexpr uint32_t OOB = 0x80000000u;
+  for (int pr = blockIdx.x; pr < p.N * p.heads; pr += gridDim.x) {
+    const int n = pr / p.heads, hd = pr - n * p.heads;
+    const size_t base = (size_t)n * T1 * ld + hd * HD;
+    float4 ld_[3];
+    const int li = tid >> 4, ldd = (tid & 15) * 4;
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3)
+      ld_[r3] = b.qkv.ld16f(li < T1 ? (uint32_t)((base + (size_t)li * ld + (size_t)r3 * p.H + ldd) * 4) : OOB);
+    *reinterpret_cast<float4*>(&s.q[li][ldd]) = ld_[0];
+    *reinterpret_cast<float4*>(&s.k[li][ldd]) = ld_[1];
+    *reinterpret_cast<float4*>(&s.v[li][ldd]) = ld_[2];
+    __syncthreads();
+    const int j = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int i = (tid >> 5) + 16 * pass;
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const float4 q4 = *reinterpret_cast<const float4*>(&s.q[i][d]), k4 = *reinterpret_cast<const float4*>(&s.k[j][d]);
+        sc += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+      }
+      sc = j < T1 ? sc * p.scale : -INFINITY;
+      float mx = sc;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float e = j < T1 ? expf(sc - mx) : 0.f;
+      float sum = e;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      if (i < T1) s.p[i][j] = e / sum;
+    }
+    __syncthreads();
+    {
+      const int i = tid >> 4, d = (tid & 15) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int jj = 0; jj < MAXT; ++jj) {
+        const float pj = s.p[i][jj];
+        const float4 v4 = *reinterpret_cast<const float4*>(&s.v[jj][d]);
+        acc.x += pj * v4.x; acc.y += pj * v4.y; acc.z += pj * v4.z; acc.w += pj * v4.w;
+      }
+      if (i < T1) b.ob.st8(tile_off(p.Mp, n * T1 + i, hd * HD + d), pack_bf16x2(acc.x, acc.y), pack_bf16x2(acc.z, acc.w));
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void walk_blocks_bf(const DitBfP& p, Smem& s, const BfBufs& b, unsigned& epoch, unsigned nblk, unsigned base) {
+  const bool work = p.dbg != 1, sync = p.dbg != 2;
+  for (int blk = 0; blk < p.depth; ++blk) {
+    const void* const* w = p.w + blk * 10;
+    DIT_STAMP(s, 0);
+    if (work) gemm_bf<BF_QKV>(p, s, b, b.hb, p.H, w[0], w[1], w[8], 3 * p.H, 1, nullptr, 0);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 0, 5);
+    DIT_STAMP(s, 0);
+    if (work && p.dbg != 3) attention_bf(p, s, b);
+    DIT_STAMP(s, 1); DIT_STAMP(s, 2); DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 1, 5);
+    DIT_STAMP(s, 0);
+    if (work) gemm_bf<BF_RES>(p, s, b, b.ob, p.H, w[2], w[3], nullptr, p.H, p.s_proj, p.cnt_proj, (base + (unsigned)blk + 1u) * p.s_proj);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 2, 5);
+    DIT_STAMP(s, 0);
+    if (work) gemm_bf<BF_FC1>(p, s, b, b.hb, p.H, w[4], w[5], w[9], p.I, 1, nullptr, 0);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 3, 5);
+    DIT_STAMP(s, 0);
+    if (work) gemm_bf<BF_RES>(p, s, b, b.ab, p.I, w[6], w[7], nullptr, p.H, p.s_fc2, p.cnt_fc2, (base + (unsigned)blk + 1u) * p.s_fc2);
+    DIT_STAMP(s, 3);
+    if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+    DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 4, 5);
+  }
+}
+
+struct DitSampleBfP {
+  DitBfP blk;
+  float* x; const float* ze; const float* te; const float* pos; const float* xw; const float* xb; const float* fw; const float* fb;
+  const float* coef; float* xpp; float* eps;
+  int steps, A, nb, use_cfg;
+  float cfg_scale;
+};
+
+__global__ __launch_bounds__(512) void dit_sample_bf16_k(const DitSampleBfP sp) {
+  __shared__ Smem s;
+  __shared__ float xs[MAXM * MAXA];
+  const DitBfP& p = sp.blk;
+  unsigned epoch = 0;
+  const unsigned nblk = gridDim.x;
+  const int T = p.T1 - 1, A = sp.A, H = p.H, nx = sp.nb * T * A;
+  const BfBufs b(p);
+  const Act xin(sp.x, (size_t)nx), xpp(sp.xpp, (size_t)2 * nx), epsg(sp.eps, (size_t)p.M * MAXA), hact(p.h, (size_t)p.M * p.H);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(DXA_DIT_STAMPS)
+  if (threadIdx.x < 40) s.stamp[threadIdx.x / 8][threadIdx.x % 8] = 0ull;
+  __syncthreads();
+#endif
+  auto load_x = [&](int step) {          // as in dit_sample_fused_k
+    if (tid < nx) {
+      float xv;
+      if (step == 0) {
+        xv = xin.ld1(tid);
+      } else {
+        const int k = tid % A, t = (tid / A) % T, n = tid / (A * T);
+        float eps = epsg.ld1((size_t)(n * p.T1 + 1 + t) * MAXA + k);
+        if (sp.use_cfg) {
+          const float eu = epsg.ld1((size_t)((n + sp.nb) * p.T1 + 1 + t) * MAXA + k);
+          eps = eu + sp.cfg_scale * (eps - eu);
+        }
+        const float c_recip = sp.coef[(step - 1) * 4], c_recipm1 = sp.coef[(step - 1) * 4 + 1], ab_prev = sp.coef[(step - 1) * 4 + 2];
+        const float xo = xpp.ld1((size_t)((step - 1) & 1) * nx + tid);
+        const float x0 = c_recip * xo - c_recipm1 * eps;
+        const float eps2 = (c_recip * xo - x0) / c_recipm1;
+        xv = x0 * sqrtf(ab_prev) + sqrtf(1.f - ab_prev - 0.f) * eps2;
+      }
+      xs[tid] = xv;
+      if (blockIdx.x == 0) {
+        if (step < sp.steps) xpp.st1((size_t)(step & 1) * nx + tid, xv);
+        else xin.st1(tid, xv);
+      }
+    }
+    __syncthreads();
+  };
+  const int ntile = H / 16;
+  for (int step = 0; step < sp.steps; ++step) {
+    load_x(step);
+    // ---- assemble h = [t_emb + z_emb ; x W_x^T + b_x] + pos: four lanes per (row, 16-column tile), each four columns
+    for (int g = blockIdx.x * 512 + tid; (g >> 2) < ((p.M * ntile + 127) / 128) * 128; g += gridDim.x * 512) {
+      const int item = g >> 2, q = g & 3;
+      const bool valid = item < p.M * ntile;
+      const int m = valid ? item / ntile : 0, ct = valid ? item - m * ntile : 0, c = ct * 16 + 4 * q;
+      const int n = m / p.T1, t = m - n * p.T1;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (t == 0) {
+          v[e] = sp.te[(size_t)step * H + c + e] + sp.ze[(size_t)n * H + c + e];
+        } else {
+          const float* xr = xs + ((n % sp.nb) * T + (t - 1)) * A;
+          float a = sp.xb[c + e];
+          for (int k = 0; k < A; ++k) a += xr[k] * sp.xw[(size_t)(c + e) * A + k];
+          v[e] = a;
+        }
+        v[e] += sp.pos[(size_t)t * H + c + e];
+      }
+      write_h(p, b, m, c, make_float4(v[0], v[1], v[2], v[3]), valid, q == 0, 1, 2);
+    }
+    grid_sync(p.bar, nblk, epoch, true);
+    walk_blocks_bf(p, s, b, epoch, nblk, (unsigned)step * (unsigned)p.depth);
+    // ---- final layer on the action tokens (fp32, from the fp32 residual stream): one wave per row
+    for (int m = blockIdx.x * 8 + wave; m < p.M; m += gridDim.x * 8) {
+      if (m % p.T1 == 0) continue;
+      float v[16];
+      float sx = 0.f, sxx = 0.f;
+      const int per = H / 64;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v[j] = 0.f;
+        if (j < per) { v[j] = hact.ld1((size_t)m * H + j * 64 + lane); sx += v[j]; sxx += v[j] * v[j]; }
+      }
+      sx = wave_sum(sx); sxx = wave_sum(sxx);
+      const float mu = sx / (float)H;
+      const float rs = rsqrtf(fmaxf(sxx / (float)H - mu * mu, 0.f) + p.eps);
+      for (int k = 0; k < A; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j < per) d += (v[j] - mu) * rs * sp.fw[(size_t)k * H + j * 64 + lane];
+        d = wave_sum(d);
+        if (lane == 0) epsg.st1((size_t)m * MAXA + k, d + sp.fb[k]);
+      }
+    }
+    grid_sync(p.bar, nblk, epoch, true);
+  }
+  if (blockIdx.x == 0) load_x(sp.steps);
+#if defined(DXA_DIT_STAMPS)
+  __syncthreads();
+  if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x < 40) g_dit_stamps[threadIdx.x / 8][threadIdx.x % 8] = s.stamp[threadIdx.x / 8][threadIdx.x % 8];
+#endif
+  if (threadIdx.x == 0) {                 // leave_clean
+    unsigned* exit_cnt = p.bar + 48;
+    const unsigned out = __hip_atomic_fetch_add(exit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (out == nblk) {
+      for (int i = 0; i < 64; ++i) {
+        __hip_atomic_store(p.cnt_proj + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.cnt_fc2 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(p.bar + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---- weight packing: one workgroup per (block, matrix, 16 output columns); thread (r = tid / 16, t = tid % 16) walks row nb * 16 + r
+struct PackP { const float* const* w; char* arena; const void** table; int depth, H, I; size_t per_block, off[6]; };
+__global__ __launch_bounds__(256) void dit_bf16_pack_k(const PackP q) {
+  const int nbq = 3 * q.H / 16, nbp = q.H / 16, nb1 = q.I / 16, nb2 = q.H / 16, per_blk = nbq + nbp + nb1 + nb2;
+  const int blk = blockIdx.x / per_blk;
+  int r0 = blockIdx.x - blk * per_blk, mat, K;
+  if (r0 < nbq) { mat = 0; K = q.H; } else if ((r0 -= nbq) < nbp) { mat = 1; K = q.H; } else if ((r0 -= nbp) < nb1) { mat = 2; K = q.H; } else { r0 -= nb1; mat = 3; K = q.I; }
+  const int nb = r0, tid = threadIdx.x, r = tid >> 4, t = tid & 15, npc = K / 32;
+  const float* W = q.w[blk * 8 + 2 * mat];
+  char* base = q.arena + (size_t)blk * q.per_block;
+  const size_t woff[4] = {q.off[0], q.off[2], q.off[3], q.off[5]};
+  bf16_t* out = reinterpret_cast<bf16_t*>(base + woff[mat]);
+  float sum = 0.f;
+  const float* row = W + (size_t)(nb * 16 + r) * K;
+  for (int k4 = t; k4 < K / 4; k4 += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(row + 4 * k4);
+    const uint32_t lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+    sum += (__uint_as_float(lo << 16) + __uint_as_float(lo & 0xffff0000u)) + (__uint_as_float(hi << 16) + __uint_as_float(hi & 0xffff0000u));
+    const int k = 4 * k4, pc = k >> 5, sl = k & 31;
+    *reinterpret_cast<uint2*>(out + (((size_t)nb * npc + pc) * 16 + r) * 32 + sl) = make_uint2(lo, hi);
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (t == 0 && (mat == 0 || mat == 2)) reinterpret_cast<float*>(base + (mat == 0 ? q.off[1] : q.off[4]))[nb * 16 + r] = sum;
+  if (blockIdx.x % per_blk == 0 && tid < 10) {
+    const void* e;
+    switch (tid) {
+      case 0: e = base + q.off[0]; break;  case 1: e = q.w[blk * 8 + 1]; break;
+      case 2: e = base + q.off[2]; break;  case 3: e = q.w[blk * 8 + 3]; break;
+      case 4: e = base + q.off[3]; break;  case 5: e = q.w[blk * 8 + 5]; break;
+      case 6: e = base + q.off[5]; break;  case 7: e = q.w[blk * 8 + 7]; break;
+      case 8: e = base + q.off[1]; break;  default: e = base + q.off[4]; break;
+    }
+    q.table[blk * 10 + tid] = e;
+  }
+}
+
+void bf16_layout(int H, int I, size_t off[6], size_t* per_block) {
+  size_t o = 0;
+  auto put = [&](int i, size_t bytes) { off[i] = o; o += (bytes + 255) / 256 * 256; };
+  put(0, (size_t)3 * H * H * 2); put(1, (size_t)3 * H * 4); put(2, (size_t)H * H * 2); put(3, (size_t)I * H * 2); put(4, (size_t)I * 4);
+  put(5, (size_t)H * I * 2);
+  *per_block = o;
+}
+size_t bf_ws_bytes(int M, int H, int I, size_t off[8]) {
+  const size_t Mp = (size_t)((M + 1) & ~1);
+  size_t o = 0;
+  auto put = [&](int i, size_t bytes) { off[i] = o; o += (bytes + 255) / 256 * 256; };
+  put(0, (size_t)M * H * 4);                       // h
+  put(1, (size_t)M * 3 * H * 4);                   // qkv
+  put(2, Mp * (H / 16) * 8);                       // stats
+  put(3, (size_t)SMAX * (H / 16) * Mp * 64);       // part
+  put(4, (size_t)(H / 32) * Mp * 64);              // hb
+  put(5, (size_t)(H / 32) * Mp * 64);              // ob
+  put(6, (size_t)(I / 32) * Mp * 64);              // ab
+  put(7, 3 * MAXM * MAXA * sizeof(float));         // x ping-pong + eps rows
+  return o;
+}
+
+}  // namespace
+
+extern "C" size_t dxa_dit_bf16_pack_bytes(int depth, int H, int I) {
+  if (depth <= 0 || H <= 0 || I <= 0) return 0;
+  size_t off[6], per = 0;
+  bf16_layout(H, I, off, &per);
+  return per * depth;
+}
+
+extern "C" int dxa_dit_bf16_pack(const float* const* weights, int depth, int H, int I, void* packed, size_t packed_bytes,
+                                 const void** table, dxa_stream_t stream) {
+  DXA_CHECK_ARG(weights && packed && table, "dxa_dit_bf16_pack: null buffer");
+  DXA_CHECK_ARG(depth >= 1 && H % 64 == 0 && I % 64 == 0, "dxa_dit_bf16_pack: needs H, I %% 64 == 0");
+  DXA_CHECK_ARG(packed_bytes >= dxa_dit_bf16_pack_bytes(depth, H, I), "dxa_dit_bf16_pack: arena too small");
+  DXA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) % 256) == 0, "dxa_dit_bf16_pack: the arena must be 256-byte aligned");
+  PackP q;
+  q.w = weights; q.arena = reinterpret_cast<char*>(packed); q.table = table; q.depth = depth; q.H = H; q.I = I;
+  bf16_layout(H, I, q.off, &q.per_block);
+  const int per_blk = 3 * H / 16 + H / 16 + I / 16 + H / 16;
+  hipLaunchKernelGGL(dit_bf16_pack_k, dim3(depth * per_blk), dim3(256), 0, (hipStream_t)stream, q);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" size_t dxa_dit_sample_bf16_workspace(int M, int H, int I) {
+  if (M <= 0 || H <= 0 || I <= 0) return 0;
+  size_t off[8];
+  return bf_ws_bytes(M, H, I, off);
+}
+
+extern "C" int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w,
+                                       const float* x_b, const float* final_w, const float* final_b, const float* coef, int steps, int A,
+                                       int nb, int use_cfg, float cfg_scale, const void* const* packed_table, int depth, int N, int T1,
+                                       int H, int heads, int I, float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  const char* who = "dxa_dit_sample_bf16_fwd";
+  DXA_CHECK_ARG(x && z_emb && t_emb && pos && x_w && x_b && final_w && final_b && coef && workspace && packed_table, "%s: null buffer", who);
+  DXA_CHECK_ARG(steps >= 1 && A >= 1 && A <= MAXA && nb >= 1 && N == (use_cfg ? 2 * nb : nb),
+                "%s: needs 1 <= action_dim <= %d and N == nb (or 2 nb with guidance)", who, MAXA);
+  DXA_CHECK_ARG(depth >= 1 && T1 >= 1 && heads >= 1, "%s: bad sizes", who);
+  const int M = N * T1;
+  DXA_CHECK_ARG(M <= MAXM && T1 <= MAXT, "%s: at most %d rows / %d tokens per sample (got %d / %d)", who, MAXM, MAXT, M, T1);
+  DXA_CHECK_ARG(H % 64 == 0 && I % 64 == 0 && H == heads * HD && H <= 1024, "%s: needs head width 64, H <= 1024 and H, I %% 64 == 0", who);
+  DXA_CHECK_ARG(nb * (T1 - 1) * A <= 512 && nb * (T1 - 1) * A <= MAXM * MAXA, "%s: the sample has too many elements", who);
+  size_t off[8];
+  DXA_CHECK_ARG(workspace_bytes >= bf_ws_bytes(M, H, I, off), "%s: workspace too small", who);
+  DXA_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) % 256) == 0, "%s: the workspace must be 256-byte aligned", who);
+  hipStream_t st = (hipStream_t)stream;
+  DitSampleBfP sp;
+  DitBfP& p = sp.blk;
+  char* ws = reinterpret_cast<char*>(workspace);
+  p.h = reinterpret_cast<float*>(ws + off[0]); p.qkv = reinterpret_cast<float*>(ws + off[1]); p.stats = reinterpret_cast<float*>(ws + off[2]);
+  p.part = reinterpret_cast<float*>(ws + off[3]); p.hb = reinterpret_cast<bf16_t*>(ws + off[4]); p.ob = reinterpret_cast<bf16_t*>(ws + off[5]);
+  p.ab = reinterpret_cast<bf16_t*>(ws + off[6]);
+  float* extra = reinterpret_cast<float*>(ws + off[7]);
+  unsigned* tail = nullptr;
+  if (int rc = get_sync_block(st, &tail)) return rc;
+  p.bar = tail; p.cnt_proj = tail + 64; p.cnt_fc2 = tail + 128;
+  p.w = packed_table;
+  p.M = M; p.Mp = (M + 1) & ~1; p.N = N; p.T1 = T1; p.H = H; p.heads = heads; p.I = I; p.depth = depth;
+  p.eps = eps; p.scale = 1.f / sqrtf((float)HD);
+  static const int dbg = getenv("DXA_DIT_DBG") ? atoi(getenv("DXA_DIT_DBG")) : 0;
+  p.dbg = dbg;
+  int grid = I / 16;
+  if (3 * H / 16 > grid) grid = 3 * H / 16;
+  static int resident = 0;
+  if (resident == 0) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    DXA_CHECK_HIP(hipGetDevice(&dev));
+    DXA_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    DXA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dit_sample_bf16_k, 512, 0));
+    resident = per_cu * prop.multiProcessorCount;
+    DXA_CHECK_ARG(resident >= 1, "%s: the kernel does not fit on this device", who);
+  }
+  if (grid > resident) grid = resident;
+  static const int grid_cap = getenv("DXA_DIT_GRID") ? atoi(getenv("DXA_DIT_GRID")) : 0;
+  if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+  static const int no_slice = getenv("DXA_DIT_NO_SLICE") ? 1 : 0;
+  p.s_proj = no_slice ? 1 : pick_slices(H / 16, H / 64, grid);
+  p.s_fc2 = no_slice ? 1 : pick_slices(H / 16, I / 64, grid);
+  sp.x = x; sp.ze = z_emb; sp.te = t_emb; sp.pos = pos; sp.xw = x_w; sp.xb = x_b; sp.fw = final_w; sp.fb = final_b; sp.coef = coef;
+  sp.steps = steps; sp.A = A; sp.nb = nb; sp.use_cfg = use_cfg; sp.cfg_scale = cfg_scale;
+  sp.xpp = extra; sp.eps = extra + 2 * MAXM * MAXA;
+  hipLaunchKernelGGL(dit_sample_bf16_k, dim3(grid), dim3(512), 0, st, sp);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

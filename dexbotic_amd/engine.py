@@ -134,6 +134,8 @@ class ParamStore:
         # optimizer (torch.optim.AdamW on the arena views) moved the fp32 masters (w(): version counter of the arena).
         self.managed = False
         self._shadow_version: Optional[int] = None
+        self.native_epoch = 0                      # bumped by every native update of the masters (FusedAdamW): with master._version the
+                                                   # key of caches derived from the weights (weights_key())
         self._grad_version: Optional[int] = None
         self._external_fresh = True                     # nothing written since the last begin_step
         self._external_trained = False                  # a training forward ran under an external loop since the last sync
@@ -182,6 +184,11 @@ class ParamStore:
         self.set_expected(())
 
     # ---- views --------------------------------------------------------------------------------------
+    def weights_key(self):
+        """changes whenever the fp32 masters may have changed: torch-side writes move the arena's version counter, the native
+        optimizer bumps native_epoch"""
+        return (self.master.data_ptr(), self.master._version, self.native_epoch)
+
     def wait_pending(self, bucket: Optional[int] = None) -> None:
         """make the current stream wait for the overlapped optimizer update of ``bucket`` (None: of every bucket still
         pending).  Readers that bypass the view accessors (raw master pointers, ``state_dict()``, ``p.data``) call this."""
@@ -688,6 +695,7 @@ class FusedAdamW:
             wds = d_wds if wds is None else wds
         lrs, wds = [float(x) for x in lrs], [float(x) for x in wds]
         assert len(lrs) == len(wds) == len(self.group_keys)
+        st.native_epoch += 1                       # the masters move under raw pointers: derived copies (packed DiT weights) are stale
         if not self.overlap:
             K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
                     lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)

@@ -217,6 +217,32 @@ class DiT(nn.Module):
             self._wtab = torch.tensor(ptrs, dtype=torch.int64).to(self.store.device)
         return self._wtab
 
+    def _bf16_sampler(self, N: int, T1: int) -> bool:
+        """the one-launch sampler multiplies in bf16 when the model is served in bfloat16 (DXA_DIT_BF16=0: exact fp32 products)"""
+        from .... import kernels as K
+        return (self.store.compute_dtype == torch.bfloat16 and os.environ.get("DXA_DIT_BF16", "1") != "0" and
+                K.dit_sample_bf16_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden))
+
+    def _packed_table(self, st) -> torch.Tensor:
+        """bf16 operand copy of the blocks' matrices (K.dit_bf16_pack), re-packed INTO THE SAME arena whenever the fp32 masters
+        may have moved (ParamStore.weights_key): a captured graph that holds its pointers stays valid.  The first build allocates:
+        not under stream capture (the first eager request of a shape builds it)."""
+        from .... import kernels as K
+        key = self.store.weights_key()
+        ent = getattr(self, "_bf16_pack", None)
+        if ent is None:
+            arena, table = K.dit_bf16_pack(self._weight_table(st), self.depth, self.hidden_size, self.mlp_hidden)
+            self._bf16_pack = ent = (key, arena, table)
+        elif ent[0] != key:
+            K.dit_bf16_pack(self._weight_table(st), self.depth, self.hidden_size, self.mlp_hidden, out=(ent[1], ent[2]))
+            self._bf16_pack = ent = (key, ent[1], ent[2])
+        return ent[2]
+
+    def refresh_packed(self) -> None:
+        """before a graph replay (no Python of this module runs in it): bring an existing packed copy up to date"""
+        if getattr(self, "_bf16_pack", None) is not None:
+            self._packed_table(Fp32View(self.store))
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor, drop_ids: Optional[torch.Tensor] = None,
                 train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None, per_kv: Optional[list] = None):
         """x (N,T,A) noisy actions, t (N,) timesteps, z (N,1,token) conditions -> eps_hat (N,T,A).
@@ -307,6 +333,15 @@ class DiT(nn.Module):
         x = noise.float().contiguous().clone()
         self.used_fused = True
         self.store.wait_pending()                  # the kernel reads the masters through raw pointers
+        if self._bf16_sampler(N, T + 1):
+            # a model served in bfloat16 multiplies with bf16 operands, like the reference's bf16 head (cogact_exp.py:134-138);
+            # residual stream, LayerNorm, attention and accumulation stay fp32 (csrc/dit_fused.hip, dit_sample_bf16_k)
+            K.dit_sample_bf16_fwd(x, ze.contiguous(), te.contiguous(), st.w(p + "positional_embedding").reshape(T + 1, h),
+                                  st.w(p + "x_embedder.linear.weight"), st.w(p + "x_embedder.linear.bias"),
+                                  st.w(p + "final_layer.linear.weight"), st.w(p + "final_layer.linear.bias"), coef, nb,
+                                  cfg_scale is not None, float(cfg_scale or 0.0), self._packed_table(st), self.depth, T + 1, h,
+                                  self.num_heads, self.mlp_hidden, 1e-6)
+            return x
         K.dit_sample_fwd(x, ze.contiguous(), te.contiguous(), st.w(p + "positional_embedding").reshape(T + 1, h),
                          st.w(p + "x_embedder.linear.weight"), st.w(p + "x_embedder.linear.bias"),
                          st.w(p + "final_layer.linear.weight"), st.w(p + "final_layer.linear.bias"), coef, nb,

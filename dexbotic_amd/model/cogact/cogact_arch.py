@@ -164,6 +164,8 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
         head.net.used_fused = False
         graph_stream = None
         if dev.type == "cuda" and use_graph and not return_traj:
+            if hasattr(head.net, "refresh_packed"):
+                head.net.refresh_packed()          # derived weight copies a captured graph reads (bf16 sampler): up to date before the replay
             samples = self._graph_sample(images, plan.plan.reshape(-1), B, S, noise, float(cfg_scale), int(num_ddim_steps))
             traj = None
             ent = self._infer_graphs[(tuple(images.shape), B, S, float(cfg_scale), int(num_ddim_steps))]

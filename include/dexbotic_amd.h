@@ -450,6 +450,27 @@ int dxa_dit_sample_fwd(float* x, const float* z_emb, const float* t_emb, const f
                        void* workspace, size_t workspace_bytes, dxa_stream_t stream);
 int dxa_dit_blocks_status(dxa_stream_t stream, int* timed_out);
 
+/* The same sampler with bf16 MFMA operands, for a model SERVED in bfloat16 — how the reference serves action inference
+ * (dexbotic/exp/cogact_exp.py:134-138 loads the whole model, DiT head included, with torch_dtype=torch.bfloat16 and
+ * inference_action, cogact_arch.py:149-204, runs it without the training forward's autocast(float32) of :133).  Residual stream,
+ * LayerNorm statistics, attention, GELU and accumulation stay fp32; the products read bf16 weights and bf16 copies of their
+ * input activations (what every nn.Linear of the reference's bf16 head reads).
+ *   dxa_dit_bf16_pack: `weights` as for dxa_dit_blocks_fwd (device array of depth*8 fp32 pointers) -> `packed`, an arena of
+ *   dxa_dit_bf16_pack_bytes(depth, H, I) bytes (256-byte aligned) holding, per block, the four matrices rounded to bf16 in the
+ *   MFMA operand order ([16 output columns][32 k] tiles of 1 KiB) and sum_k W[n, k] of the two LayerNorm-fed matrices; and `table`,
+ *   a DEVICE array of depth*10 pointers (packed qkv_w, qkv_b, packed proj_w, proj_b, packed fc1_w, fc1_b, packed fc2_w, fc2_b,
+ *   qkv_wsum, fc1_wsum) that dxa_dit_sample_bf16_fwd takes as `packed_table`.  Re-pack when the fp32 weights change.
+ *   dxa_dit_sample_bf16_fwd: arguments, limits (N*T1 <= 48 rows), co-residency contract and watchdog (dxa_dit_blocks_status) as
+ *   dxa_dit_sample_fwd; the workspace (dxa_dit_sample_bf16_workspace bytes) must be 256-byte aligned. */
+size_t dxa_dit_bf16_pack_bytes(int depth, int H, int I);
+int dxa_dit_bf16_pack(const float* const* weights, int depth, int H, int I, void* packed, size_t packed_bytes, const void** table,
+                      dxa_stream_t stream);
+size_t dxa_dit_sample_bf16_workspace(int M, int H, int I);
+int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w, const float* x_b,
+                            const float* final_w, const float* final_b, const float* coef, int steps, int A, int nb, int use_cfg,
+                            float cfg_scale, const void* const* packed_table, int depth, int N, int T1, int H, int heads, int I,
+                            float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,13 @@
 //   7  phase emulation, flag-array barrier (5) instead
 //   8  phase emulation, flags in the data (LL): every value travels as an 8-byte (value, epoch) pair, consumers poll the pairs
 //   9  like 6 with the activation loads through the XCD's L2 (no sc1) — wrong for coherence, shows what the bypass costs
+//  10  operand burst, round-3/4 pattern: every wave 24 x dwordx4 loads whose 64 lanes touch 16 rows x 64 bytes (row stride 3 KB),
+//      192 KB per workgroup per iteration out of a 1 GB buffer (cold), all workgroups at once, __syncthreads between iterations
+//  11  the same bytes as 1 KB-contiguous wave loads (what tile-major operands would give)
+//  12  shared operand, write-once addresses: after a device-wide barrier EVERY workgroup reads the same 104 KB region, a region never
+//      touched before in this launch (iteration i reads region i of the 1 GB buffer), plain cached loads, 16 rows x 64 B per wave load
+//  13  the same with agent-scope (sc1) loads: what dit_fused.hip does today on re-used addresses
+//  14 / 15  like 12 / 13 with 1 KB-contiguous wave loads
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,7 +67,7 @@ __device__ __forceinline__ void bar_flags(unsigned* flags, unsigned nblk, unsign
   __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void probe_k(unsigned* bar, unsigned* flags, float* act, u32x2_t* ll, float* sink, int mode, int iters) {
+__global__ __launch_bounds__(512) void probe_k(unsigned* bar, unsigned* flags, float* act, u32x2_t* ll, float* sink, int mode, int iters, const float* big, size_t big_floats) {
   const unsigned nblk = gridDim.x;
   const int tid = threadIdx.x;
   unsigned epoch = 0, spins = 0;
@@ -141,6 +148,48 @@ __global__ __launch_bounds__(512) void probe_k(unsigned* bar, unsigned* flags, f
       __syncthreads();
     }
   }
+  if (mode == 10 || mode == 11) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const size_t wg_bytes = 8 * 24 * 1024, total = big_floats * 4;
+    for (int it = 0; it < iters; ++it) {
+      const size_t chunk = ((size_t)it * gridDim.x + blockIdx.x) * wg_bytes % (total - wg_bytes);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(big) + chunk / 4, 0, (int)wg_bytes, 0x00020000);
+      u32x4_t v[24];
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        // 10: wave's 16 rows of 3072 B = 48 KB region per TWO waves... keep it simple: rows (wave % 4) * 16 + l16 of a [64 rows][3072 B] panel
+        //     (192 KB), instruction i covers bytes (wave / 4) * 1536 + i * 64 .. + 63 of each row
+        const unsigned off = mode == 10 ? (unsigned)((((wave & 3) * 16 + (lane & 15)) * 3072) + (wave >> 2) * 1536 + i * 64 + (lane >> 4) * 16)
+                                        : (unsigned)(wave * 24576 + i * 1024 + lane * 16);
+        v[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)off, 0, 0);
+      }
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) sacc += __uint_as_float(v[i][0]) + __uint_as_float(v[i][3]);
+      acc += sacc * 1e-30f;
+      __syncthreads();
+    }
+  }
+  if (mode >= 12 && mode <= 15) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int it = 0; it < iters; ++it) {
+      bar_atomic(bar, nblk, epoch, spins);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(big) + (size_t)it * (ROWS * KW), 0, ROWS * KW * 4, 0x00020000);
+      u32x4_t v[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        // strided: wave load = 16 rows x 64 B of the [34][768] fp32 matrix (rows 16 (i % 3) + l16; out of range past row 33: zeros)
+        const int row = 16 * (i % 3) + (lane & 15), col16 = (wave * 13 + i) / 3 % 48;
+        const unsigned off = (mode & 2) ? (unsigned)((wave * 13 + i) * 1024 + lane * 16)
+                                        : (row < ROWS ? (unsigned)(row * KW * 4 + col16 * 64 + (lane >> 4) * 16) : 0x80000000u);
+        v[i] = (mode & 1) ? __builtin_amdgcn_raw_buffer_load_b128(rb, (int)off, 0, SC1) : __builtin_amdgcn_raw_buffer_load_b128(rb, (int)off, 0, 0);
+      }
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 13; ++i) sacc += __uint_as_float(v[i][0]) + __uint_as_float(v[i][3]);
+      acc += sacc * 1e-30f;
+    }
+  }
   if (spins >= SPIN) atomicAdd(&g_timeouts, 1u);
   if (acc == 12345.678f) sink[0] = acc;
 }
@@ -155,28 +204,35 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&act, ROWS * KW * 4));
   CHECK(hipMalloc(&ll, ROWS * KW * 8));
   CHECK(hipMalloc(&sink, 64));
+  float* big;
+  const size_t big_floats = (size_t)1 << 28;      // 1 GB
+  CHECK(hipMalloc(&big, big_floats * 4));
+  CHECK(hipMemset(big, 0, big_floats * 4));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  const char* names[10] = {"store + ack", "sc1 load chain", "flag ping-pong, different XCDs (2 hops)", "flag ping-pong, same XCD (2 hops)",
+  const char* names[16] = {"store + ack", "sc1 load chain", "flag ping-pong, different XCDs (2 hops)", "flag ping-pong, same XCD (2 hops)",
                            "barrier: atomic counter + flag (shipped)", "barrier: flag array, no atomics", "phase: store, shipped barrier, 104 KB sc1 loads",
                            "phase: store, flag-array barrier, 104 KB sc1 loads", "phase: (value, epoch) pairs, poll the data (208 KB)",
-                           "phase: store, shipped barrier, 104 KB loads through L2"};
-  for (int mode = 0; mode < 10; ++mode) {
+                           "phase: store, shipped barrier, 104 KB loads through L2",
+                           "operand burst 192 KB / workgroup, 16 rows x 64 B per wave load", "operand burst 192 KB / workgroup, 1 KB contiguous per wave load",
+                           "barrier + shared 104 KB, fresh addresses, cached, 16 x 64 B", "barrier + shared 104 KB, fresh addresses, sc1, 16 x 64 B",
+                           "barrier + shared 104 KB, fresh addresses, cached, 1 KB contiguous", "barrier + shared 104 KB, fresh addresses, sc1, 1 KB contiguous"};
+  for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < 16; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       CHECK(hipMemset(bar, 0, 1024));
       CHECK(hipMemset(flags, 0, 4096));
       CHECK(hipMemset(ll, 0, ROWS * KW * 8));
       CHECK(hipDeviceSynchronize());
       CHECK(hipEventRecord(e0, 0));
-      hipLaunchKernelGGL(probe_k, dim3(grid), dim3(512), 0, 0, bar, flags, act, ll, sink, mode, iters);
+      hipLaunchKernelGGL(probe_k, dim3(grid), dim3(512), 0, 0, bar, flags, act, ll, sink, mode, mode >= 10 && mode < 12 ? 200 : iters, big, big_floats);
       CHECK(hipEventRecord(e1, 0));
       CHECK(hipEventSynchronize(e1));
       float ms = 0.f;
       CHECK(hipEventElapsedTime(&ms, e0, e1));
       unsigned to = 0;
       CHECK(hipMemcpyFromSymbol(&to, HIP_SYMBOL(g_timeouts), sizeof(to)));
-      if (rep == 1) printf("mode %d  %-62s %7.3f us per iteration%s\n", mode, names[mode], ms * 1e3f / iters, to ? "  (POLL BUDGET EXHAUSTED)" : "");
+      if (rep == 1) printf("mode %d  %-62s %7.3f us per iteration%s\n", mode, names[mode], ms * 1e3f / (mode >= 10 && mode < 12 ? 200 : iters), to ? "  (POLL BUDGET EXHAUSTED)" : "");
     }
   }
   return 0;

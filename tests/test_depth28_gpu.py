@@ -85,5 +85,7 @@ def test_bf16_request_at_depth_28_tracks_the_reference_classes(depth28):
     dfu = rel_err(acts_fused, acts_steps)
     print(f"  one-launch sampler vs per-step sampler (de-normalised chunk): {dfu:.2e}")
     assert not bad, bad
-    assert dfu < 2e-3, dfu
+    # the one-launch sampler of a bf16-served model multiplies with bf16 operands (like the reference's bf16 head); the per-step path
+    # above runs its fp32 products: the two differ by operand rounding, bounded by the reference's own bf16-vs-fp32 distance
+    assert dfu <= ref_gap["actions"], (dfu, ref_gap["actions"])
     assert rel_err(acts_fused, g["fp32/actions"]) <= 2.0 * ref_gap["actions"]

@@ -814,6 +814,121 @@ def test_dit_blocks_fused(cfg, offset):
         K.dit_blocks_fwd(torch.zeros(48, H, device=DEV), table, depth, 2, 24, H, heads, I, 1e-6)     # 48 rows: no spare row for the ones trick
 
 
+# ------------------------------------------------------------------------------------------------ bf16-operand DiT sampler
+def _dit_weights(H, I, depth, seed0=50):
+    ws, ptrs = [], []
+    for k in range(depth):
+        blk = [rnd(3 * H, H, seed=seed0 + 10 * k, scale=H ** -0.5), rnd(3 * H, seed=seed0 + 1 + 10 * k, scale=0.1),
+               rnd(H, H, seed=seed0 + 2 + 10 * k, scale=H ** -0.5), rnd(H, seed=seed0 + 3 + 10 * k, scale=0.1),
+               rnd(I, H, seed=seed0 + 4 + 10 * k, scale=H ** -0.5), rnd(I, seed=seed0 + 5 + 10 * k, scale=0.1),
+               rnd(H, I, seed=seed0 + 6 + 10 * k, scale=I ** -0.5), rnd(H, seed=seed0 + 7 + 10 * k, scale=0.1)]
+        ws.append(blk)
+        ptrs += [w.data_ptr() for w in blk]
+    return ws, torch.tensor(ptrs, dtype=torch.int64).to(DEV)
+
+
+@pytest.mark.parametrize("H,I,depth", [(768, 3072, 2), (192, 768, 3), (128, 512, 1)])
+def test_dit_bf16_pack_is_the_rounded_matrix_in_operand_order(H, I, depth):
+    """dxa_dit_bf16_pack: every matrix rounded to bf16 (round to nearest even, what torch's .to(bfloat16) does) laid out as
+    [16 output columns][K / 32][16][32] tiles, bit for bit; sum_k of the ROUNDED weights for the two LayerNorm-fed matrices;
+    the pointer table; re-packing in place after the weights moved"""
+    ws, table = _dit_weights(H, I, depth)
+    arena, ptab = K.dit_bf16_pack(table, depth, H, I)
+    per = arena.numel() // depth
+    tab = ptab.cpu().tolist()
+    base = arena.data_ptr()
+
+    def check():
+        for k, (qw, qb, pw, pb, w1, b1, w2, b2) in enumerate(ws):
+            e = tab[10 * k: 10 * k + 10]
+            assert [e[1], e[3], e[5], e[7]] == [qb.data_ptr(), pb.data_ptr(), b1.data_ptr(), b2.data_ptr()]
+            for w, addr in ((qw, e[0]), (pw, e[2]), (w1, e[4]), (w2, e[6])):
+                Nn, Kk = w.shape
+                off = addr - base
+                assert k * per <= off < (k + 1) * per and off % 256 == 0
+                got = arena[off: off + Nn * Kk * 2].view(torch.bfloat16).view(Nn // 16, Kk // 32, 16, 32)
+                want = w.to(torch.bfloat16).view(Nn // 16, 16, Kk // 32, 32).permute(0, 2, 1, 3)
+                assert torch.equal(got.view(torch.int16), want.contiguous().view(torch.int16))
+            for w, addr in ((qw, e[8]), (w1, e[9])):
+                off = addr - base
+                got = arena[off: off + w.shape[0] * 4].view(torch.float32)
+                want = w.to(torch.bfloat16).double().sum(1)
+                assert_close(got, want, 1e-5, 1e-5 * float(want.abs().max()), "sum of the rounded weights")
+    check()
+    for blk in ws:
+        for w in blk:
+            w.mul_(1.5).add_(0.01)
+    K.dit_bf16_pack(table, depth, H, I, out=(arena, ptab))
+    assert ptab.cpu().tolist() == tab
+    check()
+
+
+def _dit_sampler_restated(x, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, cfg_scale, round_ops):
+    """float64 restatement of the one-launch sampler (DiT.forward_with_cfg, dit.py:273-311, inside ddim_sample_loop,
+    diffusion.py:714-794); round_ops: the products read bf16 weights and bf16 copies of their input activations, LayerNorm is
+    folded as rs (bf16(h) W^T - mu sum_k W) like csrc/dit_fused.hip does"""
+    R = (lambda t: t.to(torch.bfloat16).double()) if round_ops else (lambda t: t.double())
+    x = x.double().clone()
+    nb, T, A = x.shape
+    H = ze.shape[1]
+    ln = lambda h: (h.mean(-1, keepdim=True), (h.var(-1, unbiased=False, keepdim=True) + 1e-6).rsqrt())
+    for s in range(te.shape[0]):
+        xe = (x @ xw.double().T + xb.double()).repeat(N // nb, 1, 1)
+        h = torch.cat([(te[s].double()[None, :] + ze.double())[:, None, :], xe], 1) + pos.double()[None]
+        for qw, qb, pw, pb, w1, b1, w2, b2 in ws:
+            mu, rs = ln(h)
+            Wq = R(qw)
+            qkv = rs * (R(h) @ Wq.T - mu * Wq.sum(1)) + qb.double()
+            q, kk, v = qkv.reshape(N, T + 1, 3, heads, 64).permute(2, 0, 3, 1, 4)
+            o = (torch.softmax((q @ kk.transpose(-1, -2)) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(N, T + 1, H)
+            h = h + R(o) @ R(pw).T + pb.double()
+            mu, rs = ln(h)
+            W1 = R(w1)
+            a = F.gelu(rs * (R(h) @ W1.T - mu * W1.sum(1)) + b1.double(), approximate="tanh")
+            h = h + R(a) @ R(w2).T + b2.double()
+        mu, rs = ln(h)
+        eps = (((h - mu) * rs) @ fw.double().T + fb.double())[:, 1:, :]
+        if cfg_scale is not None:
+            eps = eps[nb:] + cfg_scale * (eps[:nb] - eps[nb:])
+        c0, c1, ab = (coef[s, i].double() for i in range(3))
+        x0 = c0 * x - c1 * eps
+        x = x0 * ab.sqrt() + (1 - ab).sqrt() * ((c0 * x - x0) / c1)
+    return x
+
+
+@pytest.mark.parametrize("cfg", [(768, 12, 3072, 1, 1, True), (768, 12, 3072, 12, 10, True), (192, 3, 768, 3, 10, False), (128, 2, 512, 2, 4, True)])
+def test_dit_sample_bf16_operands(cfg):
+    """dxa_dit_sample_bf16_fwd (the sampler of a model served in bfloat16: bf16 MFMA operands, fp32 residual stream / LayerNorm /
+    attention / accumulation) against the fp64 restatement of ITS arithmetic.  One block and one step: 5e-4 (fp32 accumulation and a rounding flip or two; measured 1.5e-4
+    accumulation separates them).  At depth: two evaluations of the same bf16-operand arithmetic that differ by 1e-7 somewhere round
+    a few hundred of the 10^7 operand elements to DIFFERENT bf16 neighbours, and each flip is worth 4e-3 of that element — they end
+    ~1e-3 apart, as far as either is from the exact result; bound 6e-3, and within 8e-3 of the exact fp64 sampler (the reference's
+    own bf16 head sits 6e-3 from its fp32 head over the whole request, tests/golden/cogact_depth28_ref.npz).  Run-to-run bit-identical."""
+    H, heads, I, depth, steps, use_cfg = cfg
+    T, A, nb = 16, 7, 1
+    N = 2 if use_cfg else 1
+    ws, table = _dit_weights(H, I, depth, seed0=150)
+    x0 = rnd(nb, T, A, seed=7)
+    ze, te, pos = rnd(N, H, seed=8, scale=0.5), rnd(steps, H, seed=9, scale=0.5), rnd(T + 1, H, seed=10, scale=0.1)
+    xw, xb, fw, fb = rnd(H, A, seed=11, scale=0.3), rnd(H, seed=12, scale=0.1), rnd(A, H, seed=13, scale=H ** -0.5), rnd(A, seed=14, scale=0.1)
+    ab = torch.linspace(0.05, 0.95, steps + 1, device=DEV, dtype=torch.float64)
+    coef = torch.zeros(steps, 4, device=DEV)
+    coef[:, 0] = (1.0 / ab[:-1]).sqrt().float(); coef[:, 1] = (1.0 / ab[:-1] - 1.0).sqrt().float(); coef[:, 2] = ab[1:].float()
+    assert K.dit_sample_bf16_supported(N, T + 1, H, heads, I)
+    arena, ptab = K.dit_bf16_pack(table, depth, H, I)
+    outs = [K.dit_sample_bf16_fwd(x0.clone(), ze, te, pos, xw, xb, fw, fb, coef, nb, use_cfg, 1.5, ptab, depth, T + 1, H, heads, I, 1e-6)
+            for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not K.dit_blocks_timed_out()
+    want = _dit_sampler_restated(x0, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, 1.5 if use_cfg else None, True)
+    exact = _dit_sampler_restated(x0, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, 1.5 if use_cfg else None, False)
+    scale = float(exact.abs().max())
+    d_same, d_exact = float((outs[0].double() - want).abs().max()) / scale, float((outs[0].double() - exact).abs().max()) / scale
+    print(f"bf16-operand sampler {cfg}: vs its restatement {d_same:.2e}, vs exact {d_exact:.2e}")
+    assert d_same < (5e-4 if depth * steps == 1 else 6e-3), d_same
+    assert d_exact < 8e-3, d_exact
+
+
 # --------------------------------------------------------------- sum(g^2) out of the dW product's epilogue
 @pytest.mark.parametrize("M,N,Kd,accum", [(512, 768, 300, False), (770, 520, 4592, True), (3584, 4608, 1024, False),
                                          (70, 50, 96, False)])
