@@ -7,7 +7,8 @@ BASELINE.json configs[4] shapes: Qwen2.5-7B-class decoder widths (d 3584, 28 q /
 attention in every block**, memory of 4 past frames ('tome' consolidation above that), 2 retrieval layers with timestep PE and
 gate fusion.  One 'group' batch of 6 consecutive frames of one episode: the bank grows to its depth of 4 and consolidates
 twice.  Retrieval dropout off (the deterministic configuration; memvla_drop_t1.npz pins the dropout path at the tiny size).
-fp32 training step (loss, per-group gradient norms, strided gradient samples) + a 5-frame inference episode.
+fp32 training step AND the same step under bf16 autocast (loss, per-group gradient norms, strided gradient samples; their
+relative distances under ref_bf16_vs_fp32/*) + a 5-frame fp32 inference episode.
 tests/golden/memvla_t1.npz (hidden 256, DiT 3 x 128) reaches neither the MFMA tile widths nor DiT-L's per_attn shapes."""
 from __future__ import annotations
 
@@ -85,15 +86,35 @@ def main():
            "frames_crc": np.int64(zlib.crc32(x["infer_frames"].tobytes()))}
     res.update({k: v for k, v in x.items() if k not in ("images", "infer_frames")})
     m.train()
-    with inject_rng(noise=t(x["noise"]), timesteps=t(x["timesteps"]), drop_u=t(x["drop_u"])):
-        out = m(input_ids=t(x["input_ids"]), attention_mask=t(x["attention_mask"]), images=t(x["images"]),
-                actions=t(x["actions"]), indexes=[list(map(int, r)) for r in x["indexes"]])
-    out.loss.backward()
-    r = summarize({n: p.grad for n, p in m.named_parameters()}, out.loss.item())
-    print("fp32 loss", float(r["loss"]), {k: round(float(v), 5) for k, v in r.items() if k.startswith("gnorm/")},
-          f"{time.time()-t0:.0f}s", flush=True)
-    for k, v in r.items():
-        res["fp32/" + k] = v
+    # "fp32": the plain float32 step.  "bf16" (round 4): the same step under torch.autocast("cpu", bfloat16) with fp32 weights — what
+    # HF Trainer does for bf16=True (exp/trainer.py:100-124) — with the ONE shim of gen_golden_realwidth_ref.py: the reference wraps
+    # the action-head loss in autocast('cuda', float32) (memvla_arch.py:647), which on its real device switches autocast off for the
+    # head; that context manager does not touch the CPU autocast state, so the head is taken out of it here (fp32 inputs).
+    head = m.model.action_head_module
+    head_loss = head.loss
+
+    def fp32_head_loss(xx, zz, *a, **k):
+        with torch.autocast("cpu", enabled=False):
+            return head_loss(xx.float(), zz.float(), *a, **{n: (v.float() if torch.is_tensor(v) else v) for n, v in k.items()})
+    for tag, ac in (("fp32", False), ("bf16", True)):
+        m.zero_grad(set_to_none=True)
+        head.loss = fp32_head_loss
+        try:
+            with inject_rng(noise=t(x["noise"]), timesteps=t(x["timesteps"]), drop_u=t(x["drop_u"])):
+                with torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac):
+                    out = m(input_ids=t(x["input_ids"]), attention_mask=t(x["attention_mask"]), images=t(x["images"]),
+                            actions=t(x["actions"]), indexes=[list(map(int, r)) for r in x["indexes"]])
+        finally:
+            head.loss = head_loss
+        out.loss.backward()
+        r = summarize({n: p.grad for n, p in m.named_parameters()}, out.loss.item())
+        print(tag, "loss", float(r["loss"]), {k: round(float(v), 5) for k, v in r.items() if k.startswith("gnorm/")},
+              f"{time.time()-t0:.0f}s", flush=True)
+        for k, v in r.items():
+            res[tag + "/" + k] = v
+    for k in [k for k in res if k.startswith("bf16/")]:
+        a, b = np.asarray(res[k], dtype=np.float64), np.asarray(res["fp32/" + k[5:]], dtype=np.float64)
+        res["ref_bf16_vs_fp32/" + k[5:]] = np.float64(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
     m.zero_grad(set_to_none=True)
     m.eval()
     norms = {"min": [-1.0] * REAL.action_dim, "max": [1.0] * REAL.action_dim}

@@ -209,19 +209,24 @@ def test_fp32_memvla_real_size_step_and_episode_match_reference_classes(golden_d
         assert rel_err(np.array(acts), g["fp32/infer_actions"][f]) < FP32_TOL, f
 
 
-def test_bf16_memvla_real_size_step_tracks_fp32_reference(golden_dir):
-    """bf16 compute at the real size against the reference's fp32 step (no bf16-autocast fixture for MemVLA: its bank walks
-    the batch serially on the CPU, ~2 min per run): loss and per-group gradient norms within the bounds printed below"""
+def test_bf16_memvla_real_size_step_tracks_the_reference_under_autocast(golden_dir):
+    """bf16 compute at the real size against the reference's OWN step under torch.autocast(bfloat16) (round 4 fixture: bf16/* in
+    memvla_real_ref.npz; oracle/gen_golden_memvla_real.py) and against its fp32 step.  The reference's two runs sit
+    ref_bf16_vs_fp32/* apart (loss 4.4e-4, gradient norms <= 6e-4, gradient samples <= 1.2e-2); the product — a third bf16 evaluation
+    that rounds in its own order — is held to the bf16 run at: loss 6e-4, gradient norms 1e-3, gradient samples 4e-2 (max-norm
+    relative; measured 1.2e-4 / <= 2.1e-4 / <= 1.34e-2, profiles/r04_memvla_real_bf16_fixture.txt; round 3 allowed 2e-1 against the
+    fp32 run alone: a sign error in a small block would have passed)"""
     g, x, m = _real(golden_dir, "bfloat16", True)
     m.train()
     from dexbotic_amd import kernels as K
     with K.f32_gemm_mode("bf16x3"):
         got = _memvla_step(m, x)
     worst = {}
+    print("product bf16 vs reference bf16-autocast | vs reference fp32 | reference bf16 vs fp32")
     for k, v in got.items():
-        d = rel_err(v, g["fp32/" + k])
-        print(f"  {k:75s} {d:.2e}")
-        bound = 5e-3 if k == "loss" else (3e-2 if k.startswith("gnorm") else 2e-1)
-        if d >= bound:
-            worst[k] = (d, bound)
+        d16, d32 = rel_err(v, g["bf16/" + k]), rel_err(v, g["fp32/" + k])
+        print(f"  {k:75s} {d16:.2e} | {d32:.2e} | {float(g['ref_bf16_vs_fp32/' + k]):.2e}")
+        bound = 6e-4 if k == "loss" else (1e-3 if k.startswith("gnorm") else 4e-2)
+        if d16 >= bound:
+            worst[k] = (d16, bound)
     assert not worst, worst
