@@ -118,45 +118,35 @@ struct Act {
 // microseconds with a garbage result, and dxa_dit_blocks_status() reports it to the host, which re-runs the request on
 // the unfused path (persistent kernel needs a watchdog).
 constexpr unsigned SPIN_LIMIT = 1u << 21;
+// Round 4: SIXTEEN arrival counters, one 4 KiB apart from the next (bar + 1024 (g + 1) words), workgroup b arrives at counter b % 16
+// with a no-return atomic and lanes 0-15 of wave 0 poll one counter each until every counter shows its whole group.  The single
+// counter + flag of rounds 1-3 cost 1.0 us + 10 ns per WORKGROUP (2.97 us at 192, 1.06 us at 8: `profiles/r04_barrier_vs_grid.txt`) —
+// device-scope atomics on one address are applied one after the other at the memory side, and the flag hop is a second dependent
+// round trip behind them; spread over 16 lines in 16 places the same arrivals take 1.27 us and nobody waits for a publisher
+// (`scripts/probes/sync_probe.hip` modes 4 / 16: `profiles/r04_barrier_split.txt`).
+constexpr unsigned NCTR = 16;
 __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch, bool sleep, Smem* sst = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
   if (sst) DIT_STAMP(*sst, 4);
-  if (threadIdx.x == 0) {
+  epoch += 1;                                                // every thread keeps the count (wave 0's lanes need it)
+  if (threadIdx.x < 64) {
     unsigned* abortw = bar + 56;
-    epoch += 1;
-    const unsigned target = epoch * nblk;
-    const unsigned arrived = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (threadIdx.x == 0)
+      (void)__hip_atomic_fetch_add(bar + 1024u * (blockIdx.x % NCTR + 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned g = threadIdx.x % NCTR;
+    const unsigned target = epoch * ((nblk + NCTR - 1u - g) / NCTR);      // workgroups b < nblk with b % NCTR == g, `epoch` times
+    const unsigned* mine = bar + 1024u * (g + 1u);
     unsigned spins = 0;
-#if !defined(DXA_DIT_COUNTER_POLL)
-    // the last arrival publishes the epoch in a flag on another cache line and the others poll that flag: 3.5 us per
-    // barrier against 4.7 us when everybody polls the counter (scripts/probes/grid_barrier_probe.hip), and the pollers
-    // stay off the memory-side atomic unit the arrivals need (0.68 vs 0.86 ms per 12-block forward)
-    unsigned* flag = bar + 32;
-    if (arrived == target) {
-      __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-        if (sleep) __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0u) {
-          if (spins >= SPIN_LIMIT) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
+    while (true) {
+      const unsigned v = threadIdx.x < NCTR ? __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+      if (__builtin_amdgcn_ballot_w64(v < target) == 0ull) break;
+      if (sleep) __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 15u) == 0u) {            // the abort word: every 16th poll (a launch that was aborted drains in milliseconds)
+        if (spins >= SPIN_LIMIT && threadIdx.x == 0) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins >= SPIN_LIMIT) break;
       }
     }
-#else
-    if (arrived != target)
-      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (sleep) __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0u) {
-          if (spins >= SPIN_LIMIT) __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-      }
-#endif
-#if defined(DXA_DIT_CACHED_LOADS) && !defined(DXA_DIT_NOACQ)   /* NOACQ: timing experiment only (stale reads) */
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop stale activation lines from this CU's L1 / this XCD's L2
-#endif
   }
   __syncthreads();
 }
@@ -375,6 +365,7 @@ __device__ __forceinline__ void attention_phase(const DitP& p, Smem& s, const Ac
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int i = (tid >> 5) + 16 * pass;                      // half-wave uniform
+      if (i >= T1) continue;                                      // 17 tokens: the second pass is one row of one half-wave
       float sc = 0.f;
 #pragma unroll
       for (int d = 0; d < HD; d += 4) {
@@ -396,8 +387,9 @@ __device__ __forceinline__ void attention_phase(const DitP& p, Smem& s, const Ac
     {
       const int i = tid >> 4, d = (tid & 15) * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int jj = 0; jj < MAXT; ++jj) {
+      const int T1r = (T1 + 3) & ~3;                 // keys T1 .. T1r-1: p is an exact zero, v a zero row
+#pragma unroll 4
+      for (int jj = 0; jj < T1r; ++jj) {
         const float pj = s.p[i][jj];
         const float4 v4 = *reinterpret_cast<const float4*>(&s.v[jj][d]);
         acc.x += pj * v4.x; acc.y += pj * v4.y; acc.z += pj * v4.z; acc.w += pj * v4.w;
@@ -454,8 +446,8 @@ __device__ __forceinline__ void leave_clean(const DitP& p, unsigned nblk) {
         __hip_atomic_store(p.cnt_proj + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.cnt_fc2 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __hip_atomic_store(p.bar + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned g = 0; g < NCTR; ++g)
+        __hip_atomic_store(p.bar + 1024u * (g + 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -594,9 +586,10 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
   leave_clean(p, nblk);
 }
 
-// Barrier counter, flag, exit counter and the two per-tile counter arrays (H / 16 <= 64 entries each): one 1 KiB block
-// per (device, stream), zeroed when it is created and left zeroed by every launch.
-constexpr size_t SYNC_BYTES = 1024;
+// Exit counter, abort word and the two per-tile counter arrays (H / 16 <= 64 entries each) in the first KiB, the 16 arrival counters
+// of the device-wide barrier 4 KiB apart behind it: one 68 KiB block per (device, stream), zeroed when it is created and left
+// zeroed by every launch.
+constexpr size_t SYNC_BYTES = 4096 * (NCTR + 1);      // the first KiB: exit counter, abort word, tile counters; then the arrival counters
 int get_sync_block(hipStream_t st, unsigned** out) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, unsigned*> tab;
@@ -956,6 +949,9 @@ __device__ __forceinline__ void gemm_bf_u(const DitBfP& p, Smem& s, const BfBufs
       }
     }
     if (S > 1) {
+      // (tried in round 4 and dropped: the partial tiles as 8-byte (value, tag) pairs polled by the workgroup of slice 0 instead of
+      // counter + gather — the fold segment grew from 4,100 to 6,600 cycles: a poll round is a full round trip and the first one
+      // always misses, profiles/r04_sampler_pairs.txt)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
@@ -1011,6 +1007,7 @@ __device__ __forceinline__ void attention_bf(const DitBfP& p, Smem& s, const BfB
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int i = (tid >> 5) + 16 * pass;
+      if (i >= T1) continue;                                      // 17 tokens: the second pass is one row of one half-wave
       float sc = 0.f;
 #pragma unroll
       for (int d = 0; d < HD; d += 4) {
@@ -1031,8 +1028,9 @@ __device__ __forceinline__ void attention_bf(const DitBfP& p, Smem& s, const BfB
     {
       const int i = tid >> 4, d = (tid & 15) * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int jj = 0; jj < MAXT; ++jj) {
+      const int T1r = (T1 + 3) & ~3;                 // keys T1 .. T1r-1: p is an exact zero, v a zero row
+#pragma unroll 4
+      for (int jj = 0; jj < T1r; ++jj) {
         const float pj = s.p[i][jj];
         const float4 v4 = *reinterpret_cast<const float4*>(&s.v[jj][d]);
         acc.x += pj * v4.x; acc.y += pj * v4.y; acc.z += pj * v4.z; acc.w += pj * v4.w;
@@ -1187,8 +1185,8 @@ __global__ __launch_bounds__(512) void dit_sample_bf16_k(const DitSampleBfP sp) 
         __hip_atomic_store(p.cnt_proj + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.cnt_fc2 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __hip_atomic_store(p.bar + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned g = 0; g < NCTR; ++g)
+        __hip_atomic_store(p.bar + 1024u * (g + 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(exit_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -21,6 +21,9 @@
 //      touched before in this launch (iteration i reads region i of the 1 GB buffer), plain cached loads, 16 rows x 64 B per wave load
 //  13  the same with agent-scope (sc1) loads: what dit_fused.hip does today on re-used addresses
 //  14 / 15  like 12 / 13 with 1 KB-contiguous wave loads
+//  16  barrier: EIGHT arrival counters 4 KB apart (workgroup b arrives at counter b % 8 with a no-return atomic), lanes 0-7 of wave 0
+//      poll one counter each — no single address takes more than 1/8 of the atomics, no second dependent round trip
+//  17  barrier 16 inside the phase emulation of mode 6
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -67,6 +70,26 @@ __device__ __forceinline__ void bar_flags(unsigned* flags, unsigned nblk, unsign
   __syncthreads();
 }
 
+// eight counters, 4 KB apart (1024 words): counter g counts the arrivals of the workgroups b with b % 8 == g
+__device__ int g_nc = 8;      // number of arrival counters of modes 16 / 17 (argv[5])
+__device__ __forceinline__ void bar_split8(unsigned* ctr, unsigned nblk, unsigned& epoch, unsigned& spins) {
+  const unsigned NC = (unsigned)g_nc;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  epoch += 1;
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ctr + (blockIdx.x % NC) * 1024, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned g = threadIdx.x % NC;
+    const unsigned target = epoch * ((nblk + NC - 1u - g) / NC);
+    while (true) {
+      const unsigned v = threadIdx.x < NC ? __hip_atomic_load(ctr + g * 1024, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+      if (__builtin_amdgcn_ballot_w64(v < target) == 0ull || ++spins >= SPIN) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(512) void probe_k(unsigned* bar, unsigned* flags, float* act, u32x2_t* ll, float* sink, int mode, int iters, const float* big, size_t big_floats) {
   const unsigned nblk = gridDim.x;
   const int tid = threadIdx.x;
@@ -108,6 +131,23 @@ __global__ __launch_bounds__(512) void probe_k(unsigned* bar, unsigned* flags, f
     for (int it = 0; it < iters; ++it) bar_atomic(bar, nblk, epoch, spins);
   } else if (mode == 5) {
     for (int it = 0; it < iters; ++it) bar_flags(flags, nblk, epoch, spins);
+  } else if (mode == 16) {
+    for (int it = 0; it < iters; ++it) bar_split8(flags, nblk, epoch, spins);
+  } else if (mode == 17) {
+    for (int it = 0; it < iters; ++it) {
+      if (tid < ROWS) {
+        const u32x4_t v = {__float_as_uint(acc + 1.f), __float_as_uint(acc + 2.f), __float_as_uint(acc + 3.f), __float_as_uint(acc)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, ra, (int)((tid * KW + (blockIdx.x % 192) * 4) * 4), 0, SC1);
+      }
+      bar_split8(flags, nblk, epoch, spins);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ra, (j * 512 + tid) * 16, 0, SC1);
+        s += __uint_as_float(v[0]) + __uint_as_float(v[3]);
+      }
+      acc = s * 1e-30f;
+    }
   } else if (mode == 6 || mode == 7 || mode == 9) {
     // a workgroup produces 4 columns of the 34 x 768 activation (192 x 4 = 768), then reads all of it
     for (int it = 0; it < iters; ++it) {
@@ -200,7 +240,8 @@ int main(int argc, char** argv) {
   float *act, *sink;
   u32x2_t* ll;
   CHECK(hipMalloc(&bar, 1024));
-  CHECK(hipMalloc(&flags, 4096));
+  CHECK(hipMalloc(&flags, 65536 * 4));
+  { const int nc = argc > 5 ? atoi(argv[5]) : 8; CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_nc), &nc, sizeof(nc))); }
   CHECK(hipMalloc(&act, ROWS * KW * 4));
   CHECK(hipMalloc(&ll, ROWS * KW * 8));
   CHECK(hipMalloc(&sink, 64));
@@ -211,17 +252,18 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  const char* names[16] = {"store + ack", "sc1 load chain", "flag ping-pong, different XCDs (2 hops)", "flag ping-pong, same XCD (2 hops)",
+  const char* names[18] = {"store + ack", "sc1 load chain", "flag ping-pong, different XCDs (2 hops)", "flag ping-pong, same XCD (2 hops)",
                            "barrier: atomic counter + flag (shipped)", "barrier: flag array, no atomics", "phase: store, shipped barrier, 104 KB sc1 loads",
                            "phase: store, flag-array barrier, 104 KB sc1 loads", "phase: (value, epoch) pairs, poll the data (208 KB)",
                            "phase: store, shipped barrier, 104 KB loads through L2",
                            "operand burst 192 KB / workgroup, 16 rows x 64 B per wave load", "operand burst 192 KB / workgroup, 1 KB contiguous per wave load",
                            "barrier + shared 104 KB, fresh addresses, cached, 16 x 64 B", "barrier + shared 104 KB, fresh addresses, sc1, 16 x 64 B",
-                           "barrier + shared 104 KB, fresh addresses, cached, 1 KB contiguous", "barrier + shared 104 KB, fresh addresses, sc1, 1 KB contiguous"};
-  for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < 16; ++mode) {
+                           "barrier + shared 104 KB, fresh addresses, cached, 1 KB contiguous", "barrier + shared 104 KB, fresh addresses, sc1, 1 KB contiguous",
+                           "barrier: 8 arrival counters 4 KB apart, 8 lanes poll", "phase: store, 8-counter barrier, 104 KB sc1 loads"};
+  for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < (argc > 4 ? atoi(argv[4]) + 1 : 18); ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       CHECK(hipMemset(bar, 0, 1024));
-      CHECK(hipMemset(flags, 0, 4096));
+      CHECK(hipMemset(flags, 0, 65536 * 4));
       CHECK(hipMemset(ll, 0, ROWS * KW * 8));
       CHECK(hipDeviceSynchronize());
       CHECK(hipEventRecord(e0, 0));

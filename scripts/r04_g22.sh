@@ -1,5 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-(echo "== bf16-operand sampler"; DXA_LIB=_abl/lib_ditstamp0.so timeout 120 python scripts/dit_sample_stamps.py 2>&1 | grep -v amdgpu.ids | tail -8
-for d in 5 6; do echo "== bf16-operand sampler, DXA_DIT_DBG=$d"; DXA_DIT_DBG=$d DXA_LIB=_abl/lib_ditstamp0.so timeout 120 python scripts/dit_sample_stamps.py 2>&1 | grep -v amdgpu.ids | tail -8; done
-echo "== exact-fp32 sampler"; DXA_DIT_BF16=0 DXA_LIB=_abl/lib_ditstamp0.so timeout 120 python scripts/dit_sample_stamps.py 2>&1 | grep -v amdgpu.ids | tail -8) | tee gpurun_out/r04_dit_sample_stamps.txt
+(for w in 0 100; do echo "== bf16-operand sampler, 16-counter barrier, workgroup $w"; DXA_LIB=_abl/lib_ditstamp$w.so timeout 120 python scripts/dit_sample_stamps.py 2>&1 | grep -v amdgpu.ids | tail -8; done
+echo "== barriers only (DXA_DIT_DBG=1)"; DXA_DIT_DBG=1 timeout 120 python scripts/sampler_bf16_check.py 2>&1 | grep "ms per"
+echo "== work only (DXA_DIT_DBG=2)"; DXA_DIT_DBG=2 timeout 120 python scripts/sampler_bf16_check.py 2>&1 | grep "ms per") | tee gpurun_out/r04_dit_sample_stamps_16ctr.txt
