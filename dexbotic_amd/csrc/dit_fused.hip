@@ -708,6 +708,8 @@ int setup_blocks(DitP& p, int* grid_out, float* h, const float* const* weights, 
   static const int no_slice = getenv("DXA_DIT_NO_SLICE") ? 1 : 0;
   p.s_proj = no_slice ? 1 : pick_slices(H / 16, H / 64, grid);
   p.s_fc2 = no_slice ? 1 : pick_slices(H / 16, I / 64, grid);
+  static const int proj_cap = getenv("DXA_DIT_PROJ_SLICES") ? atoi(getenv("DXA_DIT_PROJ_SLICES")) : 0;      // tuning aid
+  if (proj_cap > 0 && p.s_proj > proj_cap && (H / 64) % proj_cap == 0) p.s_proj = proj_cap;
   *grid_out = grid;
   return DXA_OK;
 }
@@ -1331,6 +1333,11 @@ extern "C" int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float
   static const int no_slice = getenv("DXA_DIT_NO_SLICE") ? 1 : 0;
   p.s_proj = no_slice ? 1 : pick_slices(H / 16, H / 64, grid);
   p.s_fc2 = no_slice ? 1 : pick_slices(H / 16, I / 64, grid);
+  // the output projection is NOT K-sliced here: with bf16 operands a workgroup's whole K = 768 slab is 25 KB of weights + 52 KB of
+  // activations (the qkv phase's load), while a sliced product pays the partial exchange — store, acknowledge, tile counter, gather by
+  // the last arrival — after its MFMAs: 3.90 ms per sample with 4 slices, 3.82 with 2, 3.70 with 1 (profiles/r04_proj_slices.txt)
+  static const int proj_cap = getenv("DXA_DIT_PROJ_SLICES") ? atoi(getenv("DXA_DIT_PROJ_SLICES")) : 1;
+  if (proj_cap > 0 && p.s_proj > proj_cap && (H / 64) % proj_cap == 0) p.s_proj = proj_cap;
   sp.x = x; sp.ze = z_emb; sp.te = t_emb; sp.pos = pos; sp.xw = x_w; sp.xb = x_b; sp.fw = final_w; sp.fb = final_b; sp.coef = coef;
   sp.steps = steps; sp.A = A; sp.nb = nb; sp.use_cfg = use_cfg; sp.cfg_scale = cfg_scale;
   sp.xpp = extra; sp.eps = extra + 2 * MAXM * MAXA;
