@@ -1523,6 +1523,186 @@ template __global__ void gemm_pp_kernel<float, bf16_t, true, false, true>(const 
 template __global__ void gemm_pp_kernel<float, bf16_t, true, true, true>(const GemmP);
 template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, true, true>(const GemmP);
 
+// =====================================================================================================
+// Fast path 2b (round 4): the ping-pong schedule on a 192-row tile — bf16 NT, K % 64 == 0, both operands K-contiguous.
+//
+// Row counts that pad badly to 256 (the one-request prefill: 543 rows = 2.1 tiles of 256, 2.8 of 192) ran on the round-1 ring
+// kernel with 192-row tiles, whose eight waves all do their own LDS-DMA, fragment reads and MFMAs in lockstep (one barrier per
+// 32-deep slab): 0.80-0.86 PF/s where the ping-pong kernel reaches 1.24-1.41 on its 256-row tiles.  This is that kernel's schedule
+// — two wave groups one barrier interval apart alternating memory and compute clusters, fragment reads in the gaps of the
+// compute cluster before the one that needs them — for 8 waves as 2 (M) x 4 (N) with 96 x 64 per wave:
+//   K tile = 3 phases; phase q: compute cluster C_q = A block q (32 rows) x (B0, B1) x 4 k-steps = 8 MFMAs.
+//   Both B halves stay in registers for the whole K tile (two sets, swapped per tile), the A block registers are double-buffered.
+//   reads in the gaps:  C0: A1(t);   C1: A2(t), B0(t+1);   C2: A0(t+1), B1(t+1)            (4 / 8 / 8 ds_read_b128)
+//   LDS-DMA pieces per K tile: A0, A1, A2 (64 rows = 8 KiB: 1 instruction per wave) and B0, B1 (128 rows: 2 per wave) into two
+//   buffers of 56 KiB;  issue  M0: A2(t+1), B0(t+2);  M1: A0(t+2), B1(t+2);  M2: A1(t+2) — each exactly two phases after the read of
+//   the bytes it overwrites — and every piece is waited for by every wave at the end of the memory cluster BEFORE the compute
+//   cluster that reads it: always vmcnt(7) in the steady state (7 instructions per wave and K tile).
+// Same MFMA (v_mfma_f32_32x32x16_bf16), same K order, same epilogue (tile_finish<.., 3, ..>) as the ring kernel: bit-identical.
+// =====================================================================================================
+template <typename TO, typename TE>
+__global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int AREG = 192 * 128, BREG = 256 * 128, BUFSZ = AREG + BREG;      // 24 KiB + 32 KiB per K tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l32 = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  int split_j = 0, split_s = 1, tail_i = 0;
+  if (bid < p.full) {
+    const int q = p.full >> 3, r = p.full & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  } else {
+    const int idx = bid - p.full;
+    tail_i = idx % p.tail_r;
+    split_j = idx / p.tail_r;
+    split_s = p.split_s;
+    bid = p.full + tail_i;
+  }
+  const int width = p.group_m * p.tn;
+  const int group = bid / width;
+  const int first_pm = group * p.group_m;
+  const int gsz = min(p.tm - first_pm, p.group_m);
+  const int pm = first_pm + (bid % width) % gsz;
+  const int pn = (bid % width) / gsz;
+  const int64_t m0 = (int64_t)pm * 192, n0 = (int64_t)pn * 256;
+
+  const uint32_t bytesA = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t bytesB = (uint32_t)(((p.N - 1) * p.ldb + p.K) * 2);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, bytesB, 0x00020000);
+  // LDS-DMA: an instruction covers 8 tile rows (lane -> row0 + lane / 8, LDS slot lane % 8, source chunk slot ^ ((row >> 1) & 7)).
+  //   A block g: this wave's instruction = rows (wave >> 2) * 96 + 32 g + (wave & 3) * 8 ..+7   (both wave rows' block g: 64 rows)
+  //   B half h : instructions j = 0, 1 = rows ((2 wave + j) >> 2) * 64 + ((2 wave + j) & 3) * 8 + 32 h ..+7   (as the 256-row kernel)
+#define P3_A_ROW0(g) ((wave >> 2) * 96 + 32 * (g) + (wave & 3) * 8)
+#define P3_B_ROW0(h, j) ((((wave * 2 + (j)) >> 2) * 64) + (((wave * 2 + (j)) & 3) * 8) + 32 * (h))
+  uint32_t voA[3], voB[2][2];
+  {
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int ra = P3_A_ROW0(g) + lrow;
+      const int64_t ga = m0 + ra;
+      voA[g] = ga < p.M ? (uint32_t)ga * lda2 + (uint32_t)((lslot ^ ((ra >> 1) & 7)) << 4) : 0x80000000u;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rb = P3_B_ROW0(h, j) + lrow;
+        const int64_t gb = n0 + rb;
+        voB[h][j] = gb < p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+      }
+  }
+  const int nk_tot = (int)(p.K / 64);
+  const int k_lo = split_j * nk_tot / split_s;
+  const int nk = (split_j + 1) * nk_tot / split_s - k_lo;   // K tiles of this workgroup (>= 1)
+#define P3_DMA(rsrc, vo, ldsoff, buf, tile) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(smem + (buf) * BUFSZ + (ldsoff)), 16, vo, (k_lo + (tile)) * 128, 0, 0)
+#define P3_DMA_A(g, buf, tile) P3_DMA(rA, voA[g], P3_A_ROW0(g) * 128, buf, tile)
+#define P3_DMA_B(h, buf, tile) do { P3_DMA(rB, voB[h][0], AREG + P3_B_ROW0(h, 0) * 128, buf, tile); P3_DMA(rB, voB[h][1], AREG + P3_B_ROW0(h, 1) * 128, buf, tile); } while (0)
+
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row base | ((lh ^ sw) << 4), XOR (ks << 5) per k-step; one base per buffer (56 KiB is no power of two)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int sw = (l32 >> 1) & 7;
+  const uint32_t ya0 = (lds0 + (wm * 96 + l32) * 128) | (uint32_t)((lh ^ sw) << 4), ya1 = ya0 + BUFSZ;
+  const uint32_t yb0 = (lds0 + AREG + (wn * 64 + l32) * 128) | (uint32_t)((lh ^ sw) << 4), yb1 = yb0 + BUFSZ;
+  u32x4_t af[2][4], bq[2][2][4];
+#define P3_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define P3_RD_A(buf, g, set, ks) P3_READ(af[set][ks], ((buf) ? ya1 : ya0) ^ (uint32_t)(32 * (ks)), (g) * 4096)
+#define P3_RD_B(buf, h, bset, ks) P3_READ(bq[bset][h][ks], ((buf) ? yb1 : yb0) ^ (uint32_t)(32 * (ks)), (h) * 4096)
+#define P3_MFMA(g, set, bset, j, ks) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bq[bset][j][ks]), __builtin_bit_cast(bf16x8_t, af[set][ks]), acc[g][j], 0, 0, 0)
+#define P3_SB() __builtin_amdgcn_sched_barrier(0)
+#define P3_BAR() do { P3_SB(); __builtin_amdgcn_s_barrier(); P3_SB(); } while (0)
+  // compute cluster of A block g (registers af[set]) against both B halves (registers bq[bset]); R(ks) rides in the gap after k-step ks
+#define P3_COMPUTE(g, set, bset, R)                                                                 \
+  do {                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+    P3_SB();                                                                                        \
+    P3_MFMA(g, set, bset, 0, 0); P3_MFMA(g, set, bset, 1, 0); P3_SB(); R(0); P3_SB();               \
+    P3_MFMA(g, set, bset, 0, 1); P3_MFMA(g, set, bset, 1, 1); P3_SB(); R(1); P3_SB();               \
+    P3_MFMA(g, set, bset, 0, 2); P3_MFMA(g, set, bset, 1, 2); P3_SB(); R(2); P3_SB();               \
+    P3_MFMA(g, set, bset, 0, 3); P3_MFMA(g, set, bset, 1, 3); P3_SB(); R(3); P3_SB();               \
+  } while (0)
+#define P3_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  // One K tile in buffer cur = t & 1.  A blocks alternate between the two register sets phase by phase (3 phases per tile: the
+  // parity flips per tile, hence `par`), the B sets per tile.
+  //   tile with par = 0: A0 in af[0], A1 -> af[1], A2 -> af[0], A0(t+1) -> af[1];   par = 1: the mirror image
+#define P3_TILE(cur, t)                                                                                                  \
+  do {                                                                                                                   \
+    constexpr int cur_ = (cur), s0_ = (cur), s1_ = (cur) ^ 1;        /* af set of A0 / of A1; B set of this tile = cur */    \
+    const bool more1 = (t) + 1 < nk, more2 = (t) + 2 < nk;                                                               \
+    /* phase 0 */                                                                                                        \
+    if (more1) P3_DMA_A(2, cur_ ^ 1, (t) + 1);                                                                           \
+    if (more2) { P3_DMA_B(0, cur_, (t) + 2); P3_SB(); P3_VMCNT(7); } else if (more1) { P3_SB(); P3_VMCNT(5); } else { P3_VMCNT(0); } \
+    P3_BAR();                                                                                                            \
+    P3_COMPUTE(0, s0_, cur_, P3_R_A1);                                                                                   \
+    P3_BAR();                                                                                                            \
+    /* phase 1 */                                                                                                        \
+    if (more2) { P3_DMA_A(0, cur_, (t) + 2); P3_DMA_B(1, cur_, (t) + 2); P3_SB(); P3_VMCNT(7); } else if (more1) { P3_VMCNT(2); } \
+    P3_BAR();                                                                                                            \
+    P3_COMPUTE(1, s1_, cur_, P3_R_A2B0);                                                                                 \
+    P3_BAR();                                                                                                            \
+    /* phase 2 */                                                                                                        \
+    if (more2) { P3_DMA_A(1, cur_, (t) + 2); P3_SB(); P3_VMCNT(7); } else if (more1) { P3_VMCNT(1); }                    \
+    P3_BAR();                                                                                                            \
+    P3_COMPUTE(2, s0_, cur_, P3_R_A0B1);                                                                                 \
+    P3_BAR();                                                                                                            \
+  } while (0)
+#define P3_R_A1(ks) P3_RD_A(cur_, 1, s1_, ks)
+#define P3_R_A2B0(ks) do { P3_RD_A(cur_, 2, s0_, ks); if (more1) P3_RD_B(cur_ ^ 1, 0, cur_ ^ 1, ks); } while (0)
+#define P3_R_A0B1(ks) do { if (more1) { P3_RD_A(cur_ ^ 1, 0, s1_, ks); P3_RD_B(cur_ ^ 1, 1, cur_ ^ 1, ks); } } while (0)
+
+  // ---- prologue: tile 0 and what the steady state would have issued for tile 1 before M0(0), in its order:
+  //      B0(0) A0(0) B1(0) | A1(0) | A2(0) B0(1) | A0(1) B1(1) | A1(1);   B0, A0, B1, A1 of tile 0 landed for every wave before the first read
+  P3_DMA_B(0, 0, 0); P3_DMA_A(0, 0, 0); P3_DMA_B(1, 0, 0); P3_DMA_A(1, 0, 0); P3_DMA_A(2, 0, 0);
+  if (nk > 1) { P3_DMA_B(0, 1, 1); P3_DMA_A(0, 1, 1); P3_DMA_B(1, 1, 1); P3_DMA_A(1, 1, 1); }
+  P3_SB();
+  if (nk > 1) { P3_VMCNT(7); } else { P3_VMCNT(1); }
+  P3_BAR();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { P3_RD_A(0, 0, 0, ks); P3_RD_B(0, 0, 0, ks); P3_RD_B(0, 1, 0, ks); }
+  P3_SB();
+  if (wm == 1) P3_BAR();            // group 1 runs one barrier interval behind group 0
+  for (int t = 0; t < nk; t += 2) {
+    P3_TILE(0, t);
+    if (t + 1 < nk) P3_TILE(1, t + 1);
+  }
+  if (wm == 0) P3_BAR();            // every wave has now passed the same number of barriers
+#undef P3_A_ROW0
+#undef P3_B_ROW0
+#undef P3_DMA
+#undef P3_DMA_A
+#undef P3_DMA_B
+#undef P3_READ
+#undef P3_RD_A
+#undef P3_RD_B
+#undef P3_MFMA
+#undef P3_SB
+#undef P3_BAR
+#undef P3_COMPUTE
+#undef P3_VMCNT
+#undef P3_TILE
+#undef P3_R_A1
+#undef P3_R_A2B0
+#undef P3_R_A0B1
+  tile_finish<TO, 3, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+template __global__ void gemm_pp3_kernel<bf16_t, bf16_t>(const GemmP);
+template __global__ void gemm_pp3_kernel<float, bf16_t>(const GemmP);
+
 // x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
 __global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
                                                 int64_t rows, int64_t cols, int side) {
@@ -1864,6 +2044,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   } while (0)
     // ---- ping-pong main loop: 256-row tiles, K % 64 == 0; the lean epilogue when it is made of whole 16-byte accesses
     static const bool pp_off = getenv("DXA_GEMM_NO_PP") != nullptr;
+    static const bool pp3_on = !(getenv("DXA_GEMM_PP3") && atoi(getenv("DXA_GEMM_PP3")) == 0);
     const bool pp = ks_layout || (!pp_off && ai == 4 && d->K % 64 == 0);
     const bool lean = pp && lean_ok;
 #define LAUNCH_PP(TO_, TE_, LEAN_, AKS_, BKS_)                                                                  \
@@ -1902,6 +2083,21 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
       else LAUNCH_PP(float, bf16_t, false, false, false);
     }
 #undef LAUNCH_PP
+    // ---- 192-row tiles on the ping-pong schedule (round 4): bf16 epilogue operands, K % 64 == 0; DXA_GEMM_PP3=0: the ring kernel
+    else if (ai == 3 && pp3_on && !d->epi_f32 && d->K % 64 == 0 && d->layout == DXA_NT) {
+#define LAUNCH_PP3(TO_)                                                                                         \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp3_kernel<TO_, bf16_t>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((gemm_pp3_kernel<TO_, bf16_t>), fgrid, dim3(512), RING_LDS, st, p);                      \
+  } while (0)
+      if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t); else LAUNCH_PP3(float);
+#undef LAUNCH_PP3
+    }
     else if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }
     else if (ai == 3) { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 3, bf16_t); else LAUNCH_RING(float, 3, bf16_t); }
     else { if (d->out_dtype == DXA_BF16) LAUNCH_RING(bf16_t, 4, bf16_t); else LAUNCH_RING(float, 4, bf16_t); }
