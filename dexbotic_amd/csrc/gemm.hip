@@ -1540,10 +1540,17 @@ template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, true, true>(const 
 //   cluster that reads it: always vmcnt(7) in the steady state (7 instructions per wave and K tile).
 // Same MFMA (v_mfma_f32_32x32x16_bf16), same K order, same epilogue (tile_finish<.., 3, ..>) as the ring kernel: bit-identical.
 // =====================================================================================================
-template <typename TO, typename TE>
+#if defined(DXA_PP3_STAMPS)      // tuning build: s_memtime at entry / first operands landed / main loop done / epilogue done of ONE workgroup
+__device__ unsigned long long g_pp3_stamps[4];
+#define P3_STAMP(i) do { if (blockIdx.x == DXA_PP3_STAMPS && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_pp3_stamps[i] = t_; } } while (0)
+#else
+#define P3_STAMP(i) do { } while (0)
+#endif
+template <typename TO, typename TE, bool LEAN>
 __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  P3_STAMP(0);
   constexpr int AREG = 192 * 128, BREG = 256 * 128, BUFSZ = AREG + BREG;      // 24 KiB + 32 KiB per K tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1671,6 +1678,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
   P3_SB();
   if (nk > 1) { P3_VMCNT(7); } else { P3_VMCNT(1); }
   P3_BAR();
+  P3_STAMP(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) { P3_RD_A(0, 0, 0, ks); P3_RD_B(0, 0, 0, ks); P3_RD_B(0, 1, 0, ks); }
   P3_SB();
@@ -1680,6 +1688,7 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
     if (t + 1 < nk) P3_TILE(1, t + 1);
   }
   if (wm == 0) P3_BAR();            // every wave has now passed the same number of barriers
+  P3_STAMP(2);
 #undef P3_A_ROW0
 #undef P3_B_ROW0
 #undef P3_DMA
@@ -1697,11 +1706,22 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
 #undef P3_R_A1
 #undef P3_R_A2B0
 #undef P3_R_A0B1
-  tile_finish<TO, 3, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
+  if constexpr (LEAN) {          // C = alpha acc + bias (+ residual) (+ C) over whole 16-byte accesses: the 256-row kernel's epilogue
+    if (!tile_split_exchange<3>(p, acc, tid, split_j, split_s, tail_i)) return;
+    __builtin_amdgcn_sched_barrier(0);
+    sk_epilogue<TO, TE, 3>(p, acc, smem + wave * 4096, lane, wm, wn, (int)m0, (int)n0, reinterpret_cast<float*>(smem + 8 * 4096), bid);
+  } else {
+    tile_finish<TO, 3, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P3_STAMP(3);
 #endif  // __HIP_DEVICE_COMPILE__
 }
-template __global__ void gemm_pp3_kernel<bf16_t, bf16_t>(const GemmP);
-template __global__ void gemm_pp3_kernel<float, bf16_t>(const GemmP);
+#undef P3_STAMP
+template __global__ void gemm_pp3_kernel<bf16_t, bf16_t, true>(const GemmP);
+template __global__ void gemm_pp3_kernel<float, bf16_t, true>(const GemmP);
+template __global__ void gemm_pp3_kernel<bf16_t, bf16_t, false>(const GemmP);
+template __global__ void gemm_pp3_kernel<float, bf16_t, false>(const GemmP);
 
 // x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
 __global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
@@ -2085,17 +2105,18 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
 #undef LAUNCH_PP
     // ---- 192-row tiles on the ping-pong schedule (round 4): bf16 epilogue operands, K % 64 == 0; DXA_GEMM_PP3=0: the ring kernel
     else if (ai == 3 && pp3_on && !d->epi_f32 && d->K % 64 == 0 && d->layout == DXA_NT) {
-#define LAUNCH_PP3(TO_)                                                                                         \
+#define LAUNCH_PP3(TO_, LEAN_)                                                                                  \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp3_kernel<TO_, bf16_t>),                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp3_kernel<TO_, bf16_t, LEAN_>),            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((gemm_pp3_kernel<TO_, bf16_t>), fgrid, dim3(512), RING_LDS, st, p);                      \
+    hipLaunchKernelGGL((gemm_pp3_kernel<TO_, bf16_t, LEAN_>), fgrid, dim3(512), RING_LDS, st, p);               \
   } while (0)
-      if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t); else LAUNCH_PP3(float);
+      if (lean_ok) { if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t, true); else LAUNCH_PP3(float, true); }
+      else { if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t, false); else LAUNCH_PP3(float, false); }
 #undef LAUNCH_PP3
     }
     else if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }
@@ -2264,3 +2285,11 @@ extern "C" int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows,
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
+
+#if defined(DXA_PP3_STAMPS)
+extern "C" int dxa_gemm_debug_pp3_stamps(unsigned long long* out) {
+  DXA_CHECK_HIP(hipDeviceSynchronize());
+  DXA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp3_stamps), sizeof(unsigned long long) * 4));
+  return DXA_OK;
+}
+#endif

@@ -340,8 +340,8 @@ template <> struct SkIO<bf16_t> {
 // whose epilogue carries the whole menu.
 // sk_epilogue_rows: the 128 x 64 block of one wave (rows m0 + 128 wm + ..., columns n0 + 64 wn + ...); returns the lane's share of
 // the sum of squares of what it stored.  sk_epilogue: the 8-wave (2 x 4) kernels' tile = one such block per wave + the fold.
-template <typename TO, typename TE>
-__device__ __forceinline__ float sk_epilogue_rows(const GemmP& p, f32x16_t (&acc)[4][2], char* slab, int lane, int wm, int wn,
+template <typename TO, typename TE, int AI = 4>
+__device__ __forceinline__ float sk_epilogue_rows(const GemmP& p, f32x16_t (&acc)[AI][2], char* slab, int lane, int wm, int wn,
                                                   int m0, int n0) {
   float ssq = 0.f;                                   // sum of squares of the values this lane stores (p.sumsq)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -351,7 +351,7 @@ __device__ __forceinline__ float sk_epilogue_rows(const GemmP& p, f32x16_t (&acc
   const int l32 = lane & 31, lh = lane >> 5, r16 = l32 & 15;
   const int lr = lane / LPR, lc = (lane % LPR) * CPL;
   const int n = n0 + wn * 64 + lc;
-  const int rowb = m0 + wm * 128 + lr;             // + 32 i + 16 hh + RPI it
+  const int rowb = m0 + wm * (32 * AI) + lr;       // + 32 i + 16 hh + RPI it   (AI = 3: the 192-row tile's 96 x 64 block)
   const bool col_ok = n < (int)p.N;
   const uint32_t Mi = (uint32_t)p.M;
   const uint32_t esO = sizeof(TO), esE = sizeof(TE);
@@ -373,7 +373,7 @@ __device__ __forceinline__ float sk_epilogue_rows(const GemmP& p, f32x16_t (&acc
   const float alpha = p.alpha;
   const bool want_ssq = p.sumsq != nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AI; ++i)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       if ((l32 >> 4) == hh) {
@@ -441,11 +441,11 @@ __device__ __forceinline__ float sk_epilogue_rows(const GemmP& p, f32x16_t (&acc
 #endif
   return ssq;
 }
-template <typename TO, typename TE>
-__device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[4][2], char* slab, int lane, int wm, int wn,
+template <typename TO, typename TE, int AI = 4>
+__device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[AI][2], char* slab, int lane, int wm, int wn,
                                             int m0, int n0, float* red, int tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  float ssq = sk_epilogue_rows<TO, TE>(p, acc, slab, lane, wm, wn, m0, n0);
+  float ssq = sk_epilogue_rows<TO, TE, AI>(p, acc, slab, lane, wm, wn, m0, n0);
   {
     // global-norm clip: this tile's share of sum(g^2), folded lane -> wave -> workgroup in a fixed order and written to
     // the tile's own slot (the host adds the slots in index order): the separate 30 GB pass over the gradient arena that

@@ -196,8 +196,10 @@ def test_gemm_pingpong_strided_operands(case):
                                    (192, 256, 32), (1050, 777, 2048)])
 @pytest.mark.parametrize("f32out", [False, True])
 def test_gemm_ring_192_row_tiles(shape, f32out):
-    """bf16 NT ring kernel, 192-row tile variant (chosen when it trims the row padding: the B=1 prefill shapes);
-    with and without the split-K tail, ragged M and N edges"""
+    """bf16 NT products on 192-row tiles (chosen when they trim the row padding: the B=1 prefill shapes): the ping-pong 192-row
+    kernel (round 4: gemm_pp3_kernel, K % 64 == 0 — lean epilogue, or the generic one where N is ragged) and the ring kernel
+    (K % 64 != 0); with and without the split-K tail, ragged M and N edges.  scripts/pp3_check.py: the two kernels agree bit for bit
+    wherever they cut K at the same places (profiles/r04_pp3_vs_ring.txt)"""
     M, N, Kd = shape
     assert -(-M // 192) * 192 * 27 < -(-M // 256) * 256 * 25          # dispatch takes the 192-row variant
     a, w = rnd(M, Kd, dtype=torch.bfloat16, seed=25), rnd(N, Kd, dtype=torch.bfloat16, seed=26, scale=0.1)
