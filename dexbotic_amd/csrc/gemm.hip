@@ -1722,6 +1722,8 @@ template __global__ void gemm_pp3_kernel<bf16_t, bf16_t, true>(const GemmP);
 template __global__ void gemm_pp3_kernel<float, bf16_t, true>(const GemmP);
 template __global__ void gemm_pp3_kernel<bf16_t, bf16_t, false>(const GemmP);
 template __global__ void gemm_pp3_kernel<float, bf16_t, false>(const GemmP);
+template __global__ void gemm_pp3_kernel<float, float, true>(const GemmP);      // fp32 epilogue operands (bf16x3 products of the fp32 head)
+template __global__ void gemm_pp3_kernel<float, float, false>(const GemmP);
 
 // x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
 __global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
@@ -2103,20 +2105,21 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
       else LAUNCH_PP(float, bf16_t, false, false, false);
     }
 #undef LAUNCH_PP
-    // ---- 192-row tiles on the ping-pong schedule (round 4): bf16 epilogue operands, K % 64 == 0; DXA_GEMM_PP3=0: the ring kernel
-    else if (ai == 3 && pp3_on && !d->epi_f32 && d->K % 64 == 0 && d->layout == DXA_NT) {
-#define LAUNCH_PP3(TO_, LEAN_)                                                                                  \
+    // ---- 192-row tiles on the ping-pong schedule (round 4): K % 64 == 0; DXA_GEMM_PP3=0: the ring kernel
+    else if (ai == 3 && pp3_on && d->K % 64 == 0 && d->layout == DXA_NT) {
+#define LAUNCH_PP3(TO_, TE_, LEAN_)                                                                             \
   do {                                                                                                          \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp3_kernel<TO_, bf16_t, LEAN_>),            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp3_kernel<TO_, TE_, LEAN_>),               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((gemm_pp3_kernel<TO_, bf16_t, LEAN_>), fgrid, dim3(512), RING_LDS, st, p);               \
+    hipLaunchKernelGGL((gemm_pp3_kernel<TO_, TE_, LEAN_>), fgrid, dim3(512), RING_LDS, st, p);                  \
   } while (0)
-      if (lean_ok) { if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t, true); else LAUNCH_PP3(float, true); }
-      else { if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t, false); else LAUNCH_PP3(float, false); }
+      if (d->epi_f32) { if (lean_ok) LAUNCH_PP3(float, float, true); else LAUNCH_PP3(float, float, false); }
+      else if (lean_ok) { if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t, bf16_t, true); else LAUNCH_PP3(float, bf16_t, true); }
+      else { if (d->out_dtype == DXA_BF16) LAUNCH_PP3(bf16_t, bf16_t, false); else LAUNCH_PP3(float, bf16_t, false); }
 #undef LAUNCH_PP3
     }
     else if (d->epi_f32) { if (ai == 3) LAUNCH_RING(float, 3, float); else LAUNCH_RING(float, 4, float); }
