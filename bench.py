@@ -303,6 +303,12 @@ def main():
                          "gpurun_out/r03_b_ov.json vs r03_b_noov.json) — the forward GEMMs slow from 254 to 363 us per launch while "
                          "the update streams beside them, which gives the hidden 36 ms back (DESIGN.md section 4)")
     ap.add_argument("--accum", type=int, default=1, help="gradient accumulation steps of the HEADLINE measurement")
+    ap.add_argument("--recompute", action="store_true",
+                    help="activation recompute (the reference's gradient_checkpointing=True, base_exp.py:245) for the headline "
+                         "measurement: layers keep their input only and re-run their forward in backward.  Off: resident")
+    ap.add_argument("--profile-stride", dest="profile_stride", type=int, default=5,
+                    help="the live roofline times every n-th launch of each GEMM layout with HIP events (a deterministic sample over "
+                         "the whole timed region; 1 = every launch: 1240 event pairs per step cost the step ~2 %%)")
     ap.add_argument("--no-recipe", dest="no_recipe", action="store_true",
                     help="skip the second figure: the reference recipe 8 episodes x 2 accumulation steps per GPU "
                          "(cogact_exp.py:41-46), same 16 episodes per optimizer step")
@@ -342,6 +348,8 @@ def main():
 
     model, cfg, llm, vis = build_model(args, device)
     model.train()
+    if args.recompute:
+        model.gradient_checkpointing_enable()
     trainer = NativeTrainer(model, OptimConfig(base_lr=2e-5, weight_decay=0.0, max_grad_norm=1.0),
                             total_steps=1000, force_reducer=args.force_reducer,
                             grad_comm_dtype=getattr(torch, args.grad_comm), grad_accum=args.accum,
@@ -375,7 +383,7 @@ def main():
     # dominant kernel: gemm_pp_kernel, whose three instantiations carry every large product of the step:
     # NT (forward linears, bf16 out), NN (dX = dY W, bf16 out), TN (dW = dY^T X, fp32 out into the gradient arena)
     prof_keys = {"NT fwd": (L.NT, in_dt, in_dt), "NN dX": (L.NN, in_dt, in_dt), "TN dW": (L.TN, in_dt, L.F32)}
-    prof = K.GemmProfile(*set(prof_keys.values()))
+    prof = K.GemmProfile(*set(prof_keys.values()), stride=args.profile_stride)
     K.GEMM_PROFILE = prof if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -398,25 +406,39 @@ def main():
     recipe = None
     if not args.no_recipe and args.accum == 1 and args.batch % 2 == 0 and not args.static_batch:
         # second figure: the reference recipe, 8 episodes x 2 accumulation steps per GPU per optimizer
-        # step (cogact_exp.py:41-46) — dW becomes read-modify-write on the second micro-batch and the sum of squares is read back
-        # (the dW epilogues' share is only final after the last micro-batch)
+        # step (cogact_exp.py:41-46), measured twice: pass by pass (half-height GEMM grids; the linears' dW is one product over both
+        # micro-batches' (dY, X) pairs) and with the group coalesced into one pass
         trainer.set_grad_accum(2)
         feed2 = DeviceFeeder(rotating_batches(host_batches(8, args.batch // 2, args.views, args.s_text, 4321 + 100 * rank), seed=7 + rank),
                              device)
         n_rec = max(3, args.steps // 2)
-        for _ in range(2 * 2):
-            trainer.step(next(feed2))
-        sync()
-        tr0 = time.perf_counter()
-        for _ in range(2 * n_rec):
-            trainer.step(next(feed2))
-        sync()
-        rdt = torch.tensor([time.perf_counter() - tr0], device=device, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(rdt, op=dist.ReduceOp.MAX)
-        recipe = {"episodes_per_s": round(args.batch * world * n_rec / float(rdt.item()), 3),
-                  "ms_per_optimizer_step": round(1e3 * float(rdt.item()) / n_rec, 2), "optimizer_steps": n_rec,
-                  "micro_batch": args.batch // 2, "grad_accum": 2}
+
+        def recipe_leg():
+            for _ in range(2 * 2):
+                trainer.step(next(feed2))
+            sync()
+            tr0 = time.perf_counter()
+            for _ in range(2 * n_rec):
+                trainer.step(next(feed2))
+            sync()
+            rdt = torch.tensor([time.perf_counter() - tr0], device=device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(rdt, op=dist.ReduceOp.MAX)
+            return {"episodes_per_s": round(args.batch * world * n_rec / float(rdt.item()), 3),
+                    "ms_per_optimizer_step": round(1e3 * float(rdt.item()) / n_rec, 2)}
+        two_pass = recipe_leg()                 # micro-batch by micro-batch, as HF's loop hands them over
+        # ... and as exp/trainer.NativeDexboticTrainer runs that recipe by default: the two micro-batches of an optimizer step
+        # held and run as ONE 16-episode pass (trainer.NativeTrainer coalesce_micro_batches; same mean loss, gradients equal
+        # up to fp32 summation order: tests/test_hf_trainer_gpu.py)
+        trainer.coalesce = bool(getattr(model, "coalescible_micro_batches", False))
+        c0 = trainer.coalesced_steps
+        one_pass = recipe_leg() if trainer.coalesce else None
+        assert one_pass is None or trainer.coalesced_steps - c0 == n_rec + 2, "the coalesced leg did not coalesce"
+        trainer.coalesce = False
+        recipe = dict(one_pass or two_pass, optimizer_steps=n_rec, micro_batch=args.batch // 2, grad_accum=2,
+                      execution=("the 2 micro-batches of an optimizer step coalesced into one pass (NativeDexboticTrainer default)"
+                                 if one_pass else "micro-batch by micro-batch"),
+                      two_passes=two_pass)
         trainer.set_grad_accum(1)
         del feed2
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -449,6 +471,8 @@ def main():
                                   "memory on a copy stream one step ahead" + (", every 4th batch right-padded" if args.ragged else ""))
     result["config"]["optimizer"] = "AdamW serial" if not args.overlap else "AdamW overlapped with the next forward (side stream, per-bucket events)"
     result["config"]["grad_accum"] = args.accum
+    result["config"]["activations"] = "recomputed in backward (gradient checkpointing)" if args.recompute else "resident"
+    result["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 1)
     if comm_stats is not None:
         result.update(comm_stats)
     if rank == 0:
@@ -465,7 +489,7 @@ def main():
         for tag, key in prof_keys.items():
             kn, kms, kfl, kby = prof.summary(key)
             if kn:
-                by_layout[tag] = {"launches": kn, "avg_launch_us": round(1e3 * kms / kn, 1),
+                by_layout[tag] = {"launches": prof.launches(key), "timed": kn, "avg_launch_us": round(1e3 * kms / kn, 1),
                                   "achieved": round(kfl / (kms * 1e-3) / 1e12, 1)}
         result["roofline"] = {"bound": "mfma",
                               "kernel": "gemm_pp_kernel (dxa_gemm, 16-bit operands: the NT / NN / TN instantiations of the one "
@@ -478,7 +502,10 @@ def main():
                                                 "XCD L2s, Infinity-Cache hits included: this is L2-miss (fabric-side) traffic, an upper "
                                                 "bound on HBM bytes, not HBM bytes",
                               "traffic_kind": "l2_miss_bytes_per_launch",
-                              "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
+                              "launches": prof.launches(), "launches_timed": n,
+                              "timing": f"HIP events around every {prof.stride}-th launch of each layout, over the whole timed region"
+                                        if prof.stride > 1 else "HIP events around every launch of the timed region",
+                              "avg_launch_us": round(1e3 * ms / max(n, 1), 1),
                               "avg_launch_gflop": round(fl / max(n, 1) / 1e9, 2),
                               "algorithmic_bytes_per_launch": int(by / max(n, 1)), "by_layout": by_layout}
         if not args.no_latency and world == 1:

@@ -78,6 +78,9 @@ class ParamStore:
         self.compute_dtype = compute_dtype
         self.slots: Dict[str, Slot] = {}
         self.epi_sumsq = False                  # the trainer turns it on: one GPU, clip enabled
+        # activation recompute (the reference's gradient checkpointing, base_exp.py:245): the transformer-layer Functions keep
+        # only their input and re-run their forward inside their backward (functional._recompute).  Off: activations resident.
+        self.recompute = False
         # gradient accumulation: only the LAST micro-batch's dW products (accumulate = 1: what they store is the step's final
         # gradient) leave their share of sum(g^2); the trainer keeps this flag current (True without accumulation)
         self.last_micro = True

@@ -66,7 +66,7 @@ class TrainerConfig:
     save_only_model: bool = True
     logging_steps: int = 10
     wandb_project: str = "dexbotic"
-    gradient_checkpointing: bool = True        # accepted, not forwarded: activations stay resident
+    gradient_checkpointing: bool = True        # honoured with DEXBOTIC_AMD_GRAD_CHECKPOINTING=1 (exp/trainer.py); else resident
     dataloader_num_workers: int = 8
     model_max_length: int = 2048
     debug_mode: bool = False

@@ -13,9 +13,16 @@ scheduler, logging, checkpoint cadence, callbacks) stays in charge.  What change
     exchange by engine.GradReducer (not DDP: the weight gradients are written by the dW kernels' epilogues, autograd never
     sees them), sum of squares folded under the backward.  ``max_grad_norm`` (1.0, trainer.py:122) is applied inside the fused
     step, so HF's own ``clip_grad_norm_`` pass is switched off (``TrainingArguments.max_grad_norm = 0``).
-  * ``gradient_checkpointing`` and ``deepspeed`` of the exp config are NOT forwarded: activations stay resident (288 GB HBM)
-    and the optimizer state is not sharded (144 GB resident, engine.py header).
+  * ``deepspeed`` of the exp config is NOT forwarded: the optimizer state is not sharded (144 GB resident, engine.py header).
+    ``gradient_checkpointing`` (reference default True, there to fit 80 GB parts) is forwarded only with
+    ``DEXBOTIC_AMD_GRAD_CHECKPOINTING=1``: activations stay resident by default (25 GB of 288 at the CogACT batch); with the
+    switch HF's loop calls ``model.gradient_checkpointing_enable()`` and the layer Functions recompute (functional.py).
   * integer inputs stay on the host (``_prepare_inputs``): the splice plan is host arithmetic (splice.py).
+  * ``gradient_accumulation_steps`` (2 in the reference recipe, there to fit 80 GB parts) is honoured as a GROUPING: HF hands
+    over micro-batch after micro-batch, the core holds them and runs the group as one pass over the concatenated batch
+    (trainer.NativeTrainer ``coalesce_micro_batches``: same mean loss, same gradients up to fp32 summation order, the one-pass
+    rate).  ``training_step`` then returns 0 for the held micro-batches and the group's sum for the last, so HF's running loss
+    is unchanged.  DEXBOTIC_AMD_COALESCE=0 runs pass by pass.
 
 The unmodified ``DexboticTrainer`` / plain HF ``Trainer`` + ``torch.optim.AdamW`` also train the native model on ONE GPU
 (ParamStore.external_prelude: gradients re-attached, stale bf16 shadows re-derived) — slower (a foreach AdamW over ~800 arena
@@ -23,6 +30,7 @@ views + an 8 B-element shadow cast per step); see INTEGRATION.md.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -82,7 +90,11 @@ def link_exp_config(exp_config, **overrides) -> TrainingArguments:
                 run_name=getattr(tc, "run_name", None), remove_unused_columns=False, learning_rate=oc.base_lr,
                 adam_beta1=oc.adam_beta1, adam_beta2=oc.adam_beta2, warmup_steps=oc.warmup_steps,
                 weight_decay=oc.weight_decay,
-                gradient_checkpointing=False, deepspeed=None,       # resident activations, unsharded optimizer state
+                # resident activations unless asked for (module docstring); unsharded optimizer state
+                gradient_checkpointing=bool(getattr(tc, "gradient_checkpointing", False)) and
+                os.environ.get("DEXBOTIC_AMD_GRAD_CHECKPOINTING", "0") != "0",
+                gradient_checkpointing_kwargs={"use_reentrant": False},          # trainer.py:120
+                deepspeed=None,
                 max_grad_norm=0.0)                                   # the 1.0 clip runs inside the fused optimizer step
     args.update(overrides)
     return TrainingArguments(**args)
@@ -121,8 +133,12 @@ class NativeDexboticTrainer(Trainer):
             groups = [{"names": [name_of[id(p)] for p in g["params"] if id(p) in name_of],
                        "lr": float(g.get("lr", self.args.learning_rate)), "weight_decay": float(g.get("weight_decay", 0.0))}
                       for g in self._grouped_parameters()]
+            # the accumulation micro-batches of an optimizer step run as ONE pass where the model allows it (trainer.NativeTrainer
+            # coalesce_micro_batches; DEXBOTIC_AMD_COALESCE=0 or native={"coalesce_micro_batches": False}: pass by pass)
+            kw = dict(coalesce_micro_batches=os.environ.get("DEXBOTIC_AMD_COALESCE", "1") != "0")
+            kw.update(self._core_kw)
             self._core = NativeTrainer(self.model, cfg, grad_accum=self.args.gradient_accumulation_steps,
-                                       optimizer_groups=groups, **self._core_kw)
+                                       optimizer_groups=groups, **kw)
         return self._core
 
     def create_optimizer(self) -> torch.optim.Optimizer:
@@ -169,7 +185,8 @@ class NativeDexboticTrainer(Trainer):
         # micro-batch gradients are then summed, not averaged, before the 1.0 clip.  Mirrored here.
         summed = bool(getattr(self, "model_accepts_loss_kwargs", False)) and num_items_in_batch is not None
         loss = core.micro_step(inputs, loss_scale=1.0 if summed else None)
-        self._cache_losses(core.last_output)
+        if core.last_output is not None:              # (a coalesced group reports with its last micro-batch)
+            self._cache_losses(core.last_output)
         accum = core.grad_accum
         return loss if (summed or accum == 1) else loss / accum
 

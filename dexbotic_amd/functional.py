@@ -8,8 +8,11 @@ accumulate, for gradient accumulation — straight into the fp32 gradient arena 
 An ``anchor`` parameter (any trainable tensor of the block) is passed through ``apply`` only so that
 autograd schedules the backward even when the activations upstream do not require grad.
 
-With 288 GB of HBM per MI355X every block keeps its activations (no recompute): the reference's
-gradient checkpointing (base_exp.py:243) exists to fit 80 GB parts and costs a 4th forward.
+With 288 GB of HBM per MI355X every block keeps its activations by default; the reference's gradient
+checkpointing (base_exp.py:245, trainer.py:101,120: HF checkpoints every decoder / encoder layer) is the
+opt-in ``ParamStore.recompute`` (``model.gradient_checkpointing_enable()``): the transformer-layer Functions
+then keep only their INPUT and re-run their forward launches at the top of their backward (same kernels, same
+order: bit-identical gradients) — ~0.75 GB -> 33 MB kept per decoder layer at 16 x 287 tokens, for a 4th forward.
 """
 from __future__ import annotations
 
@@ -72,6 +75,11 @@ def _use(ctx, st: ParamStore, *groups) -> None:
         if g is None:
             continue
         st.note_use(*[n for n in _names(g) if n is not None])
+
+
+def _recompute(ctx, st: ParamStore) -> bool:
+    """activation recompute for this call: opted in on the store and a backward can actually run"""
+    return bool(getattr(st, "recompute", False)) and _OUTER_GRAD[0] and any(ctx.needs_input_grad)
 
 
 def _f32_nt(dy2d: torch.Tensor) -> bool:
@@ -216,7 +224,8 @@ class Qwen2LayerFn(_StoreFn):
     x + o_proj(attn(rope(qkv(rmsnorm(x))))) ; then + down(silu(gate)*up) of rmsnorm."""
 
     @staticmethod
-    def forward(ctx, x, anchor, st: ParamStore, sp: Qwen2LayerSpec, cos_t, sin_t, kv_start, kv_end):
+    def _run(st: ParamStore, sp: Qwen2LayerSpec, x, cos_t, sin_t, kv_start, kv_end):
+        """the layer's forward launches -> (y, what the backward reads besides x)"""
         B, S, Hq, Hkv, D, d, F_ = sp.B, sp.S, sp.Hq, sp.Hkv, sp.D, sp.d, sp.F
         M = B * S
         nq = (Hq + 2 * Hkv) * D
@@ -231,17 +240,30 @@ class Qwen2LayerFn(_StoreFn):
         gu = K.mm_nt(h2, st.w(*sp.gu_w, shape=(2 * F_, d)))
         a = K.swiglu_fwd(gu)
         y = K.mm_nt(a, st.w(sp.down_w), residual=x2)
+        return y, (rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a)
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, sp: Qwen2LayerSpec, cos_t, sin_t, kv_start, kv_end):
+        y, saved = Qwen2LayerFn._run(st, sp, x, cos_t, sin_t, kv_start, kv_end)
         ctx.st, ctx.sp = st, sp
         _use(ctx, st, sp.ln1, sp.qkv_w, sp.qkv_b, sp.o_w, sp.ln2, sp.gu_w, sp.down_w)
         ctx.aux = (cos_t, sin_t, kv_start, kv_end)
-        ctx.save_for_backward(x, rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a)
+        ctx.recompute = _recompute(ctx, st)
+        if ctx.recompute:
+            ctx.save_for_backward(x)              # gradient checkpointing: the input only, the rest is re-run in backward
+        else:
+            ctx.save_for_backward(x, *saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         st, sp = ctx.st, ctx.sp
         cos_t, sin_t, kv_start, kv_end = ctx.aux
-        x, rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a = ctx.saved_tensors
+        if ctx.recompute:
+            (x,) = ctx.saved_tensors
+            rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a = Qwen2LayerFn._run(st, sp, x, cos_t, sin_t, kv_start, kv_end)[1]
+        else:
+            x, rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a = ctx.saved_tensors
         B, S, Hq, Hkv, D, d, F_ = sp.B, sp.S, sp.Hq, sp.Hkv, sp.D, sp.d, sp.F
         M = B * S
         nq = (Hq + 2 * Hkv) * D
@@ -309,6 +331,8 @@ class VitBlockSpec:
     H: int = 0
     D: int = 0
     I: int = 0      # mlp width
+    ckpt: bool = True   # recomputed under ParamStore.recompute (HF checkpoints its encoder layers; the DiT head's blocks are
+                        # plain nn.Modules in the reference and keep their activations: False there)
 
 
 def _padded_head_dim(D: int, dtype) -> int:
@@ -324,12 +348,12 @@ class VitBlockFn(_StoreFn):
     (cogact/action_model/dit.py:137-162 with timm Attention/Mlp; LN without affine eps 1e-6, tanh-GELU)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, st: ParamStore, sp: VitBlockSpec):
+    def _run(st: ParamStore, sp: VitBlockSpec, x):
+        """the block's forward launches on x [M, C] -> (y [M, C], what the backward reads besides x)"""
         N, T, H, D, I = sp.N, sp.T, sp.H, sp.D, sp.I
         C_ = H * D
         M = N * T
         w = lambda n: st.w(n) if n is not None else None
-        x = x.reshape(M, C_)
         h1, mean1, rstd1 = K.layernorm_fwd(x, w(sp.ln1_w), w(sp.ln1_b), sp.eps)
         qkv = K.mm_nt(h1, st.w(*sp.qkv_w, shape=(3 * C_, C_)), bias=st.w(*sp.qkv_b, shape=(3 * C_,)))
         Dp = _padded_head_dim(D, x.dtype)
@@ -347,16 +371,31 @@ class VitBlockFn(_StoreFn):
         pre = torch.empty((M, I), device=x.device, dtype=x.dtype)
         a = K.mm_nt(h2, st.w(sp.fc1_w), bias=st.w(sp.fc1_b), act=sp.act, aux_out=pre)
         y = K.mm_nt(a, st.w(sp.fc2_w), bias=st.w(sp.fc2_b), residual=x2)
+        return y, (mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a)
+
+    @staticmethod
+    def forward(ctx, x, anchor, st: ParamStore, sp: VitBlockSpec):
+        N, T, C_ = sp.N, sp.T, sp.H * sp.D
+        x = x.reshape(N * T, C_)
+        y, saved = VitBlockFn._run(st, sp, x)
         ctx.st, ctx.sp = st, sp
         _use(ctx, st, sp.ln1_w, sp.ln1_b, sp.qkv_w, sp.qkv_b, sp.out_w, sp.out_b, sp.ln2_w, sp.ln2_b, sp.fc1_w, sp.fc1_b,
              sp.fc2_w, sp.fc2_b)
-        ctx.save_for_backward(x, mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a)
+        ctx.recompute = sp.ckpt and _recompute(ctx, st)
+        if ctx.recompute:
+            ctx.save_for_backward(x)
+        else:
+            ctx.save_for_backward(x, *saved)
         return y.view(N, T, C_)
 
     @staticmethod
     def backward(ctx, dy):
         st, sp = ctx.st, ctx.sp
-        x, mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a = ctx.saved_tensors
+        if ctx.recompute:
+            (x,) = ctx.saved_tensors
+            mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a = VitBlockFn._run(st, sp, x)[1]
+        else:
+            x, mean1, rstd1, h1, qkv, o, lse, x2, mean2, rstd2, h2, pre, a = ctx.saved_tensors
         N, T, H, D, I = sp.N, sp.T, sp.H, sp.D, sp.I
         C_ = H * D
         M = N * T
@@ -842,11 +881,11 @@ class Pi0MotLayerFn(_StoreFn):
     never reads — it is not computed (the reference computes it and its parameters get no gradient)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, anchor, st: ParamStore, sp0: GemmaLayerSpec, sp1: GemmaLayerSpec, geom, cos_t, sin_t,
-                pos0, pos1, q_limit, key_valid, skip_post0: bool):
+    def _run(st: ParamStore, sps, geom, skip_post0: bool, x0, x1, cos_t, sin_t, pos0, pos1, q_limit, key_valid):
+        """the layer's forward launches -> ((y0, y1), what the backward reads besides x0, x1)"""
         B, S0, S1, Hq, Hkv, D = geom
         nq = (Hq + 2 * Hkv) * D
-        xs, sps, Ss, poss = (x0, x1), (sp0, sp1), (S0, S1), (pos0, pos1)
+        xs, Ss, poss = (x0, x1), (S0, S1), (pos0, pos1)
         h1, rstd1, qs, ks, vs = [], [], [], [], []
         for x, sp, S, pos in zip(xs, sps, Ss, poss):
             h, r = K.rmsnorm_fwd(x, st.w(sp.ln1).float() + 1.0, sp.eps)
@@ -870,14 +909,25 @@ class Pi0MotLayerFn(_StoreFn):
             act = K.glu_fwd(gu, L.ACT_GELU_TANH)
             ys.append(K.mm_nt(act, st.w(sp.down), residual=r))
             saved += [a, r, rs2, h2, gu, act]
+        return (ys[0], ys[1]), (h1[0], h1[1], rstd1[0], rstd1[1], q, k, v, o, lse, *saved)
+
+    @staticmethod
+    def forward(ctx, x0, x1, anchor, st: ParamStore, sp0: GemmaLayerSpec, sp1: GemmaLayerSpec, geom, cos_t, sin_t,
+                pos0, pos1, q_limit, key_valid, skip_post0: bool):
+        sps = (sp0, sp1)
+        ys, saved = Pi0MotLayerFn._run(st, sps, geom, skip_post0, x0, x1, cos_t, sin_t, pos0, pos1, q_limit, key_valid)
         ctx.st, ctx.sps, ctx.geom, ctx.skip_post0 = st, sps, geom, skip_post0
         for i, sp in enumerate(sps):
             _use(ctx, st, sp.ln1, sp.qkv)
             if not (i == 0 and skip_post0):
                 _use(ctx, st, sp.o, sp.ln2, sp.gu, sp.down)
         ctx.aux = (cos_t, sin_t, pos0, pos1, q_limit, key_valid)
-        ctx.save_for_backward(x0, x1, h1[0], h1[1], rstd1[0], rstd1[1], q, k, v, o, lse, *saved)
-        return ys[0], ys[1]
+        ctx.recompute = _recompute(ctx, st)
+        if ctx.recompute:
+            ctx.save_for_backward(x0, x1)
+        else:
+            ctx.save_for_backward(x0, x1, *saved)
+        return ys
 
     @staticmethod
     def backward(ctx, dy0, dy1):
@@ -885,6 +935,9 @@ class Pi0MotLayerFn(_StoreFn):
         B, S0, S1, Hq, Hkv, D = ctx.geom
         cos_t, sin_t, pos0, pos1, q_limit, key_valid = ctx.aux
         sv = ctx.saved_tensors
+        if ctx.recompute:
+            sv = tuple(sv) + tuple(Pi0MotLayerFn._run(st, sps, ctx.geom, skip_post0, sv[0], sv[1], cos_t, sin_t, pos0, pos1,
+                                                       q_limit, key_valid)[1])
         xs, h1, rstd1 = sv[0:2], sv[2:4], sv[4:6]
         q, k, v, o, lse = sv[6:11]
         per = [sv[11:17], sv[17:23]]

@@ -71,7 +71,7 @@ class DiT(nn.Module):
                 out_w=b + "attn.proj.weight", out_b=b + "attn.proj.bias", ln2_w=None, ln2_b=None,
                 fc1_w=b + "mlp.fc1.weight", fc1_b=b + "mlp.fc1.bias", fc2_w=b + "mlp.fc2.weight",
                 fc2_b=b + "mlp.fc2.bias", act=L.ACT_GELU_TANH, eps=1e-6, H=num_heads, D=h // num_heads,
-                I=self.mlp_hidden))
+                I=self.mlp_hidden, ckpt=False))
         store.register([(p + "final_layer.linear.weight", (A, h)), (p + "final_layer.linear.bias", (A,))])
         self._freqs = {}
         self.training_mode_drop = True

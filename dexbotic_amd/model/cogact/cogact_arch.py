@@ -60,6 +60,9 @@ class CogActModel(DexboticVLMModel):
 
 class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
     config_class = CogActConfig
+    # every sample of a batch is processed independently of the others and of the call order: the micro-batches of a gradient
+    # accumulation group may run as one batch (trainer.NativeTrainer coalesce_micro_batches)
+    coalescible_micro_batches = True
 
     def _real_init(self, config: CogActConfig):
         self.model = CogActModel(config, self.store)

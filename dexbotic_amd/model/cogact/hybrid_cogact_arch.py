@@ -18,6 +18,9 @@ from .cogact_arch import CogActConfig, CogACTForCausalLM
 
 class HybridCogACTForCausalLM(CogACTForCausalLM):
     config_class = CogActConfig
+    # the text loss is a mean over the batch's labelled tokens: the mean over a merged batch is not the mean of the micro-batch
+    # means when their token counts differ
+    coalescible_micro_batches = False
 
     def unused_parameter_names(self):
         """lm_head trains here; the rest as in CogACT"""

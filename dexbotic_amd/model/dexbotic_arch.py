@@ -154,9 +154,9 @@ class CausalLMOutputDexbotic:
 
 class DexboticVLMModel(nn.Module):
     """vision tower -> projector -> splice into LLM embeddings -> LLM backbone."""
-    # activation recompute is not implemented: every block keeps its activations (25 GB of 288 at the CogACT batch);
-    # gradient_checkpointing_enable() says so instead of silently ignoring the request
-    supports_gradient_checkpointing = False
+    # dexbotic_arch.py:40.  Off by default (25 GB of kept activations out of 288 at the CogACT batch);
+    # gradient_checkpointing_enable() on the causal-LM wrapper turns on ParamStore.recompute (functional.py)
+    supports_gradient_checkpointing = True
 
     def __init__(self, config: DexboticConfig, store: ParamStore):
         super().__init__()
@@ -338,24 +338,32 @@ class NativePreTrainedMixin:
     def post_load(self) -> None:
         self.store.sync_shadow()
 
+    supports_gradient_checkpointing = True      # dexbotic_arch.py:40
+
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None) -> None:
-        """base_exp.py:245 / trainer.py:120 turn this on to fit 80 GB parts (a 4th forward per step).  The native blocks
-        keep their activations — ~0.75 GB per decoder layer at 16 x 287 tokens against 288 GB of HBM — and have no
-        recompute path: refuse loudly rather than pretend."""
+        """HF ``PreTrainedModel.gradient_checkpointing_enable`` as base_exp.py:245 / trainer.py:101,120 switch it on (HF then
+        checkpoints every Qwen2 decoder layer and every CLIP encoder layer: only the layer input is kept and the layer's forward
+        runs again inside its backward).  Native form: ``ParamStore.recompute`` — the decoder / vision / pi0 layer Functions keep
+        their INPUT only and re-run their forward launches at the top of their backward (functional.Qwen2LayerFn / VitBlockFn /
+        Pi0MotLayerFn; same kernels in the same order, so the gradients are bit-identical to the resident-activation step).
+        Kept activations drop from ~0.75 GB to 33 MB per decoder layer at 16 x 287 tokens, for one more forward per step.
+        ``gradient_checkpointing_kwargs`` (``use_reentrant``) has no meaning here and is accepted.  Resident activations remain
+        the default: on a 288 GB part the CogACT recipe keeps 25 GB of them; DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING=1 /
+        ``config.accept_gradient_checkpointing`` keep their old meaning (accept the call, stay resident) for exp scripts whose
+        TrainerConfig default asks for checkpointing only to fit 80 GB parts."""
         if os.environ.get("DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING", "0") != "0" or \
                 getattr(self.config, "accept_gradient_checkpointing", False):
-            # explicit opt-in (env / config flag) for unmodified exp scripts whose TrainerConfig defaults to
-            # gradient_checkpointing=True (base_exp.py:243): accepted and IGNORED — activations stay resident
             import warnings
             warnings.warn("dexbotic_amd: gradient_checkpointing requested and ignored (activations stay resident in HBM)")
             return None
-        raise NotImplementedError("dexbotic_amd keeps block activations resident (MI355X: 288 GB HBM); activation "
-                                  "recompute is not implemented — run with gradient_checkpointing=False (or opt in to "
-                                  "accept-and-ignore: DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING=1 / "
-                                  "config.accept_gradient_checkpointing=True)")
+        self.store.recompute = True
 
     def gradient_checkpointing_disable(self) -> None:
-        return None
+        self.store.recompute = False
+
+    @property
+    def is_gradient_checkpointing(self) -> bool:
+        return bool(self.store.recompute)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         # checkpoints written under transformers 4.51 carry ".vision_tower.vision_model." (SURVEY.md App. B)

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import os
 
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
@@ -20,14 +20,66 @@ from . import kernels as K
 from .engine import FusedAdamW, GradNormTracker, GradReducer, OptimConfig, cosine_lr_scale
 
 
+# ---------------------------------------------------------------------------------- micro-batch coalescing
+_ROW_KEYS = ("input_ids", "attention_mask", "labels", "images", "actions", "states")     # leading dimension B
+_DRAW_KEYS = ("noise", "timesteps", "drop_ids")                                          # leading dimension R * B, index r * B + b
+_PAD = {"input_ids": 0, "attention_mask": 0, "labels": -100}                             # what a right-padded position holds
+
+
+def coalesce_batches(batches: List[Dict[str, torch.Tensor]]) -> Optional[Dict[str, torch.Tensor]]:
+    """The micro-batches of ONE optimizer step as a single batch, or None when they cannot be put together (keys this function
+    does not know, unequal micro-batch sizes — the mean over the merged batch would weigh the samples differently — or
+    unequal trailing shapes).  Token rows of unequal length are right-padded to the longest (pad id 0 / mask 0 / label -100:
+    the splice drops masked positions before it lays the sequence out, dexbotic_arch.py:182-373, so the result depends on the
+    real tokens only).  Injected draws ([R * B, ...], row r * B + b, cogact_arch.py:110-125) are re-interleaved per repeat."""
+    keys = set(batches[0])
+    if any(set(b) != keys for b in batches) or not keys <= set(_ROW_KEYS + _DRAW_KEYS):
+        return None
+    if not all(torch.is_tensor(b[k]) for b in batches for k in keys) or "input_ids" not in keys:
+        return None
+    B = batches[0]["input_ids"].shape[0]
+    if any(b["input_ids"].shape[0] != B for b in batches):
+        return None
+    out = {}
+    for k in keys & set(_ROW_KEYS):
+        vs = [b[k] for b in batches]
+        if any(v.shape[0] != B or v.dim() != vs[0].dim() or v.dtype != vs[0].dtype or v.device != vs[0].device for v in vs):
+            return None
+        if k in _PAD and vs[0].dim() == 2:
+            S = max(v.shape[1] for v in vs)
+            vs = [v if v.shape[1] == S else torch.nn.functional.pad(v, (0, S - v.shape[1]), value=_PAD[k]) for v in vs]
+        if any(v.shape[1:] != vs[0].shape[1:] for v in vs):
+            return None
+        out[k] = torch.cat(vs, dim=0)
+    for k in keys & set(_DRAW_KEYS):
+        vs = [b[k] for b in batches]
+        if any(v.shape != vs[0].shape or v.shape[0] % B != 0 or v.dtype != vs[0].dtype or v.device != vs[0].device for v in vs):
+            return None
+        R = vs[0].shape[0] // B
+        out[k] = torch.cat([v.reshape(R, B, *v.shape[1:]) for v in vs], dim=1).reshape(R * B * len(vs), *vs[0].shape[1:])
+    return out
+
+
 class NativeTrainer:
     def __init__(self, model, optim: Optional[OptimConfig] = None, total_steps: int = 0, warmup_steps: int = 0,
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
                  force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag",
                  grad_dtype: torch.dtype = torch.float32, overlap_optimizer: bool = False, optimizer_groups=None,
-                 native_avg_world1: bool = False):
+                 native_avg_world1: bool = False, coalesce_micro_batches: Optional[bool] = None):
         import torch.distributed as dist
         self.model = model
+        # coalesce_micro_batches: the ``grad_accum`` micro-batches of an optimizer step run as ONE forward / backward over their
+        # concatenation (coalesce_batches).  Gradient accumulation exists in the reference recipe (8 episodes x 2, cogact_exp.py:
+        # 41-46) to fit 80 GB parts; the mean loss over the merged batch IS the mean of the micro-batch means, so the step is the
+        # same up to fp32 summation order, and on 288 GB it runs at the one-pass rate (full 256-row tile grids, one dW product,
+        # half the small launches).  Only for models that declare ``coalescible_micro_batches`` (stateless in the batch: not
+        # MemVLA, whose bank walks the batch in order).  Default: env DEXBOTIC_AMD_COALESCE (off); exp/trainer.NativeDexboticTrainer
+        # turns it on.  A group that cannot be merged — or that runs out of memory merged — runs micro-batch by micro-batch.
+        if coalesce_micro_batches is None:
+            coalesce_micro_batches = os.environ.get("DEXBOTIC_AMD_COALESCE", "0") != "0"
+        self.coalesce = bool(coalesce_micro_batches) and bool(getattr(model, "coalescible_micro_batches", False))
+        self._held: list = []
+        self.coalesced_steps = 0
         self.store = model.store
         self.cfg = optim or OptimConfig()
         unused = list(model.unused_parameter_names()) if hasattr(model, "unused_parameter_names") else []
@@ -84,7 +136,8 @@ class NativeTrainer:
 
     def set_grad_accum(self, n: int) -> None:
         """change the number of micro-batches per optimizer step (between optimizer steps only)"""
-        assert not self.update_due and self.micro % self.grad_accum == 0, "set_grad_accum() in the middle of an optimizer step"
+        assert not self.update_due and self.micro % self.grad_accum == 0 and not self._held, \
+            "set_grad_accum() in the middle of an optimizer step"
         assert n == 1 or not self.store.bf16_grads, "bf16 gradient arena needs one micro-batch per step"
         self.grad_accum, self.micro = int(n), 0
         local = self.reducer is None or self.reducer.local_only
@@ -111,13 +164,46 @@ class NativeTrainer:
         data-parallel exchange and the sum of squares are brought to completion and ``update_due`` is set.  Split from
         ``apply_update`` so that a loop which owns the optimizer call — HF ``Trainer``: ``training_step`` per micro-batch,
         ``optimizer.step()`` at the boundary (exp/trainer.NativeDexboticTrainer) — drives the same machinery.
-        ``loss_scale``: factor on the loss before backward; default 1 / grad_accum (the mean over micro-batches)."""
-        first = self.micro % self.grad_accum == 0
-        last = (self.micro + 1) % self.grad_accum == 0
+        ``loss_scale``: factor on the loss before backward; default 1 / grad_accum (the mean over micro-batches).
+        With ``coalesce`` the first grad_accum - 1 calls of a group only hold their batch (and return a zero loss); the last
+        call runs the whole group in one pass and returns the SUM of the group's micro-batch losses, so that a caller that
+        adds up what the calls return (HF ``Trainer``: tr_loss) sees the same total."""
+        if not (self.coalesce and self.grad_accum > 1):
+            return self._micro(batch, loss_scale)
+        self._held.append((batch, loss_scale))
+        if len(self._held) < self.grad_accum:
+            return torch.zeros((), device=self.store.device, dtype=torch.float32)
+        held, self._held = self._held, []
+        n = len(held)
+        scales = {sc for _, sc in held}
+        merged = coalesce_batches([b for b, _ in held]) if len(scales) == 1 else None
+        if merged is not None:
+            sc = held[0][1]
+            try:
+                loss = self._micro(merged, 1.0 if sc is None else float(sc) * n, group=n)
+                self.coalesced_steps += 1
+                return loss * n
+            except torch.OutOfMemoryError:
+                # the merged pass does not fit: this and every later group runs micro-batch by micro-batch (begin_step of the
+                # first one starts the gradient arenas afresh: every slot's first write replaces)
+                self.coalesce = False
+                self.store.flush_wgrads()
+                self.store._accum_stash.clear()
+                torch.cuda.empty_cache()
+        total = None
+        for b, sc in held:
+            l_ = self._micro(b, sc)
+            total = l_ if total is None else total + l_
+        return total
+
+    def _micro(self, batch: Dict[str, torch.Tensor], loss_scale: Optional[float] = None, group: Optional[int] = None) -> torch.Tensor:
+        """one pass; ``group`` = n: the pass covers a whole accumulation group of n micro-batches (first and last at once)"""
+        first = group is not None or self.micro % self.grad_accum == 0
+        last = group is not None or (self.micro + 1) % self.grad_accum == 0
         self.store.last_micro = last
         # exactly two micro-batches: dW of the linears = one product over both (the pair of micro-batch 1 is held until 2)
-        self.store.accum_merge = self.grad_accum == 2 and self.store.device.type == "cuda" and not self.store.bf16_grads \
-            and os.environ.get("DXA_NO_ACCUM_MERGE") is None
+        self.store.accum_merge = group is None and self.grad_accum == 2 and self.store.device.type == "cuda" \
+            and not self.store.bf16_grads and os.environ.get("DXA_NO_ACCUM_MERGE") is None
         if first:
             self.store.begin_step()
         else:
@@ -143,7 +229,7 @@ class NativeTrainer:
         if last and self.store._accum_stash:
             from .functional import flush_accum
             flush_accum(self.store)             # (a parameter the last micro-batch did not use)
-        self.micro += 1
+        self.micro += 1 if group is None else group
         if last:
             if not self._zeroed_unused:
                 # slots no kernel ever writes (lm_head, unused CLIP layer, history_embedder) stay exactly zero

@@ -108,9 +108,10 @@ def test_native_dexbotic_trainer_steps_and_full_train_loop(golden_dir):
     args = link_exp_config(exp, report_to=[])
     assert args.max_grad_norm == 0.0 and not args.gradient_checkpointing and args.deepspeed is None
     m = build_product(cfg, w, "bfloat16", DEV, train=True)
-    tr = NativeDexboticTrainer(model=m, args=args, train_dataset=[0] * 8, exp_config=exp)
+    # pass by pass here (the bit-for-bit comparison with NativeTrainer's two passes); the coalesced default: the test below
+    tr = NativeDexboticTrainer(model=m, args=args, train_dataset=[0] * 8, exp_config=exp, native={"coalesce_micro_batches": False})
     tr.create_optimizer_and_scheduler(num_training_steps=STEPS)
-    assert isinstance(tr.optimizer, ArenaAdamW)
+    assert isinstance(tr.optimizer, ArenaAdamW) and not tr.core.coalesce
     tr.current_gradient_accumulation_steps = 2
     got = []
     m.zero_grad()
@@ -144,6 +145,73 @@ def test_native_dexbotic_trainer_steps_and_full_train_loop(golden_dir):
     assert (m2.store.master - before).abs().max().item() > 0
     # integer inputs stayed on the host all the way into the model (no device->host copy for the splice plan)
     assert not tr2._prepare_inputs({"input_ids": torch.zeros(2, 4, dtype=torch.long), "images": torch.zeros(2, 3)})["input_ids"].is_cuda
+
+
+def test_accumulation_group_coalesced_into_one_pass_equals_two_passes(golden_dir):
+    """the reference recipe's two micro-batches per optimizer step (cogact_exp.py:41-46) run as ONE pass over the concatenated
+    batch (NativeTrainer coalesce_micro_batches, NativeDexboticTrainer's default): HF's training_step sequence reports 0 for the
+    held micro-batch and the group's loss sum for the last; losses, the clipped global norm and the parameters after three
+    optimizer steps against the pass-by-pass run — same arithmetic up to the order of fp32 sums over the batch rows.  Token rows
+    of unequal length are right-padded to the longer micro-batch."""
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.exp.config import ExpConfig, OptimizerConfig, TrainerConfig
+    from dexbotic_amd.exp.trainer import NativeDexboticTrainer, link_exp_config
+    from dexbotic_amd.trainer import NativeTrainer, coalesce_batches
+    g, cfg, w = load_golden(golden_dir, "t1")
+    batches = _batches(g, 2 * STEPS)
+    for dtype, tol in (("float32", 2e-5), ("bfloat16", 2e-3)):
+        want, want_master = _native_losses(g, cfg, w, dtype, batches, accum=2)
+        exp = ExpConfig(TrainerConfig(output_dir=tempfile.mkdtemp(), num_train_steps=STEPS, per_device_train_batch_size=2,
+                                      gradient_accumulation_steps=2, logging_steps=1, dataloader_num_workers=0,
+                                      lr_scheduler_type="constant", save_strategy="no", bf16=(dtype == "bfloat16")),
+                        OptimizerConfig(base_lr=LR, weight_decay=0.0))
+        m = build_product(cfg, w, dtype, DEV, train=True)
+        tr = NativeDexboticTrainer(model=m, args=link_exp_config(exp, report_to=[]), train_dataset=[0] * 8, exp_config=exp)
+        tr.create_optimizer_and_scheduler(num_training_steps=STEPS)
+        assert tr.core.coalesce
+        tr.current_gradient_accumulation_steps = 2
+        got = []
+        m.zero_grad()
+        for i, b in enumerate(batches):
+            got.append(float(tr.training_step(m, b)))
+            if i % 2 == 1:
+                tr.optimizer.step()
+                tr.lr_scheduler.step()
+                m.zero_grad()
+        torch.cuda.synchronize()
+        assert tr.core.coalesced_steps == STEPS and tr.core.global_step == STEPS
+        print(dtype, "two passes", want, "coalesced", got)
+        for k in range(STEPS):
+            assert got[2 * k] == 0.0
+            pair = 0.5 * (want[2 * k] + want[2 * k + 1])                      # mean of the two micro-batch losses
+            assert abs(got[2 * k + 1] - pair) <= tol * abs(pair), (dtype, k, got, want)
+        # Adam's first steps are sign-like: a gradient that is ~0 may step either way under another summation order (up to
+        # 2 LR per step, as in the plain-HF test above); everywhere else the parameters agree to rounding
+        diff = (m.store.master - want_master).abs()
+        far = (diff > 0.5 * LR).float().mean().item()
+        print(dtype, "parameters: max distance", diff.max().item(), "share further than LR/2 apart", far)
+        assert diff.max().item() <= 6.5 * LR and far < 0.02, (dtype, diff.max().item(), far)
+    # the injected draws ([R * B, ...], row r * B + b) are re-interleaved per repeat; ragged token rows are right-padded
+    b0, b1 = _batch(g), _batch(g)
+    B, R = b0["input_ids"].shape[0], b0["noise"].shape[0] // b0["input_ids"].shape[0]
+    b1 = dict(b1, noise=b1["noise"] + 1.0)
+    b1["input_ids"] = torch.nn.functional.pad(b1["input_ids"], (0, 3), value=5)
+    b1["attention_mask"] = torch.nn.functional.pad(b1["attention_mask"], (0, 3), value=1)
+    b1["labels"] = torch.nn.functional.pad(b1["labels"], (0, 3), value=5)
+    mg = coalesce_batches([b0, b1])
+    S = b1["input_ids"].shape[1]
+    assert mg["input_ids"].shape == (2 * B, S) and mg["noise"].shape[0] == 2 * R * B
+    assert torch.equal(mg["attention_mask"][:B, -3:], torch.zeros_like(mg["attention_mask"][:B, -3:]))
+    assert torch.equal(mg["labels"][:B, -3:], torch.full_like(mg["labels"][:B, -3:], -100))
+    for r in range(R):
+        assert torch.equal(mg["noise"][r * 2 * B:r * 2 * B + B], b0["noise"][r * B:(r + 1) * B])
+        assert torch.equal(mg["noise"][r * 2 * B + B:(r + 1) * 2 * B], b1["noise"][r * B:(r + 1) * B])
+    assert coalesce_batches([b0, dict(b1, extra=torch.zeros(1))]) is None
+    # ... and the merged ragged pair gives the loss the two batches give apart
+    m = build_product(cfg, w, "float32", DEV, train=False)
+    with torch.no_grad():
+        l0, l1, lm = m(**b0).loss.item(), m(**b1).loss.item(), m(**mg).loss.item()
+    assert abs(lm - 0.5 * (l0 + l1)) <= 2e-5 * abs(lm), (l0, l1, lm)
 
 
 def test_native_dexbotic_trainer_short_last_group_and_checkpoints(golden_dir):
@@ -188,17 +256,57 @@ def test_native_dexbotic_trainer_short_last_group_and_checkpoints(golden_dir):
     assert torch.equal(back.store.master, m.store.master)
 
 
-def test_gradient_checkpointing_is_refused_unless_opted_in(golden_dir, monkeypatch):
+def test_gradient_checkpointing_enable_recomputes_and_the_hf_loop_honours_it(golden_dir, monkeypatch):
+    """the reference trains with gradient_checkpointing=True (base_exp.py:245; trainer.py:101,120 hand it to HF, which calls
+    model.gradient_checkpointing_enable): on the native model that switch is ParamStore.recompute.  HF's whole loop with the
+    switch forwarded (DEXBOTIC_AMD_GRAD_CHECKPOINTING=1) ends on the same parameters, bit for bit, as with resident activations."""
+    from dexbotic_amd.exp.config import ExpConfig, OptimizerConfig, TrainerConfig
+    from dexbotic_amd.exp.trainer import NativeDexboticTrainer, link_exp_config
     g, cfg, w = load_golden(golden_dir, "t1")
     m = build_product(cfg, w, "float32", DEV, train=True)
-    with pytest.raises(NotImplementedError):
-        m.gradient_checkpointing_enable()
-    monkeypatch.setenv("DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING", "1")
+    assert m.supports_gradient_checkpointing and not m.is_gradient_checkpointing
+    m.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"use_reentrant": False})
+    assert m.store.recompute and m.is_gradient_checkpointing
+    m.gradient_checkpointing_disable()
+    assert not m.store.recompute
+    monkeypatch.setenv("DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING", "1")       # old opt-in: accept the call, stay resident
     with pytest.warns(UserWarning):
-        m.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"use_reentrant": False})
+        m.gradient_checkpointing_enable()
+    assert not m.store.recompute
+    monkeypatch.delenv("DEXBOTIC_AMD_ACCEPT_GRAD_CHECKPOINTING")
     with pytest.raises(NotImplementedError):
         m.to(torch.bfloat16)
     assert m.to(DEV) is m and m.cuda() is m
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 16
+
+        def __getitem__(self, i):
+            rs = np.random.RandomState(i)
+            return {"input_ids": torch.from_numpy(g["input_ids"][i % 2]), "attention_mask": torch.from_numpy(g["attention_mask"][i % 2]),
+                    "labels": torch.from_numpy(g["input_ids"][i % 2]), "images": torch.from_numpy(g["images"][i % 2]),
+                    "actions": torch.from_numpy(rs.uniform(-1, 1, size=g["actions"].shape[1:]).astype(np.float32))}
+    exp = ExpConfig(TrainerConfig(output_dir=tempfile.mkdtemp(), num_train_steps=STEPS, per_device_train_batch_size=2,
+                                  gradient_accumulation_steps=2, logging_steps=1, dataloader_num_workers=0,
+                                  lr_scheduler_type="constant", save_strategy="no"),
+                    OptimizerConfig(base_lr=LR, weight_decay=0.0))
+    assert exp.trainer_config.gradient_checkpointing                       # the reference default
+    finals = {}
+    for tag in ("resident", "recompute"):
+        if tag == "recompute":
+            monkeypatch.setenv("DEXBOTIC_AMD_GRAD_CHECKPOINTING", "1")
+        args = link_exp_config(exp, report_to=[], seed=7, data_seed=7)
+        assert args.gradient_checkpointing == (tag == "recompute")
+        m2 = build_product(cfg, w, "bfloat16", DEV, train=True)
+        tr = NativeDexboticTrainer(model=m2, args=args, train_dataset=DS(), exp_config=exp)
+        torch.manual_seed(11)                                              # the model draws noise / timesteps / drops itself
+        out = tr.train()
+        torch.cuda.synchronize()
+        assert out.global_step == STEPS and m2.store.recompute == (tag == "recompute")
+        finals[tag] = (m2.store.master.clone(), out.training_loss)
+    assert finals["resident"][1] == finals["recompute"][1]
+    assert torch.equal(finals["resident"][0], finals["recompute"][0])
 
 
 def test_inference_single_on_an_image_file(golden_dir, tmp_path):

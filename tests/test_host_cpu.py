@@ -287,3 +287,56 @@ def test_backward_reenters_the_fp32_product_mode_of_its_forward():
     with K.f32_gemm_mode("bf16x3"):
         y2.sum().backward()
     assert seen == {"fwd": "exact", "bwd": "exact"}
+
+
+def test_coalesce_batches_interleaves_draws_pads_ragged_rows_and_refuses_what_it_does_not_know():
+    """host arithmetic of trainer.coalesce_batches (the accumulation micro-batches of an optimizer step as ONE batch): rows are
+    concatenated, the injected draws ([R * B, ...], row r * B + b as cogact_arch.py:110-125 repeats the batch) re-interleaved per
+    repeat, token rows right-padded to the longest micro-batch (id 0 / mask 0 / label -100)"""
+    from dexbotic_amd.trainer import coalesce_batches
+    B, R, S = 3, 4, 6
+    rs = np.random.RandomState(0)
+
+    def mk(S_, off):
+        return dict(input_ids=torch.arange(B * S_).reshape(B, S_) + off, attention_mask=torch.ones(B, S_, dtype=torch.bool),
+                    labels=torch.arange(B * S_).reshape(B, S_) + off, images=torch.from_numpy(rs.randn(B, 3, 4, 4).astype(np.float32)),
+                    actions=torch.from_numpy(rs.randn(B, 16, 7).astype(np.float32)),
+                    noise=torch.from_numpy(rs.randn(R * B, 16, 7).astype(np.float32)), timesteps=torch.arange(R * B) + off,
+                    drop_ids=torch.from_numpy(rs.rand(R * B) < 0.5))
+    a, b, c = mk(S, 0), mk(S + 2, 1000), mk(S, 2000)
+    m = coalesce_batches([a, b, c])
+    assert m["input_ids"].shape == (3 * B, S + 2) and m["images"].shape[0] == 3 * B and m["noise"].shape[0] == 3 * R * B
+    assert torch.equal(m["input_ids"][:B, :S], a["input_ids"]) and torch.equal(m["input_ids"][B:2 * B], b["input_ids"])
+    assert (m["input_ids"][:B, S:] == 0).all() and not m["attention_mask"][:B, S:].any() and (m["labels"][2 * B:, S:] == -100).all()
+    assert m["attention_mask"].dtype == torch.bool and m["attention_mask"][B:2 * B].all()
+    for key in ("noise", "timesteps", "drop_ids"):
+        for r in range(R):
+            for j, src in enumerate((a, b, c)):
+                assert torch.equal(m[key][r * 3 * B + j * B:r * 3 * B + (j + 1) * B], src[key][r * B:(r + 1) * B]), (key, r, j)
+    # what the merged batch means to the model: repeat(R) of the merged rows lines up with the merged draws
+    acts_rep = m["actions"].repeat(R, 1, 1)
+    for r in range(R):
+        assert torch.equal(acts_rep[r * 3 * B + B:r * 3 * B + 2 * B], b["actions"])
+    assert coalesce_batches([a, dict(c, states=torch.zeros(B, 2))]) is None                    # other key sets
+    assert coalesce_batches([a, dict(c, episode=torch.zeros(B))]) is None
+    assert coalesce_batches([dict(a, episode=torch.zeros(B)), dict(c, episode=torch.zeros(B))]) is None      # a key it does not know
+    small = {k: v[:2] if k in ("input_ids", "attention_mask", "labels", "images", "actions") else v[:2 * R] for k, v in c.items()}
+    assert coalesce_batches([a, small]) is None                                                # unequal micro-batch sizes
+    assert coalesce_batches([a, dict(c, images=torch.zeros(B, 3, 8, 8))]) is None              # unequal image shapes
+
+
+def test_exp_config_gradient_checkpointing_is_forwarded_only_on_request(monkeypatch, tmp_path):
+    """TrainerConfig.gradient_checkpointing defaults to True in the reference (base_exp.py:245, there to fit 80 GB parts): the
+    native trainer keeps activations resident unless DEXBOTIC_AMD_GRAD_CHECKPOINTING=1 forwards the switch to HF's loop, which
+    then calls model.gradient_checkpointing_enable() -> ParamStore.recompute"""
+    from dexbotic_amd.exp.config import ExpConfig, OptimizerConfig, TrainerConfig
+    from dexbotic_amd.exp.trainer import link_exp_config
+    exp = ExpConfig(TrainerConfig(output_dir=str(tmp_path), bf16=False), OptimizerConfig())
+    assert exp.trainer_config.gradient_checkpointing
+    monkeypatch.delenv("DEXBOTIC_AMD_GRAD_CHECKPOINTING", raising=False)
+    assert not link_exp_config(exp, report_to=[], use_cpu=True).gradient_checkpointing
+    monkeypatch.setenv("DEXBOTIC_AMD_GRAD_CHECKPOINTING", "1")
+    args = link_exp_config(exp, report_to=[], use_cpu=True)
+    assert args.gradient_checkpointing and args.gradient_checkpointing_kwargs == {"use_reentrant": False}
+    exp.trainer_config.gradient_checkpointing = False
+    assert not link_exp_config(exp, report_to=[], use_cpu=True).gradient_checkpointing

@@ -1,0 +1,139 @@
+"""Activation recompute (the reference's gradient checkpointing: base_exp.py:245, trainer.py:101,120, dexbotic_arch.py:40) on
+the MI355X: with ``ParamStore.recompute`` the decoder / vision / pi0 layer Functions keep only their input and re-run their
+forward launches inside their backward.  Same kernels in the same order, so the bar is BIT-identical losses and gradient
+arenas against the resident-activation step, fp32 and bf16, plus a lower peak of live device memory at a depth where the kept
+activations dominate."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_product, load_golden
+from tests.test_parity_gpu import _batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cogact_step(cfg, w, dtype, b, recompute):
+    m = build_product(cfg, w, dtype, DEV, train=True)
+    m.train()
+    if recompute:
+        m.gradient_checkpointing_enable()
+    m.store.begin_step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = m(**b)
+    held = torch.cuda.memory_allocated() - base          # what the autograd graph keeps alive between forward and backward
+    out.loss.backward()
+    torch.cuda.synchronize()
+    return out.loss.item(), m.store.grad.clone(), held, sorted(m.store.never_written())
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_cogact_step_with_recompute_is_bit_identical(golden_dir, tag, dtype):
+    g, cfg, w = load_golden(golden_dir, tag)
+    b = _batch(g)
+    l0, g0, held0, nw0 = _cogact_step(cfg, w, dtype, b, False)
+    l1, g1, held1, nw1 = _cogact_step(cfg, w, dtype, b, True)
+    assert l0 == l1 and nw0 == nw1
+    assert torch.equal(g0, g1)
+    assert g0.abs().max().item() > 0
+    assert held1 < held0, (held0, held1)
+
+
+def test_recompute_under_two_micro_batch_accumulation_and_clip(golden_dir):
+    """the reference recipe (8 x accum 2) with checkpointing on: the merged two-segment dW products read the RECOMPUTED
+    activations of both micro-batches; parameters after the clipped AdamW step equal the resident run bit for bit"""
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    g, cfg, w = load_golden(golden_dir, "t2")
+    b = _batch(g)
+    B = b["input_ids"].shape[0]
+    R = b["noise"].shape[0] // B
+    res = {}
+    for rc in (False, True):
+        m = build_product(cfg, w, "bfloat16", DEV, train=True)
+        if rc:
+            m.gradient_checkpointing_enable()
+        tr = NativeTrainer(m, OptimConfig(base_lr=1e-3, max_grad_norm=1.0), grad_accum=2)
+        half = B // 2
+        for i in range(2):
+            rows = torch.arange(i * half, (i + 1) * half, device=DEV)
+            sel = (torch.arange(R, device=DEV)[:, None] * B + rows[None, :]).reshape(-1)
+            tr.micro_step(dict(input_ids=b["input_ids"][i * half:(i + 1) * half], attention_mask=b["attention_mask"][i * half:(i + 1) * half],
+                               images=b["images"][i * half:(i + 1) * half], actions=b["actions"][i * half:(i + 1) * half],
+                               noise=b["noise"][sel], timesteps=b["timesteps"][sel], drop_ids=b["drop_ids"][sel]))
+        assert m.store.accum_merge and not m.store._accum_stash
+        tr.apply_update()
+        torch.cuda.synchronize()
+        res[rc] = (m.store.grad.clone(), float(tr._sumsq), m.store.master.clone())
+    assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1]
+    assert torch.equal(res[False][2], res[True][2])
+
+
+def test_pi0_step_with_recompute_is_bit_identical(golden_dir):
+    """pi0 trains with gradient_checkpointing too (pi0_exp.py:97): the dual-expert layer (Pi0MotLayerFn) and the SigLIP blocks"""
+    from tests.test_pi0_gpu import T, build
+    res = {}
+    for dtype in ("float32", "bfloat16"):
+        for rc in (False, True):
+            g, m = build(golden_dir, dtype, train=True)
+            m.train()
+            if rc:
+                m.gradient_checkpointing_enable()
+            st = m.store
+            st.set_expected(m.unused_parameter_names())
+            st.begin_step()
+            out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]),
+                    image_masks=T(g["image_masks"]), states=T(g["states"]), actions=T(g["actions"]), noise=T(g["noise"]),
+                    time=g["time"])
+            out.loss.backward()
+            torch.cuda.synchronize()
+            res[rc] = (out.loss.item(), st.grad.clone())
+        assert res[False][0] == res[True][0], dtype
+        assert torch.equal(res[False][1], res[True][1]), dtype
+        assert res[False][1].abs().max().item() > 0
+
+
+def test_recompute_lowers_the_peak_at_real_width():
+    """four decoder layers at the BASELINE widths (d 3584, 28q/4kv x 128, ffn 18944), 4 x 287 tokens, bf16: a resident layer keeps
+    x, h1, q, k, v, o, x2, h2 (d-wide each, k / v 512-wide), gate|up (2 F) and the SwiGLU output (F) per token — ~0.18 GB here —
+    against its d-wide input alone with recompute (8 MB); gradients bit-identical"""
+    from dexbotic_amd.engine import ParamStore, attach_parameters
+    from dexbotic_amd.model.llm.qwen2 import Qwen2Backbone, Qwen2Config
+    L_, B, S, d = 4, 4, 287, 3584
+    res = {}
+    for rc in (False, True):
+        st = ParamStore(DEV, torch.bfloat16)
+        cfg = Qwen2Config(vocab_size=1024, hidden_size=d, intermediate_size=18944, num_hidden_layers=L_, num_attention_heads=28,
+                          num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
+        llm = Qwen2Backbone(st, "model.llm.", cfg)
+        st.finalize(train=True)
+        attach_parameters(llm, st)
+        gen = torch.Generator(device="cpu").manual_seed(5)
+        for n in st.slots:
+            wv = st.w32(n)
+            if wv.dim() >= 2:
+                wv.copy_((torch.randn(wv.shape, generator=gen) * 0.02).to(DEV))
+            elif n.endswith("norm.weight"):
+                wv.fill_(1.0)
+            else:
+                wv.zero_()
+        st.sync_shadow()
+        st.recompute = rc
+        st.begin_step()
+        x = (torch.randn((B, S, d), generator=gen) * 0.5).to(DEV).to(torch.bfloat16).requires_grad_(True)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        y = llm(x)
+        held = torch.cuda.memory_allocated() - base
+        y.float().square().mean().backward()
+        torch.cuda.synchronize()
+        res[rc] = (st.grad.clone(), x.grad.clone(), held)
+        del st, llm, x, y
+        torch.cuda.empty_cache()
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    print(f"kept between forward and backward: resident {res[False][2] / 2**20:.1f} MiB, recompute {res[True][2] / 2**20:.1f} MiB")
+    assert res[True][2] * 8 < res[False][2], (res[False][2], res[True][2])
