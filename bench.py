@@ -521,7 +521,7 @@ def main():
                 lat.append(1e3 * (time.perf_counter() - t1))       # inference_action ends with a .cpu() sync
             result["p50_action_inference_ms"] = round(float(np.median(lat[5:])), 2)
             result["config"]["inference_workload"] = ("DB-CogACT bf16 action inference, batch 1, 2 views 224x224, "
-                                                      "32-token instruction (S=543), CFG 1.5, 10 DDIM steps, eager launches")
+                                                      "32-token instruction (S=543), CFG 1.5, 10 DDIM steps, through inference_action (HIP-graph replay from the third request of a shape on)")
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, llm, vis)

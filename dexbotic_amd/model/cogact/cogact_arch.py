@@ -139,11 +139,12 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
 
     @torch.no_grad()
     def inference_action(self, input_ids, image_tensor, inference_args={}, **kwargs):
-        """Reference contract (cogact_arch.py:151-204).  With ``inference_args["use_graph"]`` (or env
-        DXA_INFER_GRAPH=1) the device work of a given request shape is captured once into a HIP graph (second call
-        with that shape) and replayed afterwards: a 10-step DDIM sample is ~1.4k small launches and the graph
-        removes their per-launch host cost.  Off by default: on the MI355X host the request is GPU-bound and the
-        replay measured 1 ms slower than eager launches (30.7 vs 29.6 ms); it pays on hosts with slow cores."""
+        """Reference contract (cogact_arch.py:151-204).  The device work of a given request shape is captured once into a
+        HIP graph (second call with that shape; the first runs eagerly) and replayed afterwards — bit-identical to the eager
+        launches (tests/test_parity_gpu.py).  The request is GPU-bound (436 launches, 19.3 ms of kernels at the BASELINE shape),
+        the replay removes the launch gaps: p50 19.76 -> 19.46 ms (profiles/r04_infer_eager_vs_graph.txt; rounds 1-3 measured it
+        level or slower and kept it off).  ``inference_args["use_graph"]=False`` or env DXA_INFER_GRAPH=0: eager launches.  At most
+        ``MAX_INFER_GRAPHS`` request shapes keep a graph (least recently used dropped): instruction lengths vary in serving."""
         cfg_scale = inference_args.get("cfg_scale", 1.5)
         num_ddim_steps = inference_args.get("num_ddim_steps", 10)
         action_norms = inference_args.get("action_norms")
@@ -162,7 +163,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
         if noise is None:
             noise = torch.randn(B, self.config.chunk_size, self.config.action_dim, device=dev, dtype=torch.float32)
         noise = noise.to(device=dev, dtype=torch.float32)
-        use_graph = inference_args.get("use_graph", os.environ.get("DXA_INFER_GRAPH", "0") != "0")
+        use_graph = inference_args.get("use_graph", os.environ.get("DXA_INFER_GRAPH", "1") != "0")
         from ... import kernels as K
         head.net.used_fused = False
         graph_stream = None
@@ -195,11 +196,17 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             return actions, samples, traj
         return actions
 
+    MAX_INFER_GRAPHS = 8
+
     def _graph_sample(self, images, plan_np, B, S, noise, cfg_scale, num_ddim_steps):
         key = (tuple(images.shape), B, S, cfg_scale, num_ddim_steps)
         cache = self.__dict__.setdefault("_infer_graphs", {})
-        ent = cache.get(key)
+        ent = cache.pop(key, None)
+        if ent is not None:
+            cache[key] = ent                                   # most recently used last
         if ent is None:
+            while len(cache) >= self.MAX_INFER_GRAPHS:
+                cache.pop(next(iter(cache)))                   # least recently used: its graph and static buffers are freed
             # first request of this shape: eager on a private stream (this also lets every lazily created
             # resource — split-K scratch of that stream, device tables, kernel attributes — come into being)
             # ONE private stream for every request shape of this model: the library keeps per-stream scratch (64 MiB of split-K
