@@ -81,6 +81,13 @@ class ParamStore:
         # activation recompute (the reference's gradient checkpointing, base_exp.py:245): the transformer-layer Functions keep
         # only their input and re-run their forward inside their backward (functional._recompute).  Off: activations resident.
         self.recompute = False
+        # weight-gradient products on a side HIP stream (functional._wgrad_now): dW = dY^T X depends on nothing downstream in the
+        # backward chain, so it may run beside the next dX product; the compute stream joins (join_wgrad) before anything reads the
+        # gradient arena — a bucket's completion hook, the norm / reducer finish, the optimizer.  None: same stream (default).
+        self.wgrad_stream: Optional["torch.cuda.Stream"] = None
+        self.wgrad_stream_f32_only = False      # only the fp32 action head's dW products (low occupancy: 1088 rows) go there
+        self.bgrad_on_side = False              # the bias gradients' column sums too
+        self._wgrad_pending = False
         # gradient accumulation: only the LAST micro-batch's dW products (accumulate = 1: what they store is the step's final
         # gradient) leave their share of sum(g^2); the trainer keeps this flag current (True without accumulation)
         self.last_micro = True
@@ -289,7 +296,14 @@ class ParamStore:
                 self._bucket_pending[b] -= 1
                 if self._bucket_pending[b] == 0 and self.on_bucket_ready is not None and not self._bucket_fired[b]:
                     self._bucket_fired[b] = True
+                    self.join_wgrad()               # the bucket's dW products may still be in flight on the side stream
                     self.on_bucket_ready(b)
+
+    def join_wgrad(self) -> None:
+        """the current stream waits for the weight-gradient products enqueued on the side stream so far"""
+        if self._wgrad_pending and self.wgrad_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+        self._wgrad_pending = False
 
     def flush_wgrads(self) -> None:
         """weight-gradient products still waiting for a last use that never came (autograd pruned one of the consumers)"""

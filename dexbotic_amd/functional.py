@@ -154,6 +154,25 @@ def _wgrad_flush(st: ParamStore, key: tuple) -> None:
 
 def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape, accumulate: bool,
                first_write: Optional[bool] = None, seg2=None) -> None:
+    side = st.wgrad_stream
+    if side is not None and st.wgrad_stream_f32_only and dy2d.dtype != torch.float32:
+        side = None                                # (only the fp32 action head's products leave the compute stream)
+    if side is None:
+        _wgrad_product(st, names, dy2d, x2d, shape, accumulate, first_write, seg2)
+    else:
+        # the product runs on the side stream, ordered after everything enqueued on the compute stream so far (its operands);
+        # all dW products share that stream, so successive writes of one slot stay ordered; readers join (ParamStore.join_wgrad)
+        side.wait_stream(torch.cuda.current_stream(st.device))
+        with torch.cuda.stream(side):
+            _wgrad_product(st, names, dy2d, x2d, shape, accumulate, first_write, seg2)
+        for t in (dy2d, x2d) + (tuple(seg2) if seg2 is not None else ()):
+            t.record_stream(side)                  # the allocator must not hand the operands out again before the product has read them
+        st._wgrad_pending = True
+    st.mark_written(*names)
+
+
+def _wgrad_product(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, shape, accumulate: bool,
+                   first_write: Optional[bool], seg2) -> None:
     kw2 = {} if seg2 is None else {"a2": seg2[0], "b2": seg2[1]}
     if st.bf16_grads and st.gradc is not None and dy2d.dtype == torch.bfloat16 and x2d.dtype == torch.bfloat16:
         # bf16 gradient arena: the product writes bf16 only (ParamStore.bf16_grads); the slots count as already copied
@@ -161,7 +180,6 @@ def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, sha
         ssq = st.sumsq_out(names, out.shape[0], out.shape[1], first_write) if out.dim() == 2 else None
         K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, sumsq=ssq, **kw2)
         st._mirrored.update(names)
-        st.mark_written(*names)
         return
     out = st.g(*names, shape=shape)
     # bf16 data parallelism: the product's epilogue also writes the bf16 communication copy of this gradient
@@ -173,7 +191,6 @@ def _wgrad_now(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor, sha
         K.mm_tn_f32(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq)
     else:
         K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq, **kw2)
-    st.mark_written(*names)
 
 
 def _bgrad(st: ParamStore, names, dy2d: torch.Tensor) -> None:
@@ -181,7 +198,15 @@ def _bgrad(st: ParamStore, names, dy2d: torch.Tensor) -> None:
     if not all(st.trainable(n) for n in names):
         return
     n = sum(st.slots[nm].numel for nm in names)
-    K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
+    side = st.wgrad_stream if st.bgrad_on_side else None
+    if side is None:
+        K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
+    else:
+        side.wait_stream(torch.cuda.current_stream(st.device))
+        with torch.cuda.stream(side):
+            K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
+        dy2d.record_stream(side)
+        st._wgrad_pending = True
     st.mark_written(*names)
 
 

@@ -63,6 +63,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
     # every sample of a batch is processed independently of the others and of the call order: the micro-batches of a gradient
     # accumulation group may run as one batch (trainer.NativeTrainer coalesce_micro_batches)
     coalescible_micro_batches = True
+    gradient_side_stream = True      # trainer.NativeTrainer: the fp32 head's dW products and the bias column sums beside the dX chain
 
     def _real_init(self, config: CogActConfig):
         self.model = CogActModel(config, self.store)

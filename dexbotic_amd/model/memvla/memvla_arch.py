@@ -317,6 +317,7 @@ class MemVLAModel(CogActModel):
 class MemVLAForCausalLM(CogACTForCausalLM):
     config_class = MemVLAConfig
     coalescible_micro_batches = False      # the memory bank walks the batch in order: micro-batches are not interchangeable
+    gradient_side_stream = False           # measured slower here (trainer.NativeTrainer)
 
     def _real_init(self, config: MemVLAConfig):
         self.model = MemVLAModel(config, self.store)

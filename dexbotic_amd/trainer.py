@@ -130,6 +130,20 @@ class NativeTrainer:
         self.store.invalidate_embed_tracking()
         self._zeroed_unused = False
         self.store.managed = True               # this object calls begin_step / begin_micro (the model's pre-hook stands down)
+        # Gradient work that nothing downstream in the backward chain waits for runs on a side HIP stream, beside the dX chain
+        # (ParamStore.wgrad_stream; the compute stream joins before a bucket's completion hook, the norm / reducer finish and the
+        # optimizer).  DXA_WGRAD_STREAM = 3 (default): the fp32 action head's dW products (1088 rows: a fifth of the CUs each) and
+        # the bias gradients' column sums — 244.7 -> 241.3 ms per step, bit-identical gradients, the big products' launch times
+        # unchanged (profiles/r04_wgrad_stream_abc.txt); 2: the head's dW only (242.7); 1: EVERY dW product (240.1 on another box,
+        # but a 16-bit dW beside the next dX shares the CUs with it: each launch then takes 400-500 us and the per-launch roofline
+        # of section 5 stops meaning anything); 0: everything on the compute stream.  Default per model (``gradient_side_stream``):
+        # on for DB-CogACT; MemVLA's step — a thousand small fp32 products and column sums, 9,000 launches — measured 363 -> 372 ms
+        # with it (a cross-stream dependency per product) and keeps one stream, as does pi0 (not measured).
+        mode = os.environ.get("DXA_WGRAD_STREAM", "3" if getattr(model, "gradient_side_stream", False) else "0")
+        if mode != "0" and self.store.device.type == "cuda":
+            self.store.wgrad_stream = torch.cuda.Stream(device=self.store.device)
+            self.store.wgrad_stream_f32_only = mode in ("2", "3")
+            self.store.bgrad_on_side = mode == "3"
         self.update_due = False
         self._sumsq, self._reducing = None, False
         self.last_output = None
@@ -229,6 +243,7 @@ class NativeTrainer:
         if last and self.store._accum_stash:
             from .functional import flush_accum
             flush_accum(self.store)             # (a parameter the last micro-batch did not use)
+        self.store.join_wgrad()                 # (dW products on the side stream, if any)
         self.micro += 1 if group is None else group
         if last:
             if not self._zeroed_unused:

@@ -255,3 +255,44 @@ def test_two_micro_batches_write_each_weight_gradient_once(golden_dir, monkeypat
     assert rel_err(gm.cpu().numpy(), gr.cpu().numpy()) < 1e-5
     assert abs(res["merge"][1] - res["rmw"][1]) < 1e-5 * res["rmw"][1]
     assert rel_err(res["merge"][2].cpu().numpy(), res["rmw"][2].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["3", "1"])
+def test_gradient_work_on_the_side_stream_is_bit_identical(golden_dir, monkeypatch, mode):
+    """the fp32 head's dW products and the bias column sums run on a side HIP stream beside the dX chain (trainer.NativeTrainer,
+    DXA_WGRAD_STREAM, default 3; 1 = every dW product): same kernels on the same operands, joined before anything reads the
+    gradient arena — gradients, the clipped norm and the parameters after two optimizer steps (accumulation 2 on the second model
+    pass: the merged two-segment dW products) equal the single-stream run bit for bit"""
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    g, cfg, w = load_golden(golden_dir, "t2")
+    b = _batch(g)
+    B = b["input_ids"].shape[0]
+    R = b["noise"].shape[0] // B
+    half = B // 2
+    micro = []
+    for i in range(2):
+        rows = torch.arange(i * half, (i + 1) * half, device=DEV)
+        sel = (torch.arange(R, device=DEV)[:, None] * B + rows[None, :]).reshape(-1)
+        micro.append(dict(input_ids=b["input_ids"][i * half:(i + 1) * half], attention_mask=b["attention_mask"][i * half:(i + 1) * half],
+                          images=b["images"][i * half:(i + 1) * half], actions=b["actions"][i * half:(i + 1) * half],
+                          noise=b["noise"][sel], timesteps=b["timesteps"][sel], drop_ids=b["drop_ids"][sel]))
+    res = {}
+    for m_ in ("0", mode):
+        monkeypatch.setenv("DXA_WGRAD_STREAM", m_)
+        out = []
+        for dtype in ("float32", "bfloat16"):
+            m = build_product(cfg, w, dtype, DEV, train=True)
+            tr = NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=0.01, max_grad_norm=1.0))
+            assert (m.store.wgrad_stream is not None) == (m_ != "0")
+            tr.step(b)
+            g1 = m.store.grad.clone()
+            tr.set_grad_accum(2)
+            for mb in micro:
+                tr.step(mb)
+            torch.cuda.synchronize()
+            out.append((g1, m.store.grad.clone(), float(tr.opt.norm.item()), m.store.master.clone()))
+        res[m_] = out
+    for a, c in zip(res["0"], res[mode]):
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and a[2] == c[2] and torch.equal(a[3], c[3])
+        assert a[0].abs().max().item() > 0
