@@ -17,6 +17,7 @@ struct AdamP {
   float lr[8], wd[8];
   float b1, b2, eps, bc1, bc2;
   const float* clip;
+  uint8_t* state;      // per-chunk sparse-table state (dxa_adamw_desc.chunk_state) or null
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float wd, const AdamP& a,
@@ -64,6 +65,19 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   bf16_t* sh = a.shadow ? a.shadow + start : nullptr;
   const bool vec = ((start & 3) == 0);
   const int n4 = vec ? (len >> 2) : 0;
+  if (a.state != nullptr && a.state[c] == 1 && wd == 0.f) {
+    // chunk of a sparsely touched table that never had a gradient (m = v = 0): an all-zero gradient leaves p, m, v unchanged
+    // (m' = 0, v' = 0, p' = p - step * 0 / (0 + eps)); one read of g decides, NaN / Inf count as non-zero
+    typedef float f4z __attribute__((ext_vector_type(4)));
+    int nz = 0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const f4z gz = GradLd<TG>::ld4(g, i);
+      nz |= !(gz.x == 0.f && gz.y == 0.f && gz.z == 0.f && gz.w == 0.f);
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < len; i += 256) nz |= !(ldf<TG>(g + i) == 0.f);
+    if (!__syncthreads_or(nz)) return;
+    if (threadIdx.x == 0) a.state[c] = 2;
+  }
   // two float4 groups per thread in flight (8 independent 16-B loads); g, m, v and the stores stream through HBM
   // exactly once per step, so they carry the nontemporal hint and leave L2/MALL to the master weights' neighbours
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -223,6 +237,7 @@ extern "C" int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream) {
   for (int i = 0; i < 8; ++i) { a.lr[i] = d->lr[i]; a.wd[i] = d->wd[i]; }
   a.b1 = d->beta1; a.b2 = d->beta2; a.eps = d->eps; a.bc1 = d->bc1; a.bc2 = d->bc2;
   a.clip = d->clip_coef;
+  a.state = d->chunk_state;
   if (d->g_dtype == DXA_BF16) hipLaunchKernelGGL(adamw_k<bf16_t>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(adamw_k<float>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
   DXA_CHECK_LAUNCH();

@@ -605,7 +605,11 @@ class FusedAdamW:
         # groups: (lr_key, decay?) -> index  (<= 8 groups, as the reference builds them)
         self.group_keys: List[Tuple[str, bool]] = []
         self.group_of: Dict[str, Tuple[str, bool]] = {}      # parameter name -> (lr key, weight-decayed?)
-        cs, cl, cg = [], [], []
+        cs, cl, cg, cst = [], [], [], []
+        # token-embedding tables receive gradient in <= B * S_text rows per step: their chunks start in state 1 = "never saw a
+        # non-zero gradient" and the kernel leaves such a chunk alone while its gradient is all-zero and its weight decay is 0 —
+        # exactly what AdamW computes for it (dxa_adamw_desc.chunk_state).  DXA_ADAMW_SPARSE=0: every chunk ordinary.
+        sparse_tables = __import__("os").environ.get("DXA_ADAMW_SPARSE", "1") != "0"
         explicit = None
         self._explicit_defaults: Optional[List[Tuple[Optional[float], Optional[float]]]] = None
         if groups is not None:
@@ -640,6 +644,7 @@ class FusedAdamW:
                 cs.append(s.offset + o)
                 cl.append(ln)
                 cg.append(gi)
+                cst.append(1 if sparse_tables and s.name.endswith("embed_tokens.weight") else 0)
                 o += ln
         assert len(self.group_keys) <= 8
         # segments for the overlapped update: [first chunk, one past the last chunk, buckets covered]
@@ -666,6 +671,7 @@ class FusedAdamW:
         self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
         self.chunk_len = torch.tensor(cl, dtype=torch.int32, device=dev)
         self.chunk_grp = torch.tensor(cg, dtype=torch.int32, device=dev)
+        self.chunk_state = torch.tensor(cst, dtype=torch.uint8, device=dev) if any(cst) and dev.type == "cuda" else None
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.coef = torch.ones(1, device=dev, dtype=torch.float32)
@@ -715,7 +721,7 @@ class FusedAdamW:
         st.native_epoch += 1                       # the masters move under raw pointers: derived copies (packed DiT weights) are stale
         if not self.overlap:
             K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
-                    lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip)
+                    lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip, chunk_state=self.chunk_state)
             return
         cur = torch.cuda.current_stream(st.device)
         self.stream.wait_stream(cur)               # gradients, sum(g^2) and the clip coefficient are final on `cur`
@@ -724,7 +730,7 @@ class FusedAdamW:
                 if i1 > i0:
                     K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start[i0:i1], self.chunk_len[i0:i1],
                             self.chunk_grp[i0:i1], lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count,
-                            clip=clip)
+                            clip=clip, chunk_state=None if self.chunk_state is None else self.chunk_state[i0:i1])
                 ev.record(self.stream)
                 for b in buckets:
                     st._pending[b] = ev
@@ -732,6 +738,11 @@ class FusedAdamW:
     def synchronize(self) -> None:
         """the current stream waits for an overlapped update still in flight"""
         self.store.wait_pending()
+
+    def moments_replaced(self) -> None:
+        """m / v were written from outside (an optimizer state dict was loaded): no chunk may be assumed to hold zero moments"""
+        if self.chunk_state is not None:
+            self.chunk_state.zero_()
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:

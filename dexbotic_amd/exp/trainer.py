@@ -75,6 +75,7 @@ class ArenaAdamW(torch.optim.Optimizer):
                 self.core.opt.m.copy_(arena["m"])
                 self.core.opt.v.copy_(arena["v"])
             self.core.opt.step_count = int(arena["step"])
+            self.core.opt.moments_replaced()
 
 
 def link_exp_config(exp_config, **overrides) -> TrainingArguments:

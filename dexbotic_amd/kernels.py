@@ -806,8 +806,11 @@ def scale_dev_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1, beta2, eps, step, clip=None):
+def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1, beta2, eps, step, clip=None, chunk_state=None):
     d = L.AdamWDesc()
+    if chunk_state is not None:
+        assert chunk_state.dtype == torch.uint8 and chunk_state.numel() == chunk_start.numel() and chunk_state.is_contiguous()
+    d.chunk_state = _ptr(chunk_state)
     d.p, d.g, d.m, d.v, d.shadow = _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow)
     d.g_dtype = dt(g)
     d.chunk_start, d.chunk_len, d.chunk_grp = _ptr(chunk_start), _ptr(chunk_len), _ptr(chunk_grp)

@@ -339,6 +339,12 @@ typedef struct dxa_adamw_desc {
   int32_t g_dtype;             /* DXA_F32: g is the fp32 gradient arena; DXA_BF16: g is its bf16 communication copy (the
                                   data-parallel run averages bf16 gradients like the reference's DeepSpeed bf16 config,
                                   script/deepspeed/zero2.json, and the optimizer reads the averaged copy directly) */
+  uint8_t* chunk_state;        /* or NULL.  One byte per chunk, device memory, kept by the caller across steps: 0 = ordinary chunk;
+                                  1 = chunk of a sparsely touched table (nn.Embedding weight: dexbotic_arch.py:182-373 scatters
+                                  gradients into <= B * S_text rows per step) that has never seen a non-zero gradient: its m and v
+                                  are exactly 0, so while its gradient is all-zero and its group's weight decay is 0 torch's AdamW
+                                  leaves p, m, v bit-for-bit unchanged — the kernel reads g only and returns; the first non-zero
+                                  gradient turns the byte into 2 = ordinary from then on */
 } dxa_adamw_desc;
 int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream);
 /* out[0] = sum x^2 over n fp32 / bf16 elements (deterministic two-stage; scratch >= 4096 doubles) */

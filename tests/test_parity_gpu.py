@@ -296,3 +296,44 @@ def test_gradient_work_on_the_side_stream_is_bit_identical(golden_dir, monkeypat
     for a, c in zip(res["0"], res[mode]):
         assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and a[2] == c[2] and torch.equal(a[3], c[3])
         assert a[0].abs().max().item() > 0
+
+
+def test_adamw_leaves_untouched_embedding_chunks_alone_and_nothing_changes(golden_dir, monkeypatch):
+    """dxa_adamw_desc.chunk_state: chunks of embed_tokens.weight that never saw a non-zero gradient are skipped while their gradient
+    is all-zero (weight decay 0) — what torch's AdamW computes for them is p, m, v unchanged.  Three optimizer steps with OTHER token
+    ids each time, against DXA_ADAMW_SPARSE=0: parameters and both moments bit-identical; most embedding chunks stay in state 1;
+    with weight decay on, nothing is skipped and the results are again bit-identical"""
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    g, cfg, w = load_golden(golden_dir, "t2")
+    for wd in (0.0, 0.01):
+        res = {}
+        for sparse in ("1", "0"):
+            monkeypatch.setenv("DXA_ADAMW_SPARSE", sparse)
+            m = build_product(cfg, w, "bfloat16", DEV, train=True)
+            # (chunks of 128 elements: a couple of toy-width table rows each, so that three steps leave table chunks untouched)
+            tr = NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=wd, max_grad_norm=1.0, chunk=128))
+            assert (tr.opt.chunk_state is not None) == (sparse == "1")
+            states = []
+            for k in range(3):
+                b = _batch(g)
+                ids = b["input_ids"].clone()
+                text = ids >= 0
+                ids[text] = (ids[text] + 7 * k) % cfg.vocab_size          # other instruction tokens every step
+                b["input_ids"], b["labels"] = ids, ids
+                tr.step(b)
+                if tr.opt.chunk_state is not None:
+                    states.append(tr.opt.chunk_state.clone())
+            torch.cuda.synchronize()
+            res[sparse] = (m.store.master.clone(), tr.opt.m.clone(), tr.opt.v.clone(), m.store.shadow.clone(), states)
+        for i in range(4):
+            assert torch.equal(res["1"][i], res["0"][i]), (wd, i)
+        st = res["1"][4]
+        cand = st[0] > 0
+        assert cand.any()
+        if wd == 0.0:
+            # activated chunks only ever grow, and some table chunks are still untouched after three steps
+            assert ((st[0] == 2) & ~(st[1] == 2)).sum().item() == 0 and ((st[1] == 2) & ~(st[2] == 2)).sum().item() == 0
+            assert (st[0] == 2).any() and (st[2][cand] == 1).any()
+        else:
+            assert (st[2][cand] == 1).all()                                  # decayed every step: never skipped, never promoted
