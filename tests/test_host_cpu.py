@@ -340,3 +340,66 @@ def test_exp_config_gradient_checkpointing_is_forwarded_only_on_request(monkeypa
     assert args.gradient_checkpointing and args.gradient_checkpointing_kwargs == {"use_reentrant": False}
     exp.trainer_config.gradient_checkpointing = False
     assert not link_exp_config(exp, report_to=[], use_cpu=True).gradient_checkpointing
+
+
+def test_coalescing_control_flow_holds_merges_and_falls_back():
+    """NativeTrainer.micro_step with coalesce on (host logic only; the pass itself is stubbed): the first grad_accum - 1 calls of a
+    group hold their batch and return 0, the last runs ONE pass over the merged batch with loss scale 1 (n x the caller's scale
+    when given) and returns n x its loss; a group that cannot be merged runs pass by pass and returns the losses' sum; an
+    out-of-memory error in the merged pass switches coalescing off and re-runs the group pass by pass"""
+    from dexbotic_amd.trainer import NativeTrainer
+
+    class Store:
+        device = torch.device("cpu")
+        _accum_stash = {}
+
+        def flush_wgrads(self):
+            pass
+    calls = []
+
+    def mk(fail_merged=False):
+        tr = NativeTrainer.__new__(NativeTrainer)
+        tr.coalesce, tr.grad_accum, tr._held, tr.coalesced_steps, tr.store = True, 2, [], 0, Store()
+
+        def _micro(batch, loss_scale=None, group=None):
+            if fail_merged and group is not None:
+                raise torch.OutOfMemoryError("merged pass does not fit")
+            calls.append((batch["input_ids"].shape[0], loss_scale, group))
+            return torch.tensor(float(batch["input_ids"].shape[0]))
+        tr._micro = _micro
+        return tr
+    b = lambda n, **extra: dict(input_ids=torch.zeros(n, 4, dtype=torch.long), actions=torch.zeros(n, 2), **extra)
+    tr = mk()
+    assert tr.micro_step(b(8)).item() == 0.0 and not calls
+    out = tr.micro_step(b(8))
+    assert calls == [(16, 1.0, 2)] and out.item() == 32.0 and tr.coalesced_steps == 1 and not tr._held
+    calls.clear()
+    tr.micro_step(b(8), loss_scale=1.0)                                       # HF's summed micro-batch gradients
+    tr.micro_step(b(8), loss_scale=1.0)
+    assert calls == [(16, 2.0, 2)]
+    calls.clear()
+    tr.micro_step(b(8))
+    out = tr.micro_step(b(8, episode=torch.zeros(8)))                         # a key the merge does not know: pass by pass
+    assert calls == [(8, None, None), (8, None, None)] and out.item() == 16.0 and tr.coalesced_steps == 2
+    calls.clear()
+    tr = mk(fail_merged=True)
+    tr.micro_step(b(8))
+    out = tr.micro_step(b(8))
+    assert calls == [(8, None, None), (8, None, None)] and out.item() == 16.0 and tr.coalesce is False
+    calls.clear()
+    tr.micro_step(b(8))                                                       # ... and stays pass by pass
+    assert calls == [(8, None, None)]
+
+
+def test_gemm_profile_stride_samples_every_product_of_a_layer_equally():
+    """bench.py's live roofline times every 5th launch of a layout: with the four products a transformer layer launches per
+    layout (qkv, o, gate_up, down) a stride coprime with 4 visits each of them equally often; ``launches`` counts them all"""
+    from dexbotic_amd import kernels as K
+    key = (0, 1, 1)
+    prof = K.GemmProfile(key, stride=5)
+    timed = [i % 4 for i in range(28 * 4 * 5) if prof.wants(*key)]
+    assert prof.launches(key) == 28 * 4 * 5 and len(timed) == 28 * 4
+    assert [timed.count(r) for r in range(4)] == [28] * 4
+    assert not prof.wants(2, 1, 1) and prof.launches() == 28 * 4 * 5
+    every = K.GemmProfile(key)
+    assert all(every.wants(*key) for _ in range(7)) and every.launches(key) == 7
