@@ -159,6 +159,7 @@ SIGNATURES = {
     "dxa_dit_sample_bf16_workspace": (_sz, [_int, _int, _int]),
     "dxa_dit_sample_bf16_fwd": (_int, [_vp] * 9 + [_int, _int, _int, _int, _f32, _vp, _int, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "dxa_clip_coef": (_int, [_vp, _f32, _vp, _vp, _vp]),
+    "dxa_clip_coef_scaled": (_int, [_vp, _f32, _f32, _vp, _vp, _vp]),
     "dxa_scale": (_int, [_vp, _i64, _f32, _vp]),
     "dxa_scale_dev": (_int, [_vp, _i64, _vp, _vp]),
 }

@@ -205,13 +205,13 @@ __global__ __launch_bounds__(1024) void sum_f32_k(const float* __restrict__ x, i
   }
   if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)red[0] : (float)red[0];
 }
-__global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, float* __restrict__ norm_out,
+__global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, float grad_scale, float* __restrict__ norm_out,
                             float* __restrict__ coef_out) {
-  const float norm = sqrtf(sumsq[0]);
+  const float norm = sqrtf(sumsq[0]) * grad_scale;
   if (norm_out) norm_out[0] = norm;
   if (coef_out) {
     const float c = max_norm / (norm + 1e-6f);
-    coef_out[0] = c < 1.f ? c : 1.f;
+    coef_out[0] = (c < 1.f ? c : 1.f) * grad_scale;
   }
 }
 __global__ __launch_bounds__(256) void scale_k(float* __restrict__ x, int64_t n, float s) {
@@ -275,7 +275,15 @@ extern "C" int dxa_sum_f32(const float* x, int64_t n, float* out, int accumulate
 
 extern "C" int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream) {
   DXA_CHECK_ARG(sumsq, "dxa_clip_coef: null");
-  hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, norm_out, coef_out);
+  hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, 1.f, norm_out, coef_out);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+
+extern "C" int dxa_clip_coef_scaled(const float* sumsq, float max_norm, float grad_scale, float* norm_out, float* coef_out,
+                                    dxa_stream_t stream) {
+  DXA_CHECK_ARG(sumsq && grad_scale > 0.f, "dxa_clip_coef_scaled: null sum / non-positive scale");
+  hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, grad_scale, norm_out, coef_out);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

@@ -315,6 +315,14 @@ class ParamStore:
                 self._uses[nm] = 1
             _wgrad_flush(self, key)
 
+    def drop_pending_wgrads(self) -> None:
+        """forget the weight-gradient products and accumulation pairs of a backward that was ABORTED (out of memory in the
+        middle of a coalesced pass, trainer.NativeTrainer.micro_step): nothing is launched, nothing is allocated — the pass is
+        re-run from begin_step, whose first writes replace whatever the aborted one left in the gradient arenas"""
+        self._wg_stash.clear()
+        self._accum_stash.clear()
+        self.join_wgrad()
+
     def unfired_touched(self) -> List[int]:
         """buckets (highest first = backward order) that received gradient writes this micro-batch but never
         completed their countdown: a frozen / unused slot, or a Function whose backward autograd pruned"""
@@ -694,11 +702,13 @@ class FusedAdamW:
 
     def step(self, lr_scale: float = 1.0, sumsq: Optional[torch.Tensor] = None,
              grads: Optional[torch.Tensor] = None, lrs: Optional[Sequence[float]] = None,
-             wds: Optional[Sequence[float]] = None) -> None:
+             wds: Optional[Sequence[float]] = None, grad_scale: float = 1.0) -> None:
         """``sumsq``: device scalar holding sum(g^2) over the arena if someone already accumulated it (GradNormTracker
         does, bucket by bucket under the backward); otherwise one pass over the gradient arena computes it here.
         ``grads``: arena to read the gradients from (default the fp32 gradient arena; the averaged bf16 communication
-        copy under bf16 data parallelism)."""
+        copy under bf16 data parallelism).  ``grad_scale``: the arena holds gradient / grad_scale (data parallelism with SUM
+        collectives: world x the mean, grad_scale = 1 / world) — the norm is the scaled gradient's and the factor rides in the
+        clip coefficient, so the update is exactly the mean gradient's."""
         from . import kernels as K
         st, c = self.store, self.cfg
         grads = st.grad if grads is None else grads
@@ -710,7 +720,10 @@ class FusedAdamW:
             if sumsq is None:
                 K.sumsq(grads, self.sumsq, self.scratch)
                 sumsq = self.sumsq
-            K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef)
+            K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef, grad_scale=float(grad_scale))
+            clip = self.coef
+        elif grad_scale != 1.0:
+            self.coef.fill_(float(grad_scale))
             clip = self.coef
         if lrs is None or wds is None:
             d_lrs, d_wds = self._lrs_wds(lr_scale)
@@ -743,6 +756,19 @@ class FusedAdamW:
         """m / v were written from outside (an optimizer state dict was loaded): no chunk may be assumed to hold zero moments"""
         if self.chunk_state is not None:
             self.chunk_state.zero_()
+
+    def load_moments(self, m: torch.Tensor, v: torch.Tensor, step: int) -> None:
+        """THE way to write the moment arenas from outside (resume, tests copying a state in): the sparse-table skip of
+        ``adamw_k`` (chunk_state == 1: "this embedding chunk never saw a non-zero gradient, so m = v = 0") is an invariant of
+        moments this object produced itself — every external write resets it.  ``m`` / ``v`` may be the arenas themselves
+        (state dict round trip in place)."""
+        self.store.wait_pending()
+        if m.data_ptr() != self.m.data_ptr():
+            self.m.copy_(m)
+        if v.data_ptr() != self.v.data_ptr():
+            self.v.copy_(v)
+        self.step_count = int(step)
+        self.moments_replaced()
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:
@@ -877,9 +903,18 @@ class GradReducer:
 
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
                  skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32,
-                 algo: str = "rs_ag", local_only: bool = False, native_avg_world1: bool = False):
+                 algo: str = "rs_ag", local_only: bool = False, native_avg_world1: bool = False,
+                 reduce_op: str = "sum"):
         import torch.distributed as dist
         self.dist = dist
+        # reduce_op = "sum" (default since round 5): the collectives ADD the ranks' gradients and the 1 / world of the mean is
+        # folded into the clip coefficient AdamW multiplies every gradient by anyway (``grad_scale``; FusedAdamW.step,
+        # dxa_clip_coef_scaled): the arena then holds world x the mean gradient, the reported norm and the update are the
+        # mean's.  RCCL's AVG is a pre-multiply inside the reduction kernel; next to the backward's GEMM grids the AVG sequence
+        # measured 274 ms per step against 252 for SUM on one MI355X (profiles/r04_reducer_contention.json).  "avg": the
+        # collectives average (native AVG on RCCL, SUM + divide on gloo) and the arena holds the mean.
+        assert reduce_op in ("sum", "avg")
+        self.reduce_op = reduce_op
         self.force = force or local_only   # run the bucket pipeline even at world size 1 (exercises the RCCL path)
         # local_only: no process group at all — the per-bucket pipeline (bf16 copy of the slots no epilogue wrote, sum of squares
         # on the side stream) without any collective: the single-GPU bf16-gradient step
@@ -900,6 +935,12 @@ class GradReducer:
         init = dist.is_available() and dist.is_initialized() and not local_only
         self.world = dist.get_world_size(group) if init else 1
         self.rank = dist.get_rank(group) if init else 0
+        self.backend = str(dist.get_backend(group)) if init else "none"
+        # what the optimizer multiplies the exchanged gradients by (1.0: the arena already holds the mean)
+        self.grad_scale = 1.0 / self.world if (reduce_op == "sum" and self.world > 1) else 1.0
+        # a backend without device collectives (gloo: the 2-rank MODEL step on one MI355X, tests/test_dp2_gpu.py) gets the
+        # slices through pinned host memory; RCCL ("nccl") takes the device pointers
+        self.stage_host = store.device.type == "cuda" and self.backend != "nccl"
         self.min_bucket_bytes = min_bucket_bytes
         self.skip_buckets = set()
         self.comm_stream = torch.cuda.Stream(device=store.device) if store.device.type == "cuda" else None
@@ -959,12 +1000,39 @@ class GradReducer:
             st.gradc[lo:hi].copy_(st.grad[lo:hi])
 
     # ---- the exchange ------------------------------------------------------------------------------------------------
+    def _all_reduce(self, t: torch.Tensor, op) -> None:
+        if self.stage_host:
+            h = t.to("cpu")                                     # (synchronises the communication stream: test path only)
+            self.dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h, non_blocking=False)
+        else:
+            self.dist.all_reduce(t, op=op, group=self.group)
+
+    def _reduce_scatter(self, shard: torch.Tensor, body: torch.Tensor, op) -> None:
+        if self.stage_host:
+            hb = body.to("cpu")
+            hs = torch.empty(shard.shape, dtype=shard.dtype)
+            self.dist.reduce_scatter_tensor(hs, hb, op=op, group=self.group)
+            shard.copy_(hs, non_blocking=False)
+        else:
+            self.dist.reduce_scatter_tensor(shard, body, op=op, group=self.group)
+
+    def _all_gather(self, body: torch.Tensor, shard: torch.Tensor) -> None:
+        if self.stage_host:
+            hb = torch.empty(body.shape, dtype=body.dtype)
+            self.dist.all_gather_into_tensor(hb, shard.to("cpu"), group=self.group)
+            body.copy_(hb, non_blocking=False)
+        else:
+            self.dist.all_gather_into_tensor(body, shard, group=self.group)
+
     def _avg(self, t: torch.Tensor, native_avg: bool) -> None:
         d = self.dist
-        if native_avg:
-            d.all_reduce(t, op=d.ReduceOp.AVG, group=self.group)
+        if self.reduce_op == "sum":
+            self._all_reduce(t, d.ReduceOp.SUM)
+        elif native_avg:
+            self._all_reduce(t, d.ReduceOp.AVG)
         else:                                                    # gloo has no AVG
-            d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
+            self._all_reduce(t, d.ReduceOp.SUM)
             t.copy_((t.float() / self.world).to(t.dtype))
 
     def _exchange(self, buf: torch.Tensor) -> None:
@@ -974,7 +1042,7 @@ class GradReducer:
         # AVG is native on RCCL.  With ONE rank (force=True: the path is exercised on a single GPU) the mean is the
         # identity and SUM is asked for instead: RCCL's one-rank AVG runs a separate pre-multiply pass over the whole
         # buffer (oneRankReduce<FuncPreMulSum>, 43 ms per step for the 30 GB arena) that no multi-rank ring contains
-        native_avg = buf.is_cuda and (w > 1 or self.native_avg_world1)
+        native_avg = buf.is_cuda and self.backend == "nccl" and (w > 1 or self.native_avg_world1)
         if w == 1 and not self.native_avg_world1:
             if self.algo == "allreduce":
                 d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group)
@@ -994,12 +1062,14 @@ class GradReducer:
             return
         body = per * w
         shard = buf[self.rank * per:(self.rank + 1) * per]
-        if native_avg:
-            d.reduce_scatter_tensor(shard, buf[:body], op=d.ReduceOp.AVG, group=self.group)
+        if self.reduce_op == "sum" and w > 1:
+            self._reduce_scatter(shard, buf[:body], d.ReduceOp.SUM)
+        elif native_avg:
+            self._reduce_scatter(shard, buf[:body], d.ReduceOp.AVG)
         else:
-            d.reduce_scatter_tensor(shard, buf[:body], op=d.ReduceOp.SUM, group=self.group)
+            self._reduce_scatter(shard, buf[:body], d.ReduceOp.SUM)
             shard.copy_((shard.float() / w).to(shard.dtype))
-        d.all_gather_into_tensor(buf[:body], shard, group=self.group)
+        self._all_gather(buf[:body], shard)
         self.collectives += 2
         if body < n:
             self._avg(buf[body:], native_avg)
@@ -1032,6 +1102,13 @@ class GradReducer:
             self._exchange(buf)
             if self.after_reduce is not None:
                 self.after_reduce(lo, hi, None)
+
+    def reset(self) -> None:
+        """forget the slice an aborted backward left pending (single-rank out-of-memory fallback; under data parallelism an
+        aborted backward is not recoverable: collectives may already be in flight)"""
+        assert self.world == 1, "GradReducer.reset() with peers"
+        self._pending_lo = self._pending_hi = None
+        self._t0 = None
 
     def bucket_ready(self, b: int) -> None:
         if b in self.skip_buckets:

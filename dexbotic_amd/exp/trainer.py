@@ -51,9 +51,18 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.core = core
         assert len(self.param_groups) == len(core.opt.group_keys), "core was built from other parameter groups"
 
-    @torch.no_grad()
     def step(self, closure=None):
         assert closure is None, "ArenaAdamW takes no closure"
+        core = self.core
+        if not core.update_due and (core._held or core.micro % core.grad_accum != 0):
+            # HF closed a SHORT accumulation group (last batches of an epoch whose length does not divide by
+            # gradient_accumulation_steps) without telling training_step its size — transformers 4.51, which the reference
+            # pins, has no Trainer.current_gradient_accumulation_steps: whatever is held or half-accumulated IS the group
+            core.close_short_group()
+        with torch.no_grad():
+            self._apply()
+
+    def _apply(self):
         self.core.apply_update(lrs=[float(g["lr"]) for g in self.param_groups],
                                wds=[float(g["weight_decay"]) for g in self.param_groups])
 
@@ -71,11 +80,8 @@ class ArenaAdamW(torch.optim.Optimizer):
         arena = state_dict.get("arena")
         super().load_state_dict({k: v for k, v in state_dict.items() if k != "arena"})
         if arena is not None:
-            if arena["m"].data_ptr() != self.core.opt.m.data_ptr():          # (accelerate round-trips the state dict in place)
-                self.core.opt.m.copy_(arena["m"])
-                self.core.opt.v.copy_(arena["v"])
-            self.core.opt.step_count = int(arena["step"])
-            self.core.opt.moments_replaced()
+            # (accelerate round-trips the state dict in place: load_moments skips the copy then, and resets the sparse-table state)
+            self.core.opt.load_moments(arena["m"], arena["v"], int(arena["step"]))
 
 
 def link_exp_config(exp_config, **overrides) -> TrainingArguments:
@@ -245,10 +251,13 @@ class NativeDexboticTrainer(Trainer):
                 weights = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items() if "mm_projector" in k}
                 torch.save(weights, os.path.join(output_dir, "mm_projector.bin"))
             return
-        try:
-            super()._save_checkpoint(model, trial)
-        except TypeError:
+        # transformers 4.x: _save_checkpoint(model, trial, metrics=None); 5.x dropped ``metrics`` — picked from the signature, not
+        # by catching TypeError around the whole save (that would re-run a half-written save and hide the real error)
+        import inspect
+        if "metrics" in inspect.signature(Trainer._save_checkpoint).parameters:
             super()._save_checkpoint(model, trial, metrics)
+        else:
+            super()._save_checkpoint(model, trial)
         if main:
             self._copy_norm_stats_to_checkpoint(output_dir)
 

@@ -789,8 +789,12 @@ def gemm_sumsq_slots(M: int, N: int) -> int:
     return int(lib.dxa_gemm_sumsq_slots(M, N))
 
 
-def clip_coef(sumsq_t, max_norm: float, norm_out, coef_out):
-    L.check(lib.dxa_clip_coef(_ptr(sumsq_t), max_norm, _ptr(norm_out), _ptr(coef_out), _stream()), "dxa_clip_coef")
+def clip_coef(sumsq_t, max_norm: float, norm_out, coef_out, grad_scale: float = 1.0):
+    if grad_scale == 1.0:
+        L.check(lib.dxa_clip_coef(_ptr(sumsq_t), max_norm, _ptr(norm_out), _ptr(coef_out), _stream()), "dxa_clip_coef")
+    else:
+        L.check(lib.dxa_clip_coef_scaled(_ptr(sumsq_t), max_norm, grad_scale, _ptr(norm_out), _ptr(coef_out), _stream()),
+                "dxa_clip_coef_scaled")
 
 
 def scale_(x: torch.Tensor, s: float) -> torch.Tensor:

@@ -47,6 +47,10 @@ def coalesce_batches(batches: List[Dict[str, torch.Tensor]]) -> Optional[Dict[st
             return None
         if k in _PAD and vs[0].dim() == 2:
             S = max(v.shape[1] for v in vs)
+            if "attention_mask" not in keys and any(v.shape[1] != S for v in vs):
+                # no mask (= every position valid, splice.py): padding a shorter micro-batch would turn pad ids into real
+                # tokens of its samples — such a group runs pass by pass
+                return None
             vs = [v if v.shape[1] == S else torch.nn.functional.pad(v, (0, S - v.shape[1]), value=_PAD[k]) for v in vs]
         if any(v.shape[1:] != vs[0].shape[1:] for v in vs):
             return None
@@ -65,7 +69,7 @@ class NativeTrainer:
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
                  force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag",
                  grad_dtype: torch.dtype = torch.float32, overlap_optimizer: bool = False, optimizer_groups=None,
-                 native_avg_world1: bool = False, coalesce_micro_batches: Optional[bool] = None):
+                 native_avg_world1: bool = False, coalesce_micro_batches: Optional[bool] = None, grad_reduce_op: str = "sum"):
         import torch.distributed as dist
         self.model = model
         # coalesce_micro_batches: the ``grad_accum`` micro-batches of an optimizer step run as ONE forward / backward over their
@@ -107,7 +111,8 @@ class NativeTrainer:
             # native_avg_world1: at world size 1 take the exact collective sequence of N > 1 (bench.py --native-avg: RCCL kernels
             # sharing the GPU with the backward's GEMM grids — the contention measurement of DESIGN.md section 6)
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
-                                       comm_dtype=grad_comm_dtype, algo=grad_sync, native_avg_world1=native_avg_world1)
+                                       comm_dtype=grad_comm_dtype, algo=grad_sync, native_avg_world1=native_avg_world1,
+                                       reduce_op=grad_reduce_op)
         elif bf16_grads:
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, comm_dtype=torch.bfloat16,
                                        local_only=True)
@@ -157,6 +162,56 @@ class NativeTrainer:
         local = self.reducer is None or self.reducer.local_only
         self.store.epi_sumsq = local and self.norm_tracker is not None
 
+    def close_short_group(self) -> None:
+        """An optimizer step is wanted although the accumulation group is not full: HF closes a SHORT group at the end of an
+        epoch whose length does not divide by gradient_accumulation_steps (Trainer._inner_training_loop) and calls
+        ``optimizer.step()``.  transformers 5.x announces the group's size (``current_gradient_accumulation_steps``, followed by
+        exp/trainer.NativeDexboticTrainer.training_step); 4.51 — the version the reference pins — does not, so the optimizer
+        facade lands here.  What was handed over so far IS the group; every micro-batch keeps the scale it was given (default
+        1 / grad_accum of the NOMINAL size, as HF 4.51 scales it), and the data-parallel exchange / the sum of squares that the
+        last micro-batch of a full group brings to completion are brought to completion now.  The losses of held micro-batches
+        were already reported as 0 to the caller and stay unreported."""
+        assert not self.update_due
+        nominal = self.grad_accum
+        if self._held:                                    # coalescing: nothing has run yet
+            held, self._held = self._held, []
+            n = len(held)
+            scales = [float(sc) if sc is not None else 1.0 / nominal for _, sc in held]
+            self.grad_accum, self.micro = n, 0
+            try:
+                merged = coalesce_batches([b for b, _ in held]) if len(set(scales)) == 1 else None
+                if merged is not None:
+                    self._micro(merged, scales[0] * n, group=n)
+                else:
+                    for (b, _), sc in zip(held, scales):
+                        self._micro(b, sc)
+            finally:
+                self.grad_accum, self.micro = nominal, 0
+            return
+        k = self.micro % nominal
+        assert k > 0, "close_short_group() with nothing accumulated"
+        st = self.store
+        if st._accum_stash:
+            from .functional import flush_accum
+            st.last_micro = True
+            flush_accum(st)                               # (dY, X) pairs held for a second micro-batch that never came
+        st.join_wgrad()
+        if not self._zeroed_unused:
+            for nm in st.never_written():
+                st.g(nm).zero_()
+            self._zeroed_unused = True
+        reducing = self.reducer is not None and (self.reducer.world > 1 or self.reducer.force)
+        if reducing:
+            st._mirrored = set()                          # bf16 exchange: cast every written slot (no epilogue mirrored the sum)
+            st._bucket_fired = [True] * len(st.bucket_ranges)
+            for b in reversed(range(len(st.bucket_ranges))):
+                self.reducer.bucket_ready(b)
+            self.reducer.finish()
+        self._sumsq = None                                # FusedAdamW.step takes the norm in one pass over the arena
+        self._reducing = reducing
+        self.update_due = True
+        self.micro = 0
+
     def synchronize(self) -> None:
         """make the current stream wait for an overlapped optimizer update still in flight"""
         self.store.wait_pending()
@@ -193,16 +248,28 @@ class NativeTrainer:
         merged = coalesce_batches([b for b, _ in held]) if len(scales) == 1 else None
         if merged is not None:
             sc = held[0][1]
+            if self.reducer is not None and self.reducer.world > 1:
+                # data parallel: no out-of-memory fallback — the aborted backward of ONE rank may already have fired bucket
+                # collectives its peers are waiting in, and the ranks would disagree on ``coalesce`` afterwards
+                loss = self._micro(merged, 1.0 if sc is None else float(sc) * n, group=n)
+                self.coalesced_steps += 1
+                return loss * n
             try:
                 loss = self._micro(merged, 1.0 if sc is None else float(sc) * n, group=n)
                 self.coalesced_steps += 1
                 return loss * n
             except torch.OutOfMemoryError:
                 # the merged pass does not fit: this and every later group runs micro-batch by micro-batch (begin_step of the
-                # first one starts the gradient arenas afresh: every slot's first write replaces)
+                # first one starts the gradient arenas afresh: every slot's first write replaces).  The pending dW products and
+                # accumulation pairs of the aborted backward are DROPPED, not run: their operands belong to a graph that is
+                # being torn down, and running them would allocate while the failed pass still holds its memory
                 self.coalesce = False
-                self.store.flush_wgrads()
-                self.store._accum_stash.clear()
+                self.store.drop_pending_wgrads()
+                self.last_output = None
+                if self.reducer is not None:
+                    self.reducer.reset()
+                if self.norm_tracker is not None:
+                    self.norm_tracker.begin()
                 torch.cuda.empty_cache()
         total = None
         for b, sc in held:
@@ -267,6 +334,7 @@ class NativeTrainer:
         assert self.update_due, "apply_update() before the last micro-batch of the step"
         # under bf16 data parallelism the averaged gradients live in the bf16 communication copy
         self.opt.step(self.lr_scale() if lr_scale is None else lr_scale, sumsq=self._sumsq,
-                      grads=self.reducer.result_arena if self._reducing else None, lrs=lrs, wds=wds)
+                      grads=self.reducer.result_arena if self._reducing else None, lrs=lrs, wds=wds,
+                      grad_scale=self.reducer.grad_scale if self._reducing else 1.0)
         self.update_due = False
         self.global_step += 1

@@ -357,6 +357,12 @@ int dxa_sumsq_ranges(const void* base, int dtype, const int64_t* starts, const i
 int dxa_sum_f32(const float* x, int64_t n, float* out, int accumulate, dxa_stream_t stream);
 /* norm = sqrt(sumsq); coef = min(1, max_norm/(norm+1e-6))  (torch.nn.utils.clip_grad_norm_) */
 int dxa_clip_coef(const float* sumsq, float max_norm, float* norm_out, float* coef_out, dxa_stream_t stream);
+/* the same for an arena that holds gradient / grad_scale (data parallelism with SUM collectives leaves world x the mean,
+ * grad_scale = 1 / world; replaces DDP's gradient mean + clip_grad_norm_, dexbotic/exp/trainer.py:110,121-122):
+ * norm = grad_scale * sqrt(sumsq); coef = grad_scale * min(1, max_norm/(norm+1e-6)) — dxa_adamw multiplies every
+ * gradient by coef, so the update is the mean gradient's */
+int dxa_clip_coef_scaled(const float* sumsq, float max_norm, float grad_scale, float* norm_out, float* coef_out,
+                         dxa_stream_t stream);
 int dxa_scale(float* x, int64_t n, float s, dxa_stream_t stream);
 /* x *= s[0] with s a DEVICE scalar (upstream loss gradient; no host sync) */
 int dxa_scale_dev(float* x, int64_t n, const float* s, dxa_stream_t stream);

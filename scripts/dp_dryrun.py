@@ -55,7 +55,7 @@ def main():
         arena = red.result_arena
         for n in names:
             s = st.slots[n]
-            got = arena[s.offset:s.offset + s.numel].float().view(s.shape)
+            got = arena[s.offset:s.offset + s.numel].float().view(s.shape) * red.grad_scale   # SUM exchange: 1 / world rides in the clip coefficient
             mean = sum((g[n].to(comm).float() if comm == torch.bfloat16 else g[n]) for g in gathered) / world
             # bf16 exchange: every partial sum of the ring is rounded to bf16 (2^-9 of the running sum per step)
             ok_n = bool(torch.allclose(got, mean, rtol=2e-2, atol=4e-2)) if comm == torch.bfloat16 else \

@@ -48,8 +48,13 @@ def _worker(rank, world, port, tmp):
         gathered = [None] * world
         # --- plain step: backward walks the buckets in reverse, marks slots written.  Both exchange algorithms:
         #     reduce-scatter + all-gather (odd slice lengths: divisible prefix + all-reduced tail) and one all-reduce
-        for algo, min_bytes in (("rs_ag", 64), ("rs_ag", 1 << 20), ("allreduce", 64)):
-            red = GradReducer(st, min_bucket_bytes=min_bytes, skip=["unused.w"], algo=algo)
+        for algo, min_bytes, op in (("rs_ag", 64, "sum"), ("rs_ag", 1 << 20, "sum"), ("allreduce", 64, "sum"),
+                                    ("rs_ag", 64, "avg"), ("allreduce", 64, "avg")):
+            # reduce_op "sum" (the default): the arena ends up holding world x the mean and grad_scale = 1 / world is what the
+            # optimizer multiplies by; "avg": the arena holds the mean itself
+            red = GradReducer(st, min_bucket_bytes=min_bytes, skip=["unused.w"], algo=algo, reduce_op=op)
+            assert red.grad_scale == (1.0 / world if op == "sum" else 1.0)
+            assert GradReducer(st, skip=["unused.w"]).reduce_op == "sum"       # the default exchange
             st.begin_step()
             st.on_bucket_ready = red.bucket_ready
             local = {}
@@ -63,12 +68,13 @@ def _worker(rank, world, port, tmp):
             dist.all_gather_object(gathered, local)
             for n in names:
                 mean = sum(g[n] for g in gathered) / world
-                assert torch.allclose(st.g(n), mean, atol=1e-6), (algo, n)
+                assert torch.allclose(st.g(n) * red.grad_scale, mean, atol=1e-6), (algo, op, n)
             assert torch.all(st.g("unused.w") == float(rank + 1))
             assert red.bytes_reduced >= sum(st.slots[n].numel for n in names) * 4   # alignment padding may ride along
             if algo == "rs_ag" and min_bytes == 64:
                 assert red.collectives == 3 * 5, red.collectives   # per bucket: RS + AG on 40 elements, AR on the 41st
         red = GradReducer(st, min_bucket_bytes=64, skip=["unused.w"])
+        sc = red.grad_scale
         # --- gradient accumulation: 2 micro-batches, communication only on the last
         st.begin_step()
         red.bytes_reduced = 0
@@ -91,7 +97,7 @@ def _worker(rank, world, port, tmp):
         dist.all_gather_object(gathered, acc)
         for n in names:
             mean = sum(g[n] for g in gathered) / world
-            assert torch.allclose(st.g(n), mean, atol=1e-6), n
+            assert torch.allclose(st.g(n) * sc, mean, atol=1e-6), n
         # --- a bucket with a frozen slot still gets reduced by finish()
         st.params["blk2.b"].requires_grad_(False)
         st.set_expected(["unused.w"])
@@ -103,7 +109,7 @@ def _worker(rank, world, port, tmp):
             st.g(n).fill_(float(rank))
             st.mark_written(n)
         red.finish()
-        assert torch.allclose(st.g("blk2.w"), torch.full((7, 5), (world - 1) / 2.0))
+        assert torch.allclose(st.g("blk2.w") * sc, torch.full((7, 5), (world - 1) / 2.0))
         # --- bf16 gradient communication (what the reference's DeepSpeed bf16 run reduces): half the bytes; what is
         #     exchanged is the bf16 copy of the arena (ParamStore.gradc), the averaged result stays there (AdamW reads it)
         #     and the local fp32 gradients are left alone.  One slot plays a GEMM epilogue that mirrored its own output.
@@ -127,7 +133,7 @@ def _worker(rank, world, port, tmp):
         dist.all_gather_object(gathered, local)
         for n in names:
             mean = (sum(g[n] for g in gathered)).to(torch.bfloat16).float() / world
-            assert torch.allclose(st.gc(n).float(), mean, rtol=1e-2, atol=1e-6), n
+            assert torch.allclose(st.gc(n).float() * red16.grad_scale, mean, rtol=1e-2, atol=1e-6), n
             assert torch.equal(st.g(n), local32[n]), n
         assert red16.bytes_reduced >= sum(st.slots[n].numel for n in names) * 2     # 2 bytes per element sent
         # --- a parameter applied 3x in one forward (MemVLA's per-sample retrieval blocks): its bucket must be
@@ -158,7 +164,7 @@ def _worker(rank, world, port, tmp):
         dist.all_gather_object(gathered, final)
         for n in names:
             mean = sum(g[n] for g in gathered) / world
-            assert torch.allclose(st.g(n), mean, atol=1e-6), n
+            assert torch.allclose(st.g(n) * red3.grad_scale, mean, atol=1e-6), n
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

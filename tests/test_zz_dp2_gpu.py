@@ -1,0 +1,160 @@
+"""A TWO-RANK model step on ONE MI355X (round 5, verdict item 3): the whole data-parallel path — rank-sharded episodes -> real
+backward firing ``bucket_ready`` -> engine.GradReducer exchange -> sum of squares over the exchanged slices -> clip coefficient
+with 1 / world folded in -> fused AdamW — executed by two processes that share ``cuda:0``.
+
+RCCL refuses two ranks on one device, so the process group is ``gloo`` and the reducer stages each slice through host memory
+(GradReducer.stage_host: any backend but "nccl" with a device arena); everything else — bucket order, skip set, the SUM
+exchange, the Σg² fold on the communication stream, the scaled clip coefficient, AdamW — is the code an 8-GPU RCCL run takes.
+Checked after three optimizer steps, against ONE process running the concatenated batch (reference behaviour: DDP's gradient
+mean followed by clip_grad_norm_(1.0) and AdamW, dexbotic/exp/trainer.py:110,121-122): per-step loss (mean over ranks), the
+clipped norm, every parameter; parameters that never receive a gradient (lm_head, the unused last CLIP layer) are not
+communicated; two accumulation micro-batches exchange once.  fp32 compute, fp32 exchange: the only difference between the two
+runs is the order of fp32 sums over the batch rows."""
+import datetime
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+STEPS = 3
+B, ST = 4, 12
+SEED = 31
+VARIANTS = (("allreduce", 1, "sum"), ("rs_ag", 1, "sum"), ("allreduce", 2, "sum"), ("rs_ag", 1, "avg"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _episodes():
+    """B episodes at the toy widths (tests/helpers.CFGS["t1"]); draws indexed r * B + b like the reference's repeat(4)"""
+    from tests.helpers import CFGS
+    cfg = CFGS["t1"]
+    rs = np.random.RandomState(SEED)
+    ids = rs.randint(10, 500, size=(B, ST)).astype(np.int64)
+    ids[:, 1] = -200
+    mask = np.ones((B, ST), dtype=bool)
+    mask[1, 9:] = False                                     # ragged: one right-padded episode per rank shard
+    mask[2, 7:] = False
+    images = np.clip(rs.standard_normal((B, 3, cfg.v_image, cfg.v_image)), -2.5, 2.5).astype(np.float32)
+    actions = rs.uniform(-1, 1, size=(B, cfg.chunk_size * cfg.action_dim)).astype(np.float32)
+    noise = rs.standard_normal((4 * B, cfg.chunk_size, cfg.action_dim)).astype(np.float32)
+    ts = rs.randint(0, 100, size=(4 * B,)).astype(np.int64)
+    drop = rs.uniform(size=(4 * B,)) < 0.15
+    return dict(input_ids=ids, attention_mask=mask, images=images, actions=actions, noise=noise, timesteps=ts, drop_ids=drop)
+
+
+def _shard(x, episodes):
+    """the batch dict of a subset of episodes (rows) with its share of the injected draws"""
+    e = np.asarray(episodes)
+    draw = np.concatenate([r * B + e for r in range(4)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+    out = {k: t(x[k][e]) for k in ("input_ids", "attention_mask", "images", "actions")}
+    out["labels"] = out["input_ids"]
+    out.update({k: t(x[k][draw]) for k in ("noise", "timesteps", "drop_ids")})
+    return out
+
+
+def _build(grad_accum=1, **kw):
+    from dexbotic_amd.engine import OptimConfig
+    from dexbotic_amd.trainer import NativeTrainer
+    from oracle.weights import cogact_shapes, make_weights
+    from tests.helpers import CFGS, build_product
+    cfg = CFGS["t1"]
+    m = build_product(cfg, make_weights(cogact_shapes(cfg), SEED), "float32", "cuda", train=True)
+    m.train()
+    tr = NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=0.01, max_grad_norm=1.0), min_bucket_bytes=1 << 14,
+                       grad_accum=grad_accum, **kw)
+    return m, tr
+
+
+def _worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                                 # BOTH ranks on the one GPU of the box
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        x = _episodes()
+        for vi, (algo, accum, op) in enumerate(VARIANTS):
+            m, tr = _build(grad_accum=accum, distributed=True, grad_sync=algo, grad_reduce_op=op)
+            red = tr.reducer
+            assert red is not None and red.world == 2 and red.stage_host and red.reduce_op == op
+            assert red.grad_scale == (0.5 if op == "sum" else 1.0)
+            mine = list(range(rank, B, world))               # episodes rank::2
+            losses, norms, coll = [], [], []
+            for _ in range(STEPS):
+                c0 = red.collectives
+                if accum == 1:
+                    loss = tr.step(_shard(x, mine))
+                else:                                        # one episode per micro-batch, exchange on the last only
+                    loss = sum(tr.step(_shard(x, [e])) for e in mine) / accum
+                losses.append(float(loss))
+                norms.append(float(tr.opt.norm.item()))
+                coll.append(red.collectives - c0)
+            torch.cuda.synchronize()
+            st = m.store
+            # never communicated: buckets all of whose slots the path does not write (lm_head, the unused last CLIP layer)
+            unused = set(m.unused_parameter_names())
+            assert unused and red.skip_buckets
+            for nm in unused:
+                assert float(st.g(nm).abs().max()) == 0.0, nm
+            assert any(st.slots[nm].bucket in red.skip_buckets for nm in unused)
+            sent = sum(hi - lo for b, (lo, hi) in enumerate(st.bucket_ranges) if b not in red.skip_buckets)
+            assert red.bytes_reduced <= STEPS * sent * 4 and red.bytes_reduced > 0
+            np.savez(os.path.join(tmp, f"v{vi}_rank{rank}.npz"), losses=np.asarray(losses), norms=np.asarray(norms),
+                     coll=np.asarray(coll), master=st.master.detach().cpu().numpy())
+            del m, tr
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_model_step_equals_single_process_on_the_concatenated_batch(tmp_path):
+    import torch.multiprocessing as mp
+    # ---- ONE process, all four episodes in one batch
+    x = _episodes()
+    m, tr = _build()
+    assert tr.reducer is None
+    ref_losses, ref_norms = [], []
+    for _ in range(STEPS):
+        ref_losses.append(float(tr.step(_shard(x, list(range(B))))))
+        ref_norms.append(float(tr.opt.norm.item()))
+    torch.cuda.synchronize()
+    ref_master = m.store.master.detach().cpu().numpy()
+    names = {s.name: (s.offset, s.numel) for s in m.store.slots.values()}
+    del m, tr
+    torch.cuda.empty_cache()
+    # ---- TWO processes on the same GPU, two episodes each
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+    for vi, (algo, accum, op) in enumerate(VARIANTS):
+        r = [np.load(tmp_path / f"v{vi}_rank{k}.npz") for k in range(2)]
+        tag = f"{algo}/accum{accum}/{op}"
+        # both ranks hold the same parameters, bit for bit (same exchanged gradients, same update)
+        assert np.array_equal(r[0]["master"], r[1]["master"]), tag
+        assert np.array_equal(r[0]["norms"], r[1]["norms"]), tag
+        loss = (r[0]["losses"] + r[1]["losses"]) / 2
+        dl = np.abs(loss - ref_losses).max() / np.abs(ref_losses).max()
+        dn = np.abs(r[0]["norms"] - ref_norms).max() / np.abs(ref_norms).max()
+        dp = np.abs(r[0]["master"] - ref_master)
+        worst = max(names, key=lambda n: dp[names[n][0]:names[n][0] + names[n][1]].max())
+        print(f"{tag}: loss {dl:.2e}  clipped norm {dn:.2e}  parameters max abs {dp.max():.2e} ({worst})  "
+              f"collectives per step {r[0]['coll'].tolist()}")
+        assert dl < 2e-5 and dn < 2e-5, (tag, dl, dn)
+        # parameters: three AdamW steps of lr 1e-3; a gradient that is mathematically zero (k_proj biases: softmax shift
+        # invariance) is rounding noise of either sign and moves its parameter by up to lr per step in EITHER run
+        torch.testing.assert_close(torch.from_numpy(r[0]["master"]), torch.from_numpy(ref_master), rtol=1e-4, atol=2e-4)
+        loose = dp > 2e-5
+        assert loose.mean() < 2e-3, (tag, float(loose.mean()))
+        assert len(set(r[0]["coll"].tolist())) == 1, tag        # the same number of collectives every step
+    # accumulation: two micro-batches per optimizer step exchange ONCE — as many collectives as the one-pass step
+    c = {v: np.load(tmp_path / f"v{vi}_rank0.npz")["coll"][0] for vi, v in enumerate(VARIANTS)}
+    assert c[("allreduce", 2, "sum")] == c[("allreduce", 1, "sum")]
