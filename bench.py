@@ -255,10 +255,46 @@ def cpu_baseline(args, cfg_llm, cfg_vis):
                        f"({per_layer:.2f} s per decoder layer)")}
 
 
+def process_frame_latency(model, n_req: int = 50, views: int = 2) -> dict:
+    """the wire format of BASELINE.json configs[0] / [1] (dexbotic/client.py:33-61 -> POST /process_frame,
+    dexbotic/exp/base_exp.py:638-653, cogact_exp.py:146-177) through the Flask test client: multipart PNG frames + text ->
+    PNG decode on the host -> pad / resize / crop / normalise on the device -> prompt -> inference_action -> JSON."""
+    import io
+    import types
+    from dexbotic_amd.serve import InferenceServer, encode_png
+    vocab = int(model.config.llm_config.vocab_size)
+
+    class WordHashTokenizer:                       # no tokenizer files offline: one id per word (what travels is the id COUNT)
+        bos_token_id = None
+
+        def __call__(self, text):
+            return types.SimpleNamespace(input_ids=[3 + (sum(map(ord, wd)) % (vocab - 3)) for wd in text.split()])
+
+    srv = InferenceServer(model, WordHashTokenizer(), norm_stats={"min": [-1.0] * 7, "max": [1.0] * 7})
+    client = srv.create_app().test_client()
+    rs = np.random.RandomState(5)
+    pngs = [encode_png(rs.randint(0, 256, (256, 256, 3)).astype(np.uint8)) for _ in range(8)]      # libero frames are 256 x 256
+    texts = ["pick up the black bowl and place it on the plate", "open the top drawer and put the bowl inside",
+             "turn on the stove and put the moka pot on it", "put the wine bottle on top of the cabinet"]
+    lat = []
+    for i in range(5 + n_req):
+        data = {"text": texts[i % len(texts)],
+                "image": [(io.BytesIO(pngs[(i + v) % len(pngs)]), f"{v}.png") for v in range(views)]}
+        t0 = time.perf_counter()
+        r = client.post("/process_frame", content_type="multipart/form-data", data=data)
+        lat.append(1e3 * (time.perf_counter() - t0))
+        assert r.status_code == 200 and len(r.get_json()["response"]) == 16
+    lat = np.asarray(lat[5:])
+    srv.model = None                                   # (the Flask app's closures keep the server alive: let go of the 169 GB)
+    return {"n_requests": n_req, "views": views, "frame": "256x256 PNG", "p50_ms": round(float(np.median(lat)), 2),
+            "p90_ms": round(float(np.percentile(lat, 90)), 2)}
+
+
 def secondary_workloads(timeout_s: float = 150.0) -> dict:
     import subprocess
     out = {}
-    for key, script, argv in (("db_pi0_finetune", "pi0_bench.py", ["3", "16"]), ("memvla_finetune", "memvla_bench.py", ["3", "16"])):
+    for key, script, argv in (("db_pi0_finetune", "pi0_bench.py", ["3", "16"]), ("memvla_finetune", "memvla_bench.py", ["3", "16"]),
+                              ("discrete_decode", "decode_bench.py", ["32", "--json"])):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + argv, capture_output=True, text=True,
                                timeout=timeout_s)
@@ -481,10 +517,12 @@ def main():
         # HBM bytes per launch of that kernel come from the committed rocprofv3 PMC passes over this same command
         # (separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, checked on a known byte count)
         traffic = None
-        pmc_path = next((pth for pth in (os.path.join(ROOT, "profiles", f"r0{r}_pmc.json") for r in (4, 3, 2)) if os.path.exists(pth)), None)
+        pmc_path = next((pth for pth in (os.path.join(ROOT, "profiles", f"r0{r}_pmc.json") for r in (5, 4, 3, 2)) if os.path.exists(pth)), None)
+        pmc_commit = None
         if pmc_path and in_dt == L.BF16:
             with open(pmc_path) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                pmc = json.load(f)
+            traffic, pmc_commit = pmc.get("hbm_bytes_per_launch"), pmc.get("collected_on_commit")
         by_layout = {}
         for tag, key in prof_keys.items():
             kn, kms, kfl, kby = prof.summary(key)
@@ -502,6 +540,9 @@ def main():
                                                 "XCD L2s, Infinity-Cache hits included: this is L2-miss (fabric-side) traffic, an upper "
                                                 "bound on HBM bytes, not HBM bytes",
                               "traffic_kind": "l2_miss_bytes_per_launch",
+                              # a committed measurement, not one of THIS run (PMC passes serialise the kernels): the commit whose
+                              # gemm.hip it was collected on is carried so that a later kernel change shows as a mismatch
+                              "traffic_collected_on_commit": pmc_commit,
                               "launches": prof.launches(), "launches_timed": n,
                               "timing": f"HIP events around every {prof.stride}-th launch of each layout, over the whole timed region"
                                         if prof.stride > 1 else "HIP events around every launch of the timed region",
@@ -510,18 +551,29 @@ def main():
                               "algorithmic_bytes_per_launch": int(by / max(n, 1)), "by_layout": by_layout}
         if not args.no_latency and world == 1:
             model.eval()
-            b1 = synthetic_batch(1, 2, args.s_text, device, seed=7)     # BASELINE.json configs[1]: batch 1, 2 views
+            # BASELINE.json configs[1]: batch 1, 2 views.  SURVEY.md section 8(d): p50 over 200 requests — here 8 DIFFERENT
+            # requests (token ids, both views) rotated, fresh sampler noise drawn inside every call
+            reqs = [synthetic_batch(1, 2, args.s_text, device, seed=7 + 13 * i) for i in range(8)]
             norms = {"min": [-1.0] * 7, "max": [1.0] * 7}
+            n_warm, n_req = 10, 200
             lat = []
-            for i in range(25):
+            for i in range(n_warm + n_req):
+                b1 = reqs[i % len(reqs)]
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 model.inference_action(b1["input_ids"], b1["images"], {"cfg_scale": 1.5, "num_ddim_steps": 10,
                                                                         "action_norms": norms})
                 lat.append(1e3 * (time.perf_counter() - t1))       # inference_action ends with a .cpu() sync
-            result["p50_action_inference_ms"] = round(float(np.median(lat[5:])), 2)
+            lat = np.asarray(lat[n_warm:])
+            result["p50_action_inference_ms"] = round(float(np.median(lat)), 2)
+            result["action_inference"] = {"n_requests": n_req, "distinct_inputs": len(reqs), "p50_ms": round(float(np.median(lat)), 2),
+                                          "p90_ms": round(float(np.percentile(lat, 90)), 2), "min_ms": round(float(lat.min()), 2)}
             result["config"]["inference_workload"] = ("DB-CogACT bf16 action inference, batch 1, 2 views 224x224, "
                                                       "32-token instruction (S=543), CFG 1.5, 10 DDIM steps, through inference_action (HIP-graph replay from the third request of a shape on)")
+            try:
+                result["action_inference"]["process_frame"] = process_frame_latency(model, n_req=50)
+            except Exception as e:  # noqa: BLE001  (never break the headline line)
+                result["action_inference"]["process_frame"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, llm, vis)
@@ -530,7 +582,8 @@ def main():
         if not args.no_secondary and world == 1:
             # BASELINE.json configs[3] / [4] as driver-visible lines: each runs in its own process (its own arenas, a crash
             # or a timeout there cannot take the headline line with it) once this process has given the GPU memory back
-            del trainer, model
+            del trainer, model, feed
+            reqs = b1 = None
             import gc
             gc.collect()
             torch.cuda.empty_cache()

@@ -237,8 +237,15 @@ constexpr float LOG2E = 1.4426950408889634f;
 // NW waves of 16 queries each share one staged K/V tile: 4 (64 queries per workgroup) or 8 (128 queries: the tile's staging is
 // amortised over twice the MFMA work and every SIMD holds two waves that hide each other's LDS reads and softmax — head_dim 256,
 // whose 64 accumulator + 32 query registers leave room for only one 4-wave workgroup per CU)
-template <int D, int NW>
+// DV < D (round 5): a head width the tiles are not built for (SigLIP-So400m: 72) runs on the next tile width with only
+// its DV real columns loaded (the chunks past them are zeros in registers / LDS, never fetched), the k-steps and output
+// blocks past DV skipped (72: 3 of 4 k-steps of QK^T, 5 of 8 output blocks of PV) and only DV columns stored — no padded
+// copies of q / k / v / o in HBM.  DV % 8 == 0.
+template <int D, int NW, int DV = D>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
+  static_assert(DV % 8 == 0 && DV <= D && DV > D / 2, "valid head width: a multiple of 8 in (D/2, D]");
+  constexpr int DSN = (DV + 31) / 32;   // k-steps of 32 that hold real columns
+  constexpr int DIN = (DV + 15) / 16;   // 16-column output blocks that hold real columns
   constexpr int NT = 64 * NW;
   constexpr int NCH = D / 8;          // 16-B chunks per K row
   constexpr int KROW = D * 2;         // bytes per K row
@@ -260,15 +267,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
 
   // Q fragments: MFMA second operand, lane (q = l16, k-group lg) holds d = 32*ds + 8*lg .. +7
   const int qi = q0 + wave * 16 + l16;
-  uint4 qf[D / 32];
+  uint4 qf[DSN];
 #pragma unroll
-  for (int ds = 0; ds < D / 32; ++ds) {
+  for (int ds = 0; ds < DSN; ++ds) {
     qf[ds] = make_uint4(0, 0, 0, 0);
-    if (qi < p.Sq) qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
+    if (qi < p.Sq && 32 * ds + 8 * lg < DV) qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
   }
-  f32x4_t oacc[D / 16];
+  f32x4_t oacc[DIN];
 #pragma unroll
-  for (int i = 0; i < D / 16; ++i) oacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DIN; ++i) oacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   const float sc2 = p.scale * LOG2E;   // softmax in base 2: exp(x) = 2^(x log2 e), one v_exp_f32 per score
 
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
     for (int i = 0; i < KPT; ++i) {
       const int key = key0 + tid / NCH + RPI * i;
       kreg[i] = make_uint4(0, 0, 0, 0);
-      if (key < p.Sk) kreg[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + c * 8);
+      if (key < p.Sk && c * 8 < DV) kreg[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + c * 8);
     }
 #pragma unroll
     for (int w = 0; w < VWI; ++w) {
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
       for (int e = 0; e < 8; ++e) {
         const int key = key0 + kc * 8 + e;
         vreg[w][e] = make_uint2(0, 0);
-        if (wi < 8 * (D / 4) && key < p.Sk) vreg[w][e] = *reinterpret_cast<const uint2*>(vb + (int64_t)key * p.v_ss + dg * 4);
+        if (wi < 8 * (D / 4) && dg * 4 < DV && key < p.Sk) vreg[w][e] = *reinterpret_cast<const uint2*>(vb + (int64_t)key * p.v_ss + dg * 4);
       }
     }
   };
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
       sacc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const int r = n * 16 + l16;
 #pragma unroll
-      for (int ds = 0; ds < D / 32; ++ds) {
+      for (int ds = 0; ds < DSN; ++ds) {
         const int c = 4 * ds + lg;
         const uint4 kf = *reinterpret_cast<const uint4*>(Ks + r * KROW + ((c ^ (r & (NCH - 1))) << 4));
         sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
-    for (int i = 0; i < D / 16; ++i) {
+    for (int i = 0; i < DIN; ++i) {
       oacc[i][0] *= alpha; oacc[i][1] *= alpha; oacc[i][2] *= alpha; oacc[i][3] *= alpha;
     }
     // ---- O^T += V^T P^T.  k-slot (lg, e) of 32-key block kb2 <-> key 32*kb2 + 16*(e>>2) + 4*lg + (e&3):
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
     for (int kb2 = 0; kb2 < 2; ++kb2) {
       const uint4 pf = make_uint4(pk[4 * kb2], pk[4 * kb2 + 1], pk[4 * kb2 + 2], pk[4 * kb2 + 3]);
 #pragma unroll
-      for (int di = 0; di < D / 16; ++di) {
+      for (int di = 0; di < DIN; ++di) {
         const int d = di * 16 + l16;
         const int sw = (d >> 1) & 7;
         const int k1 = 32 * kb2 + 4 * lg, k2 = k1 + 16;
@@ -437,11 +444,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
   if (qi < p.Sq) {
     bf16_t* orow = reinterpret_cast<bf16_t*>(p.o) + bz * p.o_sb + h * p.o_sh + (int64_t)qi * p.o_ss;
 #pragma unroll
-    for (int di = 0; di < D / 16; ++di) {
+    for (int di = 0; di < DIN; ++di) {
       uint2 ov;
       ov.x = pack_bf16(oacc[di][0] * inv, oacc[di][1] * inv);
       ov.y = pack_bf16(oacc[di][2] * inv, oacc[di][3] * inv);
-      *reinterpret_cast<uint2*>(orow + di * 16 + 4 * lg) = ov;
+      if (di * 16 + 4 * lg < DV) *reinterpret_cast<uint2*>(orow + di * 16 + 4 * lg) = ov;
     }
     // (a key range in which this query sees nothing: -inf, so that the fold gives it no weight; unsplit: 0 like the other kernels)
     if (lg == 0 && p.lse)
@@ -620,15 +627,17 @@ typedef uint32_t tile_reg_t __attribute__((ext_vector_type(4)));   // 16 bytes o
 
 // global -> registers: thread (c = tid % NCH, r = tid / NCH + RPI*i) holds chunk c of row r.  Rows past the end
 // are clamped to the last row (finite data; the score mask zeroes whatever they produce) — no divergent loads.
-template <int D, int NT = 256>
+template <int D, int NT = 256, int DV = D>
 __device__ __forceinline__ void tile_gload(tile_reg_t* __restrict__ reg, const bf16_t* base, int64_t stride, int row0,
                                            int nrows, int tid) {
   using FT = FlashTile<D, NT>;
   const bf16_t* src = base + (tid % FT::NCH) * 8;
+  const bool real = DV == D || (tid % FT::NCH) * 8 < DV;     // chunks past the head's DV real columns: zeros, never fetched
 #pragma unroll
   for (int i = 0; i < FT::NPASS; ++i) {
     const int r = min(row0 + tid / FT::NCH + FT::RPI * i, nrows - 1);
-    reg[i] = *reinterpret_cast<const tile_reg_t*>(src + (int64_t)r * stride);
+    reg[i] = (tile_reg_t){0u, 0u, 0u, 0u};
+    if (real) reg[i] = *reinterpret_cast<const tile_reg_t*>(src + (int64_t)r * stride);
   }
 }
 template <int D, int NT = 256>
@@ -679,9 +688,10 @@ struct AttnBwdP {
   char* dv; int64_t dv_sb, dv_sh, dv_ss;
 };
 
-template <int D, int NW>
+template <int D, int NW, int DV = D>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
+  constexpr int DSN = (DV + 31) / 32, DIN = (DV + 15) / 16;     // k-steps / output blocks with real columns (attn_fwd_flash_k)
   constexpr int NT = 64 * NW;                  // NW waves of 16 queries share a staged K/V tile (see attn_fwd_flash_k)
   using FT = FlashTile<D, NT>;
   __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES];
@@ -699,12 +709,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
   const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
   const bf16_t* ob = reinterpret_cast<const bf16_t*>(p.o) + b * p.o_sb + h * p.o_sh;
-  uint4 qf[D / 32], dof[D / 32];
+  uint4 qf[DSN], dof[DSN];
   float dlt = 0.f;   // delta = rowsum(dO * O): this lane's 8-wide slices, folded over the 4 lane groups below
 #pragma unroll
-  for (int ds = 0; ds < D / 32; ++ds) {
+  for (int ds = 0; ds < DSN; ++ds) {
     qf[ds] = dof[ds] = make_uint4(0, 0, 0, 0);
-    if (qi < p.Sq) {
+    if (qi < p.Sq && 32 * ds + 8 * lg < DV) {
       qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
       dof[ds] = *reinterpret_cast<const uint4*>(dob + (int64_t)qi * bp.do_ss + 32 * ds + 8 * lg);
       const uint2 o0 = *reinterpret_cast<const uint2*>(ob + (int64_t)qi * p.o_ss + 32 * ds + 8 * lg);
@@ -722,9 +732,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   if (qi < p.Sq && lg == 0) bp.delta[rowid] = dlt;               // the dK/dV kernel (launched next) reads it
   const float lse2 = (qi < p.Sq ? p.lse[rowid] : 0.f) * LOG2E;   // exp(x) = 2^(x log2 e): one v_exp_f32
   const float sc2 = p.scale * LOG2E;
-  f32x4_t acc[D / 16];
+  f32x4_t acc[DIN];
 #pragma unroll
-  for (int i = 0; i < D / 16; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < DIN; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   int j_lo = p.kv_start ? p.kv_start[b] : 0;
   int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
   j_lo = max(j_lo, 0);
@@ -738,8 +748,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
   tile_reg_t rk[FT::NPASS], rv[FT::NPASS];
   if (t_lo < t_hi) {
-    tile_gload<D, NT>(rk, kb, p.k_ss, t_lo * 64, p.Sk, tid);
-    tile_gload<D, NT>(rv, vb, p.v_ss, t_lo * 64, p.Sk, tid);
+    tile_gload<D, NT, DV>(rk, kb, p.k_ss, t_lo * 64, p.Sk, tid);
+    tile_gload<D, NT, DV>(rv, vb, p.v_ss, t_lo * 64, p.Sk, tid);
   }
   for (int kt = t_lo; kt < t_hi; ++kt) {
     const int key0 = kt * 64;
@@ -748,8 +758,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
     tile_sstore<D, NT>(Vs, rv, tid);
     __syncthreads();
     if (kt + 1 < t_hi) {                   // next tile's loads fly during this tile's MFMAs
-      tile_gload<D, NT>(rk, kb, p.k_ss, key0 + 64, p.Sk, tid);
-      tile_gload<D, NT>(rv, vb, p.v_ss, key0 + 64, p.Sk, tid);
+      tile_gload<D, NT, DV>(rk, kb, p.k_ss, key0 + 64, p.Sk, tid);
+      tile_gload<D, NT, DV>(rv, vb, p.v_ss, key0 + 64, p.Sk, tid);
     }
     unsigned long long kmask = ~0ull;       // validity of this tile's 64 keys: one coalesced byte load per lane + ballot
     if (kvld) {
@@ -761,7 +771,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
     for (int n = 0; n < 4; ++n) {
       f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ds = 0; ds < D / 32; ++ds) {
+      for (int ds = 0; ds < DSN; ++ds) {
         const uint4 kf = lds_frag(Ks + fa.row[ds] + n * 16 * FT::ROW);
         const uint4 vf = lds_frag(Vs + fa.row[ds] + n * 16 * FT::ROW);
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ds]), s, 0, 0, 0);
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
     for (int kb2 = 0; kb2 < 2; ++kb2) {
       const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
 #pragma unroll
-      for (int di = 0; di < D / 16; ++di) {
+      for (int di = 0; di < DIN; ++di) {
         const uint4 ktf = lds_frag_col<D>(Ks + fa.col[di] + kb2 * 32 * FT::ROW);
         acc[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ktf), __builtin_bit_cast(bf16x8_t, dsf), acc[di], 0, 0, 0);
       }
@@ -791,18 +801,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   if (qi < p.Sq) {
     bf16_t* row = reinterpret_cast<bf16_t*>(bp.dq) + b * bp.dq_sb + h * bp.dq_sh + (int64_t)qi * bp.dq_ss;
 #pragma unroll
-    for (int di = 0; di < D / 16; ++di) {
+    for (int di = 0; di < DIN; ++di) {
       uint2 ov;
       ov.x = pack_bf16(acc[di][0], acc[di][1]);
       ov.y = pack_bf16(acc[di][2], acc[di][3]);
-      *reinterpret_cast<uint2*>(row + di * 16 + 4 * lg) = ov;
+      if (di * 16 + 4 * lg < DV) *reinterpret_cast<uint2*>(row + di * 16 + 4 * lg) = ov;
     }
   }
 }
 
-template <int D>
+template <int D, int DV = D>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
+  constexpr int DSN = (DV + 31) / 32, DIN = (DV + 15) / 16;     // k-steps / output blocks with real columns (attn_fwd_flash_k)
   using FT = FlashTile<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 tiles + 3 x 64 floats (65 KiB at D = 256)
   char* Qs = smem;
@@ -817,18 +828,18 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
   const int key = key0 + wave * 16 + l16;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
-  uint4 kf[D / 32], vf[D / 32];
+  uint4 kf[DSN], vf[DSN];
 #pragma unroll
-  for (int ds = 0; ds < D / 32; ++ds) {
+  for (int ds = 0; ds < DSN; ++ds) {
     kf[ds] = vf[ds] = make_uint4(0, 0, 0, 0);
-    if (key < p.Sk) {
+    if (key < p.Sk && 32 * ds + 8 * lg < DV) {
       kf[ds] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.k_ss + 32 * ds + 8 * lg);
       vf[ds] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * p.v_ss + 32 * ds + 8 * lg);
     }
   }
-  f32x4_t dka[D / 16], dva[D / 16];
+  f32x4_t dka[DIN], dva[DIN];
 #pragma unroll
-  for (int i = 0; i < D / 16; ++i) { dka[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dva[i] = dka[i]; }
+  for (int i = 0; i < DIN; ++i) { dka[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dva[i] = dka[i]; }
   int j_lo = p.kv_start ? p.kv_start[b] : 0;
   int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
   j_lo = max(j_lo, 0);
@@ -848,8 +859,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
     const int h = hk * G + it / nqt, q0 = (qt_lo + it % nqt) * 64;
     const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
     const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
-    tile_gload<D>(rq, qb, p.q_ss, q0, p.Sq, tid);
-    tile_gload<D>(ro, dob, bp.do_ss, q0, p.Sq, tid);
+    tile_gload<D, 256, DV>(rq, qb, p.q_ss, q0, p.Sq, tid);
+    tile_gload<D, 256, DV>(ro, dob, bp.do_ss, q0, p.Sq, tid);
     if (tid < 128) {
       const int q = q0 + (tid & 63);
       const float* src = (tid < 64 ? p.lse : bp.delta) + ((int64_t)b * p.Hq + h) * p.Sq;
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
     for (int n = 0; n < 4; ++n) {
       f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ds = 0; ds < D / 32; ++ds) {
+      for (int ds = 0; ds < DSN; ++ds) {
         const uint4 qfr = lds_frag(Qs + fa.row[ds] + n * 16 * FT::ROW);
         const uint4 ofr = lds_frag(Os + fa.row[ds] + n * 16 * FT::ROW);
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qfr), __builtin_bit_cast(bf16x8_t, kf[ds]), s, 0, 0, 0);
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
       const uint4 pf = make_uint4(pp[4 * kb2], pp[4 * kb2 + 1], pp[4 * kb2 + 2], pp[4 * kb2 + 3]);
       const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
 #pragma unroll
-      for (int di = 0; di < D / 16; ++di) {
+      for (int di = 0; di < DIN; ++di) {
         const uint4 otf = lds_frag_col<D>(Os + fa.col[di] + kb2 * 32 * FT::ROW);
         const uint4 qtf = lds_frag_col<D>(Qs + fa.col[di] + kb2 * 32 * FT::ROW);
         dva[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, otf), __builtin_bit_cast(bf16x8_t, pf), dva[di], 0, 0, 0);
@@ -919,12 +930,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
     bf16_t* krow = reinterpret_cast<bf16_t*>(bp.dk) + b * bp.dk_sb + hk * bp.dk_sh + (int64_t)key * bp.dk_ss;
     bf16_t* vrow = reinterpret_cast<bf16_t*>(bp.dv) + b * bp.dv_sb + hk * bp.dv_sh + (int64_t)key * bp.dv_ss;
 #pragma unroll
-    for (int di = 0; di < D / 16; ++di) {
+    for (int di = 0; di < DIN; ++di) {
       uint2 ok, ov;
       ok.x = pack_bf16(dka[di][0], dka[di][1]); ok.y = pack_bf16(dka[di][2], dka[di][3]);
       ov.x = pack_bf16(dva[di][0], dva[di][1]); ov.y = pack_bf16(dva[di][2], dva[di][3]);
-      *reinterpret_cast<uint2*>(krow + di * 16 + 4 * lg) = ok;
-      *reinterpret_cast<uint2*>(vrow + di * 16 + 4 * lg) = ov;
+      if (di * 16 + 4 * lg < DV) {
+        *reinterpret_cast<uint2*>(krow + di * 16 + 4 * lg) = ok;
+        *reinterpret_cast<uint2*>(vrow + di * 16 + 4 * lg) = ov;
+      }
     }
   }
 }
@@ -959,11 +972,14 @@ int check_common(const dxa_attn_desc* d, const char* who) {
 
 }  // namespace
 
+// head widths of the fused flash kernels: the tile widths themselves and 72 (SigLIP-So400m, siglip_encoder.py:49-52 of the
+// reference: 1152 / 16 heads), which runs on the 128-wide tiles with its 72 real columns only (attn_fwd_flash_k, DV)
+static bool flash_head_dim(int D) { return D == 64 || D == 72 || D == 128 || D == 256; }
 static bool fwd_flash_ok(const dxa_attn_desc* d) {
   const bool strides8 = d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->q_sb % 8 == 0 && d->q_sh % 8 == 0 &&
                         d->k_sb % 8 == 0 && d->k_sh % 8 == 0 && d->v_ss % 4 == 0 && d->v_sb % 4 == 0 &&
                         d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
-  return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && strides8 &&
+  return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && flash_head_dim(d->D) && strides8 &&
          al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
 }
 
@@ -990,7 +1006,7 @@ static bool fwd_materialise(const dxa_attn_desc* d) {
 // workgroup per (query tile, head, batch, range), and the ranges' normalised partials are folded by their log-sum-exps.
 static int fwd_flash_splits(const dxa_attn_desc* d) {
   static const int off = getenv("DXA_ATTN_NO_KSPLIT") != nullptr;
-  if (off || !fwd_flash_ok(d) || d->Sk < 512) return 1;      // (a 300-key decode step measured the same cut or whole: 4.63 vs 4.57 ms/token)
+  if (off || !fwd_flash_ok(d) || d->Sk < 512 || d->D == 72) return 1;      // (a 300-key decode step measured the same cut or whole: 4.63 vs 4.57 ms/token)
   const int64_t wgs = (int64_t)((d->Sq + 63) / 64) * d->Hq * d->B;
   if (wgs > 64) return 1;
   const int tiles = (d->Sk + 63) / 64;
@@ -1090,10 +1106,12 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
     if (nw == 8) {
       if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 8>), grid, dim3(512), 0, st, p);
       else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 8>), grid, dim3(512), 0, st, p);
+      else if (d->D == 72) hipLaunchKernelGGL((attn_fwd_flash_k<128, 8, 72>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((attn_fwd_flash_k<64, 8>), grid, dim3(512), 0, st, p);
     } else {
       if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 4>), grid, dim3(256), 0, st, p);
       else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 4>), grid, dim3(256), 0, st, p);
+      else if (d->D == 72) hipLaunchKernelGGL((attn_fwd_flash_k<128, 4, 72>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((attn_fwd_flash_k<64, 4>), grid, dim3(256), 0, st, p);
     }
     DXA_CHECK_LAUNCH();
@@ -1142,7 +1160,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
 static bool bwd_flash_ok(const dxa_attn_desc* d) {
   auto s8 = [](int64_t a, int64_t b, int64_t c) { return a % 8 == 0 && b % 8 == 0 && c % 8 == 0; };
   auto s4 = [](int64_t a, int64_t b, int64_t c) { return a % 4 == 0 && b % 4 == 0 && c % 4 == 0; };
-  return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && (d->D == 64 || d->D == 128 || d->D == 256) && d->B <= 65535 && d->Hq <= 65535 &&
+  return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && flash_head_dim(d->D) && d->B <= 65535 && d->Hq <= 65535 &&
          s8(d->q_sb, d->q_sh, d->q_ss) && s8(d->k_sb, d->k_sh, d->k_ss) && s8(d->v_sb, d->v_sh, d->v_ss) &&
          s8(d->do_sb, d->do_sh, d->do_ss) && s4(d->o_sb, d->o_sh, d->o_ss) && s4(d->dq_sb, d->dq_sh, d->dq_ss) &&
          s4(d->dk_sb, d->dk_sh, d->dk_ss) && s4(d->dv_sb, d->dv_sh, d->dv_ss) && al(d->q, 16) && al(d->k, 16) &&
@@ -1177,20 +1195,21 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     const int nwq = nwq_env ? nwq_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
     dim3 gq((unsigned)((d->Sq + 16 * nwq - 1) / (16 * nwq)), (unsigned)d->Hq, (unsigned)d->B);
     dim3 gk((unsigned)((d->Sk + 63) / 64), (unsigned)d->Hkv, (unsigned)d->B);
-#define LAUNCH_BWD(D_)                                                                                           \
+#define LAUNCH_BWD(D_, DV_)                                                                                      \
   do {                                                                                                            \
     constexpr int lds_ = 2 * FlashTile<D_>::RM_BYTES + 3 * 64 * (int)sizeof(float);                               \
     static bool attr_ = false;                                                                                    \
     if (!attr_ && lds_ > 48 * 1024) {                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k<D_>),                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k<D_, DV_>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                \
       attr_ = true;                                                                                               \
     }                                                                                                             \
-    if (nwq == 8) hipLaunchKernelGGL((attn_bwd_dq_k<D_, 8>), gq, dim3(512), 0, st, bp);                           \
-    else hipLaunchKernelGGL((attn_bwd_dq_k<D_, 4>), gq, dim3(256), 0, st, bp);                                    \
-    hipLaunchKernelGGL((attn_bwd_dkv_k<D_>), gk, dim3(256), lds_, st, bp);                                        \
+    if (nwq == 8) hipLaunchKernelGGL((attn_bwd_dq_k<D_, 8, DV_>), gq, dim3(512), 0, st, bp);                      \
+    else hipLaunchKernelGGL((attn_bwd_dq_k<D_, 4, DV_>), gq, dim3(256), 0, st, bp);                               \
+    hipLaunchKernelGGL((attn_bwd_dkv_k<D_, DV_>), gk, dim3(256), lds_, st, bp);                                   \
   } while (0)
-    if (d->D == 256) LAUNCH_BWD(256); else if (d->D == 128) LAUNCH_BWD(128); else LAUNCH_BWD(64);
+    if (d->D == 256) LAUNCH_BWD(256, 256); else if (d->D == 128) LAUNCH_BWD(128, 128);
+    else if (d->D == 72) LAUNCH_BWD(128, 72); else LAUNCH_BWD(64, 64);
 #undef LAUNCH_BWD
     DXA_CHECK_LAUNCH();
     return DXA_OK;

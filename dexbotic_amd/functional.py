@@ -16,6 +16,8 @@ order: bit-identical gradients) — ~0.75 GB -> 33 MB kept per decoder layer at 
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -362,7 +364,10 @@ class VitBlockSpec:
 
 def _padded_head_dim(D: int, dtype) -> int:
     """head width the MFMA attention kernels run at for a model head_dim D (bf16 only; fp32 uses the generic kernels)"""
-    if dtype != torch.bfloat16 or D in (64, 128, 256) or D > 256 or D % 8 != 0:
+    # 72 (SigLIP-So400m) runs natively on the 128-wide tiles since round 5: only its 72 real columns are loaded / stored
+    # (DXA_ATTN_PAD72=1: the round-3/4 zero-padded copies, kept for the A/B of profiles/r05_pi0_hd72.txt)
+    native = (64, 128, 256) if os.environ.get("DXA_ATTN_PAD72") == "1" else (64, 72, 128, 256)
+    if dtype != torch.bfloat16 or D in native or D > 256 or D % 8 != 0:
         return D
     return 64 if D < 64 else (128 if D < 128 else 256)
 

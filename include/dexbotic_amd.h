@@ -162,7 +162,8 @@ int dxa_rope_merge(const void* dq, const void* dk, const void* dv, void* dqkv, c
  * HF:clip/modeling_clip.py:259-330 (full), timm Attention in dit.py:145-149 (full, 17 tokens).
  * Element (b,h,s,d) of q/k/v/o lives at base + b*sb + h*sh + s*ss + d (element strides).
  * softmax in fp32; keys j visible to query i iff kv_start[b] <= j < kv_end[b] and (!causal || j <= i).
- * Forward: fused flash kernel (bf16, D in {64,128}: K/V tiles staged in LDS, MFMA QK^T and PV,
+ * Forward: fused flash kernel (bf16, D in {64,72,128,256} — 72 = SigLIP-So400m's head width, run on the 128-wide tiles with
+ * its 72 real columns only: K/V tiles staged in LDS, MFMA QK^T and PV,
  * wavefront-shuffle softmax reductions) or a generic fp32-accumulate kernel (any dtype / D).
  * Saves lse[b,h,i] = log sum_j exp(scale*s_ij) for the backward.
  * Backward: dq/dk/dv from (q,k,v,o,do,lse); `workspace` must hold dxa_attn_bwd_workspace(desc) bytes.

@@ -7,7 +7,7 @@
 and batch of oracle/gen_golden_realwidth_ref.py) driven through FIVE optimizer steps of what HF ``Trainer`` does for the
 reference's recipe (dexbotic/exp/trainer.py:25-36,88-124; base_exp.py:95-203): forward under ``torch.autocast(bfloat16)``
 (and, second run, plain fp32) -> backward -> ``clip_grad_norm_(1.0)`` -> ``torch.optim.AdamW`` with the reference's decay /
-no-decay grouping (lr 1e-4, betas (0.9, 0.999), eps 1e-8, weight decay 0.01, constant lr).  Every step sees the same episodes with
+no-decay grouping (lr 2e-5 = the recipe's base_lr, betas (0.9, 0.999), eps 1e-8, weight decay 0.01, constant lr).  Every step sees the same episodes with
 FRESH injected draws (noise, timesteps, condition drop).  Stored per run: the five losses, the five pre-clip gradient norms and
 strided samples of (parameters after step 5 - initial parameters) for ten tensors; plus the distance between the reference's own
 bf16 and fp32 trajectories, which is the yardstick for the product's bf16 bound.
@@ -31,7 +31,7 @@ from . import gen_golden_realwidth_ref as R
 from .weights import cogact_shapes, fast_sample_crc, fast_weight_items, make_weights, weights_crc
 
 STEPS = 5
-LR, WD = 1e-4, 0.01
+LR, WD = 2e-5, 0.01           # the recipe's base_lr (dexbotic/exp/base_exp.py: OptimizerConfig.base_lr = 2e-5)
 DSTRIDE = 1009
 REAL12 = dataclasses.replace(R.REAL4, num_hidden_layers=12)
 SEED12 = 53
@@ -85,6 +85,52 @@ def run_traj(m, x, autocast: bool, names):
     return {"losses": np.asarray(losses), "norms": np.asarray(norms), **{"delta/" + n: v for n, v in pd.items()}}
 
 
+def oracle_step(sd, cfg, x, noise, ts, drop_u, autocast: bool):
+    """the CPU restatement's forward + backward on the same inputs and draws (oracle/cogact_oracle.py)"""
+    from . import cogact_oracle as O
+    t = torch.from_numpy
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+        feats = O.extract_vision_features(sd, cfg, t(x["images"]))
+        src, new_mask, _ = O.splice_plan(x["input_ids"], x["attention_mask"], feats.shape[1], None, "right")
+        hidden = O.qwen2_forward(sd, cfg, O.splice_embeds(sd, src, feats.float()), t(new_mask))
+        cog = O.cognition_features(hidden, t(new_mask))
+    with torch.autocast("cpu", enabled=False):
+        loss, _, _ = O.action_loss(sd, cfg, t(x["actions"]), cog.float(), t(noise), t(ts), t(drop_u) < 0.1, 4)
+    loss.backward()
+    return loss, cog
+
+
+def run_traj_oracle(w, x, autocast: bool, names, steps=STEPS):
+    """the same five optimizer steps driven through the ORACLE (its tensors as torch.optim.AdamW parameters)"""
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in w.items()}
+    p0 = {n: sd[n].detach().reshape(-1)[::DSTRIDE].clone() for n in names}
+    opt, losses, norms = None, [], []
+    for s in range(steps):
+        noise, ts, du = step_draws(s)
+        for p in sd.values():
+            p.grad = None
+        loss, _ = oracle_step(sd, R.REAL4, x, noise, ts, du, autocast)
+        with_grad = [(n, p) for n, p in sd.items() if p.grad is not None]
+        if opt is None:
+            opt = torch.optim.AdamW([dict(params=[p for n, p in with_grad if not G.no_decay_name(n)], weight_decay=WD),
+                                     dict(params=[p for n, p in with_grad if G.no_decay_name(n)], weight_decay=0.0)],
+                                    lr=LR, betas=(0.9, 0.999), eps=1e-8)
+        norms.append(float(torch.nn.utils.clip_grad_norm_([p for _, p in with_grad], 1.0)))
+        opt.step()
+        losses.append(float(loss.item()))
+    pd = {n: (sd[n].detach().reshape(-1)[::DSTRIDE] - p0[n]).float().numpy().copy() for n in names}
+    return {"losses": np.asarray(losses), "norms": np.asarray(norms), **{"delta/" + n: v for n, v in pd.items()}}
+
+
+def traj_dist(got, ref):
+    out = {}
+    for k in ref:
+        a, b = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+        out[k] = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)) if k.startswith("delta/") else \
+            float(np.abs(a - b).max() / np.abs(b).max())
+    return out
+
+
 def main_traj():
     t0 = time.time()
     w = make_weights(cogact_shapes(R.REAL4), R.SEED)
@@ -108,6 +154,12 @@ def main_traj():
         else:
             res["ref_bf16_vs_fp32/" + k] = np.float64(np.abs(a - b).max() / np.abs(b).max())
     print({k: f"{float(v):.2e}" for k, v in res.items() if k.startswith("ref_bf16_vs_fp32/")}, flush=True)
+    # the ORACLE through the same five steps (fp32): its distance to the reference's trajectory is recorded here and re-checked by
+    # tests/test_oracle_realwidth.py (re-run there only with DXA_HEAVY_TESTS=1: ten minutes of CPU)
+    d = traj_dist(run_traj_oracle(w, x, False, R.GSAMP), runs["fp32"])
+    print("oracle vs reference fp32 trajectory", {k[-40:]: f"{v:.2e}" for k, v in d.items()}, f"{time.time()-t0:.0f}s", flush=True)
+    for k, v in d.items():
+        res["oracle_vs_ref/fp32/" + k] = np.float64(v)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cogact_traj_ref.npz")
     np.savez_compressed(dst, **res)
     print("wrote", dst, os.path.getsize(dst), "bytes")
@@ -165,6 +217,20 @@ def main_depth12():
     for k in runs["fp32"]:
         res["ref_bf16_vs_fp32/" + k] = np.float64(R.rel(runs["bf16"][k], runs["fp32"][k]))
     print({k: f"{float(v):.2e}" for k, v in res.items() if k.startswith("ref_bf16_vs_fp32/")}, flush=True)
+    # the ORACLE at depth 12 on the reference's own fp32 storage (views: no second copy of 11 GB)
+    sd = {k: v.detach().requires_grad_(True) for k, v in m.state_dict().items()}
+    del m
+    loss, cog = oracle_step(sd, cfg, x, x["noise"], x["timesteps"], x["drop_u"], False)
+    od = {"loss": R.rel(loss.item(), runs["fp32"]["loss"]), "cognition": R.rel(cog.detach().float().numpy(), runs["fp32"]["cognition"])}
+    for g_, pre in R.GROUPS.items():
+        sq = sum(float(p.grad.double().pow(2).sum()) for n, p in sd.items() if n.startswith(pre) and p.grad is not None)
+        od[f"gnorm/{g_}"] = R.rel(sq ** 0.5, runs["fp32"][f"gnorm/{g_}"])
+    for n in GSAMP12:
+        if n in sd and sd[n].grad is not None:
+            od["gsamp/" + n] = R.rel(sd[n].grad.reshape(-1)[::R.STRIDE].float().numpy(), runs["fp32"]["gsamp/" + n])
+    print("oracle vs reference fp32 at depth 12", {k[-40:]: f"{v:.2e}" for k, v in od.items()}, f"{time.time()-t0:.0f}s", flush=True)
+    for k, v in od.items():
+        res["oracle_vs_ref/fp32/" + k] = np.float64(v)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cogact_depth12_ref.npz")
     if dry:
         dst = "/tmp/cogact_depth12_dry.npz"

@@ -24,6 +24,8 @@ def main():
     m.eval()
     b = bench.synthetic_batch(1, 1, 32, dev, seed=3)
     n_new = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    as_json = "--json" in sys.argv
+    pres, pers = [], []
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -35,8 +37,37 @@ def main():
         t2 = time.perf_counter()
         pre = 1e3 * (t1 - t0)
         per = 1e3 * ((t2 - t1) - (t1 - t0)) / (n_new - 1)
-        print(f"rep {rep}: prefill+1 token {pre:.1f} ms, decode {per:.2f} ms/token "
-              f"({15.2e9 * 1e-9 / per:.2f} TB/s of weight streaming)", flush=True)
+        pres.append(pre)
+        pers.append(per)
+        if not as_json:
+            print(f"rep {rep}: prefill+1 token {pre:.1f} ms, decode {per:.2f} ms/token "
+                  f"({15.2e9 * 1e-9 / per:.2f} TB/s of weight streaming)", flush=True)
+    if as_json:
+        # greedy ids of the KV-cached loop against an UNCACHED re-forward of the growing sequence (full prefill kernels at
+        # every length instead of the skinny cached-step kernels): the first n_chk new tokens
+        import json
+        n_chk = 6
+        seq = m.generate(b["input_ids"], images=b["images"], max_new_tokens=n_chk)
+        got = seq[0, b["input_ids"].shape[1]:].tolist()
+        cur, want, margins = b["input_ids"], [], []
+        with torch.no_grad():
+            for _ in range(n_chk):
+                lg = m(input_ids=cur, images=b["images"]).logits[0, -1].float()
+                top = torch.topk(lg, 2).values
+                margins.append(float(top[0] - top[1]))
+                want.append(int(lg.argmax()))
+                cur = torch.cat([cur, torch.tensor([[want[-1]]], device=cur.device)], dim=1)
+        agree = 0
+        for a, w_ in zip(got, want):
+            if a != w_:
+                break
+            agree += 1
+        print(json.dumps({"metric": "ms per generated token, discrete VLA greedy decode (BASELINE.json configs[0] shape at the "
+                                    "Qwen2.5-7B-class size, bf16, batch 1, 1 view, KV cache)",
+                          "ms_per_token": round(min(pers), 3), "prefill_plus_first_token_ms": round(min(pres), 2),
+                          "new_tokens": n_new, "weight_stream_tb_s": round(15.2e9 * 1e-9 / min(pers), 2),
+                          "greedy_ids_vs_uncached_reforward": {"checked": n_chk, "agree_prefix": agree, "cached": got, "uncached": want,
+                                                               "min_top1_top2_logit_margin": round(min(margins), 4)}}), flush=True)
 
 
 if __name__ == "__main__":

@@ -323,6 +323,11 @@ def test_coalesce_batches_interleaves_draws_pads_ragged_rows_and_refuses_what_it
     small = {k: v[:2] if k in ("input_ids", "attention_mask", "labels", "images", "actions") else v[:2 * R] for k, v in c.items()}
     assert coalesce_batches([a, small]) is None                                                # unequal micro-batch sizes
     assert coalesce_batches([a, dict(c, images=torch.zeros(B, 3, 8, 8))]) is None              # unequal image shapes
+    # no attention mask = every position valid (splice.py): rows of unequal length cannot be padded without turning pad ids
+    # into real tokens (advisor, round 4); equal lengths still merge
+    nomask = lambda d: {k: v for k, v in d.items() if k != "attention_mask"}
+    assert coalesce_batches([nomask(a), nomask(b)]) is None
+    assert coalesce_batches([nomask(a), nomask(c)])["input_ids"].shape == (2 * B, S)
 
 
 def test_exp_config_gradient_checkpointing_is_forwarded_only_on_request(monkeypatch, tmp_path):
@@ -349,17 +354,24 @@ def test_coalescing_control_flow_holds_merges_and_falls_back():
     out-of-memory error in the merged pass switches coalescing off and re-runs the group pass by pass"""
     from dexbotic_amd.trainer import NativeTrainer
 
+    dropped = []
+
     class Store:
         device = torch.device("cpu")
         _accum_stash = {}
 
         def flush_wgrads(self):
-            pass
+            raise AssertionError("the out-of-memory fallback must DROP the aborted pass's pending products, not launch them")
+
+        def drop_pending_wgrads(self):
+            dropped.append(1)
     calls = []
 
     def mk(fail_merged=False):
         tr = NativeTrainer.__new__(NativeTrainer)
         tr.coalesce, tr.grad_accum, tr._held, tr.coalesced_steps, tr.store = True, 2, [], 0, Store()
+        tr.reducer = tr.norm_tracker = tr.last_output = None
+        tr.update_due, tr.micro = False, 0
 
         def _micro(batch, loss_scale=None, group=None):
             if fail_merged and group is not None:
@@ -385,10 +397,34 @@ def test_coalescing_control_flow_holds_merges_and_falls_back():
     tr = mk(fail_merged=True)
     tr.micro_step(b(8))
     out = tr.micro_step(b(8))
-    assert calls == [(8, None, None), (8, None, None)] and out.item() == 16.0 and tr.coalesce is False
+    assert calls == [(8, None, None), (8, None, None)] and out.item() == 16.0 and tr.coalesce is False and dropped == [1]
     calls.clear()
     tr.micro_step(b(8))                                                       # ... and stays pass by pass
     assert calls == [(8, None, None)]
+    # under data parallelism the merged pass has NO out-of-memory fallback (an aborted backward may have fired collectives)
+    calls.clear()
+    tr = mk(fail_merged=True)
+    tr.reducer = type("R", (), {"world": 2})()
+    tr.micro_step(b(8))
+    try:
+        tr.micro_step(b(8))
+        raise AssertionError("expected the out-of-memory error to propagate")
+    except torch.OutOfMemoryError:
+        pass
+    # a SHORT accumulation group (HF 4.51 closes the last group of an epoch without announcing its size): the optimizer facade
+    # asks for the step with one of three micro-batches held -> it runs as a group of one at the NOMINAL 1/3 scale
+    calls.clear()
+    tr = mk()
+    tr.grad_accum = 3
+    tr.micro_step(b(8))
+    assert not calls and len(tr._held) == 1
+    tr.close_short_group()
+    assert calls == [(8, 1.0 / 3, 1)] and not tr._held and tr.grad_accum == 3 and tr.micro == 0
+    calls.clear()
+    tr.micro_step(b(8))
+    tr.micro_step(b(8))
+    tr.close_short_group()                                                    # two of three: merged, scale 2/3 on the merged mean
+    assert len(calls) == 1 and calls[0][0] == 16 and abs(calls[0][1] - 2.0 / 3) < 1e-12 and calls[0][2] == 2
 
 
 def test_gemm_profile_stride_samples_every_product_of_a_layer_equally():

@@ -423,6 +423,8 @@ ATTN_CASES = [
     (2, 2, 1, 64, 128, True, True, True),
     (2, 8, 1, 200, 256, False, True, True),    # Gemma-like MQA, head_dim 256 (pi0)
     (1, 4, 1, 70, 256, True, False, True),
+    (2, 3, 3, 256, 72, False, False, False),   # SigLIP-So400m head width, token-major fused qkv: 72 real columns on 128-wide tiles
+    (2, 4, 2, 150, 72, True, True, True),      # ... with GQA, causal and right padding (every mask path at DV < D)
 ]
 
 

@@ -87,3 +87,37 @@ def test_depth28_fixture_pins_the_oracle_to_the_reference_classes(golden_dir):
         samples = O.ddim_sample(sd, D.REAL28, cog, t(x["infer_init"]), 1.5, 10)
     assert D.rel(cog.numpy(), g["fp32/infer_cognition"]) < 2e-5
     assert D.rel(samples.numpy(), g["fp32/infer_samples"]) < 2e-5
+
+
+def test_trajectory_and_depth12_fixtures_pin_the_oracle_to_the_reference_classes(fixture, golden_dir):
+    """Round 5: tests/golden/cogact_traj_ref.npz (five optimizer steps of the reference at 4 layers) and cogact_depth12_ref.npz
+    (one step at 12 decoder layers), oracle/gen_golden_traj.py.  The generator ran the ORACLE through the same steps and stored
+    its distance to the reference's fp32 runs (a depth-12 backward and five real-width steps do not belong in the CPU suite).
+    Held here: the records; the FIRST optimizer step of the trajectory re-run live (loss and pre-clip norm: one real-width
+    forward + backward, the oracle's tensors as torch.optim.AdamW parameters); everything with DXA_HEAVY_TESTS=1."""
+    from oracle import gen_golden_traj as TJ
+    gt = np.load(os.path.join(golden_dir, "cogact_traj_ref.npz"), allow_pickle=False)
+    g12 = np.load(os.path.join(golden_dir, "cogact_depth12_ref.npz"), allow_pickle=False)
+    for k in gt.files:
+        if k.startswith("oracle_vs_ref/fp32/"):
+            # losses / norms at the oracle's fp32 bar; parameter movement: five sign-like Adam steps amplify rounding-order noise
+            # on entries whose gradient is itself noise
+            assert float(gt[k]) < (5e-3 if "/delta/" in k else 2e-5), (k, float(gt[k]))
+    assert sum(k.startswith("oracle_vs_ref/fp32/") for k in gt.files) >= 12
+    for k in g12.files:
+        if k.startswith("oracle_vs_ref/fp32/"):
+            assert float(g12[k]) < 2e-5, (k, float(g12[k]))
+    assert sum(k.startswith("oracle_vs_ref/fp32/") for k in g12.files) >= 10 and int(g12["layers"]) == 12
+    # the yardsticks the GPU bounds are multiples of must be sane numbers
+    assert 1e-6 < float(gt["ref_bf16_vs_fp32/losses"]) < 1e-2 and 1e-3 < float(g12["ref_bf16_vs_fp32/cognition"]) < 1e-1
+    _, x, _ = fixture
+    w = make_weights(cogact_shapes(REAL4), int(gt["seed"]))
+    assert weights_crc(w) == int(gt["weights_crc"])
+    steps = TJ.STEPS if os.environ.get("DXA_HEAVY_TESTS") == "1" else 1
+    got = TJ.run_traj_oracle(w, x, False, TJ.R.GSAMP, steps=steps)
+    for k in ("losses", "norms"):
+        want = np.asarray(gt["fp32/" + k])[:steps]
+        assert np.abs(got[k] - want).max() < 2e-5 * np.abs(want).max(), (k, got[k], want)
+    if steps == TJ.STEPS:
+        d = TJ.traj_dist(got, {k[5:]: gt[k] for k in gt.files if k.startswith("fp32/")})
+        assert all(v < (5e-3 if k.startswith("delta/") else 2e-5) for k, v in d.items()), d

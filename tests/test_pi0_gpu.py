@@ -116,7 +116,8 @@ def test_bf16_pi0_inference_tracks_reference(golden_dir):
 
 
 def test_bf16_siglip_tower_head_dim_72_padded_attention():
-    """SigLIP-So400m has head_dim 72: the bf16 tower runs the MFMA attention kernels at 128 on zero-padded heads.
+    """SigLIP-So400m has head_dim 72: the bf16 tower runs the MFMA attention kernels on their 128-wide tiles with the 72 real
+    columns only (round 5: no zero-padded copies of q / k / v / o any more — attention.hip, DV).
     Forward features and the gradient of a scalar against the fp32 CPU restatement."""
     from dexbotic_amd.engine import ParamStore, attach_parameters
     from dexbotic_amd.model.modules.mm_vision.siglip.siglip_encoder import SiglipVisionConfig, SiglipVisionTower

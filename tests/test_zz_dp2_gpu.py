@@ -9,7 +9,10 @@ Checked after three optimizer steps, against ONE process running the concatenate
 mean followed by clip_grad_norm_(1.0) and AdamW, dexbotic/exp/trainer.py:110,121-122): per-step loss (mean over ranks), the
 clipped norm, every parameter; parameters that never receive a gradient (lm_head, the unused last CLIP layer) are not
 communicated; two accumulation micro-batches exchange once.  fp32 compute, fp32 exchange: the only difference between the two
-runs is the order of fp32 sums over the batch rows."""
+runs is the order of fp32 sums over the batch rows (gradients agree to ~2e-6 of a tensor's largest entry:
+scripts/dp2_debug.py, profiles/r05_dp2_debug.txt).  AdamW's first steps are sign-like — an entry whose gradient is below that
+noise moves by lr in EITHER direction — so the learning rate is small (1e-5: three steps move no parameter by more than 3e-5)
+and the parameter check is "equal, except a small fraction of entries, none further apart than the steps allow"."""
 import datetime
 import os
 import socket
@@ -22,6 +25,7 @@ pytestmark = pytest.mark.gpu
 STEPS = 3
 B, ST = 4, 12
 SEED = 31
+LR = 1e-5
 VARIANTS = (("allreduce", 1, "sum"), ("rs_ag", 1, "sum"), ("allreduce", 2, "sum"), ("rs_ag", 1, "avg"))
 
 
@@ -70,7 +74,7 @@ def _build(grad_accum=1, **kw):
     cfg = CFGS["t1"]
     m = build_product(cfg, make_weights(cogact_shapes(cfg), SEED), "float32", "cuda", train=True)
     m.train()
-    tr = NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=0.01, max_grad_norm=1.0), min_bucket_bytes=1 << 14,
+    tr = NativeTrainer(m, OptimConfig(base_lr=LR, weight_decay=0.01, max_grad_norm=1.0), min_bucket_bytes=1 << 14,
                        grad_accum=grad_accum, **kw)
     return m, tr
 
@@ -107,8 +111,11 @@ def _worker(rank, world, port, tmp):
             for nm in unused:
                 assert float(st.g(nm).abs().max()) == 0.0, nm
             assert any(st.slots[nm].bucket in red.skip_buckets for nm in unused)
+            # what travelled: every exchanged bucket once per optimizer step (alignment gaps ride along), never the whole arena
             sent = sum(hi - lo for b, (lo, hi) in enumerate(st.bucket_ranges) if b not in red.skip_buckets)
-            assert red.bytes_reduced <= STEPS * sent * 4 and red.bytes_reduced > 0
+            skipped = sum(hi - lo for b, (lo, hi) in enumerate(st.bucket_ranges) if b in red.skip_buckets)
+            assert skipped > 0 and STEPS * sent * 4 <= red.bytes_reduced <= STEPS * (st.total - skipped // 2) * 4, \
+                (red.bytes_reduced, STEPS * sent * 4, STEPS * st.total * 4)
             np.savez(os.path.join(tmp, f"v{vi}_rank{rank}.npz"), losses=np.asarray(losses), norms=np.asarray(norms),
                      coll=np.asarray(coll), master=st.master.detach().cpu().numpy())
             del m, tr
@@ -146,14 +153,16 @@ def test_two_rank_model_step_equals_single_process_on_the_concatenated_batch(tmp
         dn = np.abs(r[0]["norms"] - ref_norms).max() / np.abs(ref_norms).max()
         dp = np.abs(r[0]["master"] - ref_master)
         worst = max(names, key=lambda n: dp[names[n][0]:names[n][0] + names[n][1]].max())
-        print(f"{tag}: loss {dl:.2e}  clipped norm {dn:.2e}  parameters max abs {dp.max():.2e} ({worst})  "
-              f"collectives per step {r[0]['coll'].tolist()}")
-        assert dl < 2e-5 and dn < 2e-5, (tag, dl, dn)
-        # parameters: three AdamW steps of lr 1e-3; a gradient that is mathematically zero (k_proj biases: softmax shift
-        # invariance) is rounding noise of either sign and moves its parameter by up to lr per step in EITHER run
-        torch.testing.assert_close(torch.from_numpy(r[0]["master"]), torch.from_numpy(ref_master), rtol=1e-4, atol=2e-4)
-        loose = dp > 2e-5
-        assert loose.mean() < 2e-3, (tag, float(loose.mean()))
+        apart = float((dp > 0.1 * LR).mean())
+        print(f"{tag}: loss {dl:.2e}  clipped norm {dn:.2e}  parameters max abs {dp.max():.2e} ({worst}), {apart:.2e} of the entries "
+              f"more than lr / 10 apart  collectives per step {r[0]['coll'].tolist()}")
+        print("   losses", loss.tolist(), "vs", ref_losses, " norms", r[0]["norms"].tolist(), "vs", ref_norms)
+        assert dl < 1e-5 and dn < 1e-5, (tag, dl, dn)
+        # parameters after three AdamW steps of lr 1e-5: an entry whose gradient is rounding noise (mathematically zero: k_proj
+        # biases — softmax shift invariance —, or simply below 2e-6 of its tensor's largest) moves by lr in either direction in
+        # EITHER run: at most 2 lr apart per step, and few of them
+        assert dp.max() <= STEPS * 2 * LR * 1.05, (tag, float(dp.max()))
+        assert apart < 2e-3, (tag, apart)
         assert len(set(r[0]["coll"].tolist())) == 1, tag        # the same number of collectives every step
     # accumulation: two micro-batches per optimizer step exchange ONCE — as many collectives as the one-pass step
     c = {v: np.load(tmp_path / f"v{vi}_rank0.npz")["coll"][0] for vi, v in enumerate(VARIANTS)}
