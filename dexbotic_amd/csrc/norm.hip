@@ -583,16 +583,152 @@ __global__ __launch_bounds__(256) void norm_bwd_fast8_k(const bf16_t* __restrict
   }
 }
 
+// RMSNorm backward, bf16 rows, cols % 16 == 0, cols <= 8192 (round 5).  norm_bwd_fast8_k gives a wave a whole row: x and dy
+// of the row (2 x 28 registers at 3584 columns) and the wave's column sums (56) leave two waves per SIMD, and every wave walks
+// load -> reduce -> load residual -> store for 2-3 rows in sequence: 57 us for 139 MB (2.4 TB/s) on the decoder's [4592, 3584]
+// rows.  Here a row is split between TWO waves (columns [0, cols/2) and [cols/2, cols)) of an 8-wave workgroup (4 rows at a
+// time, as before): half the registers per wave, so twice the waves — and twice the bytes — in flight per CU; the residual is
+// requested together with x and dy; the two halves of the row statistic meet in LDS and are added in a fixed order
+// (deterministic).  Same partial-sum layout as the other backward kernels: one row of column sums per workgroup.
+// NIT 16-byte chunks per lane: NIT x 64 lanes x 8 columns per half row (4: cols <= 4096); NS rows per workgroup pass (2 NS waves)
+template <typename TW, int NIT, int NS>
+__global__ __launch_bounds__(NS * 128, (NIT <= 4 ? NS : 2)) void rmsnorm_bwd_split_k(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const TW* __restrict__ w, const float* __restrict__ rstd,
+    bf16_t* __restrict__ dx, const bf16_t* __restrict__ res, float* __restrict__ partial, int64_t rows, int64_t cols) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[2][NS][2];          // [iteration parity][row slot][column half]
+  __shared__ float sh[2][NIT * 512];       // hand-over of a row slot's column sums: [column half][column of the half]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = wave >> 1, half = wave & 1;
+  const int64_t hc = cols >> 1, col0 = half * hc;
+  auto unpack = [](const u32x4& v, float (&o)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(v[e] << 16); o[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+  };
+  float aw[NIT][8];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aw[it][i] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * NS;
+  const int64_t iters = (rows + stride - 1) / stride;      // the same trip count for every wave: the loop holds a barrier
+  const float inv_cols = 1.f / (float)cols;
+  for (int64_t k = 0; k < iters; ++k) {
+    const int64_t row = (int64_t)blockIdx.x * NS + slot + k * stride;
+    const bool live = row < rows;
+    const float rs = live ? rstd[row] : 0.f;
+    u32x4 xv[NIT], gv[NIT], rv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t c = ((int64_t)it * 64 + lane) * 8;
+      const bool in = live && c < hc;
+      const int64_t off = row * cols + col0 + c;
+      xv[it] = in ? *reinterpret_cast<const u32x4*>(x + off) : (u32x4){0u, 0u, 0u, 0u};
+      gv[it] = in ? *reinterpret_cast<const u32x4*>(dy + off) : (u32x4){0u, 0u, 0u, 0u};
+      rv[it] = (in && res) ? *reinterpret_cast<const u32x4*>(res + off) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t c = ((int64_t)it * 64 + lane) * 8;
+      if (c < hc) {
+        float xf[8], gf[8], w0[4] = {1.f, 1.f, 1.f, 1.f}, w1[4] = {1.f, 1.f, 1.f, 1.f};
+        unpack(xv[it], xf); unpack(gv[it], gf);
+        if (w) { Vec<TW, 4>::ld(w0, w + col0 + c); Vec<TW, 4>::ld(w1, w + col0 + c + 4); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s2 += gf[i] * (i < 4 ? w0[i] : w1[i - 4]) * (xf[i] * rs);
+      }
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[k & 1][slot][half] = s2;
+    __syncthreads();                       // (parity-indexed slots: the next iteration's writes cannot overtake these reads)
+    const float c2 = (red[k & 1][slot][0] + red[k & 1][slot][1]) * inv_cols;
+    if (live) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int64_t c = ((int64_t)it * 64 + lane) * 8;
+        if (c < hc) {
+          float xf[8], gf[8], rf[8], o[8], w0[4] = {1.f, 1.f, 1.f, 1.f}, w1[4] = {1.f, 1.f, 1.f, 1.f};
+          unpack(xv[it], xf); unpack(gv[it], gf); unpack(rv[it], rf);
+          if (w) { Vec<TW, 4>::ld(w0, w + col0 + c); Vec<TW, 4>::ld(w1, w + col0 + c + 4); }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float xh = xf[i] * rs;
+            o[i] = rs * (gf[i] * (i < 4 ? w0[i] : w1[i - 4]) - xh * c2) + rf[i];
+            aw[it][i] += gf[i] * rnd<bf16_t>(xh);
+          }
+          u32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+          *reinterpret_cast<u32x4*>(dx + row * cols + col0 + c) = ov;
+        }
+      }
+    }
+  }
+  if (partial) {
+    // column sums: row slots NS-1 .. 1 hand theirs to slot 0's waves (same column half) through LDS, one after the other — a
+    // fixed order of additions — and slot 0 writes the workgroup's row
+    for (int turn = NS - 1; turn >= 1; --turn) {
+      __syncthreads();
+      if (slot == turn) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int64_t c = ((int64_t)it * 64 + lane) * 8;
+          if (c < hc) {
+            *reinterpret_cast<float4*>(&sh[half][c]) = make_float4(aw[it][0], aw[it][1], aw[it][2], aw[it][3]);
+            *reinterpret_cast<float4*>(&sh[half][c + 4]) = make_float4(aw[it][4], aw[it][5], aw[it][6], aw[it][7]);
+          }
+        }
+      }
+      __syncthreads();
+      if (slot == 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int64_t c = ((int64_t)it * 64 + lane) * 8;
+          if (c < hc) {
+            const float4 a = *reinterpret_cast<const float4*>(&sh[half][c]), b = *reinterpret_cast<const float4*>(&sh[half][c + 4]);
+            aw[it][0] += a.x; aw[it][1] += a.y; aw[it][2] += a.z; aw[it][3] += a.w;
+            aw[it][4] += b.x; aw[it][5] += b.y; aw[it][6] += b.z; aw[it][7] += b.w;
+          }
+        }
+      }
+    }
+    if (slot == 0) {
+      float* pr = partial + (int64_t)blockIdx.x * cols + col0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int64_t c = ((int64_t)it * 64 + lane) * 8;
+        if (c < hc) {
+          *reinterpret_cast<float4*>(pr + c) = make_float4(aw[it][0], aw[it][1], aw[it][2], aw[it][3]);
+          *reinterpret_cast<float4*>(pr + c + 4) = make_float4(aw[it][4], aw[it][5], aw[it][6], aw[it][7]);
+        }
+      }
+    }
+  }
+}
+
 constexpr int NORM_BWD_MAX_BLOCKS = 512;
 constexpr int64_t NORM_BWD_FAST_MAX_COLS = 4096;
 
 template <bool LN>
 bool launch_norm_bwd_fast(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
                           const void* res, float* partial, int64_t rows, int64_t cols, int dtype, int w_dtype, bool vec_ok, hipStream_t st) {
-  if (!vec_ok || cols % 4 != 0 || cols > NORM_BWD_FAST_MAX_COLS) return false;
   int64_t g = (rows + 3) / 4;
   if (g > NORM_BWD_MAX_BLOCKS) g = NORM_BWD_MAX_BLOCKS;
   dim3 grid((unsigned)g);
+  static const bool split_off = getenv("DXA_NORM_BWD_NO_SPLIT") != nullptr;      // A/B: profiles/r05_norm_bwd_split.txt
+  if (!LN && !split_off && vec_ok && dtype == DXA_BF16 && cols % 16 == 0 && cols <= 8192 && (cols * 4) % 16 == 0 &&
+      (!partial || (reinterpret_cast<uintptr_t>(partial) & 15) == 0)) {
+    // DXA_NORM_BWD_ROWS=3: three rows per workgroup pass (384 threads, 168 registers: no spill) instead of four (512 threads at
+    // 128 registers: a dozen spilled dwords) — tuning switch, profiles/r05_norm_bwd_split.txt
+    static const int ns = getenv("DXA_NORM_BWD_ROWS") ? atoi(getenv("DXA_NORM_BWD_ROWS")) : 4;
+#define LAUNCH_SPLIT(TW_, NIT_, NS_) hipLaunchKernelGGL((rmsnorm_bwd_split_k<TW_, NIT_, NS_>), grid, dim3(NS_ * 128), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const TW_*)w, rstd, (bf16_t*)dx, (const bf16_t*)res, partial, rows, cols)
+    if (w_dtype == DXA_BF16) { if (cols > 4096) LAUNCH_SPLIT(bf16_t, 8, 4); else if (ns == 3) LAUNCH_SPLIT(bf16_t, 4, 3); else LAUNCH_SPLIT(bf16_t, 4, 4); }
+    else { if (cols > 4096) LAUNCH_SPLIT(float, 8, 4); else if (ns == 3) LAUNCH_SPLIT(float, 4, 3); else LAUNCH_SPLIT(float, 4, 4); }
+#undef LAUNCH_SPLIT
+    return true;
+  }
+  if (!vec_ok || cols % 4 != 0 || cols > NORM_BWD_FAST_MAX_COLS) return false;
   if (dtype == DXA_BF16 && cols % 8 == 0 && !LN) {   // RMSNorm: 16-byte accesses, one read of x and dy (LayerNorm's second
                                                      // set of partial sums costs it the registers: measured 27 vs 24 us)
     if (w_dtype == DXA_BF16)

@@ -533,6 +533,17 @@ class Fp32View:
     def __getattr__(self, item):
         return getattr(self._s, item)
 
+    def __setattr__(self, item, value):
+        # attribute WRITES go to the store too.  Until round 5 they landed on the view: ``st._wgrad_pending = True`` of the
+        # action head's side-stream gradient products (functional._wgrad_now / _bgrad) never reached the store, so the head
+        # bucket's completion hook ran without joining the side stream — the gradient exchange (and the sum of squares) could
+        # read the head's last-written slots before their products had run.  Found by the 2-rank model step
+        # (tests/test_zz_dp2_gpu.py; profiles/r05_dp2_race.txt).
+        if item == "_s":
+            object.__setattr__(self, item, value)
+        else:
+            setattr(self._s, item, value)
+
 
 def attach_parameters(root: nn.Module, store: ParamStore, containers: Optional[Dict[str, nn.Module]] = None) -> None:
     """Register every arena view as an nn.Parameter under its dotted name so that ``root.state_dict()``

@@ -71,6 +71,15 @@ def main(path, marker="adamw_k"):
         print(f"{str(k):>12s} {len(lanes[k]):9d} {b / 1e6:9.2f} {100 * b / dur:6.1f}%  {top}")
     main_lane = order[0]
     m = sorted(lanes[main_lane], key=lambda r: r[1])
+    print(f"\n# main stream {main_lane}, by kernel (what the step's length is made of)")
+    byk = defaultdict(lambda: [0, 0.0])
+    for r in m:
+        e = byk[short(r[0], 90)]
+        e[0] += 1
+        e[1] += r[2] - r[1]
+    print(f"{'kernel':90s} {'calls':>6s} {'ms':>9s} {'avg_us':>8s} {'%step':>6s}")
+    for n, (c, v) in sorted(byk.items(), key=lambda x: -x[1][1])[:45]:
+        print(f"{n:90s} {c:6d} {v / 1e6:9.3f} {v / 1e3 / c:8.1f} {100 * v / dur:6.2f}")
     others = sorted((r for k in order[1:] for r in lanes[k]), key=lambda r: r[1])
     gaps = []
     prev_end = t0

@@ -208,3 +208,26 @@ def test_torchrun_launch_contract_dry_run(nproc):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["dryrun"] == "ok" and out["world"] == nproc
+
+
+def test_store_view_forwards_attribute_writes():
+    """engine.Fp32View (the action head's view of the store: fp32 masters from w()) must forward attribute WRITES: until round 5
+    ``st._wgrad_pending = True`` of the head's side-stream gradient products landed on the view, the store's flag stayed False
+    and the head bucket's completion hook — gradient exchange, sum of squares — did not join the side stream: a real race, found
+    by the 2-rank model step on the MI355X (tests/test_zz_dp2_gpu.py, profiles/r05_dp2_race.txt)."""
+    from dexbotic_amd.engine import Fp32View
+    st, names = _build_store()
+    view = Fp32View(st)
+    assert view._wgrad_pending is False
+    view._wgrad_pending = True
+    assert st._wgrad_pending is True and set(vars(view)) == {"_s"}
+    st.set_expected(["unused.w"])
+    st.begin_step()
+    joined = []
+    st.wgrad_stream = object()                           # (a side stream exists)
+    st.join_wgrad = lambda: joined.append(st._wgrad_pending)
+    st.on_bucket_ready = lambda b: None
+    for n in reversed(names):
+        view._wgrad_pending = True                       # what functional._wgrad_now / _bgrad do after a side-stream enqueue
+        view.mark_written(n)
+    assert joined and all(joined), joined                # every bucket completion saw the pending side-stream work

@@ -247,7 +247,10 @@ def traj_ref(golden_dir):
 # fp32: the product against the reference's fp32 trajectory.  Losses and norms at the north-star tolerance; the parameter movement
 # (five sign-like Adam steps: an entry whose gradient is rounding noise moves by up to lr per step in either direction) as the
 # relative L2 distance of the sampled movement vectors.
-TRAJ_FP32 = {"losses": 1e-3, "norms": 1e-3, "delta": 2e-2}
+# observed on the MI355X (round 5): losses 6.7e-5, norms 2.7e-4, movement 9e-5 .. 1.0e-4 — all held to the north-star 1e-3.
+# (Before the Fp32View fix of this round the norms sat at 2e-3: the head bucket's sum of squares was folded without waiting
+# for the side stream's last products, engine.Fp32View.__setattr__.)
+TRAJ_FP32 = {"losses": 1e-3, "norms": 1e-3, "delta": 1e-3}
 
 
 def test_fp32_five_optimizer_steps_follow_the_reference_trajectory(real_ref, traj_ref):
@@ -264,8 +267,11 @@ def test_fp32_five_optimizer_steps_follow_the_reference_trajectory(real_ref, tra
 
 # bf16: against the reference's bf16-autocast trajectory; yardstick = how far the reference's own bf16 trajectory sits from its
 # fp32 one (ref_bf16_vs_fp32/*).  Bound: TRAJ_BF16_X times that distance (floors for quantities the reference reproduces by luck).
-TRAJ_BF16_X = 2.0
-TRAJ_BF16_FLOOR = {"losses": 5e-4, "norms": 1.5e-3, "delta": 5e-2}
+# observed (round 5): losses 2.8e-4 (reference's own gap 7.0e-4), norms 5.1e-4 (4.3e-4), movement of the big matrices 3.9e-2 ..
+# 5.1e-2 (3.4e-2 .. 4.0e-2), k_proj bias 8.7e-3, norm weight 3.4e-3, head 1.5e-2 / 4.5e-2.  Floors = 1.5 x observed where the
+# reference's own gap is smaller than the observation.
+TRAJ_BF16_X = 1.75
+TRAJ_BF16_FLOOR = {"losses": 4.5e-4, "norms": 8e-4, "delta": 1.5e-2}
 
 
 def test_bf16_five_optimizer_steps_track_the_reference_under_autocast(real_ref, traj_ref):
@@ -340,8 +346,10 @@ def test_fp32_twelve_layers_real_width_matches_reference_classes(depth12):
 
 
 # bf16 at depth 12 against the reference under autocast: DEPTH12_X times the reference's own bf16-vs-fp32 distance, with floors
-DEPTH12_X = 2.0
-DEPTH12_FLOOR = {"loss": 5e-4, "cognition": 1e-2, "gnorm": 1.5e-3, "gsamp": 3e-2}
+# observed (round 5): loss 1.3e-4 (gap 1.5e-4), cognition 1.36e-2 (4.6e-3: max-norm over 3584 features after 12 layers, 3.5 bf16
+# ulps of the largest), gradient norms 6e-5 .. 1.34e-3, gradient samples 1.0e-2 .. 2.3e-2 (gaps 6e-3 .. 1.6e-2)
+DEPTH12_X = 1.75
+DEPTH12_FLOOR = {"loss": 5e-4, "cognition": 2e-2, "gnorm": 2e-3, "gsamp": 3e-2}
 
 
 def test_bf16_twelve_layers_real_width_tracks_reference_under_autocast(depth12):

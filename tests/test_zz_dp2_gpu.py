@@ -161,8 +161,9 @@ def test_two_rank_model_step_equals_single_process_on_the_concatenated_batch(tmp
         # parameters after three AdamW steps of lr 1e-5: an entry whose gradient is rounding noise (mathematically zero: k_proj
         # biases — softmax shift invariance —, or simply below 2e-6 of its tensor's largest) moves by lr in either direction in
         # EITHER run: at most 2 lr apart per step, and few of them
+        # (observed, round 5: loss 1.2e-7, norm 6.5e-8, parameters 8.3e-7 apart at most, no entry more than lr / 10 apart)
         assert dp.max() <= STEPS * 2 * LR * 1.05, (tag, float(dp.max()))
-        assert apart < 2e-3, (tag, apart)
+        assert apart < 1e-4, (tag, apart)
         assert len(set(r[0]["coll"].tolist())) == 1, tag        # the same number of collectives every step
     # accumulation: two micro-batches per optimizer step exchange ONCE — as many collectives as the one-pass step
     c = {v: np.load(tmp_path / f"v{vi}_rank0.npz")["coll"][0] for vi, v in enumerate(VARIANTS)}
