@@ -260,6 +260,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_flash_k(const AttnP p) {
   const int b = p.nsplit > 1 ? bz / p.nsplit : bz;             // key-range splits: (batch, range) on grid z
   const int sp = bz - b * p.nsplit;
   const int hk = h / (p.Hq / p.Hkv);
+  // (heaviest causal query tile first measured 1 % SLOWER here — thousands of short workgroups balance themselves:
+  //  profiles/r05_attn_order.txt; the dK/dV kernel's grid order is what matters)
   const int q0 = blockIdx.x * (16 * NW);
   const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
@@ -822,9 +824,18 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, lg = lane >> 4;
   const FragAddr<D> fa(l16, lg);
+  // grid (kv head, batch, key tile): the key tile is the SLOWEST dimension of the dispatch order.  Under the causal mask key tile 0
+  // is seen by every query tile and the last one by one (G x 5, 4, .. 1 iterations at S = 287): dealt tile-fastest, as until round
+  // 5, a compute unit that drew a light workgroup first got a heavy one behind it (makespan 42 units for 26 of work); heaviest
+  // tiles first, the light ones fill in behind them (35)
+#if defined(DXA_ATTN_OLD_ORDER)        // tuning build: the grid of rounds 1-4 (scripts/build_variant.sh, profiles/r05_attn_order.txt)
   const int b = blockIdx.z, hk = blockIdx.y;
-  const int G = p.Hq / p.Hkv;
   const int key0 = blockIdx.x * 64;
+#else
+  const int b = blockIdx.y, hk = blockIdx.x;
+  const int key0 = blockIdx.z * 64;
+#endif
+  const int G = p.Hq / p.Hkv;
   const int key = key0 + wave * 16 + l16;
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
@@ -1194,7 +1205,11 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     const int64_t wgs8 = (int64_t)((d->Sq + 127) / 128) * d->Hq * d->B;
     const int nwq = nwq_env ? nwq_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
     dim3 gq((unsigned)((d->Sq + 16 * nwq - 1) / (16 * nwq)), (unsigned)d->Hq, (unsigned)d->B);
+#if defined(DXA_ATTN_OLD_ORDER)
     dim3 gk((unsigned)((d->Sk + 63) / 64), (unsigned)d->Hkv, (unsigned)d->B);
+#else
+    dim3 gk((unsigned)d->Hkv, (unsigned)d->B, (unsigned)((d->Sk + 63) / 64));
+#endif
 #define LAUNCH_BWD(D_, DV_)                                                                                      \
   do {                                                                                                            \
     constexpr int lds_ = 2 * FlashTile<D_>::RM_BYTES + 3 * 64 * (int)sizeof(float);                               \

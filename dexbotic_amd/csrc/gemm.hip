@@ -24,10 +24,6 @@
 #include <mutex>
 #include <utility>
 
-namespace dxa_gemm_detail {
-int gemm_w4_launch(const GemmP& p, int layout, bool out_f32, bool epi_f32, hipStream_t st);   // gemm_w4.hip
-}
-
 namespace {
 
 // (typedefs, GemmP, load4 / store4 / epilogue4, the split-K hand-off, tile_finish and sk_epilogue live in gemm_common.h)
@@ -2081,15 +2077,6 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   } while (0)
     if (lean) { p.mirror = (char*)d->mirror; *mirrored = d->mirror != nullptr; }
     if (lean) { p.sumsq = d->sumsq; *summed = d->sumsq != nullptr; }
-    // ---- 4-wave kernel (gemm_w4.hip): 128 x 128 per wave, register-staged feed; same tiles, tail split and lean epilogue.
-    //      K-strided operands are read two K tiles past the end (range-checked): keep that inside 32-bit offsets.
-    const char* w4_env = getenv("DXA_GEMM_W4");          // read per call while the kernel is being tuned (scripts/w4_check.py)
-    const int w4_mode = w4_env ? atoi(w4_env) : 0;
-    if (w4_mode && pp && lean && d->K2 == 0 && bytesA + 128 * d->lda * 2 < (1ll << 31) && bytesB + 128 * d->ldb * 2 < (1ll << 31)) {
-      if (int rc = dxa_gemm_detail::gemm_w4_launch(p, d->layout, d->out_dtype == DXA_F32, d->epi_f32 != 0, st)) return rc;
-      DXA_CHECK_LAUNCH();
-      return DXA_OK;
-    }
     if (d->layout == DXA_NN) {          // dX = dY W: bf16 out (lean, or with the activation-gradient epilogue), fp32 out lean
       if (d->out_dtype == DXA_BF16) { if (lean) LAUNCH_PP(bf16_t, bf16_t, true, false, true); else LAUNCH_PP(bf16_t, bf16_t, false, false, true); }
       else LAUNCH_PP(float, bf16_t, true, false, true);

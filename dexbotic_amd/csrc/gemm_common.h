@@ -1,5 +1,5 @@
-// Device-side pieces shared by the GEMM translation units (gemm.hip: generic / few-row / ring / ping-pong kernels and the
-// dispatch; gemm_w4.hip: the 4-wave 128x128-per-wave kernel): the launch parameter block, the epilogue building blocks
+// Device-side pieces of the GEMM translation unit (gemm.hip: generic / few-row / ring / ping-pong kernels and the dispatch; also
+// included by the round-4 experiment scripts/probes/gemm_w4.hip): the launch parameter block, the epilogue building blocks
 // and the split-K hand-off.  Everything except GemmP has internal linkage (one copy per translation unit).
 #pragma once
 #include "common.h"

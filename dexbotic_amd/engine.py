@@ -809,6 +809,7 @@ class GradNormTracker:
         self._lo: Optional[int] = None
         self._hi: Optional[int] = None
         self._range_cache: Dict[tuple, tuple] = {}
+        self._small: List[Tuple[int, int]] = []      # short uncovered slices of this step, summed in finish()
 
     BIG = 1 << 20     # uncovered slices at least this long get the two-stage pass of their own, shorter ones share a launch
     CHUNK = 1 << 13   # ... cut into chunks of this many elements, one workgroup each
@@ -816,6 +817,7 @@ class GradNormTracker:
     def begin(self) -> None:
         self.acc.zero_()                       # on the compute stream; every fold waits for that stream first
         self._lo = self._hi = None
+        self._small = []
 
     def fold(self, lo: int, hi: int, after=None) -> None:
         """acc += sum(grad[lo:hi]^2) on the tracker's side stream, ordered after everything enqueued so far on ``after``
@@ -833,22 +835,32 @@ class GradNormTracker:
             if not self.store.epi_sumsq:
                 K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
                 return
-            # the dW products already left their share in the store's partial buffer: read back only what they do not cover
-            small = []
+            # the dW products already left their share in the store's partial buffer: read back only what they do not cover.
+            # Short slices (norm weights, biases, position embeddings: kilobytes each) are only NOTED here and summed by ONE launch
+            # in finish() — round 4 launched a pair of kernels per bucket for them (69 + 35 launches per step)
             for a, b in self.store.uncovered_ranges(lo, hi):
                 if b - a >= self.BIG:
                     K.sumsq(src[a:b], self.acc, self.scratch, accumulate=True)
                 else:
                     for c in range(a, b, self.CHUNK):                   # one workgroup per chunk
-                        small.append((c, min(self.CHUNK, b - c)))
-            for i in range(0, len(small), 4096):
-                chunk = tuple(small[i:i + 4096])
-                dev = self._range_cache.get(chunk)
-                if dev is None:
-                    dev = (torch.tensor([c[0] for c in chunk], dtype=torch.int64, device=src.device),
-                           torch.tensor([c[1] for c in chunk], dtype=torch.int64, device=src.device))
-                    self._range_cache[chunk] = dev
-                K.sumsq_ranges(src, dev[0], dev[1], self.acc, self.scratch, accumulate=True)
+                        self._small.append((c, min(self.CHUNK, b - c)))
+
+    def _fold_small(self) -> None:
+        """the short slices noted by fold(), one launch per 4096 of them (on the tracker's stream; every slice is final: the
+        caller has joined the gradient side stream)"""
+        from . import kernels as K
+        if not self._small:
+            return
+        src = self.store.grad if self.src is None else self.src
+        small, self._small = self._small, []
+        for i in range(0, len(small), 4096):
+            chunk = tuple(small[i:i + 4096])
+            dev = self._range_cache.get(chunk)
+            if dev is None:
+                dev = (torch.tensor([c[0] for c in chunk], dtype=torch.int64, device=src.device),
+                       torch.tensor([c[1] for c in chunk], dtype=torch.int64, device=src.device))
+                self._range_cache[chunk] = dev
+            K.sumsq_ranges(src, dev[0], dev[1], self.acc, self.scratch, accumulate=True)
 
     def bucket_ready(self, b: int) -> None:
         lo, hi = self.store.bucket_ranges[b]
@@ -880,12 +892,16 @@ class GradNormTracker:
             self._lo = self._hi = None
         if self.stream is not None:
             part = st.sumsq_partials() if st.epi_sumsq else None
-            if part is not None:
+            if part is not None or self._small:
                 from . import kernels as K
-                self.stream.wait_stream(torch.cuda.current_stream())        # the last products' epilogues
+                self.stream.wait_stream(torch.cuda.current_stream())        # the last products' epilogues, the last short slices
                 with torch.cuda.stream(self.stream):
-                    K.sum_f32(part, self.acc, accumulate=True)
+                    self._fold_small()
+                    if part is not None:
+                        K.sum_f32(part, self.acc, accumulate=True)
             torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            self._fold_small()
         return self.acc
 
 

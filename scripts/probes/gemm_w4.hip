@@ -1,3 +1,7 @@
+// ROUND-4 EXPERIMENT, NOT PART OF THE PRODUCT (moved out of dexbotic_amd/csrc in round 5).  A 4-wave 128x128-per-wave kernel, parity-green
+// and bit-identical to the ping-pong kernel, that lost its A/B on every layout (3-8 % slower: profiles/r04_w4_*.txt; MFMA busy 0.663
+// against 0.718 — one wave per SIMD pays the full issue cost of its own LDS-DMA instructions).  To run it again: copy it back next to
+// gemm.hip, add it to dexbotic_amd/build.py SOURCES and restore the DXA_GEMM_W4 hook in gemm_dispatch (git history, round 4).
 // bf16 "w4" GEMM kernel for gfx950: 256x256 tile, K tile 64, FOUR waves (2 x 2), each wave owns 128 x 128 of the tile.
 //
 // Why a second large-tile kernel.  The 8-wave ping-pong kernel (gemm.hip, gemm_pp_kernel) feeds LDS
