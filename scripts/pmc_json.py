@@ -22,7 +22,13 @@ def parse(path):
 def main(d):
     fetch, write, sq = parse(f"{d}/fetch.txt"), parse(f"{d}/write.txt"), parse(f"{d}/sq.txt")
     lean = [k for (k, c) in fetch if re.match(r"gemm_pp_kernel<[^,]+, unsigned short, true", k) and c == "FETCH_SIZE"]
-    out = {"source": "rocprofv3 --pmc, separate passes (--kernel-trace only), scripts/pmc_passes.sh around: python bench.py --steps 2 "
+    commit = None
+    try:
+        import os
+        commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".commit_stamp")).read().strip() or None
+    except OSError:
+        pass
+    out = {"collected_on_commit": commit, "source": "rocprofv3 --pmc, separate passes (--kernel-trace only), scripts/pmc_passes.sh around: python bench.py --steps 2 "
                      "--warmup 1 --no-cpu-baseline --no-latency --no-secondary --no-recipe (the code of the round named in the file name)",
            "kernel": "gemm_pp_kernel (bf16 in; the lean NT / NN / TN instantiations)",
            "correction": "FETCH_SIZE x2 on gfx950 (guide; own calibration x1.91 in round 2); WRITE_SIZE exact; unit 1024 B",

@@ -213,7 +213,7 @@ def test_whole_sampler_in_one_launch_equals_the_per_step_sampler(golden_dir, dty
         assert m.model.action_head.net.used_fused
         # operand rounding over 10 steps x 3 blocks of this toy head, whose random weights amplify it (measured 3.2e-2 of the largest
         # de-normalised action; a DiT-B-size random head: 2.6e-3, bounded in tests/test_kernels_gpu.py::test_dit_sample_bf16_operands)
-        assert rel_err(got[0], exact) < 6e-2, rel_err(got[0], exact)
+        assert rel_err(got[0], exact) < 5e-2, rel_err(got[0], exact)          # (1.5 x the 3.2e-2 measured)
     monkeypatch.setenv("DXA_DIT_SAMPLER", "0")
     want = np.asarray(m.inference_action(ids, img, args, noise=noise))
     assert rel_err(exact, want) < 2e-4, rel_err(exact, want)
