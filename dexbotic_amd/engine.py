@@ -68,6 +68,9 @@ class Slot:
     bucket: int = 0
 
 
+_HOOK_JOINS = __import__('os').environ.get('DXA_JOIN_AT_BUCKET', '0') != '1'     # 1: rounds-4 behaviour (A/B)
+
+
 class ParamStore:
     """Owns the arenas.  ``specs``: ordered list of groups; a group is a list of (name, shape) packed
     contiguously; ``bucket`` ids follow registration order (= forward order) and are the unit of the
@@ -296,8 +299,19 @@ class ParamStore:
                 self._bucket_pending[b] -= 1
                 if self._bucket_pending[b] == 0 and self.on_bucket_ready is not None and not self._bucket_fired[b]:
                     self._bucket_fired[b] = True
-                    self.join_wgrad()               # the bucket's dW products may still be in flight on the side stream
+                    # the bucket's dW products / bias sums may still be in flight on the side stream.  A hook that runs on a
+                    # stream of its own (the norm tracker, the reducer) orders THAT stream behind the side stream
+                    # (wait_side); anything else makes the compute stream wait here — which stalls the dX chain for a bias
+                    # column sum that nothing downstream of it needs (18 us per decoder layer, profiles/r05_step_timeline.txt)
+                    if not (_HOOK_JOINS and getattr(getattr(self.on_bucket_ready, "__self__", None), "joins_side", False)):
+                        self.join_wgrad()
                     self.on_bucket_ready(b)
+
+    def wait_side(self, stream) -> None:
+        """``stream`` (a hook's own: norm tracker, communication) waits for the gradient work enqueued on the side stream so
+        far; the pending flag stays up — the compute stream itself joins at the end of the backward (join_wgrad)"""
+        if self._wgrad_pending and self.wgrad_stream is not None and stream is not None:
+            stream.wait_stream(self.wgrad_stream)
 
     def join_wgrad(self) -> None:
         """the current stream waits for the weight-gradient products enqueued on the side stream so far"""
@@ -806,6 +820,7 @@ class GradNormTracker:
         self.acc = torch.zeros(1, device=dev, dtype=torch.float32)
         self.scratch = torch.empty(4096, device=dev, dtype=torch.float64)
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.joins_side = self.stream is not None    # bucket_ready orders its own stream behind the gradient side stream
         self._lo: Optional[int] = None
         self._hi: Optional[int] = None
         self._range_cache: Dict[tuple, tuple] = {}
@@ -831,6 +846,7 @@ class GradNormTracker:
             K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
             return
         self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
+        self.store.wait_side(self.stream)
         with torch.cuda.stream(self.stream):
             if not self.store.epi_sumsq:
                 K.sumsq(src[lo:hi], self.acc, self.scratch, accumulate=True)
@@ -971,6 +987,7 @@ class GradReducer:
         self.min_bucket_bytes = min_bucket_bytes
         self.skip_buckets = set()
         self.comm_stream = torch.cuda.Stream(device=store.device) if store.device.type == "cuda" else None
+        self.joins_side = self.comm_stream is not None   # _flush orders the communication stream behind the gradient side stream
         self._pending_lo: Optional[int] = None
         self._pending_hi: Optional[int] = None
         self.after_reduce = None    # callable(lo, hi, comm_stream): called once a slice's exchange is enqueued
@@ -1114,6 +1131,7 @@ class GradReducer:
             self.bytes_reduced += buf.numel() * (2 if half else 4)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            self.store.wait_side(self.comm_stream)
             with torch.cuda.stream(self.comm_stream):
                 if self.time_comm and self._t0 is None:
                     self._t0 = torch.cuda.Event(enable_timing=True)
