@@ -681,6 +681,170 @@ __device__ __forceinline__ uint4 lds_frag_col(const char* p) {
   return make_uint4(u1.x, u1.y, u2.x, u2.y);
 }
 
+// The flash forward on the BACKWARD's tile machinery (round 5).  attn_fwd_flash_k above transposes every V tile through registers
+// (8-byte global loads of 8 different rows per lane, ~100 shift / mask operations per thread and tile) and addresses its K
+// fragments through an XOR that the compiler cannot fold into immediates; at head_dim 256 that is 256 registers + 24 spilled,
+// and the scratch reloads wait on the same counter as the next tile's prefetch.  The dQ kernel below does MORE matrix work per
+// tile (S, dP, dQ: 96 MFMAs against this kernel's 64) in less time, because its tiles are staged row-major as they lie in HBM
+// (16-byte loads, no shuffling) and the transposed operand comes out of LDS with ds_read_b64_tr_b16.  Same structure here:
+// S^T = K Q^T from row fragments of K, O^T += V^T P^T from COLUMN fragments of the row-major V tile; prologue, masks, online
+// softmax, key-range splits and epilogue are attn_fwd_flash_k's, statement for statement.
+template <int D, int NW, int DV = D>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_tr_k(const AttnP p) {
+  static_assert(DV % 8 == 0 && DV <= D && DV > D / 2, "valid head width: a multiple of 8 in (D/2, D]");
+  constexpr int DSN = (DV + 31) / 32;   // k-steps of 32 that hold real columns
+  constexpr int DIN = (DV + 15) / 16;   // 16-column output blocks that hold real columns
+  constexpr int NT = 64 * NW;
+  using FT = FlashTile<D, NT>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * FT::RM_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + FT::RM_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const FragAddr<D> fa(l16, lg);
+  const int bz = blockIdx.z, h = blockIdx.y;
+  const int b = p.nsplit > 1 ? bz / p.nsplit : bz;             // key-range splits: (batch, range) on grid z
+  const int sp = bz - b * p.nsplit;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int q0 = blockIdx.x * (16 * NW);
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
+
+  // Q fragments: MFMA second operand, lane (q = l16, k-group lg) holds d = 32*ds + 8*lg .. +7
+  const int qi = q0 + wave * 16 + l16;
+  uint4 qf[DSN];
+#pragma unroll
+  for (int ds = 0; ds < DSN; ++ds) {
+    qf[ds] = make_uint4(0, 0, 0, 0);
+    if (qi < p.Sq && 32 * ds + 8 * lg < DV) qf[ds] = *reinterpret_cast<const uint4*>(qb + (int64_t)qi * p.q_ss + 32 * ds + 8 * lg);
+  }
+  f32x4_t oacc[DIN];
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) oacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc2 = p.scale * LOG2E;   // softmax in base 2: exp(x) = 2^(x log2 e), one v_exp_f32 per score
+
+  int j_lo = p.kv_start ? p.kv_start[b] : 0;
+  int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
+  j_lo = max(j_lo, 0);
+  j_hi = min(j_hi, p.Sk);
+  if (p.nsplit > 1) {
+    j_lo = max(j_lo, sp * p.split_len);
+    j_hi = min(j_hi, (sp + 1) * p.split_len);
+  }
+  const int coff = p.Sk - p.Sq;
+  int blk_hi = j_hi;  // exclusive key bound for the whole workgroup
+  if (p.causal) blk_hi = min(blk_hi, min(q0 + 16 * NW - 1, p.Sq - 1) + coff + 1);
+  int my_hi = p.causal ? min(j_hi, qi + coff + 1) : j_hi;  // exclusive bound for this lane's query
+  if (p.q_limit) my_hi = min(my_hi, qi < p.Sq ? p.q_limit[(int64_t)b * p.Sq + qi] : 0);   // block-prefix mask (pi0)
+  const uint8_t* kvld = p.key_valid ? p.key_valid + (int64_t)b * p.Sk : nullptr;
+  const int t_lo = j_lo / 64, t_hi = (blk_hi + 63) / 64;
+
+  tile_reg_t rk[FT::NPASS], rv[FT::NPASS];
+  if (t_lo < t_hi) {
+    tile_gload<D, NT, DV>(rk, kb, p.k_ss, t_lo * 64, p.Sk, tid);
+    tile_gload<D, NT, DV>(rv, vb, p.v_ss, t_lo * 64, p.Sk, tid);
+  }
+  for (int kt = t_lo; kt < t_hi; ++kt) {
+    const int key0 = kt * 64;
+    __syncthreads();                       // previous tile fully consumed
+    tile_sstore<D, NT>(Ks, rk, tid);
+    tile_sstore<D, NT>(Vs, rv, tid);
+    __syncthreads();
+    if (kt + 1 < t_hi) {                   // next tile's loads fly during this tile's MFMAs
+      tile_gload<D, NT, DV>(rk, kb, p.k_ss, key0 + 64, p.Sk, tid);
+      tile_gload<D, NT, DV>(rv, vb, p.v_ss, key0 + 64, p.Sk, tid);
+    }
+    // ---- S^T = K Q^T : sacc[n][r] = score(query l16, key key0 + 16n + 4lg + r)
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      sacc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < DSN; ++ds) {
+        const uint4 kf = lds_frag(Ks + fa.row[ds] + n * 16 * FT::ROW);
+        sacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                          __builtin_bit_cast(bf16x8_t, qf[ds]), sacc[n], 0, 0, 0);
+      }
+    }
+    // ---- online softmax for this lane's query
+    // key validity of the 64 keys of this tile as one 64-bit wave-uniform mask: lane j reads key_valid[key0 + j] (one coalesced
+    // 64-byte access) and the ballot spreads it, instead of 16 scattered byte loads per lane
+    unsigned long long kmask = ~0ull;
+    if (kvld) {
+      const int kj = key0 + lane;
+      kmask = __ballot(kj < p.Sk && kvld[kj] != 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + 16 * n + 4 * lg + r;
+        const bool vis = key >= j_lo && key < my_hi && ((kmask >> (16 * n + 4 * lg + r)) & 1ull);
+        const float s = vis ? sacc[n][r] * sc2 : -INFINITY;          // scores in log2 units
+        sacc[n][r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    float alpha = 1.f;
+    if (m_new > -INFINITY) alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0
+    float psum = 0.f;
+    uint32_t pk[8];  // bf16 pairs: pk[2*kb2 + ...] see below
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[r] = (m_new > -INFINITY) ? __builtin_amdgcn_exp2f(sacc[n][r] - m_new) : 0.f;  // 2^-inf = 0 for masked keys
+        psum += e[r];
+      }
+      pk[2 * n] = pack_bf16(e[0], e[1]);
+      pk[2 * n + 1] = pack_bf16(e[2], e[3]);
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      oacc[i][0] *= alpha; oacc[i][1] *= alpha; oacc[i][2] *= alpha; oacc[i][3] *= alpha;
+    }
+    // ---- O^T += V^T P^T: k-slot (lg, e) of 32-key block kb2 <-> key 32*kb2 + 16*(e>>2) + 4*lg + (e&3), the order in which
+    //      lds_frag_col hands out the tile rows, so that this lane's own packed scores are the other operand
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      const uint4 pf = make_uint4(pk[4 * kb2], pk[4 * kb2 + 1], pk[4 * kb2 + 2], pk[4 * kb2 + 3]);
+#pragma unroll
+      for (int di = 0; di < DIN; ++di) {
+        const uint4 vtf = lds_frag_col<D>(Vs + fa.col[di] + kb2 * 32 * FT::ROW);
+        oacc[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vtf),
+                                                           __builtin_bit_cast(bf16x8_t, pf), oacc[di], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: lane holds O[query l16][d = 16di + 4lg + r]
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (qi < p.Sq) {
+    bf16_t* orow = reinterpret_cast<bf16_t*>(p.o) + bz * p.o_sb + h * p.o_sh + (int64_t)qi * p.o_ss;
+#pragma unroll
+    for (int di = 0; di < DIN; ++di) {
+      uint2 ov;
+      ov.x = pack_bf16(oacc[di][0] * inv, oacc[di][1] * inv);
+      ov.y = pack_bf16(oacc[di][2] * inv, oacc[di][3] * inv);
+      if (di * 16 + 4 * lg < DV) *reinterpret_cast<uint2*>(orow + di * 16 + 4 * lg) = ov;
+    }
+    // (a key range in which this query sees nothing: -inf, so that the fold gives it no weight; unsplit: 0 like the other kernels)
+    if (lg == 0 && p.lse)
+      p.lse[((int64_t)bz * p.Hq + h) * p.Sq + qi] = l_tot > 0.f ? m_run * 0.6931471805599453f + logf(l_tot)
+                                                                : (p.nsplit > 1 ? -INFINITY : 0.f);
+  }
+}
+
+
 struct AttnBwdP {
   AttnP f;                 // forward tensors (o unused here) + lse
   float* delta;            // [B,Hq,Sq] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
@@ -812,11 +976,20 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   }
 }
 
-template <int D, int DV = D>
-__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const AttnBwdP bp) {
+// NW = 8 (head_dim 256, round 5): TWO waves per 16 keys.  Both compute the scores S and dP of their keys against the whole query
+// tile (the contraction over d cannot be cut without a cross-wave sum per tile), each accumulates HALF of the d range of dK / dV:
+// 64 accumulator registers per wave instead of 128, so that the workgroup's 8 waves fit 256 registers each — two waves per SIMD
+// that hide each other's LDS reads and exponentials — and the next Q / dO tile's global loads (16 registers per tile at 512
+// threads) fit in front of this tile's MFMAs again (PF).  Price: S and dP are computed twice (96 MFMAs per wave and tile instead
+// of 128, on twice the waves).  With NW = 4 at head_dim 256 the 424 registers of a wave leave one wave per SIMD.
+template <int D, int DV = D, int NW = 4, bool PF = (D <= 128)>
+__global__ __launch_bounds__(64 * NW, (D <= 128 && NW == 4 ? 2 : 1)) void attn_bwd_dkv_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
   constexpr int DSN = (DV + 31) / 32, DIN = (DV + 15) / 16;     // k-steps / output blocks with real columns (attn_fwd_flash_k)
-  using FT = FlashTile<D>;
+  constexpr int NT = 64 * NW, HS = NW / 4;                      // threads; waves that share 16 keys (each owns DIN / HS blocks of d)
+  static_assert((NW == 4 || NW == 8) && DIN % HS == 0, "4 waves, or 8 with the d range of dK / dV cut in two");
+  constexpr int DIW = DIN / HS;
+  using FT = FlashTile<D, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 tiles + 3 x 64 floats (65 KiB at D = 256)
   char* Qs = smem;
   char* Os = smem + FT::RM_BYTES;
@@ -836,7 +1009,11 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
   const int key0 = blockIdx.z * 64;
 #endif
   const int G = p.Hq / p.Hkv;
-  const int key = key0 + wave * 16 + l16;
+  const int key = key0 + (HS == 1 ? wave : (wave & 3)) * 16 + l16;
+  const int di0 = HS == 1 ? 0 : (wave >> 2) * DIW;              // first 16-column block of dK / dV this wave accumulates
+  uint32_t colw[DIW];                                           // fa.col of the wave's own blocks (static indices in the loops)
+#pragma unroll
+  for (int i = 0; i < DIW; ++i) colw[i] = (HS == 2 && (wave >> 2)) ? fa.col[(DIN - DIW) + i] : fa.col[i];
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_sb + hk * p.k_sh;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
   uint4 kf[DSN], vf[DSN];
@@ -848,9 +1025,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
       vf[ds] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * p.v_ss + 32 * ds + 8 * lg);
     }
   }
-  f32x4_t dka[DIN], dva[DIN];
+  f32x4_t dka[DIW], dva[DIW];
 #pragma unroll
-  for (int i = 0; i < DIN; ++i) { dka[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dva[i] = dka[i]; }
+  for (int i = 0; i < DIW; ++i) { dka[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dva[i] = dka[i]; }
   int j_lo = p.kv_start ? p.kv_start[b] : 0;
   int j_hi = p.kv_end ? p.kv_end[b] : p.Sk;
   j_lo = max(j_lo, 0);
@@ -870,8 +1047,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
     const int h = hk * G + it / nqt, q0 = (qt_lo + it % nqt) * 64;
     const bf16_t* qb = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_sb + h * p.q_sh;
     const bf16_t* dob = reinterpret_cast<const bf16_t*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
-    tile_gload<D, 256, DV>(rq, qb, p.q_ss, q0, p.Sq, tid);
-    tile_gload<D, 256, DV>(ro, dob, bp.do_ss, q0, p.Sq, tid);
+    tile_gload<D, NT, DV>(rq, qb, p.q_ss, q0, p.Sq, tid);
+    tile_gload<D, NT, DV>(ro, dob, bp.do_ss, q0, p.Sq, tid);
     if (tid < 128) {
       const int q = q0 + (tid & 63);
       const float* src = (tid < 64 ? p.lse : bp.delta) + ((int64_t)b * p.Hq + h) * p.Sq;
@@ -882,14 +1059,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
       rs = (p.q_limit && q < p.Sq) ? (float)p.q_limit[(int64_t)b * p.Sq + q] : 3.0e9f;
     }
   };
-  constexpr bool PREFETCH = D <= 128;     // at D = 256 the accumulators leave no room for a second tile in registers
+  constexpr bool PREFETCH = PF;           // 4 waves at D = 256: the accumulators leave no room for a second tile in registers
   if (PREFETCH && total > 0) gload(0);
   for (int it = 0; it < total; ++it) {
     const int q0 = (qt_lo + it % nqt) * 64;
     __syncthreads();                       // previous tile fully consumed
     if (!PREFETCH) gload(it);
-    tile_sstore<D>(Qs, rq, tid);
-    tile_sstore<D>(Os, ro, tid);
+    tile_sstore<D, NT>(Qs, rq, tid);
+    tile_sstore<D, NT>(Os, ro, tid);
     if (tid < 192) stat[tid >> 6][tid & 63] = rs;
     __syncthreads();
     if (PREFETCH && it + 1 < total) gload(it + 1);     // next tile's loads fly during this tile's MFMAs
@@ -929,9 +1106,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
       const uint4 pf = make_uint4(pp[4 * kb2], pp[4 * kb2 + 1], pp[4 * kb2 + 2], pp[4 * kb2 + 3]);
       const uint4 dsf = make_uint4(dsp[4 * kb2], dsp[4 * kb2 + 1], dsp[4 * kb2 + 2], dsp[4 * kb2 + 3]);
 #pragma unroll
-      for (int di = 0; di < DIN; ++di) {
-        const uint4 otf = lds_frag_col<D>(Os + fa.col[di] + kb2 * 32 * FT::ROW);
-        const uint4 qtf = lds_frag_col<D>(Qs + fa.col[di] + kb2 * 32 * FT::ROW);
+      for (int di = 0; di < DIW; ++di) {
+        const uint4 otf = lds_frag_col<D>(Os + colw[di] + kb2 * 32 * FT::ROW);
+        const uint4 qtf = lds_frag_col<D>(Qs + colw[di] + kb2 * 32 * FT::ROW);
         dva[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, otf), __builtin_bit_cast(bf16x8_t, pf), dva[di], 0, 0, 0);
         dka[di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qtf), __builtin_bit_cast(bf16x8_t, dsf), dka[di], 0, 0, 0);
       }
@@ -941,13 +1118,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_bwd_dkv_k(const 
     bf16_t* krow = reinterpret_cast<bf16_t*>(bp.dk) + b * bp.dk_sb + hk * bp.dk_sh + (int64_t)key * bp.dk_ss;
     bf16_t* vrow = reinterpret_cast<bf16_t*>(bp.dv) + b * bp.dv_sb + hk * bp.dv_sh + (int64_t)key * bp.dv_ss;
 #pragma unroll
-    for (int di = 0; di < DIN; ++di) {
+    for (int i = 0; i < DIW; ++i) {
+      const int dc = (di0 + i) * 16 + 4 * lg;
       uint2 ok, ov;
-      ok.x = pack_bf16(dka[di][0], dka[di][1]); ok.y = pack_bf16(dka[di][2], dka[di][3]);
-      ov.x = pack_bf16(dva[di][0], dva[di][1]); ov.y = pack_bf16(dva[di][2], dva[di][3]);
-      if (di * 16 + 4 * lg < DV) {
-        *reinterpret_cast<uint2*>(krow + di * 16 + 4 * lg) = ok;
-        *reinterpret_cast<uint2*>(vrow + di * 16 + 4 * lg) = ov;
+      ok.x = pack_bf16(dka[i][0], dka[i][1]); ok.y = pack_bf16(dka[i][2], dka[i][3]);
+      ov.x = pack_bf16(dva[i][0], dva[i][1]); ov.y = pack_bf16(dva[i][2], dva[i][3]);
+      if (dc < DV) {
+        *reinterpret_cast<uint2*>(krow + dc) = ok;
+        *reinterpret_cast<uint2*>(vrow + dc) = ov;
       }
     }
   }
@@ -992,6 +1170,14 @@ static bool fwd_flash_ok(const dxa_attn_desc* d) {
                         d->v_sh % 4 == 0 && d->o_ss % 4 == 0 && d->o_sb % 4 == 0 && d->o_sh % 4 == 0;
   return !d->force_generic && !d->drop_mask && d->dtype == DXA_BF16 && flash_head_dim(d->D) && strides8 &&
          al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
+}
+
+// the forward on row-major V tiles (attn_fwd_tr_k: the default since round 5, same results bit for bit — profiles/r05_attn_variants.txt:
+// head_dim 256 344 -> 198 us, 128 65 -> 52, 64 37.5 -> 27.7) loads V rows 16 bytes at a time; a V that is only 8-byte aligned
+// stays on attn_fwd_flash_k (DXA_ATTN_FWD_TR=0 sends everything there: A/B and the fallback's tests)
+static bool fwd_tr_ok(const dxa_attn_desc* d) {
+  static const int on = getenv("DXA_ATTN_FWD_TR") ? atoi(getenv("DXA_ATTN_FWD_TR")) : 1;
+  return on && d->v_ss % 8 == 0 && d->v_sb % 8 == 0 && d->v_sh % 8 == 0 && al(d->v, 16);
 }
 
 // fp32 head-sized attention (attn_fwd_small_f32_k): the [16][Sk] score slab of a workgroup has to fit the LDS
@@ -1056,7 +1242,11 @@ extern "C" int dxa_attn_fwd_ws(const dxa_attn_desc* d, void* workspace, size_t w
     p.o = (char*)op; p.o_sb = (int64_t)d->Hq * d->Sq * d->D; p.o_sh = (int64_t)d->Sq * d->D; p.o_ss = d->D;
     p.lse = lp;
     dim3 grid((unsigned)((d->Sq + 63) / 64), (unsigned)d->Hq, (unsigned)(d->B * ns));
-    if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 4>), grid, dim3(256), 0, st, p);
+    if (fwd_tr_ok(d)) {
+      if (d->D == 256) hipLaunchKernelGGL((attn_fwd_tr_k<256, 4>), grid, dim3(256), 0, st, p);
+      else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_tr_k<128, 4>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd_tr_k<64, 4>), grid, dim3(256), 0, st, p);
+    } else if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 4>), grid, dim3(256), 0, st, p);
     else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 4>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_fwd_flash_k<64, 4>), grid, dim3(256), 0, st, p);
     dim3 cgrid((unsigned)(((int64_t)d->B * d->Hq * d->Sq + 3) / 4));
@@ -1114,7 +1304,16 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
     const int64_t wgs8 = (int64_t)((d->Sq + 127) / 128) * d->Hq * d->B;
     const int nw = nw_env ? nw_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
     dim3 grid((unsigned)((d->Sq + 16 * nw - 1) / (16 * nw)), (unsigned)d->Hq, (unsigned)d->B);
-    if (nw == 8) {
+    if (fwd_tr_ok(d)) {
+#define LAUNCH_TR(D_, DV_)                                                                            \
+  do {                                                                                                 \
+    if (nw == 8) hipLaunchKernelGGL((attn_fwd_tr_k<D_, 8, DV_>), grid, dim3(512), 0, st, p);           \
+    else hipLaunchKernelGGL((attn_fwd_tr_k<D_, 4, DV_>), grid, dim3(256), 0, st, p);                   \
+  } while (0)
+      if (d->D == 256) LAUNCH_TR(256, 256); else if (d->D == 128) LAUNCH_TR(128, 128);
+      else if (d->D == 72) LAUNCH_TR(128, 72); else LAUNCH_TR(64, 64);
+#undef LAUNCH_TR
+    } else if (nw == 8) {
       if (d->D == 256) hipLaunchKernelGGL((attn_fwd_flash_k<256, 8>), grid, dim3(512), 0, st, p);
       else if (d->D == 128) hipLaunchKernelGGL((attn_fwd_flash_k<128, 8>), grid, dim3(512), 0, st, p);
       else if (d->D == 72) hipLaunchKernelGGL((attn_fwd_flash_k<128, 8, 72>), grid, dim3(512), 0, st, p);
@@ -1210,22 +1409,44 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
 #else
     dim3 gk((unsigned)d->Hkv, (unsigned)d->B, (unsigned)((d->Sk + 63) / 64));
 #endif
-#define LAUNCH_BWD(D_, DV_)                                                                                      \
+    // head_dim 256, dK / dV: 0 = 4 waves, no register prefetch (rounds 2-4); 1 = 4 waves + prefetch (416 registers); 2 = 8 waves,
+    // the d range of dK / dV cut over wave pairs, + prefetch (256 registers, 7 spilled); 3 = 8 waves without the prefetch (248
+    // registers): dQ + dK/dV at B 16 x 8 heads x 816 keys 735 / 753 / 714 / 685 us (profiles/r05_attn_variants.txt; same results
+    // bit for bit) -> 3
+    static const int dkv256 = getenv("DXA_ATTN_DKV256") ? atoi(getenv("DXA_ATTN_DKV256")) : 3;
+#define LAUNCH_DKV(D_, DV_, NW_, PF_)                                                                             \
   do {                                                                                                            \
     constexpr int lds_ = 2 * FlashTile<D_>::RM_BYTES + 3 * 64 * (int)sizeof(float);                               \
     static bool attr_ = false;                                                                                    \
     if (!attr_ && lds_ > 48 * 1024) {                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k<D_, DV_>),                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k<D_, DV_, NW_, PF_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                \
       attr_ = true;                                                                                               \
     }                                                                                                             \
+    hipLaunchKernelGGL((attn_bwd_dkv_k<D_, DV_, NW_, PF_>), gk, dim3(64 * NW_), lds_, st, bp);                    \
+  } while (0)
+#define LAUNCH_BWD(D_, DV_)                                                                                      \
+  do {                                                                                                            \
     if (nwq == 8) hipLaunchKernelGGL((attn_bwd_dq_k<D_, 8, DV_>), gq, dim3(512), 0, st, bp);                      \
     else hipLaunchKernelGGL((attn_bwd_dq_k<D_, 4, DV_>), gq, dim3(256), 0, st, bp);                               \
-    hipLaunchKernelGGL((attn_bwd_dkv_k<D_, DV_>), gk, dim3(256), lds_, st, bp);                                   \
   } while (0)
-    if (d->D == 256) LAUNCH_BWD(256, 256); else if (d->D == 128) LAUNCH_BWD(128, 128);
-    else if (d->D == 72) LAUNCH_BWD(128, 72); else LAUNCH_BWD(64, 64);
+    if (d->D == 256) {
+      LAUNCH_BWD(256, 256);
+      if (dkv256 == 2) LAUNCH_DKV(256, 256, 8, true);
+      else if (dkv256 == 3) LAUNCH_DKV(256, 256, 8, false);
+      else if (dkv256 == 1) LAUNCH_DKV(256, 256, 4, true);
+      else LAUNCH_DKV(256, 256, 4, false);
+    } else if (d->D == 128) {
+      // (the 8-wave cut at head_dim 128: 177.5 -> 172.5 us dQ + dK/dV of the decoder layer in isolation — inside the noise of the
+      //  step; the 4-wave kernel stays)
+      static const int dkv128 = getenv("DXA_ATTN_DKV128") ? atoi(getenv("DXA_ATTN_DKV128")) : 0;
+      LAUNCH_BWD(128, 128);
+      if (dkv128 == 2) LAUNCH_DKV(128, 128, 8, true); else LAUNCH_DKV(128, 128, 4, true);
+    }
+    else if (d->D == 72) { LAUNCH_BWD(128, 72); LAUNCH_DKV(128, 72, 4, true); }
+    else { LAUNCH_BWD(64, 64); LAUNCH_DKV(64, 64, 4, true); }
 #undef LAUNCH_BWD
+#undef LAUNCH_DKV
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }

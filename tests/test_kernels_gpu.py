@@ -469,6 +469,30 @@ def test_attention_fwd_bwd(dtype, force_generic, case):
     assert_close(dv, vr.grad, rt, at * 2, "attn dv")
 
 
+@pytest.mark.parametrize("D,Hq,Hkv,S,causal", [(64, 2, 2, 130, False), (128, 4, 2, 150, True), (256, 4, 1, 200, False)])
+def test_attention_forward_two_flash_kernels_agree_bit_for_bit(D, Hq, Hkv, S, causal):
+    """Round 5: the flash forward runs on row-major V tiles + transposing LDS reads (attn_fwd_tr_k, 16-byte V rows); a V that is
+    only 8-byte aligned falls back to the kernel of rounds 1-4 (attn_fwd_flash_k, V transposed through registers).  Both add
+    every output element in the same order: the same numbers, bit for bit, and both within the bf16 bound of the fp64 reference"""
+    B = 2
+    scale = D ** -0.5
+    q, k = rnd(B, Hq, S, D, dtype=torch.bfloat16, seed=70), rnd(B, Hkv, S, D, dtype=torch.bfloat16, seed=71)
+    v = rnd(B, Hkv, S, D, dtype=torch.bfloat16, seed=72)
+    kv_end = torch.tensor([S, S - 9], dtype=torch.int32, device=DEV)
+    o1 = torch.empty_like(q)
+    lse1 = K.attn_fwd(q, k, v, o1, causal=causal, scale=scale, kv_end=kv_end)
+    buf = torch.empty(v.numel() + 4, device=DEV, dtype=torch.bfloat16)
+    v8 = buf[4:].view_as(v)                                   # 8-byte aligned, not 16
+    v8.copy_(v)
+    assert v8.data_ptr() % 16 == 8
+    o2 = torch.empty_like(q)
+    lse2 = K.attn_fwd(q, k, v8, o2, causal=causal, scale=scale, kv_end=kv_end)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    ref_o, ref_lse = _attn_ref(q, k, v, causal, scale, None, kv_end)
+    assert_close(o1, ref_o, 1.0 / 64, 2e-2, "attn o")
+    assert_close(lse1, ref_lse, 1e-2, 3e-2, "attn lse")
+
+
 def test_attention_left_padding_and_flash_vs_generic():
     B, Hq, Hkv, S, D = 2, 4, 4, 200, 64
     q, k, v = (rnd(B, Hq, S, D, dtype=torch.bfloat16, seed=s) for s in (50, 51, 52))
