@@ -1172,6 +1172,17 @@ static bool fwd_flash_ok(const dxa_attn_desc* d) {
          al(d->q, 16) && al(d->k, 16) && al(d->v, 8) && al(d->o, 8) && d->B <= 65535 && d->Hq <= 65535;
 }
 
+// 8-wave workgroups (128 queries share a staged K/V tile) in the forward and dQ kernels: head_dim 256 with at least 256 queries,
+// and head width 72 on the 128-wide tiles (SigLIP: half of every staged tile row is padding, so amortising the staging over twice
+// the queries pays: forward 75.3 -> 58.1 us, dQ + dK/dV 184.8 -> 168.1 at 48 x 16 heads x 256) when the mask is not causal and
+// 128-query tiles waste no more rows than 64-query tiles.  The decoder (head_dim 128, causal, S = 287) and CLIP (64) measured
+// equal or slower with 8 waves (profiles/r05_attn_nw_probe.txt) and stay on 4.
+static bool wide_tiles(const dxa_attn_desc* d) {
+  if (d->D == 256) return d->Sq >= 256;
+  if (d->D == 72) return !d->causal && d->Sq >= 128 && (d->Sq + 127) / 128 * 128 <= (d->Sq + 63) / 64 * 64;
+  return false;
+}
+
 // the forward on row-major V tiles (attn_fwd_tr_k: the default since round 5, same results bit for bit — profiles/r05_attn_variants.txt:
 // head_dim 256 344 -> 198 us, 128 65 -> 52, 64 37.5 -> 27.7) loads V rows 16 bytes at a time; a V that is only 8-byte aligned
 // stays on attn_fwd_flash_k (DXA_ATTN_FWD_TR=0 sends everything there: A/B and the fallback's tests)
@@ -1302,7 +1313,7 @@ extern "C" int dxa_attn_fwd(const dxa_attn_desc* d, dxa_stream_t stream) {
     // 8-wave workgroups (128 queries per staged K/V tile) for head_dim 256 once there are enough queries to fill the chip that way
     static const int nw_env = getenv("DXA_ATTN_FWD_NW") ? atoi(getenv("DXA_ATTN_FWD_NW")) : 0;
     const int64_t wgs8 = (int64_t)((d->Sq + 127) / 128) * d->Hq * d->B;
-    const int nw = nw_env ? nw_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
+    const int nw = nw_env ? nw_env : (wide_tiles(d) && wgs8 >= 256 ? 8 : 4);
     dim3 grid((unsigned)((d->Sq + 16 * nw - 1) / (16 * nw)), (unsigned)d->Hq, (unsigned)d->B);
     if (fwd_tr_ok(d)) {
 #define LAUNCH_TR(D_, DV_)                                                                            \
@@ -1402,7 +1413,7 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
     static const int nwq_env = getenv("DXA_ATTN_DQ_NW") ? atoi(getenv("DXA_ATTN_DQ_NW")) : 0;
     const int64_t wgs8 = (int64_t)((d->Sq + 127) / 128) * d->Hq * d->B;
-    const int nwq = nwq_env ? nwq_env : ((d->D == 256 && d->Sq >= 256 && wgs8 >= 256) ? 8 : 4);
+    const int nwq = nwq_env ? nwq_env : (wide_tiles(d) && wgs8 >= 256 ? 8 : 4);
     dim3 gq((unsigned)((d->Sq + 16 * nwq - 1) / (16 * nwq)), (unsigned)d->Hq, (unsigned)d->B);
 #if defined(DXA_ATTN_OLD_ORDER)
     dim3 gk((unsigned)((d->Sk + 63) / 64), (unsigned)d->Hkv, (unsigned)d->B);
@@ -1437,9 +1448,10 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
       else if (dkv256 == 1) LAUNCH_DKV(256, 256, 4, true);
       else LAUNCH_DKV(256, 256, 4, false);
     } else if (d->D == 128) {
-      // (the 8-wave cut at head_dim 128: 177.5 -> 172.5 us dQ + dK/dV of the decoder layer in isolation — inside the noise of the
-      //  step; the 4-wave kernel stays)
-      static const int dkv128 = getenv("DXA_ATTN_DKV128") ? atoi(getenv("DXA_ATTN_DKV128")) : 0;
+      // the 8-wave cut at head_dim 128 (182 registers without spills against 256 + 2 spilled): dQ + dK/dV of the decoder layer
+      // 177.5 -> 172.5 and 175.2 -> 166.5 us in two sessions, the one-request shape 194.5 -> 186 (profiles/r05_attn_variants.txt,
+      // r05_attn_nw_probe.txt; same results bit for bit); DXA_ATTN_DKV128=0: the 4-wave kernel of rounds 1-4
+      static const int dkv128 = getenv("DXA_ATTN_DKV128") ? atoi(getenv("DXA_ATTN_DKV128")) : 2;
       LAUNCH_BWD(128, 128);
       if (dkv128 == 2) LAUNCH_DKV(128, 128, 8, true); else LAUNCH_DKV(128, 128, 4, true);
     }

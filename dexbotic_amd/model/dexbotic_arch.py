@@ -506,13 +506,16 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         embed = self.store.params[llm.embed_name]
         x = Fn.SpliceFn.apply(feats, embed, self.store, llm.embed_name,
                               torch.from_numpy(plan.plan.reshape(-1)).to(dev)).view(B, S, -1)
+        W_lm, W_emb = self.store.w("lm_head.weight"), self.store.w(llm.embed_name)
+        # (round 5: the decode step captured once into a HIP graph and replayed per token — rotary row, cache slot and key range in
+        #  device tensors — measured SLOWER than this eager loop, 4.84 against 4.48 ms/token at full size: the step is bound by its
+        #  ~340 short kernels on the GPU, not by the host that issues them; profiles/r05_decode_graph.txt.  Not kept.)
         cache = llm.new_cache(B, S + max_new_tokens, dev, x.dtype)
         last = llm.forward_cached(x, cache, pad)[:, -1].contiguous()
-        W_lm, W_emb = self.store.w("lm_head.weight"), self.store.w(llm.embed_name)
         seq = input_ids.to(dev)
         new_tokens, step_logits = [], []
-        for _ in range(max_new_tokens):
-            logits = K.mm_nt(last, W_lm)                                       # [B, V]
+        logits = K.mm_nt(last, W_lm)                                           # [B, V]
+        for t in range(max_new_tokens):
             if do_sample:
                 probs = torch.softmax(logits.float() / max(temperature, 1e-6), dim=-1)
                 nxt = torch.multinomial(probs, 1, generator=generator).view(-1)
@@ -525,9 +528,9 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
             done = eos_token_id is not None and bool((nxt == eos_token_id).all())
             if not done and stopping_criteria:
                 done = any(bool(torch.as_tensor(sc(seq, None)).all()) for sc in stopping_criteria)
-            if done:
+            if done or t + 1 == max_new_tokens:
                 break
-            last = llm.forward_cached(W_emb[nxt].view(B, 1, -1), cache, pad)[:, -1].contiguous()
+            logits = K.mm_nt(llm.forward_cached(W_emb[nxt].view(B, 1, -1), cache, pad)[:, -1].contiguous(), W_lm)
         if return_dict_in_generate:
             return GenerateOutput(sequences=seq, logits=tuple(step_logits) if step_logits else None)
         return seq

@@ -425,6 +425,7 @@ ATTN_CASES = [
     (1, 4, 1, 70, 256, True, False, True),
     (2, 3, 3, 256, 72, False, False, False),   # SigLIP-So400m head width, token-major fused qkv: 72 real columns on 128-wide tiles
     (2, 4, 2, 150, 72, True, True, True),      # ... with GQA, causal and right padding (every mask path at DV < D)
+    (8, 16, 16, 256, 72, False, False, False), # enough 128-query tiles to fill the chip: the 8-wave forward / dQ kernels at DV 72
 ]
 
 
