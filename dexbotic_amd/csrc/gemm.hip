@@ -678,7 +678,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(const GemmP p) {
 // bf16 twin of the skinny kernel (M <= 64): KV-cached decode (M = batch) and other few-row products are a pure
 // stream over the weight matrix.  Same decomposition — 16 output columns per workgroup, 8 waves splitting K in
 // 64-k blocks — with v_mfma_f32_16x16x32_bf16: a lane's 16-byte load IS its MFMA operand (8 consecutive k).
-template <int MB, typename TO>
+template <int MB, typename TO, int U = 2>
 __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
   __shared__ float red[8][MB][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -698,23 +698,40 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_kernel(const GemmP p) {
   for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkb = (int)(p.K / 64);
   const int kb_lo = split_j * nkb / split_s, kb_hi = (split_j + 1) * nkb / split_s;
-#pragma unroll 2
-  for (int kb = kb_lo + wave; kb < kb_hi; kb += 8) {
-    const int k0 = kb * 64;
-    u32x4n_t wv[2];
-    uint4 av[MB][2];
+  // U blocks of 64 k in flight per wave, written out by hand: the compiler REFUSES "#pragma unroll" on this loop (runtime trip
+  // count; -Wpass-failed), so until round 5 a wave had ONE block = 2 KiB of W in flight, and the products with 224 column tiles
+  // (o_proj, down_proj of the decode step: one 8-wave workgroup per CU) 16 KiB per CU against the ~50 KiB that 6 TB/s need.
+  // Blocks past the range are zeros (0 * a adds nothing); the order in which a wave adds its blocks is unchanged.
+  for (int kb = kb_lo + wave; kb < kb_hi; kb += 8 * U) {
+    u32x4n_t wv[U][2];
+    uint4 av[U][MB][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wv[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4n_t*>(W + k0 + 32 * j));
+    for (int u = 0; u < U; ++u) {
+      const int k0 = (kb + 8 * u) * 64;
+      if (kb + 8 * u < kb_hi) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+        for (int j = 0; j < 2; ++j) wv[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4n_t*>(W + k0 + 32 * j));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) av[mb][j] = *reinterpret_cast<const uint4*>(A[mb] + k0 + 32 * j);
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) av[u][mb][j] = *reinterpret_cast<const uint4*>(A[mb] + k0 + 32 * j);
+      } else {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[j]),
-                                                          __builtin_bit_cast(bf16x8_t, av[mb][j]), acc[mb], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          wv[u][j] = (u32x4n_t){0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) av[u][mb][j] = make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u][j]),
+                                                            __builtin_bit_cast(bf16x8_t, av[u][mb][j]), acc[mb], 0, 0, 0);
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -2151,9 +2168,11 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
       d->K % 64 == 0 && p.vecA && p.vecB) {
     // few column tiles (<= 128) over a deep K: K cut across workgroups (>= 8 blocks of 64 k per range), as for the fp32 twin
     static const int skb_target = getenv("DXA_SKINNY_TARGET") ? atoi(getenv("DXA_SKINNY_TARGET")) : 256;
+    static const int skb_maxtiles = getenv("DXA_SKINNY_BF16_MAXTILES") ? atoi(getenv("DXA_SKINNY_BF16_MAXTILES")) : NUM_CU / 2;
+    static const int skb_unroll = getenv("DXA_SKINNY_BF16_UNROLL") ? atoi(getenv("DXA_SKINNY_BF16_UNROLL")) : 4;
     const int64_t skb_tiles = dxa_cdiv(d->N, 16);
     int skb_split = 1;
-    if (skb_target > 0 && skb_tiles <= NUM_CU / 2)
+    if (skb_target > 0 && skb_tiles <= skb_maxtiles)
       skb_split = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, (d->K / 64) / 8), dxa_cdiv(skb_target, skb_tiles)));
     p.split_s = 1;
     if (skb_split >= 2) {
@@ -2168,7 +2187,15 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     if (d->out_dtype == DXA_BF16) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MB_, bf16_t>), sgrid, dim3(512), 0, st, p); \
     else hipLaunchKernelGGL((gemm_skinny_bf16_kernel<MB_, float>), sgrid, dim3(512), 0, st, p);                   \
   } while (0)
-    if (mb == 1) LAUNCH_SK(1); else if (mb == 2) LAUNCH_SK(2); else if (mb == 3) LAUNCH_SK(3); else LAUNCH_SK(4);
+    if (mb == 1 && skb_unroll != 2) {            // one row (the decode step): 4 blocks in flight; DXA_SKINNY_BF16_UNROLL=1: rounds 2-4
+#define LAUNCH_SK1(U_)                                                                                              \
+  do {                                                                                                              \
+    if (d->out_dtype == DXA_BF16) hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, bf16_t, U_>), sgrid, dim3(512), 0, st, p); \
+    else hipLaunchKernelGGL((gemm_skinny_bf16_kernel<1, float, U_>), sgrid, dim3(512), 0, st, p);                 \
+  } while (0)
+      if (skb_unroll == 1) LAUNCH_SK1(1); else LAUNCH_SK1(4);
+#undef LAUNCH_SK1
+    } else if (mb == 1) LAUNCH_SK(1); else if (mb == 2) LAUNCH_SK(2); else if (mb == 3) LAUNCH_SK(3); else LAUNCH_SK(4);
 #undef LAUNCH_SK
     DXA_CHECK_LAUNCH();
     return DXA_OK;

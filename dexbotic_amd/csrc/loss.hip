@@ -110,6 +110,50 @@ __global__ __launch_bounds__(256) void argmax_rows_k(const T* __restrict__ xin, 
   }
 }
 
+// A handful of rows over a vocabulary (the greedy decode step: ONE row of 152,064 logits): argmax_rows_k walks the row with 256
+// threads, 148 dependent iterations of 64-bit compares — 67 us of the 4.5 ms token (profiles/r05_decode_per_token_kernel_stats.txt).
+// 1024 threads, 16-byte loads, two loads in flight, 32-bit indices (cols < 2^31), the same (value, then LOWEST index) order.
+__global__ __launch_bounds__(1024) void argmax_rows_wide_k(const bf16_t* __restrict__ xin, int64_t ld, int64_t* __restrict__ out,
+                                                           int cols) {
+  __shared__ float red_v[16];
+  __shared__ int red_i[16];
+  const bf16_t* x = xin + (int64_t)blockIdx.x * ld;
+  float best = -INFINITY;
+  int idx = INT_MAX;
+  auto take = [&](const float (&v)[8], int i) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (v[e] > best || (v[e] == best && i + e < idx)) { best = v[e]; idx = i + e; }
+  };
+  int i = (int)threadIdx.x * 8;
+  for (; i + 1024 * 8 < cols; i += 2 * 1024 * 8) {             // cols % 8 == 0: a thread's 8 columns are all inside or all outside
+    float v0[8], v1[8];
+    Vec<bf16_t, 8>::ld(v0, x + i);
+    Vec<bf16_t, 8>::ld(v1, x + i + 1024 * 8);
+    take(v0, i);
+    take(v1, i + 1024 * 8);
+  }
+  if (i < cols) {
+    float v0[8];
+    Vec<bf16_t, 8>::ld(v0, x + i);
+    take(v0, i);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(best, o, 64);
+    const int i2 = __shfl_xor(idx, o, 64);
+    if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red_v[w] = best; red_i[w] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k)
+      if (red_v[k] > best || (red_v[k] == best && red_i[k] < idx)) { best = red_v[k]; idx = red_i[k]; }
+    out[blockIdx.x] = idx == INT_MAX ? 0 : idx;         // all -inf / NaN row: index 0 like torch
+  }
+}
+
 inline bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -163,6 +207,12 @@ extern "C" int dxa_argmax_rows(const void* x, int64_t ld, int64_t* out, int64_t 
   const size_t es = dtype == DXA_BF16 ? 2 : 4;
   const bool vec = cols % 4 == 0 && ld % 4 == 0 && al(x, 4 * es);
   dim3 grid((unsigned)rows);
+  static const bool wide_off = getenv("DXA_ARGMAX_NO_WIDE") != nullptr;
+  if (!wide_off && dtype == DXA_BF16 && rows <= 64 && cols >= 16384 && cols < (1ll << 31) && cols % 8 == 0 && ld % 8 == 0 && al(x, 16)) {
+    hipLaunchKernelGGL(argmax_rows_wide_k, grid, dim3(1024), 0, ST, (const bf16_t*)x, ld, out, (int)cols);
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
   if (dtype == DXA_BF16) {
     if (vec) hipLaunchKernelGGL((argmax_rows_k<bf16_t, 4>), grid, dim3(256), 0, ST, (const bf16_t*)x, ld, out, cols);
     else hipLaunchKernelGGL((argmax_rows_k<bf16_t, 1>), grid, dim3(256), 0, ST, (const bf16_t*)x, ld, out, cols);

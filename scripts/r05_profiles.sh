@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence, run on the GPU box from the repo root (outputs under gpurun_out/, the summaries are copied to profiles/):
-#   gpurun -- 'bash scripts/r05_profiles.sh [tests|bench|trace|timeline|infer|pi0|memvla|pmc ...]'
+#   gpurun -- 'bash scripts/r05_profiles.sh [tests|bench|trace|timeline|infer|pi0|memvla|decode|pmc ...]'
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/prof
 what="${@:-tests bench}"
 B="python $R/bench.py --no-cpu-baseline --no-latency --no-secondary --no-recipe"
@@ -30,6 +30,12 @@ pi0)     # exact per-step kernel table of the pi0 fine-tune step
   cd $R
   python profiles/rocpd_stats.py --per-step gpurun_out/prof/pi1_results.db 3 gpurun_out/prof/pi3_results.db 5 > gpurun_out/r05_pi0_train_per_step_kernel_stats.txt 2>&1
   grep "^{" gpurun_out/r05_pi0_3.log | cut -c1-300; head -26 gpurun_out/r05_pi0_train_per_step_kernel_stats.txt | cut -c1-160 ;;
+decode)  # per-TOKEN kernel table of the KV-cached greedy decode: difference of traces with 9 and 33 new tokens (6 generate calls each)
+  cd /tmp; export TMPDIR=/tmp
+  for n in 9 33; do rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o de$n -- python $R/scripts/decode_bench.py $n > $R/gpurun_out/r05_decode_$n.log 2>&1; done
+  cd $R
+  python profiles/rocpd_stats.py --per-step gpurun_out/prof/de9_results.db 48 gpurun_out/prof/de33_results.db 192 > gpurun_out/r05_decode_per_token_kernel_stats.txt 2>&1
+  tail -3 gpurun_out/r05_decode_33.log; head -24 gpurun_out/r05_decode_per_token_kernel_stats.txt | cut -c1-170 ;;
 pmc)     # hardware counters of the dominant kernel: separate --pmc passes (scripts/pmc_passes.sh), stamped with the commit
   PMC_ROUND=r05 bash scripts/pmc_passes.sh > gpurun_out/r05_pmc_passes.log 2>&1
   tail -30 gpurun_out/r05_pmc_passes.log | cut -c1-200 ;;

@@ -803,6 +803,11 @@ def test_cross_entropy_and_argmax(dtype, rows, V):
     y[2] = 0                                               # all equal: index 0
     assert torch.equal(K.argmax_rows(y), torch.argmax(y.float(), dim=1))
     assert int(K.argmax_rows(y)[0]) == 7 and int(K.argmax_rows(y)[2]) == 0
+    if rows >= 5:                                          # (5, 152064) in bf16: the 1024-thread kernel of the decode step
+        y[3, V - 1] = y[3].max() + 2                       # the maximum in the row's last element (the unpaired tail load)
+        y[4] = float("-inf")                               # nothing to find: index 0 like torch
+        got = K.argmax_rows(y)
+        assert int(got[3]) == V - 1 and int(got[4]) == 0 and torch.equal(got, torch.argmax(y.float(), dim=1))
 
 
 # ------------------------------------------------------------------------------------------------ fused DiT blocks
