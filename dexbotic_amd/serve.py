@@ -7,6 +7,7 @@ resized, cropped and normalised there (DexboticForCausalLM.process_images -> dxa
 from __future__ import annotations
 
 import io
+import os
 import time
 from typing import Callable, List, Optional
 
@@ -27,6 +28,7 @@ class InferenceServer:
         self.assistant_stub = assistant_stub                     # cogact_exp.py:159 appends ' ', base_exp.py:683 None
         self.log = log
         self.last_ms = None
+        self.stage_ms = {} if os.environ.get("DXA_SERVE_STAGES") else None
 
     # ---- one request ------------------------------------------------------------------------------------------
     def build_prompt(self, text: str) -> str:
@@ -40,15 +42,29 @@ class InferenceServer:
         """images: file-like objects / paths holding PNG (or anything PIL opens).  cogact_exp.py:146-177"""
         from PIL import Image
         t0 = time.monotonic()
+        stages = self.stage_ms if self.stage_ms is not None else None      # tuning: per-stage times (a device sync per stage)
+
+        def mark(name, t_prev):
+            if stages is None:
+                return t_prev
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t = time.monotonic()
+            stages.setdefault(name, []).append(round(1e3 * (t - t_prev), 2))
+            return t
         frames = [Image.open(f).convert("RGB") for f in images]
+        t = mark("png_decode", t0)
         pix = self.model.process_images(frames).to(dtype=self.model.dtype)
         if len(frames) > 1:
             pix = pix.unsqueeze(0)                               # [1, views, 3, H, W]
+        t = mark("process_images", t)
         ids = tokenizer_image_token(self.build_prompt(text), self.tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt")
         ids = ids.unsqueeze(0).to(self.model.device)
+        t = mark("prompt", t)
         with torch.no_grad():
             out = self.model.inference_action(ids, pix, dict(self.inference_args))
         out = out.tolist() if hasattr(out, "tolist") else out
+        mark("inference_action", t)
         self.last_ms = 1e3 * (time.monotonic() - t0)
         if self.log:
             self.log(f"process_frame: {len(frames)} view(s), {self.last_ms:.1f} ms")
