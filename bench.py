@@ -302,6 +302,8 @@ def process_frame_latency(model, n_req: int = 50, views: int = 2) -> dict:
         import gc
         gc.collect()
         gc.disable()
+    from dexbotic_amd import hostcpu
+    cg0 = hostcpu.throttle_stats()
     lat = []
     # warm-up: every prompt length three times — the request path keeps one captured HIP graph per sequence length (eager the first
     # time, captured the second, replayed from the third), and with 5 warm-up requests over 4 lengths the captures of three of them
@@ -318,7 +320,8 @@ def process_frame_latency(model, n_req: int = 50, views: int = 2) -> dict:
     srv.model = None                                   # (the Flask app's closures keep the server alive: let go of the 169 GB)
     return {"n_requests": n_req, "views": views, "frame": "256x256 PNG", "prompt_lengths": len(texts), "warmup_requests": n_warm,
             "p50_ms": round(float(np.median(lat)), 2), "p90_ms": round(float(np.percentile(lat, 90)), 2),
-            "max_ms": round(float(lat.max()), 2),
+            "max_ms": round(float(lat.max()), 2), "host_threads": srv.host_threads,
+            "cgroup": {k: v - cg0.get(k, 0) for k, v in hostcpu.throttle_stats().items()},
             **({"all_ms": [round(float(x), 1) for x in lat], "stage_ms": {k: v[n_warm:] for k, v in (srv.stage_ms or {}).items()},
                 "inner_ms": {k: v[-n_req:] for k, v in inner.items()}}
                if os.environ.get("DXA_BENCH_PF_DUMP") else {})}
@@ -416,6 +419,10 @@ def main():
     from dexbotic_amd.engine import OptimConfig
     from dexbotic_amd.trainer import NativeTrainer
 
+    # torch's intra-op pool inside the container's CPU quota (dexbotic_amd/hostcpu.py: 128 OpenMP workers on a 16-CPU cgroup get the
+    # whole process throttled; DXA_HOST_THREADS=0 leaves torch's default for an A/B)
+    from dexbotic_amd import hostcpu
+    host_threads = hostcpu.limit_host_threads()
     model, cfg, llm, vis = build_model(args, device)
     model.train()
     if args.recompute:
@@ -455,11 +462,13 @@ def main():
     prof_keys = {"NT fwd": (L.NT, in_dt, in_dt), "NN dX": (L.NN, in_dt, in_dt), "TN dW": (L.TN, in_dt, L.F32)}
     prof = K.GemmProfile(*set(prof_keys.values()), stride=args.profile_stride)
     K.GEMM_PROFILE = prof if rank == 0 else None
+    cg0 = hostcpu.throttle_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
     sync()                                  # device-wide: also covers the optimizer update still in flight on its side stream
     dt = time.perf_counter() - t0
+    cg1 = hostcpu.throttle_stats()
     K.GEMM_PROFILE = None
     comm_stats = None
     if trainer.reducer is not None and not trainer.reducer.local_only:
@@ -534,6 +543,8 @@ def main():
         "mfu_bf16": round(value * 3 * f_fwd / world / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
     result["grad_dtype"] = "bf16" if model.store.bf16_grads else "f32"
+    result["host"] = {"cpu_quota": hostcpu.cpu_quota(), "logical_cpus": os.cpu_count(), "torch_threads": host_threads,
+                      "timed_region_cgroup": {k: cg1[k] - cg0.get(k, 0) for k in cg1}}
     if recipe is not None:
         result["reference_recipe_8x_accum2"] = recipe
     result["config"]["inputs"] = ("one device-resident batch re-used" if args.static_batch else

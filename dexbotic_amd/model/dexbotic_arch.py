@@ -545,6 +545,11 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         pre = PreprocessRGB(proc, image_aspect_ratio="pad" if aspect == "pad" else None, device=self.device)
         frames = [to_uint8_hwc(im) for im in images]
         if frames and all(f.shape == frames[0].shape for f in frames):
+            if all(f.device.type == "cpu" for f in frames):
+                # host frames are stacked by numpy (one memcpy per frame): torch.stack above ATen's parallel grain wakes the whole
+                # OpenMP pool for 393 KB, and its spinning workers cost a serving process its cgroup CPU quota (hostcpu.py)
+                import numpy as np
+                return pre.batch(torch.from_numpy(np.stack([f.numpy() for f in frames])))
             return pre.batch(torch.stack(frames))
         out = [pre.batch(f[None])[0] for f in frames]
         if out and all(x.shape == out[0].shape for x in out):

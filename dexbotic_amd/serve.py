@@ -28,6 +28,11 @@ class InferenceServer:
         self.assistant_stub = assistant_stub                     # cogact_exp.py:159 appends ' ', base_exp.py:683 None
         self.log = log
         self.last_ms = None
+        # the host side of a request is one PNG decode and a few hundred KB of byte shuffling: torch's intra-op pool (sized by the
+        # host's logical CPUs) is held inside the container's CPU quota, or its spinning workers get the whole process throttled
+        # in the middle of a request (hostcpu.py; POST /process_frame p90 55 -> 22 ms)
+        from .hostcpu import limit_host_threads
+        self.host_threads = limit_host_threads(cap=8)
         self.stage_ms = {} if os.environ.get("DXA_SERVE_STAGES") else None
 
     # ---- one request ------------------------------------------------------------------------------------------

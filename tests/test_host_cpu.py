@@ -439,3 +439,39 @@ def test_gemm_profile_stride_samples_every_product_of_a_layer_equally():
     assert not prof.wants(2, 1, 1) and prof.launches() == 28 * 4 * 5
     every = K.GemmProfile(key)
     assert all(every.wants(*key) for _ in range(7)) and every.launches(key) == 7
+
+
+def test_host_thread_pool_is_held_inside_the_cgroup_cpu_quota(tmp_path, monkeypatch):
+    """hostcpu: cpu.max "1600000 100000" = 16 CPUs per period (what the MI355X pods have); the pool is clamped below it, never
+    raised, and DXA_HOST_THREADS overrides (profiles/r06_process_frame_tail.txt: the /process_frame p90 of 55 ms was this)"""
+    import torch
+    from dexbotic_amd import hostcpu as H
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert H.cpu_quota(str(tmp_path)) == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert H.cpu_quota(str(tmp_path)) is None
+    (tmp_path / "cpu.max").unlink()
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert H.cpu_quota(str(tmp_path)) == 2.5
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(H, "usable_cpus", lambda: 16)
+        monkeypatch.delenv("DXA_HOST_THREADS", raising=False)
+        monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+        torch.set_num_threads(min(before, 4))
+        assert H.limit_host_threads() == min(before, 4)                 # never raised
+        monkeypatch.setattr(H, "usable_cpus", lambda: 3)
+        assert H.limit_host_threads() == 1                               # 3 - reserve 2
+        monkeypatch.setattr(H, "usable_cpus", lambda: 64)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+        torch.set_num_threads(before)
+        assert H.limit_host_threads(cap=5) == min(before, 5, 64 // 8 - 2)
+        monkeypatch.setenv("DXA_HOST_THREADS", "2")
+        assert H.limit_host_threads() == 2
+        monkeypatch.setenv("DXA_HOST_THREADS", "0")
+        torch.set_num_threads(3)
+        assert H.limit_host_threads() == 3                               # 0 = leave torch alone
+    finally:
+        torch.set_num_threads(before)
