@@ -395,6 +395,12 @@ def main():
     ap.add_argument("--cpu-port", dest="cpu_port", action="store_true",
                     help="time the CPU oracle (port) even where /root/reference is importable")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-shard", dest="no_shard", action="store_true",
+                    help="N > 1: every rank repeats the full AdamW on all-gathered gradients (rounds 1-5) instead of the sharded "
+                         "optimizer step (engine.ShardPlan: reduce-scatter -> own-shard update -> all-gather of the bf16 shadows)")
+    ap.add_argument("--no-dp-emulation", dest="no_dp_emulation", action="store_true",
+                    help="skip dp8_emulated_ms_per_step (N = 1 only: the LOCAL work of one rank of an 8-rank step — RCCL collectives over "
+                         "the whole slices at world size 1 + AdamW over 1 / 8 of the arena; sharded and replicated, a few steps each)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -431,7 +437,8 @@ def main():
                             total_steps=1000, force_reducer=args.force_reducer,
                             grad_comm_dtype=getattr(torch, args.grad_comm), grad_accum=args.accum,
                             grad_dtype=getattr(torch, args.grad_dtype) if args.dtype == "bfloat16" else torch.float32,
-                            overlap_optimizer=args.overlap, native_avg_world1=args.native_avg)
+                            overlap_optimizer=args.overlap, native_avg_world1=args.native_avg,
+                            shard_optimizer=False if args.no_shard else None)
     if trainer.reducer is not None:
         trainer.reducer.time_comm = True
     from dexbotic_amd.data.feeder import DeviceFeeder
@@ -481,7 +488,12 @@ def main():
                       "collectives_per_step": round(red.collectives / n_opt, 1),
                       # first collective's start -> last collective's end on the communication stream (it runs under the
                       # backward: the part of it that is NOT hidden is what ms_per_step grows by against the 1-GPU line)
-                      "comm_window_ms_per_step": round(float(np.mean(win)), 2) if win else None}
+                      "comm_window_ms_per_step": round(float(np.mean(win)), 2) if win else None,
+                      # the sharded optimizer step (default for N > 1): gradients reduce-scattered, AdamW over this rank's shard,
+                      # updated bf16 shadows (+ the fp32 head's masters) all-gathered under the next forward
+                      "optimizer_step": ("sharded: reduce-scatter -> adamw over 1/N -> all-gather of the updated weights"
+                                         if trainer.sharded else "replicated: reduce-scatter + all-gather of gradients, full adamw per rank"),
+                      "weights_gathered_gb_per_step": round(red.bytes_gathered / n_opt / 1e9, 3) if trainer.sharded else None}
     recipe = None
     if not args.no_recipe and args.accum == 1 and args.batch % 2 == 0 and not args.static_batch:
         # second figure: the reference recipe, 8 episodes x 2 accumulation steps per GPU per optimizer
@@ -525,6 +537,55 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss.item())
+    peak_main = torch.cuda.max_memory_allocated(device)
+    dp_emu = None
+    if world == 1 and not args.no_dp_emulation and not args.force_reducer and args.dtype == "bfloat16" and args.accum == 1 \
+            and not args.overlap:
+        # what ONE rank of an 8-rank data-parallel step does locally, on the one GPU there is (SCALE runs need an 8-GPU node this
+        # repo never had): the RCCL collectives of the real sequence over the whole slices at world size 1 (bf16 exchange, SUM) on
+        # the communication stream under the backward, the sum of squares, AdamW — sharded: over rank 0's 1/8 of the arena, then
+        # the all-gather of the updated bf16 shadows under the next forward; replicated: reduce-scatter + all-gather of the
+        # gradients and the full AdamW (rounds 1-5).  NOT a scaling measurement: no xGMI transfer happens, the other ranks'
+        # shards are simply not updated.  The main trainer's moments (64 GB) go first.
+        try:
+            ms_plain = 1e3 * dt / args.steps
+            del trainer
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", device_id=device)
+            dp_emu = {"world_emulated": 8, "one_gpu_plain_ms_per_step": round(ms_plain, 2), "steps": max(4, args.steps // 2),
+                      "what": "local work of one rank of 8: collectives at world size 1 over the whole slices (bf16 exchange) + "
+                              "sum of squares + AdamW; no xGMI traffic — an estimate of the per-rank step, not a scaling measurement"}
+            for key, kw in (("sharded", dict(shard_optimizer=True, emulate_world=8)), ("replicated", dict(shard_optimizer=False))):
+                tr_e = NativeTrainer(model, OptimConfig(base_lr=2e-5, weight_decay=0.0, max_grad_norm=1.0), total_steps=1000,
+                                     force_reducer=True, grad_comm_dtype=torch.bfloat16, **kw)
+                for _ in range(2):
+                    tr_e.step(next(feed))
+                sync()
+                te0 = time.perf_counter()
+                for _ in range(dp_emu["steps"]):
+                    tr_e.step(next(feed))
+                sync()
+                dp_emu[key + "_ms_per_step"] = round(1e3 * (time.perf_counter() - te0) / dp_emu["steps"], 2)
+                if key == "sharded":
+                    dp_emu["plan"] = tr_e.reducer.plan.describe()
+                    dp_emu["weights_gathered_gb_per_step"] = round(tr_e.reducer.bytes_gathered / max(tr_e.global_step, 1) / 1e9, 3)
+                    dp_emu["gradients_reduced_gb_per_step"] = round(tr_e.reducer.bytes_reduced / max(tr_e.global_step, 1) / 1e9, 3)
+                tr_e.consolidate()
+                model.store.on_bucket_ready = None
+                del tr_e
+                gc.collect()
+                torch.cuda.empty_cache()
+            trainer = None
+        except Exception as e:  # noqa: BLE001  (never break the headline line)
+            dp_emu = {"error": repr(e)[:300]}
+            trainer = None
 
     f_fwd, S = flops_per_sample_fwd(llm.to_dict(), vis.to_dict(), args.views, args.s_text, 768, 12, 16, 4)
     samples = args.batch * world * args.steps
@@ -553,9 +614,12 @@ def main():
     result["config"]["optimizer"] = "AdamW serial" if not args.overlap else "AdamW overlapped with the next forward (side stream, per-bucket events)"
     result["config"]["grad_accum"] = args.accum
     result["config"]["activations"] = "recomputed in backward (gradient checkpointing)" if args.recompute else "resident"
-    result["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 1)
+    result["peak_hbm_gb"] = round(peak_main / 1e9, 1)
     if comm_stats is not None:
         result.update(comm_stats)
+    if dp_emu is not None:
+        result["dp8_emulated_ms_per_step"] = dp_emu.get("sharded_ms_per_step")
+        result["dp8_emulated"] = dp_emu
     if rank == 0:
         n, ms, fl, by = prof.summary()
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -69,7 +69,7 @@ class AdamWDesc(C.Structure):
         ("chunk_start", _vp), ("chunk_len", _vp), ("chunk_grp", _vp), ("n_chunks", _i32),
         ("lr", _f32 * 8), ("wd", _f32 * 8),
         ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("bc1", _f32), ("bc2", _f32),
-        ("clip_coef", _vp), ("g_dtype", _i32), ("chunk_state", _vp),
+        ("clip_coef", _vp), ("g_dtype", _i32), ("chunk_state", _vp), ("chunk_mv_start", _vp),
     ]
 
 

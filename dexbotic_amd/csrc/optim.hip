@@ -18,6 +18,7 @@ struct AdamP {
   float b1, b2, eps, bc1, bc2;
   const float* clip;
   uint8_t* state;      // per-chunk sparse-table state (dxa_adamw_desc.chunk_state) or null
+  const int64_t* cms;  // per-chunk start of the moments in a packed (sharded) m / v, or null: the arena offset
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float wd, const AdamP& a,
@@ -60,10 +61,11 @@ __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
   const float inv_sqrt_bc2 = sqrtf(a.bc2);  // (name kept: it is the divisor sqrt(1-beta2^t))
   float* p = a.p + start;
   const TG* g = reinterpret_cast<const TG*>(a.g) + start;
-  float* m = a.m + start;
-  float* v = a.v + start;
+  const int64_t mstart = a.cms ? a.cms[c] : start;
+  float* m = a.m + mstart;
+  float* v = a.v + mstart;
   bf16_t* sh = a.shadow ? a.shadow + start : nullptr;
-  const bool vec = ((start & 3) == 0);
+  const bool vec = (((start | mstart) & 3) == 0);
   const int n4 = vec ? (len >> 2) : 0;
   if (a.state != nullptr && a.state[c] == 1 && wd == 0.f) {
     // chunk of a sparsely touched table that never had a gradient (m = v = 0): an all-zero gradient leaves p, m, v unchanged
@@ -238,6 +240,7 @@ extern "C" int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream) {
   a.b1 = d->beta1; a.b2 = d->beta2; a.eps = d->eps; a.bc1 = d->bc1; a.bc2 = d->bc2;
   a.clip = d->clip_coef;
   a.state = d->chunk_state;
+  a.cms = d->chunk_mv_start;
   if (d->g_dtype == DXA_BF16) hipLaunchKernelGGL(adamw_k<bf16_t>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(adamw_k<float>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
   DXA_CHECK_LAUNCH();

@@ -140,6 +140,8 @@ class ParamStore:
         # afterwards (w / w32 / g / gc) first makes the CURRENT stream wait for the event, so layer i of the next step starts
         # as soon as bucket i is done while the HBM-bound update of the later buckets still runs under the MFMA-bound forward.
         self._pending: Dict[int, "torch.cuda.Event"] = {}
+        self._w32_buckets: set = set()             # buckets some TRAINING forward read through w32() (the fp32 action head)
+        self._record_w32 = False                   # up while a trainer's forward + backward runs (initialisers / loaders use w32() too)
         # ---- driven from outside (HF Trainer / the reference's DexboticTrainer / a hand-written loop) -----------------------
         # managed: a NativeTrainer (or exp.trainer.NativeDexboticTrainer) calls begin_step / begin_micro itself.  Otherwise the
         # model's forward pre-hook does (external_prelude): gradients re-attached after zero_grad(set_to_none=True), a new
@@ -238,6 +240,9 @@ class ParamStore:
         return self._view(arena, names, shape)
 
     def w32(self, *names: str, shape: Optional[Sequence[int]] = None) -> torch.Tensor:
+        # (the sharded optimizer step gathers the fp32 masters of exactly these buckets after every update: GradReducer.gather_params)
+        if self._record_w32:
+            self._w32_buckets.add(self.slots[names[0]].bucket)
         return self._view(self.master, names, shape)
 
     def g(self, *names: str, shape: Optional[Sequence[int]] = None) -> torch.Tensor:
@@ -617,8 +622,11 @@ class FusedAdamW:
 
     def __init__(self, store: ParamStore, cfg: OptimConfig, prefixes: Dict[str, str] | None = None,
                  exclude: Iterable[str] = (), overlap: bool = False, segment_elems: int = 48 << 20,
-                 groups: Optional[List[dict]] = None):
-        """``exclude``: parameters that never receive a gradient (torch.optim skips ``grad is None``
+                 groups: Optional[List[dict]] = None, ranges: Optional[Sequence[Tuple[int, int]]] = None):
+        """``ranges``: sharded optimizer state — sorted, disjoint arena ranges [a, b) this rank owns (ShardPlan.owned): only
+        parameters inside them are updated here, and m / v exist for them alone, packed back to back (``dxa_adamw_desc.
+        chunk_mv_start``) — 8 bytes per OWNED parameter instead of 8 per parameter.  None: every trainable parameter.
+        ``exclude``: parameters that never receive a gradient (torch.optim skips ``grad is None``
         parameters entirely — no weight decay either).
         ``overlap``: run the update on a side HIP stream, cut along bucket boundaries into segments of >= ``segment_elems``
         parameters in FORWARD order, one event per segment (``ParamStore._pending``): the next step's forward waits
@@ -629,16 +637,45 @@ class FusedAdamW:
         from . import kernels as K  # noqa: F401  (fail early if the library is missing)
         self.store, self.cfg = store, cfg
         self.overlap = bool(overlap) and store.device.type == "cuda"
+        assert not (self.overlap and ranges is not None), "the overlapped update and the sharded optimizer state exclude each other"
         exclude = set(exclude)
         dev = store.device
-        self.m = torch.zeros_like(store.master)
-        self.v = torch.zeros_like(store.master)
+        self.ranges = None if ranges is None else [(int(a), int(b)) for a, b in ranges if b > a]
+        if self.ranges is None:
+            self.m = torch.zeros_like(store.master)
+            self.v = torch.zeros_like(store.master)
+        else:
+            assert all(self.ranges[i][1] <= self.ranges[i + 1][0] for i in range(len(self.ranges) - 1)), "ranges must be sorted and disjoint"
+            # packed offset of every owned range inside m / v: ranges start on 16-byte boundaries there as they do in the arena
+            # (adamw_k takes its 16-byte path only when both offsets allow it)
+            self._range_base, owned = [], 0
+            for a, b in self.ranges:
+                self._range_base.append(owned)
+                owned += (b - a + 3) // 4 * 4
+            self.m = torch.zeros(max(owned, 1), device=dev, dtype=torch.float32)
+            self.v = torch.zeros(max(owned, 1), device=dev, dtype=torch.float32)
         self.step_count = 0
         prefixes = prefixes or {"mm_projector": "mm_projector", "mm_vision": "mm_vision", "action_head": "action_head"}
         # groups: (lr_key, decay?) -> index  (<= 8 groups, as the reference builds them)
         self.group_keys: List[Tuple[str, bool]] = []
         self.group_of: Dict[str, Tuple[str, bool]] = {}      # parameter name -> (lr key, weight-decayed?)
-        cs, cl, cg, cst = [], [], [], []
+        cs, cl, cg, cst, cms = [], [], [], [], []
+        import bisect as _bis
+        r_lo = [a for a, _ in self.ranges] if self.ranges is not None else None
+        r_base = self._range_base if self.ranges is not None else []
+
+        def pieces(c0: int, c1: int):
+            """[c0, c1) cut to the owned ranges -> (start, length, packed moment offset)"""
+            if self.ranges is None:
+                yield c0, c1 - c0, None
+                return
+            k = max(0, _bis.bisect_right(r_lo, c0) - 1)
+            while k < len(self.ranges) and self.ranges[k][0] < c1:
+                a, b = self.ranges[k]
+                x0, x1 = max(a, c0), min(b, c1)
+                if x1 > x0:
+                    yield x0, x1 - x0, r_base[k] + (x0 - a)
+                k += 1
         # token-embedding tables receive gradient in <= B * S_text rows per step: their chunks start in state 1 = "never saw a
         # non-zero gradient" and the kernel leaves such a chunk alone while its gradient is all-zero and its weight decay is 0 —
         # exactly what AdamW computes for it (dxa_adamw_desc.chunk_state).  DXA_ADAMW_SPARSE=0: every chunk ordinary.
@@ -674,12 +711,15 @@ class FusedAdamW:
             o = 0
             while o < s.numel:
                 ln = min(cfg.chunk, s.numel - o)
-                cs.append(s.offset + o)
-                cl.append(ln)
-                cg.append(gi)
-                cst.append(1 if sparse_tables and s.name.endswith("embed_tokens.weight") else 0)
+                for x0, xl, mo in pieces(s.offset + o, s.offset + o + ln):
+                    cs.append(x0)
+                    cl.append(xl)
+                    cg.append(gi)
+                    cst.append(1 if sparse_tables and s.name.endswith("embed_tokens.weight") else 0)
+                    cms.append(mo)
                 o += ln
         assert len(self.group_keys) <= 8
+        self.chunk_mv_start = torch.tensor(cms, dtype=torch.int64, device=dev) if self.ranges is not None else None
         # segments for the overlapped update: [first chunk, one past the last chunk, buckets covered]
         self.segments: List[Tuple[int, int, List[int]]] = []
         self.stream = None
@@ -743,6 +783,7 @@ class FusedAdamW:
         clip = None
         if c.max_grad_norm is not None:
             if sumsq is None:
+                assert self.ranges is None, "sharded optimizer state: the caller supplies the all-reduced sum of squares"
                 K.sumsq(grads, self.sumsq, self.scratch)
                 sumsq = self.sumsq
             K.clip_coef(sumsq, float(c.max_grad_norm), self.norm, self.coef, grad_scale=float(grad_scale))
@@ -759,7 +800,8 @@ class FusedAdamW:
         st.native_epoch += 1                       # the masters move under raw pointers: derived copies (packed DiT weights) are stale
         if not self.overlap:
             K.adamw(st.master, grads, self.m, self.v, st.shadow, self.chunk_start, self.chunk_len, self.chunk_grp,
-                    lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip, chunk_state=self.chunk_state)
+                    lrs, wds, c.adam_beta1, c.adam_beta2, c.adam_epsilon, self.step_count, clip=clip, chunk_state=self.chunk_state,
+                    chunk_mv_start=self.chunk_mv_start)
             return
         cur = torch.cuda.current_stream(st.device)
         self.stream.wait_stream(cur)               # gradients, sum(g^2) and the clip coefficient are final on `cur`
@@ -788,12 +830,42 @@ class FusedAdamW:
         moments this object produced itself — every external write resets it.  ``m`` / ``v`` may be the arenas themselves
         (state dict round trip in place)."""
         self.store.wait_pending()
+        if self.ranges is not None and m.numel() == self.store.total and v.numel() == self.store.total:
+            m, v = self.pack_moments(m), self.pack_moments(v)     # full arenas (a gathered checkpoint): keep the own shard
+        assert m.shape == self.m.shape and v.shape == self.v.shape, \
+            "moments of another layout (a sharded optimizer state loads full arenas or what the same world size / rank saved)"
         if m.data_ptr() != self.m.data_ptr():
             self.m.copy_(m)
         if v.data_ptr() != self.v.data_ptr():
             self.v.copy_(v)
         self.step_count = int(step)
         self.moments_replaced()
+
+
+    def pack_moments(self, full: torch.Tensor) -> torch.Tensor:
+        """arena-shaped moments -> this rank's packed shard"""
+        full = full.to(self.m.device).reshape(-1)
+        out = torch.zeros_like(self.m)
+        for (a, b), o in zip(self.ranges, self._range_base):
+            out[o:o + (b - a)] = full[a:b]
+        return out
+
+    def full_moments(self, reducer: Optional["GradReducer"] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """arena-shaped (m, v): the arenas themselves unsharded; sharded, two fresh arenas holding every rank's shard (all ranks
+        call it: the shards travel by the reducer's all-gathers) — what a checkpoint that can be resumed on another world size
+        stores.  64 GB of scratch at the 8 B size, freed by the caller."""
+        if self.ranges is None:
+            return self.m, self.v
+        out = []
+        for packed in (self.m, self.v):
+            full = torch.zeros(self.store.total, device=packed.device, dtype=torch.float32)
+            for (a, b), o in zip(self.ranges, self._range_base):
+                full[a:b] = packed[o:o + (b - a)]
+            out.append(full)
+        if reducer is not None and reducer.plan is not None and reducer.world > 1:
+            reducer._gather_slices(lambda sl: out)
+            self.store.wait_pending()
+        return out[0], out[1]
 
 
 def cosine_lr_scale(step: int, total_steps: int, warmup_steps: int = 0) -> float:
@@ -921,6 +993,91 @@ class GradNormTracker:
         return self.acc
 
 
+# ---------------------------------------------------------------------------- sharded optimizer step
+class ShardPlan:
+    """Static partition of the arena for the SHARDED optimizer step — the counterpart of the reference's default DeepSpeed
+    config (dexbotic/exp/base_exp.py:229 ``deepspeed="./script/deepspeed/zero3.json"``, script/deepspeed/zero3.json:17-25
+    ``"stage": 3, "overlap_comm": true``; the trainer side is dexbotic/exp/trainer.py:145-189): optimizer state and update are
+    partitioned over the data-parallel ranks.  Here the weights stay replicated (bf16 shadows: 16 GB of 288) and the step is
+
+        reduce-scatter(gradient slice) -> sum(g^2) over the own shard + ONE scalar all-reduce -> adamw_k over the own shard
+        -> all-gather of the updated bf16 SHADOW shard (fp32 masters only for buckets some forward reads in fp32: the action head)
+
+    instead of reduce-scatter + all-gather of the GRADIENT and a full adamw_k on every rank: the same reduce-scatter, an
+    all-gather of half the bytes (bf16 weights instead of fp32 gradients; equal with a bf16 exchange), and 1 / world of the
+    34 ms, HBM-bound update (14 % of the 1-GPU step).  fp32 masters of the other ranks' shards go stale on a rank
+    (GradReducer.gather_masters() brings them up to date for a checkpoint); m / v exist for the own shard only.
+
+    ``slices``: runs of adjacent exchanged buckets of at least ``min_bucket_bytes`` in ARENA (= forward) order — fixed, unlike the
+    replicated path's merging by completion order, because ownership must not depend on when a backward fires its buckets.
+    Slice [lo, hi) with n = hi - lo: per = n // world rounded down to 16 elements (32-byte shard starts in bf16), rank r owns
+    [lo + r per, lo + (r + 1) per); the tail [lo + world per, hi) (< 16 world elements + the remainder) is all-reduced and
+    updated by EVERY rank identically (replicated: cheaper than a ragged collective).  per < 64: the whole slice is a tail."""
+
+    def __init__(self, store: "ParamStore", world: int, rank: int, skip_buckets: Iterable[int] = (),
+                 min_bucket_bytes: int = 256 << 20):
+        assert world >= 1 and 0 <= rank < world
+        self.world, self.rank = int(world), int(rank)
+        skip = set(skip_buckets)
+        self.slices: List[dict] = []
+        cur = None
+        for b, (lo, hi) in enumerate(store.bucket_ranges):
+            if hi <= lo:
+                continue
+            if b in skip:                                   # never exchanged, never updated: a hole between slices
+                if cur is not None:
+                    self.slices.append(cur)
+                    cur = None
+                continue
+            if cur is not None and 0 <= lo - cur["hi"] < ALIGN:
+                cur["hi"] = hi
+                cur["buckets"].append(b)
+            else:
+                if cur is not None:
+                    self.slices.append(cur)
+                cur = {"lo": lo, "hi": hi, "buckets": [b]}
+            if (cur["hi"] - cur["lo"]) * 4 >= min_bucket_bytes:
+                self.slices.append(cur)
+                cur = None
+        if cur is not None:
+            self.slices.append(cur)
+        self.slice_of: Dict[int, int] = {}
+        for i, sl in enumerate(self.slices):
+            n = sl["hi"] - sl["lo"]
+            per = n // self.world
+            per = per - per % 16 if per >= 64 else 0
+            sl["per"], sl["body"] = per, per * self.world
+            for b in sl["buckets"]:
+                self.slice_of[b] = i
+
+    def shard(self, i: int, rank: Optional[int] = None) -> Tuple[int, int]:
+        sl = self.slices[i]
+        r = self.rank if rank is None else rank
+        return sl["lo"] + r * sl["per"], sl["lo"] + (r + 1) * sl["per"]
+
+    def tail(self, i: int) -> Tuple[int, int]:
+        sl = self.slices[i]
+        return sl["lo"] + sl["body"], sl["hi"]
+
+    def owned(self, rank: Optional[int] = None) -> List[Tuple[int, int]]:
+        """what rank ``rank`` updates: its shard of every slice and every (replicated) tail; sorted, adjacent ranges merged"""
+        out: List[Tuple[int, int]] = []
+        for i in range(len(self.slices)):
+            for a, b in (self.shard(i, rank), self.tail(i)):
+                if b > a:
+                    if out and out[-1][1] == a:
+                        out[-1] = (out[-1][0], b)
+                    else:
+                        out.append((a, b))
+        return sorted(out)
+
+    def describe(self) -> dict:
+        own = sum(b - a for a, b in self.owned())
+        tot = sum(sl["hi"] - sl["lo"] for sl in self.slices)
+        return {"world": self.world, "rank": self.rank, "slices": len(self.slices), "owned_elements": own, "exchanged_elements": tot,
+                "replicated_tail_elements": sum(sl["hi"] - sl["lo"] - sl["body"] for sl in self.slices)}
+
+
 # ---------------------------------------------------------------------------------------- DP reducer
 class GradReducer:
     """Data-parallel gradient averaging over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).
@@ -947,7 +1104,12 @@ class GradReducer:
     def __init__(self, store: ParamStore, group=None, min_bucket_bytes: int = 256 << 20,
                  skip: Iterable[str] = (), force: bool = False, comm_dtype: torch.dtype = torch.float32,
                  algo: str = "rs_ag", local_only: bool = False, native_avg_world1: bool = False,
-                 reduce_op: str = "sum"):
+                 reduce_op: str = "sum", shard: bool = False, emulate_world: int = 0):
+        """``shard``: the sharded optimizer step (ShardPlan): gradients are reduce-SCATTERED over fixed slices — no gradient
+        all-gather — ``after_reduce`` sees this rank's shard (and, on rank 0, the replicated tails) only, and gather_params() /
+        gather_masters() bring the updated weights back.  ``emulate_world`` = n at world size 1 (``force``): ownership as rank 0 of n
+        ranks while the collectives run over the whole slices at world size 1 — the timing of an n-rank step's local work
+        on one GPU (bench.py ``dp8_emulated_ms_per_step``); the parameters of the other n - 1 shards are simply not updated."""
         import torch.distributed as dist
         self.dist = dist
         # reduce_op = "sum" (default since round 5): the collectives ADD the ranks' gradients and the 1 / world of the mean is
@@ -992,6 +1154,7 @@ class GradReducer:
         self._pending_hi: Optional[int] = None
         self.after_reduce = None    # callable(lo, hi, comm_stream): called once a slice's exchange is enqueued
         self.bytes_reduced = 0
+        self.bytes_gathered = 0                         # sharded step: bytes of updated weights all-gathered
         self.collectives = 0
         if comm_dtype == torch.bfloat16:
             store.enable_grad_mirror()
@@ -1006,6 +1169,15 @@ class GradReducer:
         self._slots = sorted(store.slots.values(), key=lambda s: s.offset)
         self._offsets = [s.offset for s in self._slots]
         store.on_bucket_ready = self.bucket_ready
+        self.plan: Optional[ShardPlan] = None
+        self.emulate_world = int(emulate_world) if (self.world == 1 and emulate_world and emulate_world > 1) else 0
+        if shard and not local_only and (self.world > 1 or self.force):
+            assert algo == "rs_ag", "the sharded optimizer step rides on reduce-scatter + all-gather"
+            self.plan = ShardPlan(store, self.emulate_world or self.world, 0 if self.emulate_world else self.rank,
+                                  self.skip_buckets, min_bucket_bytes)
+            self._slice_left = [len(sl["buckets"]) for sl in self.plan.slices]
+            self._slice_done = [False] * len(self.plan.slices)
+            self._gather_events: List[Optional["torch.cuda.Event"]] = [None] * len(self.plan.slices)
 
     @property
     def result_arena(self) -> torch.Tensor:
@@ -1154,12 +1326,152 @@ class GradReducer:
         assert self.world == 1, "GradReducer.reset() with peers"
         self._pending_lo = self._pending_hi = None
         self._t0 = None
+        if self.plan is not None:
+            self._slice_left = [len(sl["buckets"]) for sl in self.plan.slices]
+            self._slice_done = [False] * len(self.plan.slices)
+
+    # ---- sharded optimizer step (ShardPlan) ---------------------------------------------------------------------------
+    def _exchange_shard(self, buf: torch.Tensor, i: int) -> None:
+        """slice i of the plan: reduce-scatter into this rank's shard, the tail all-reduced; no all-gather of gradients"""
+        d, sl = self.dist, self.plan.slices[i]
+        per, body, n = sl["per"], sl["body"], buf.numel()
+        native_avg = buf.is_cuda and self.backend == "nccl" and self.reduce_op == "avg"
+        if self.world == 1:
+            # one rank (forced; with emulate_world the plan is another world's): the collectives of the real sequence over the
+            # whole slice — reduce-scatter in place, the tail's all-reduce
+            if per > 0:
+                d.reduce_scatter_tensor(buf[:body], buf[:body], op=d.ReduceOp.SUM, group=self.group)
+                self.collectives += 1
+            if body < n:
+                d.all_reduce(buf[body:], op=d.ReduceOp.SUM, group=self.group)
+                self.collectives += 1
+            return
+        if per > 0:
+            shard = buf[self.rank * per:(self.rank + 1) * per]
+            if self.reduce_op == "sum" or native_avg:
+                self._reduce_scatter(shard, buf[:body], d.ReduceOp.SUM if self.reduce_op == "sum" else d.ReduceOp.AVG)
+            else:
+                self._reduce_scatter(shard, buf[:body], d.ReduceOp.SUM)
+                shard.copy_((shard.float() / self.world).to(shard.dtype))
+            self.collectives += 1
+        if body < n:
+            self._avg(buf[body:], native_avg)
+            self.collectives += 1
+
+    def _flush_slice(self, i: int) -> None:
+        sl = self.plan.slices[i]
+        self._slice_done[i] = True
+        lo, hi = sl["lo"], sl["hi"]
+        half = self.comm_dtype == torch.bfloat16
+        buf = (self.store.gradc if half else self.store.grad)[lo:hi]
+        self.bytes_reduced += buf.numel() * (2 if half else 4)
+        own, tail = self.plan.shard(i), self.plan.tail(i)
+        fold = [own] if own[1] > own[0] else []
+        if tail[1] > tail[0] and self.plan.rank == 0:
+            fold.append(tail)                                  # replicated: every rank holds it, rank 0 counts it
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            self.store.wait_side(self.comm_stream)
+            with torch.cuda.stream(self.comm_stream):
+                if self.time_comm and self._t0 is None:
+                    self._t0 = torch.cuda.Event(enable_timing=True)
+                    self._t0.record(self.comm_stream)
+                if half:
+                    self._fill_mirror(lo, hi)
+                self._exchange_shard(buf, i)
+            if self.after_reduce is not None:
+                for a, b in fold:
+                    self.after_reduce(a, b, self.comm_stream)
+        else:
+            if half:
+                self._fill_mirror(lo, hi)
+            self._exchange_shard(buf, i)
+            if self.after_reduce is not None:
+                for a, b in fold:
+                    self.after_reduce(a, b, None)
+
+    def reduce_scalar(self, t: torch.Tensor) -> torch.Tensor:
+        """sum over the ranks of a device scalar, in place (the shards' shares of sum(g^2)) on the current stream"""
+        if self.world > 1:
+            self._all_reduce(t, self.dist.ReduceOp.SUM)
+        elif self.force and not self.local_only:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _gather_slices(self, arenas_of) -> None:
+        """all-gather, slice by slice in forward order on the communication stream, of the shards of the arenas ``arenas_of(slice)``
+        names; the buckets of a slice become readable through the store's views once its event has passed (ParamStore._pending)"""
+        st, plan = self.store, self.plan
+        cur = torch.cuda.current_stream() if self.comm_stream is not None else None
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(cur)                 # the update is enqueued on the compute stream
+        ctx = torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else __import__("contextlib").nullcontext()
+        with ctx:
+            for i, sl in enumerate(plan.slices):
+                arenas = arenas_of(sl)
+                if sl["per"] == 0 or not arenas:
+                    continue                                  # replicated tail only: every rank updated it itself
+                lo, body, per = sl["lo"], sl["body"], sl["per"]
+                for arena in arenas:
+                    whole = arena[lo:lo + body]
+                    if self.world == 1:
+                        self.dist.all_gather_into_tensor(whole, whole, group=self.group)
+                    else:
+                        a, b = plan.shard(i)
+                        self._all_gather(whole, arena[a:b])
+                    self.collectives += 1
+                    self.bytes_gathered += whole.numel() * whole.element_size()
+                if self.comm_stream is not None:
+                    ev = self._gather_events[i]
+                    if ev is None:
+                        ev = self._gather_events[i] = torch.cuda.Event()
+                    ev.record(self.comm_stream)
+                    for b_ in sl["buckets"]:
+                        st._pending[b_] = ev
+
+    def gather_params(self, overlap: bool = True) -> None:
+        """after the sharded update: every rank's freshly written bf16 shadow shard to every rank (what the next forward
+        multiplies with), and the fp32 masters of the slices that hold a bucket some forward reads in fp32 (Fp32View: the action
+        head) — in fp32 compute mode there is no shadow and the masters travel.  ``overlap``: the next forward waits bucket by
+        bucket (the gathers of the later layers run under the first layers' products); False: the compute stream waits here."""
+        st = self.store
+        fp32_b = st._w32_buckets
+
+        def arenas_of(sl):
+            out = [st.shadow] if st.shadow is not None else [st.master]
+            if st.shadow is not None and any(b in fp32_b for b in sl["buckets"]):
+                out.append(st.master)
+            return out
+        self._gather_slices(arenas_of)
+        if st.shadow is not None:
+            st._shadow_version = st.master._version           # the gathers wrote master views: the shadows are NOT stale
+        if not overlap:
+            st.wait_pending()
+
+    def gather_masters(self) -> None:
+        """every rank's fp32 master shard to every rank: afterwards state_dict() / save_pretrained() see the trained weights on
+        every rank (the reference's ZeRO-3 save gathers likewise, dexbotic/exp/trainer.py:145-189).  Collective: all ranks call it."""
+        st = self.store
+        self._gather_slices(lambda sl: [st.master])
+        st.wait_pending()
+        if st.shadow is not None:
+            st._shadow_version = st.master._version
 
     def bucket_ready(self, b: int) -> None:
         if b in self.skip_buckets:
             return
         lo, hi = self.store.bucket_ranges[b]
         if hi <= lo:
+            return
+        if self.plan is not None:
+            if self.world == 1 and not self.force:
+                return
+            i = self.plan.slice_of.get(b)
+            if i is None or self._slice_done[i]:
+                return
+            self._slice_left[i] -= 1
+            if self._slice_left[i] <= 0:
+                self._flush_slice(i)
             return
         if self._pending_lo is None:
             self._pending_lo, self._pending_hi = lo, hi
@@ -1179,6 +1491,14 @@ class GradReducer:
         for b in st.unfired_touched():                     # buckets a frozen/unused slot kept from firing
             st._bucket_fired[b] = True
             self.bucket_ready(b)
+        if self.plan is not None and (self.world > 1 or self.force):
+            # slices a bucket without any gradient write kept from completing: exchanged as they are if ANY of their buckets was
+            # written (the same decision on every rank: same model, same batch structure); untouched slices are left alone
+            for i, sl in enumerate(self.plan.slices):
+                if not self._slice_done[i] and any(st._bucket_touched[b] for b in sl["buckets"]):
+                    self._flush_slice(i)
+            self._slice_left = [len(sl["buckets"]) for sl in self.plan.slices]
+            self._slice_done = [False] * len(self.plan.slices)
         self._flush()
         if not self.local_only:
             st.invalidate_embed_tracking()                 # other ranks' token rows are now non-zero here too

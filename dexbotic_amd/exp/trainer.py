@@ -73,7 +73,14 @@ class ArenaAdamW(torch.optim.Optimizer):
     def state_dict(self) -> Dict[str, Any]:
         sd = super().state_dict()
         self.core.synchronize()
-        sd["arena"] = {"m": self.core.opt.m, "v": self.core.opt.v, "step": self.core.opt.step_count}
+        # (sharded optimizer step: m / v are this rank's shard, packed — HF saves the optimizer state per rank in that case, like
+        #  the reference's ZeRO checkpoints; ``ranges`` makes a shard loaded into another layout fail loudly)
+        full = getattr(self.core, "_gathered_moments", None)
+        if full is not None:                      # NativeDexboticTrainer._save_checkpoint gathered arena-shaped moments on every rank
+            sd["arena"] = {"m": full[0], "v": full[1], "step": self.core.opt.step_count, "ranges": None}
+        else:
+            sd["arena"] = {"m": self.core.opt.m, "v": self.core.opt.v, "step": self.core.opt.step_count,
+                           "ranges": self.core.opt.ranges}
         return sd
 
     def load_state_dict(self, state_dict) -> None:
@@ -231,6 +238,7 @@ class NativeDexboticTrainer(Trainer):
         output_dir = output_dir if output_dir is not None else self.args.output_dir
         os.makedirs(output_dir, exist_ok=True)
         self.core.synchronize()                       # an overlapped optimizer update still in flight
+        # (sharded optimizer step: _save_checkpoint gathered the fp32 masters on every rank before this rank-0 write)
         self.model.save_pretrained(output_dir)
         tok = getattr(self, "processing_class", None) or getattr(self, "tokenizer", None)
         if tok is not None and hasattr(tok, "save_pretrained"):
@@ -242,6 +250,21 @@ class NativeDexboticTrainer(Trainer):
         from transformers.trainer_utils import PREFIX_CHECKPOINT_DIR
         output_dir = os.path.join(self._get_output_dir(trial=trial), f"{PREFIX_CHECKPOINT_DIR}-{self.state.global_step}")
         main = self.args.local_rank in (0, -1)
+        # sharded optimizer step (trainer.NativeTrainer shard_optimizer, the default under data parallelism): a rank's fp32 masters
+        # are current only for the shard it owns — gathered here, on EVERY rank (HF calls _save_checkpoint on all of them), as the
+        # reference's ZeRO-3 save does (dexbotic/exp/trainer.py:145-189)
+        self.core.consolidate()
+        if self.core.sharded and not self.args.save_only_model:
+            # HF writes optimizer.pt from rank 0 only: the moments are gathered into arena-shaped tensors first (all ranks take part),
+            # so that the checkpoint resumes on any world size (FusedAdamW.load_moments keeps a rank's own shard)
+            self.core._gathered_moments = self.core.opt.full_moments(self.core.reducer)
+        try:
+            self._save_checkpoint_body(model, trial, metrics, output_dir, main)
+        finally:
+            self.core._gathered_moments = None
+
+    def _save_checkpoint_body(self, model, trial, metrics, output_dir, main) -> None:
+        import os
         if getattr(getattr(self, "added_args", None), "tune_mm_mlp_adapter", False):
             # only the projector (trainer.py:41-57): config.json + mm_projector.bin
             if main:

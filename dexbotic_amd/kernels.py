@@ -810,8 +810,14 @@ def scale_dev_(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1, beta2, eps, step, clip=None, chunk_state=None):
+def adamw(p, g, m, v, shadow, chunk_start, chunk_len, chunk_grp, lrs, wds, beta1, beta2, eps, step, clip=None, chunk_state=None,
+          chunk_mv_start=None):
+    """``chunk_mv_start``: m / v are PACKED (the sharded optimizer state of engine.FusedAdamW(ranges=...)): chunk c's moments start
+    at element chunk_mv_start[c] of m and v; p, g and shadow keep the arena offset chunk_start[c]"""
     d = L.AdamWDesc()
+    if chunk_mv_start is not None:
+        assert chunk_mv_start.dtype == torch.int64 and chunk_mv_start.numel() == chunk_start.numel() and chunk_mv_start.is_contiguous()
+    d.chunk_mv_start = _ptr(chunk_mv_start)
     if chunk_state is not None:
         assert chunk_state.dtype == torch.uint8 and chunk_state.numel() == chunk_start.numel() and chunk_state.is_contiguous()
     d.chunk_state = _ptr(chunk_state)

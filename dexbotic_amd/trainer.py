@@ -69,9 +69,21 @@ class NativeTrainer:
                  grad_accum: int = 1, distributed: Optional[bool] = None, min_bucket_bytes: int = 256 << 20,
                  force_reducer: bool = False, grad_comm_dtype: torch.dtype = torch.float32, grad_sync: str = "rs_ag",
                  grad_dtype: torch.dtype = torch.float32, overlap_optimizer: bool = False, optimizer_groups=None,
-                 native_avg_world1: bool = False, coalesce_micro_batches: Optional[bool] = None, grad_reduce_op: str = "sum"):
+                 native_avg_world1: bool = False, coalesce_micro_batches: Optional[bool] = None, grad_reduce_op: str = "sum",
+                 shard_optimizer: Optional[bool] = None, emulate_world: int = 0, gather_overlap: bool = True):
         import torch.distributed as dist
         self.model = model
+        # shard_optimizer: the sharded optimizer step under data parallelism (engine.ShardPlan — the reference's default DeepSpeed
+        # ZeRO config partitions optimizer state and update, base_exp.py:229 / zero3.json): reduce-scatter of the gradients, sum(g^2)
+        # over the own shard + one scalar all-reduce, adamw_k over 1 / world of the arena, all-gather of the updated bf16 shadows
+        # (``gather_overlap``: under the next forward, bucket by bucket).  Default: on for world size > 1 with grad_sync="rs_ag"
+        # (env DXA_SHARD_OPT=0: every rank repeats the full update on all-gathered gradients, rounds 1-5).  Parameters are
+        # bit-identical to the replicated path's (tests/test_zz_dp2_gpu.py).  ``emulate_world``: engine.GradReducer.
+        if shard_optimizer is None:
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            shard_optimizer = os.environ.get("DXA_SHARD_OPT", "1") != "0" and grad_sync == "rs_ag" and not overlap_optimizer \
+                and (multi or emulate_world > 1)
+        self.gather_overlap = bool(gather_overlap) and os.environ.get("DXA_GATHER_OVERLAP", "1") != "0"
         # coalesce_micro_batches: the ``grad_accum`` micro-batches of an optimizer step run as ONE forward / backward over their
         # concatenation (coalesce_batches).  Gradient accumulation exists in the reference recipe (8 episodes x 2, cogact_exp.py:
         # 41-46) to fit 80 GB parts; the mean loss over the merged batch IS the mean of the micro-batch means, so the step is the
@@ -93,7 +105,6 @@ class NativeTrainer:
         # code that reads parameters directly (p.data, state_dict()) calls trainer.synchronize() first.
         # optimizer_groups: explicit parameter groups [{"names": [...]}, ...] (exp/trainer.NativeDexboticTrainer: the groups the
         # exp's OptimizerConfig built); default: engine.FusedAdamW's own name rule.
-        self.opt = FusedAdamW(self.store, self.cfg, exclude=unused, overlap=overlap_optimizer, groups=optimizer_groups)
         self.total_steps, self.warmup_steps, self.grad_accum = total_steps, warmup_steps, grad_accum
         self.global_step = 0
         self.micro = 0
@@ -112,11 +123,14 @@ class NativeTrainer:
             # sharing the GPU with the backward's GEMM grids — the contention measurement of DESIGN.md section 6)
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, force=force_reducer,
                                        comm_dtype=grad_comm_dtype, algo=grad_sync, native_avg_world1=native_avg_world1,
-                                       reduce_op=grad_reduce_op)
+                                       reduce_op=grad_reduce_op, shard=bool(shard_optimizer), emulate_world=emulate_world)
         elif bf16_grads:
             self.reducer = GradReducer(self.store, min_bucket_bytes=min_bucket_bytes, skip=unused, comm_dtype=torch.bfloat16,
                                        local_only=True)
         self.store.bf16_grads = bf16_grads
+        self.sharded = self.reducer is not None and self.reducer.plan is not None
+        self.opt = FusedAdamW(self.store, self.cfg, exclude=unused, overlap=overlap_optimizer and not self.sharded,
+                              groups=optimizer_groups, ranges=self.reducer.plan.owned() if self.sharded else None)
         # global-norm clip: sum(g^2) is folded in bucket by bucket under the backward (after the all-reduce under DP)
         self.norm_tracker = None
         if self.cfg.max_grad_norm is not None and self.store.device.type == "cuda":
@@ -152,6 +166,7 @@ class NativeTrainer:
         self.update_due = False
         self._sumsq, self._reducing = None, False
         self.last_output = None
+        self._gathered_moments = None
 
     def set_grad_accum(self, n: int) -> None:
         """change the number of micro-batches per optimizer step (between optimizer steps only)"""
@@ -201,13 +216,23 @@ class NativeTrainer:
                 st.g(nm).zero_()
             self._zeroed_unused = True
         reducing = self.reducer is not None and (self.reducer.world > 1 or self.reducer.force)
+        self._sumsq = None                                # FusedAdamW.step takes the norm in one pass over the arena
         if reducing:
             st._mirrored = set()                          # bf16 exchange: cast every written slot (no epilogue mirrored the sum)
             st._bucket_fired = [True] * len(st.bucket_ranges)
+            st._bucket_touched = [True] * len(st.bucket_ranges)
+            # the reducer's after_reduce folds every exchanged slice into the norm tracker: bracketed by begin() / finish() like in
+            # a full group (round 5 left those folds on the tracker's stream with nothing joining it — ADVICE r5), and their sum
+            # IS the step's sum of squares (the sharded step has no other: its shards' shares are all-reduced below)
+            if self.norm_tracker is not None:
+                self.norm_tracker.begin()
             for b in reversed(range(len(st.bucket_ranges))):
                 self.reducer.bucket_ready(b)
             self.reducer.finish()
-        self._sumsq = None                                # FusedAdamW.step takes the norm in one pass over the arena
+            if self.norm_tracker is not None:
+                self._sumsq = self.norm_tracker.finish(fire_unfired=False)
+                if self.sharded:
+                    self.reducer.reduce_scalar(self._sumsq)
         self._reducing = reducing
         self.update_due = True
         self.micro = 0
@@ -299,12 +324,16 @@ class NativeTrainer:
             if self.norm_tracker is not None:
                 self.norm_tracker.begin()
         self.store.on_bucket_ready = hook
-        with K.f32_gemm_mode(getattr(self.model.config, "fp32_matmul", "exact")):
-            out = self.model(**batch)
-            loss = out.loss
-            self.store.wait_pending()           # (overlapped optimizer: buckets the forward never touched)
-            scale = (1.0 / self.grad_accum) if loss_scale is None else float(loss_scale)
-            (loss * scale if scale != 1.0 else loss).backward()
+        self.store._record_w32 = True           # (which buckets are read as fp32 masters: the sharded step gathers those in fp32)
+        try:
+            with K.f32_gemm_mode(getattr(self.model.config, "fp32_matmul", "exact")):
+                out = self.model(**batch)
+                loss = out.loss
+                self.store.wait_pending()           # (overlapped optimizer: buckets the forward never touched)
+                scale = (1.0 / self.grad_accum) if loss_scale is None else float(loss_scale)
+                (loss * scale if scale != 1.0 else loss).backward()
+        finally:
+            self.store._record_w32 = False
         self.last_output = out
         self.store.flush_wgrads()               # (only when autograd pruned a consumer of a multiply-used parameter)
         if last and self.store._accum_stash:
@@ -324,6 +353,8 @@ class NativeTrainer:
             self._sumsq = None
             if self.norm_tracker is not None:
                 self._sumsq = self.norm_tracker.finish(fire_unfired=not reducing)
+                if reducing and self.sharded:
+                    self.reducer.reduce_scalar(self._sumsq)     # the shards' shares of sum(g^2): one 4-byte all-reduce
             self._reducing = reducing
             self.update_due = True
         return loss.detach()
@@ -336,5 +367,14 @@ class NativeTrainer:
         self.opt.step(self.lr_scale() if lr_scale is None else lr_scale, sumsq=self._sumsq,
                       grads=self.reducer.result_arena if self._reducing else None, lrs=lrs, wds=wds,
                       grad_scale=self.reducer.grad_scale if self._reducing else 1.0)
+        if self.sharded and self._reducing:
+            self.reducer.gather_params(overlap=self.gather_overlap)
         self.update_due = False
         self.global_step += 1
+
+    def consolidate(self) -> None:
+        """sharded optimizer step: bring every rank's fp32 masters up to date (all ranks call it) — before state_dict() /
+        save_pretrained() / evaluation code that reads parameters directly.  A no-op otherwise."""
+        self.store.wait_pending()
+        if self.sharded and (self.reducer.world > 1 or self.reducer.force):
+            self.reducer.gather_masters()

@@ -346,6 +346,11 @@ typedef struct dxa_adamw_desc {
                                   are exactly 0, so while its gradient is all-zero and its group's weight decay is 0 torch's AdamW
                                   leaves p, m, v bit-for-bit unchanged — the kernel reads g only and returns; the first non-zero
                                   gradient turns the byte into 2 = ordinary from then on */
+  const int64_t* chunk_mv_start; /* or NULL (m, v laid out like p: element chunk_start[c] + i).  Sharded optimizer state — the
+                                  reference's default DeepSpeed ZeRO config partitions the optimizer state over the data-parallel
+                                  ranks (dexbotic/exp/base_exp.py:229, script/deepspeed/zero3.json:17-25): a rank keeps m / v only for
+                                  the arena ranges it owns, packed back to back; chunk c's moments then start at element
+                                  chunk_mv_start[c] of m and v while p, g and shadow keep the arena offset chunk_start[c] */
 } dxa_adamw_desc;
 int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream);
 /* out[0] = sum x^2 over n fp32 / bf16 elements (deterministic two-stage; scratch >= 4096 doubles) */

@@ -21,13 +21,13 @@ def _free_port():
     return p
 
 
-def _build_store():
+def _build_store(rows: int = 7):
     from dexbotic_amd.engine import ParamStore
     st = ParamStore("cpu", torch.float32)
     names = []
     for b in range(5):                                   # 5 buckets in "forward order"
         st.new_bucket()
-        grp = [(f"blk{b}.w", (7, 5)), (f"blk{b}.b", (6,))]     # 41 elements: NOT divisible by the world size
+        grp = [(f"blk{b}.w", (rows, 5)), (f"blk{b}.b", (6,))]     # 41 elements: NOT divisible by the world size
         st.register(grp)
         names += [n for n, _ in grp]
     st.new_bucket()
@@ -231,3 +231,157 @@ def test_store_view_forwards_attribute_writes():
         view._wgrad_pending = True                       # what functional._wgrad_now / _bgrad do after a side-stream enqueue
         view.mark_written(n)
     assert joined and all(joined), joined                # every bucket completion saw the pending side-stream work
+
+
+# ------------------------------------------------------------------------------ sharded optimizer step (round 6)
+def _shard_worker(rank, world, port, tmp):
+    """engine.ShardPlan / GradReducer(shard=True) over gloo on CPU tensors: reduce-scatter into fixed shards (no gradient
+    all-gather), after_reduce sees the own shard (+ rank 0 the replicated tails), a plain SGD-like update of the owned ranges and
+    gather_params / gather_masters bring every rank to exactly what the replicated exchange + full update gives"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dexbotic_amd.engine import GradReducer
+        # one slice per bucket / two buckets per slice / one slice; 7 rows: 41-element buckets, too short to shard (< 64 per rank:
+        # replicated tails only, except the single merged slice); 61 rows: 311-element buckets, real shards + ragged tails
+        for min_bytes, rows in ((64, 7), (400, 7), (1 << 20, 7), (64, 61), (3000, 61), (1 << 20, 61)):
+            st, names = _build_store(rows)
+            st.set_expected(["unused.w"])
+            torch.manual_seed(5)
+            st.master.copy_(torch.randn(st.total))            # same weights on every rank
+            w0 = st.master.clone()
+            red = GradReducer(st, min_bucket_bytes=min_bytes, skip=["unused.w"], shard=True)
+            plan = red.plan
+            assert plan is not None and plan.world == world and plan.rank == rank
+            seen = []
+            red.after_reduce = lambda lo, hi, stream: seen.append((lo, hi))
+            torch.manual_seed(100 + rank)
+            st.begin_step()
+            st.on_bucket_ready = red.bucket_ready
+            local = {}
+            for n in reversed(names):
+                g = torch.randn(st.slots[n].shape)
+                st.g(n).copy_(g)
+                local[n] = g
+                st.mark_written(n)
+            st.g("unused.w").fill_(float(rank + 1))
+            red.finish()
+            gathered = [None] * world
+            dist.all_gather_object(gathered, local)
+            total = torch.zeros(st.total)
+            for n in names:
+                s_ = st.slots[n]
+                total[s_.offset:s_.offset + s_.numel] = sum(g[n] for g in gathered).reshape(-1)
+            owned = plan.owned()
+            own_elems = sum(b - a for a, b in owned)
+            for a, b in owned:                                # the SUM over the ranks on what this rank owns (exact for two ranks;
+                if world == 2:                                #  three ranks add in the ring's order)
+                    assert torch.equal(st.grad[a:b], total[a:b]), (min_bytes, a, b)
+                assert torch.allclose(st.grad[a:b], total[a:b], atol=1e-5), (min_bytes, a, b)
+            # after_reduce: the own shards, and the replicated tails on rank 0 only
+            tails = [plan.tail(i) for i in range(len(plan.slices)) if plan.tail(i)[1] > plan.tail(i)[0]]
+            shards = [plan.shard(i) for i in range(len(plan.slices)) if plan.slices[i]["per"] > 0]
+            assert sorted(seen) == sorted(shards + (tails if rank == 0 else [])), (seen, shards, tails)
+            # the owned ranges of all ranks: shards disjoint, tails shared, union = every exchanged element
+            all_owned = [None] * world
+            dist.all_gather_object(all_owned, owned)
+            cover = torch.zeros(st.total, dtype=torch.int32)
+            for o in all_owned:
+                for a, b in o:
+                    cover[a:b] += 1
+            for i, sl in enumerate(plan.slices):
+                assert torch.all(cover[sl["lo"]:sl["lo"] + sl["body"]] == 1)
+                assert torch.all(cover[sl["lo"] + sl["body"]:sl["hi"]] == world)
+            u = st.slots["unused.w"]
+            assert torch.all(cover[u.offset:u.offset + u.numel] == 0)
+            assert torch.all(st.g("unused.w") == float(rank + 1))             # never sent
+            # the update of the owned ranges, then the gathers: every rank ends with the full update of the summed gradient
+            for a, b in owned:
+                st.master[a:b] -= 0.1 * st.grad[a:b] * red.grad_scale
+            c0 = red.collectives
+            red.gather_params(overlap=False)
+            want = w0 - 0.1 * total / world
+            for sl in plan.slices:
+                assert torch.allclose(st.master[sl["lo"]:sl["hi"]], want[sl["lo"]:sl["hi"]], atol=2e-6), min_bytes
+            assert torch.equal(st.g("unused.w"), torch.full((11,), float(rank + 1)))
+            assert red.collectives - c0 == sum(1 for sl in plan.slices if sl["per"] > 0)
+            red.gather_masters()                              # idempotent on already gathered masters
+            both = [None] * world
+            dist.all_gather_object(both, st.master.clone())
+            assert all(torch.equal(both[0], b) for b in both)
+            if rows == 61:
+                assert all(sl["per"] > 0 for sl in plan.slices) and own_elems < sum(sl["hi"] - sl["lo"] for sl in plan.slices)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_exchange_gloo(tmp_path, world):
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_shard_plan_and_sharded_chunk_tables():
+    """ShardPlan: fixed slices in arena order, 16-element shard starts, short slices replicated; FusedAdamW(ranges=owned):
+    the chunk table covers exactly the trainable elements inside the owned ranges, moments packed back to back"""
+    from dexbotic_amd.engine import FusedAdamW, OptimConfig, ParamStore, ShardPlan
+    st = ParamStore("cpu", torch.float32)
+    for b in range(6):
+        st.new_bucket()
+        st.register([(f"l{b}.w", (40, 33)), (f"l{b}.b", (33,))])
+    st.new_bucket()
+    st.register([("head.w", (7, 3))])                         # 21 elements: a slice too short to shard
+    st.finalize(train=True)
+    world = 4
+    # (ParamStore.new_bucket() counts from 1: l0 .. l5 are buckets 1 .. 6, the head bucket 7; buckets 3 = l2 and 6 = l5 are skipped)
+    plans = [ShardPlan(st, world, r, skip_buckets=[3, 6], min_bucket_bytes=2 * 1353 * 4) for r in range(world)]
+    p0 = plans[0]
+    assert [sl["buckets"] for sl in p0.slices] == [[1, 2], [4, 5], [7]]
+    assert [sl["buckets"] for sl in p0.slices] == [sl["buckets"] for sl in plans[3].slices]
+    for sl in p0.slices:
+        assert sl["per"] % 16 == 0 and sl["body"] == sl["per"] * world and sl["lo"] + sl["body"] <= sl["hi"]
+    assert p0.slices[-1]["per"] == 0                           # the 21-element head: replicated
+    cover = torch.zeros(st.total, dtype=torch.int32)
+    for pl in plans:
+        for a, b in pl.owned():
+            cover[a:b] += 1
+    for b in (3, 6):
+        lo3, hi3 = st.bucket_ranges[b]
+        assert torch.all(cover[lo3:hi3] == 0)
+    for sl in p0.slices:
+        assert torch.all(cover[sl["lo"]:sl["lo"] + sl["body"]] == 1) and torch.all(cover[sl["lo"] + sl["body"]:sl["hi"]] == world)
+    st.params["l1.b"].requires_grad_(False)
+    for r, pl in enumerate(plans):
+        opt = FusedAdamW(st, OptimConfig(chunk=256), exclude=["l2.w", "l2.b", "l5.w", "l5.b"], ranges=pl.owned())
+        owned = torch.zeros(st.total, dtype=torch.bool)
+        for a, b in pl.owned():
+            owned[a:b] = True
+        train = torch.zeros(st.total, dtype=torch.bool)
+        for s_ in st.slots.values():
+            if st.params[s_.name].requires_grad and not s_.name.startswith(("l2.", "l5.")):
+                train[s_.offset:s_.offset + s_.numel] = True
+        hit = torch.zeros(st.total, dtype=torch.int32)
+        mv = torch.zeros(int(opt.m.numel()), dtype=torch.int32)
+        for c0, ln, m0 in zip(opt.chunk_start.tolist(), opt.chunk_len.tolist(), opt.chunk_mv_start.tolist()):
+            hit[c0:c0 + ln] += 1
+            mv[m0:m0 + ln] += 1
+        assert torch.equal(hit == 1, owned & train) and int(hit.max()) <= 1
+        assert int(mv.max()) <= 1 and int(owned.sum()) <= opt.m.numel() <= int(owned.sum()) + 3 * len(pl.owned())
+        # packed layout: the owned ranges back to back, each starting on a 16-byte boundary like in the arena
+        base = 0
+        for (a, b) in pl.owned():
+            assert base % 4 == 0 and a % 4 == 0
+            for c0, m0 in zip(opt.chunk_start.tolist(), opt.chunk_mv_start.tolist()):
+                if a <= c0 < b:
+                    assert m0 == base + (c0 - a)
+            base += (b - a + 3) // 4 * 4
+        full = torch.arange(1, st.total + 1, dtype=torch.float32)
+        packed = opt.pack_moments(full)
+        assert torch.equal(packed[packed > 0], full[owned])
+        opt.m.copy_(packed)
+        opt.v.copy_(2 * packed)
+        fm, fv = opt.full_moments()
+        assert torch.equal(fm[owned], full[owned]) and torch.equal(fv[owned], 2 * full[owned]) and float(fm[~owned].abs().sum()) == 0
+    assert FusedAdamW(st, OptimConfig(), exclude=["l2.w", "l2.b"]).chunk_mv_start is None

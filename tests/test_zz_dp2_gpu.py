@@ -26,7 +26,20 @@ STEPS = 3
 B, ST = 4, 12
 SEED = 31
 LR = 1e-5
-VARIANTS = (("allreduce", 1, "sum"), ("rs_ag", 1, "sum"), ("allreduce", 2, "sum"), ("rs_ag", 1, "avg"))
+# (exchange algorithm, accumulation micro-batches, reduce op, sharded optimizer step, compute dtype, max_grad_norm)
+VARIANTS = (("allreduce", 1, "sum", False, "float32", 1.0), ("rs_ag", 1, "sum", False, "float32", 1.0),
+            ("allreduce", 2, "sum", False, "float32", 1.0), ("rs_ag", 1, "avg", False, "float32", 1.0),
+            # round 6: the SHARDED optimizer step (engine.ShardPlan: reduce-scatter -> own-shard sum(g^2) + scalar all-reduce ->
+            # adamw over the own shard -> all-gather of the updated weights), with the clip and under accumulation
+            ("rs_ag", 1, "sum", True, "float32", 1.0), ("rs_ag", 2, "sum", True, "float32", 1.0),
+            # ... and against the replicated path BIT FOR BIT: with the clip out of the way (max_grad_norm 1e9: the coefficient
+            # is exactly 1 / world in both; under the 1.0 clip the two paths add sum(g^2) in different orders) every rank of
+            # either path must hold identical parameters — fp32 compute (masters travel) and bf16 compute (the bf16 shadows
+            # travel, the fp32 masters only for the action head, which reads them)
+            ("rs_ag", 1, "sum", False, "float32", 1e9), ("rs_ag", 1, "sum", True, "float32", 1e9),
+            ("rs_ag", 1, "sum", False, "bfloat16", 1e9), ("rs_ag", 1, "sum", True, "bfloat16", 1e9))
+BITWISE_PAIRS = ((6, 7), (8, 9))
+N_REF = 6            # the first N_REF variants are held to ONE process on the concatenated batch
 
 
 def _free_port():
@@ -66,32 +79,45 @@ def _shard(x, episodes):
     return out
 
 
-def _build(grad_accum=1, **kw):
+def _build(grad_accum=1, dtype="float32", clip=1.0, **kw):
     from dexbotic_amd.engine import OptimConfig
     from dexbotic_amd.trainer import NativeTrainer
     from oracle.weights import cogact_shapes, make_weights
     from tests.helpers import CFGS, build_product
     cfg = CFGS["t1"]
-    m = build_product(cfg, make_weights(cogact_shapes(cfg), SEED), "float32", "cuda", train=True)
+    m = build_product(cfg, make_weights(cogact_shapes(cfg), SEED), dtype, "cuda", train=True)
     m.train()
-    tr = NativeTrainer(m, OptimConfig(base_lr=LR, weight_decay=0.01, max_grad_norm=1.0), min_bucket_bytes=1 << 14,
+    tr = NativeTrainer(m, OptimConfig(base_lr=LR, weight_decay=0.01, max_grad_norm=clip), min_bucket_bytes=1 << 14,
                        grad_accum=grad_accum, **kw)
     return m, tr
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, backend="gloo", variants=VARIANTS, comm_dtype="float32"):
+    """``backend`` "gloo": both ranks on cuda:0, slices staged through host memory; "nccl" (tests/test_zz_dp_rccl_gpu.py, boxes
+    with >= 2 GPUs): one GPU per rank, RCCL collectives on device pointers — the very same steps otherwise"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)                                 # BOTH ranks on the one GPU of the box
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)  # gloo: BOTH ranks on the one GPU of the box
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
+                                device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         x = _episodes()
-        for vi, (algo, accum, op) in enumerate(VARIANTS):
-            m, tr = _build(grad_accum=accum, distributed=True, grad_sync=algo, grad_reduce_op=op)
+        for vi, (algo, accum, op, shard, dtype, clip) in enumerate(variants):
+            m, tr = _build(grad_accum=accum, dtype=dtype, clip=clip, distributed=True, grad_sync=algo, grad_reduce_op=op,
+                           shard_optimizer=shard, grad_comm_dtype=getattr(torch, comm_dtype))
             red = tr.reducer
-            assert red is not None and red.world == 2 and red.stage_host and red.reduce_op == op
+            assert red is not None and red.world == 2 and red.stage_host == (backend != "nccl") and red.reduce_op == op
             assert red.grad_scale == (0.5 if op == "sum" else 1.0)
+            assert tr.sharded == shard and (red.plan is not None) == shard
+            if shard:
+                own = sum(b - a for a, b in red.plan.owned())
+                assert own <= tr.opt.m.numel() <= own + 3 * len(red.plan.owned()) and tr.opt.m.numel() < m.store.total
+                assert tr.opt.ranges == red.plan.owned()
             mine = list(range(rank, B, world))               # episodes rank::2
             losses, norms, coll = [], [], []
             for _ in range(STEPS):
@@ -105,6 +131,15 @@ def _worker(rank, world, port, tmp):
                 coll.append(red.collectives - c0)
             torch.cuda.synchronize()
             st = m.store
+            gathered = red.bytes_gathered
+            if shard:
+                # a rank's fp32 masters are current for its own shard (and the buckets a forward reads in fp32) only:
+                # gathered before anybody looks at them, as a checkpoint save does
+                head_lo = min(st.slots[n].offset for n in st.slots if ".action_head." in n)
+                head = st.master[head_lo:head_lo + 64].clone()
+                tr.consolidate()
+                torch.cuda.synchronize()
+                assert torch.equal(head, st.master[head_lo:head_lo + 64])     # the fp32-read head was already current
             # never communicated: buckets all of whose slots the path does not write (lm_head, the unused last CLIP layer)
             unused = set(m.unused_parameter_names())
             assert unused and red.skip_buckets
@@ -112,12 +147,25 @@ def _worker(rank, world, port, tmp):
                 assert float(st.g(nm).abs().max()) == 0.0, nm
             assert any(st.slots[nm].bucket in red.skip_buckets for nm in unused)
             # what travelled: every exchanged bucket once per optimizer step (alignment gaps ride along), never the whole arena
-            sent = sum(hi - lo for b, (lo, hi) in enumerate(st.bucket_ranges) if b not in red.skip_buckets)
-            skipped = sum(hi - lo for b, (lo, hi) in enumerate(st.bucket_ranges) if b in red.skip_buckets)
-            assert skipped > 0 and STEPS * sent * 4 <= red.bytes_reduced <= STEPS * (st.total - skipped // 2) * 4, \
-                (red.bytes_reduced, STEPS * sent * 4, STEPS * st.total * 4)
+            # (an unused bucket id keeps its initial range [total, 0]: counted as empty)
+            sent = sum(max(hi - lo, 0) for b, (lo, hi) in enumerate(st.bucket_ranges) if b not in red.skip_buckets)
+            skipped = sum(max(hi - lo, 0) for b, (lo, hi) in enumerate(st.bucket_ranges) if b in red.skip_buckets)
+            esz = 2 if comm_dtype == "bfloat16" else 4
+            assert skipped > 0 and STEPS * sent * esz <= red.bytes_reduced <= STEPS * (st.total - skipped // 2) * esz, \
+                (red.bytes_reduced, STEPS * sent * esz, STEPS * st.total * esz)
+            if shard:
+                # what came back per step: the updated weights once (bf16 compute: 2 bytes per element + the fp32 head), never
+                # the gradients
+                wsz = 2 if dtype == "bfloat16" else 4
+                assert 0 < gathered <= STEPS * (sent * wsz + (sent * 4 if dtype == "bfloat16" else 0)), (gathered, sent)
+                if dtype == "bfloat16":
+                    # fp32 masters travel only for the slices holding a bucket the forward reads in fp32 (the action head)
+                    head = sum(sl["body"] for sl in red.plan.slices if any(b in st._w32_buckets for b in sl["buckets"]))
+                    allb = sum(sl["body"] for sl in red.plan.slices)
+                    assert 0 < head < allb and gathered == STEPS * (2 * allb + 4 * head), (gathered, head, allb)
+            sh = st.shadow.detach().float().cpu().numpy() if st.shadow is not None else np.zeros(1, np.float32)
             np.savez(os.path.join(tmp, f"v{vi}_rank{rank}.npz"), losses=np.asarray(losses), norms=np.asarray(norms),
-                     coll=np.asarray(coll), master=st.master.detach().cpu().numpy())
+                     coll=np.asarray(coll), master=st.master.detach().cpu().numpy(), shadow=sh)
             del m, tr
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
@@ -142,12 +190,19 @@ def test_two_rank_model_step_equals_single_process_on_the_concatenated_batch(tmp
     # ---- TWO processes on the same GPU, two episodes each
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
-    for vi, (algo, accum, op) in enumerate(VARIANTS):
+    check_against_single_process(tmp_path, VARIANTS, ref_losses, ref_norms, ref_master, names)
+
+
+def check_against_single_process(tmp_path, variants, ref_losses, ref_norms, ref_master, names, n_ref=N_REF, pairs=BITWISE_PAIRS):
+    for vi, (algo, accum, op, shard, dtype, clip) in enumerate(variants):
         r = [np.load(tmp_path / f"v{vi}_rank{k}.npz") for k in range(2)]
-        tag = f"{algo}/accum{accum}/{op}"
+        tag = f"{algo}/accum{accum}/{op}/{'sharded' if shard else 'replicated'}/{dtype}/clip{clip:g}"
         # both ranks hold the same parameters, bit for bit (same exchanged gradients, same update)
         assert np.array_equal(r[0]["master"], r[1]["master"]), tag
+        assert np.array_equal(r[0]["shadow"], r[1]["shadow"]), tag
         assert np.array_equal(r[0]["norms"], r[1]["norms"]), tag
+        if vi >= n_ref:
+            continue
         loss = (r[0]["losses"] + r[1]["losses"]) / 2
         dl = np.abs(loss - ref_losses).max() / np.abs(ref_losses).max()
         dn = np.abs(r[0]["norms"] - ref_norms).max() / np.abs(ref_norms).max()
@@ -166,5 +221,15 @@ def test_two_rank_model_step_equals_single_process_on_the_concatenated_batch(tmp
         assert apart < 1e-4, (tag, apart)
         assert len(set(r[0]["coll"].tolist())) == 1, tag        # the same number of collectives every step
     # accumulation: two micro-batches per optimizer step exchange ONCE — as many collectives as the one-pass step
-    c = {v: np.load(tmp_path / f"v{vi}_rank0.npz")["coll"][0] for vi, v in enumerate(VARIANTS)}
-    assert c[("allreduce", 2, "sum")] == c[("allreduce", 1, "sum")]
+    c = {v: np.load(tmp_path / f"v{vi}_rank0.npz")["coll"][0] for vi, v in enumerate(variants)}
+    assert c[("allreduce", 2, "sum", False, "float32", 1.0)] == c[("allreduce", 1, "sum", False, "float32", 1.0)]
+    assert c[("rs_ag", 2, "sum", True, "float32", 1.0)] == c[("rs_ag", 1, "sum", True, "float32", 1.0)]
+    # the sharded step against the replicated one, bit for bit (clip out of the way), on both ranks
+    for a, b in pairs:
+        ra, rb = np.load(tmp_path / f"v{a}_rank0.npz"), np.load(tmp_path / f"v{b}_rank1.npz")
+        assert variants[a][3] is False and variants[b][3] is True and variants[a][4] == variants[b][4]
+        assert np.array_equal(ra["master"], rb["master"]), f"sharded != replicated parameters ({variants[a][4]})"
+        assert np.array_equal(ra["shadow"], rb["shadow"]), f"sharded != replicated bf16 shadows ({variants[a][4]})"
+        assert np.array_equal(ra["losses"], np.load(tmp_path / f"v{b}_rank0.npz")["losses"])
+        print(f"sharded == replicated bit for bit after {STEPS} steps ({variants[a][4]} compute), "
+              f"max |dp| {np.abs(ra['master'] - ref_master).max():.2e} from the initial-run reference")

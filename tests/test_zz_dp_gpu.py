@@ -21,10 +21,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _trainer(m, **kw):
+def _trainer(m, clip=1.0, **kw):
     from dexbotic_amd.engine import OptimConfig
     from dexbotic_amd.trainer import NativeTrainer
-    return NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=0.01, max_grad_norm=1.0), **kw)
+    return NativeTrainer(m, OptimConfig(base_lr=1e-3, weight_decay=0.01, max_grad_norm=clip), **kw)
 
 
 def test_plain_fp32_step_is_bitwise_reproducible(golden_dir):
@@ -233,6 +233,80 @@ def test_native_avg_reduce_scatter_all_gather_in_place_at_world_one():
                     sl = st.slots[f"p{i}"]
                     assert torch.equal(got[sl.offset:sl.offset + sl.numel], want[sl.offset:sl.offset + sl.numel]), (comm, algo, i)
                 assert red.collectives >= 2 and red.bytes_reduced > 0
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_at_world_one_over_rccl(golden_dir):
+    """the sharded optimizer step (engine.ShardPlan, round 6) on RCCL with ONE rank: the plan of world size 1 owns every exchanged
+    element, so reduce-scatter in place -> sum(g^2) over the 'shard' + scalar all-reduce -> adamw over the owned ranges with PACKED
+    moments -> all-gather of the updated weights must reproduce the plain step (fp32 exchange; fp32 and bf16 compute): bit for bit
+    with the clip out of the way (max_grad_norm 1e9 — the sharded step adds sum(g^2) slice by slice, the plain one over merged
+    ranges: under the 1.0 clip the two norms differ in the last bits, 6.4568820 vs 6.4568825, and so does every parameter), within
+    that rounding with it; and ``emulate_world=8`` (bench.py dp8_emulated_ms_per_step: ownership of rank 0 of 8, collectives at world size 1) moves exactly
+    the owned eighth of the parameters — by exactly what the full step moves them."""
+    import torch.distributed as dist
+    g, cfg, w = load_golden(golden_dir, "t1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for dtype, clip in (("float32", 1e9), ("bfloat16", 1e9), ("float32", 1.0)):
+            res = {}
+            for tag, kw in (("plain", {}), ("sharded", dict(force_reducer=True, shard_optimizer=True)),
+                            ("emulated8", dict(force_reducer=True, shard_optimizer=True, emulate_world=8))):
+                m = build_product(cfg, w, dtype, DEV, train=True)
+                m.train()
+                tr = _trainer(m, clip=clip, min_bucket_bytes=1 << 14, **kw)
+                m.store.epi_sumsq = False                     # the read-back sum of squares in every leg (one summation order)
+                p0 = m.store.master.clone()
+                losses = [tr.step(_batch(g)).item() for _ in range(2)]
+                tr.consolidate()
+                torch.cuda.synchronize()
+                res[tag] = (losses, tr.opt.norm.clone(), m.store.master.clone(), None if m.store.shadow is None else m.store.shadow.clone(),
+                            p0, tr)
+            pl, sh, em = res["plain"], res["sharded"], res["emulated8"]
+            tr_s, tr_e = sh[5], em[5]
+            assert tr_s.sharded and tr_s.reducer.plan.world == 1 and tr_s.opt.chunk_mv_start is not None
+            assert tr_s.reducer.bytes_gathered > 0 and tr_s.reducer.bytes_reduced > 0
+            if clip == 1.0:
+                assert abs(sh[1].item() - pl[1].item()) <= 1e-6 * pl[1].item() and sh[0][0] == pl[0][0]
+                torch.testing.assert_close(sh[2], pl[2], rtol=1e-5, atol=5e-5)      # (floor: 5 % of one lr step, as above)
+                continue
+            assert sh[0] == pl[0], (dtype, sh[0], pl[0])
+            assert abs(sh[1].item() - pl[1].item()) <= 1e-6 * pl[1].item(), dtype      # (the reported norm: summation order)
+            dd = (sh[2] != pl[2])
+            assert not bool(dd.any()), (f"sharded step at world 1 != plain step ({dtype}): {int(dd.sum())} elements, max abs "
+                                        f"{float((sh[2] - pl[2]).abs().max()):.3e}, first at {int(torch.nonzero(dd)[0])}")
+            if pl[3] is not None:
+                assert torch.equal(sh[3], pl[3])
+            # emulation: rank 0 of 8 — packed moments for an eighth of the exchanged elements (+ the replicated tails)
+            plan = tr_e.reducer.plan
+            assert plan.world == 8 and plan.rank == 0 and tr_e.reducer.world == 1
+            owned = torch.zeros(p0.numel() if False else em[4].numel(), dtype=torch.bool, device=DEV)
+            for a, b in plan.owned():
+                owned[a:b] = True
+            exch = sum(sl["hi"] - sl["lo"] for sl in plan.slices)
+            assert int(owned.sum()) <= tr_e.opt.m.numel() <= int(owned.sum()) + 3 * len(plan.owned()) and int(owned.sum()) < 0.25 * exch
+            # first step from identical state: the owned parameters move exactly as in the full step, the others not at all
+            m1 = build_product(cfg, w, dtype, DEV, train=True)
+            m1.train()
+            t1 = _trainer(m1, clip=clip, min_bucket_bytes=1 << 14, force_reducer=True, shard_optimizer=True, emulate_world=8)
+            m1.store.epi_sumsq = False
+            m2 = build_product(cfg, w, dtype, DEV, train=True)
+            m2.train()
+            t2 = _trainer(m2, clip=clip, min_bucket_bytes=1 << 14)
+            m2.store.epi_sumsq = False
+            t1.step(_batch(g))
+            t2.step(_batch(g))
+            torch.cuda.synchronize()
+            a1, a2, start = m1.store.master, m2.store.master, em[4]
+            assert torch.equal(a1[owned], a2[owned])
+            assert torch.equal(a1[~owned], start[~owned])
+            assert not torch.equal(a2[~owned], start[~owned])
     finally:
         if created:
             dist.destroy_process_group()
