@@ -83,6 +83,15 @@ class ImageDesc(C.Structure):
     ]
 
 
+class DecodeDesc(C.Structure):
+    _fields_ = [
+        ("layers", _vp), ("x_in", _vp), ("out", _vp), ("final_norm_w", _vp), ("cos_row", _vp), ("sin_row", _vp),
+        ("workspace", _vp), ("workspace_bytes", _sz),
+        ("n_layers", _i32), ("d", _i32), ("Hq", _i32), ("Hkv", _i32), ("D", _i32), ("F", _i32), ("slot", _i32), ("kv_lo", _i32),
+        ("max_len", _i32), ("eps", _f32),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol declared in include/dexbotic_amd.h
 SIGNATURES = {
     "dxa_last_error": (C.c_char_p, []),
@@ -158,6 +167,9 @@ SIGNATURES = {
     "dxa_dit_bf16_pack": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _vp]),
     "dxa_dit_sample_bf16_workspace": (_sz, [_int, _int, _int]),
     "dxa_dit_sample_bf16_fwd": (_int, [_vp] * 9 + [_int, _int, _int, _int, _f32, _vp, _int, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
+    "dxa_decode_step_workspace": (_sz, [_int, _int, _int, _int, _int]),
+    "dxa_decode_step": (_int, [C.POINTER(DecodeDesc), _vp]),
+    "dxa_decode_status": (_int, [_vp, _vp]),
     "dxa_clip_coef": (_int, [_vp, _f32, _vp, _vp, _vp]),
     "dxa_clip_coef_scaled": (_int, [_vp, _f32, _f32, _vp, _vp, _vp]),
     "dxa_scale": (_int, [_vp, _i64, _f32, _vp]),

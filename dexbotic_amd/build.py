@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdexbotic_amd.so")
-SOURCES = ["api.cpp", "gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "optim.hip", "loss.hip", "image.hip", "dit_fused.hip", "memvla.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "optim.hip", "loss.hip", "image.hip", "dit_fused.hip", "memvla.hip", "decode_fused.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(os.path.dirname(HERE), "include", "dexbotic_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -19,6 +19,8 @@ struct AdamP {
   const float* clip;
   uint8_t* state;      // per-chunk sparse-table state (dxa_adamw_desc.chunk_state) or null
   const int64_t* cms;  // per-chunk start of the moments in a packed (sharded) m / v, or null: the arena offset
+  int n_chunks;        // chunks of this launch: a workgroup takes chunks blockIdx.x, + gridDim.x, ... (grid < n_chunks = a
+                       // bounded-footprint launch that leaves the other CUs to a concurrent stream)
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, float wd, const AdamP& a,
@@ -50,8 +52,18 @@ template <> struct GradLd<bf16_t> {
 };
 
 template <typename TG>
+__device__ __forceinline__ void adamw_chunk(const AdamP& a, const int c);
+
+template <typename TG>
 __global__ __launch_bounds__(256) void adamw_k(const AdamP a) {
-  const int c = blockIdx.x;
+  for (int c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
+    adamw_chunk<TG>(a, c);
+    if (gridDim.x < (unsigned)a.n_chunks) __syncthreads();     // (the sparse-table vote re-uses its LDS word)
+  }
+}
+
+template <typename TG>
+__device__ __forceinline__ void adamw_chunk(const AdamP& a, const int c) {
   const int64_t start = a.cs[c];
   const int len = a.cl[c];
   const int grp = a.cg[c];
@@ -241,8 +253,12 @@ extern "C" int dxa_adamw(const dxa_adamw_desc* d, dxa_stream_t stream) {
   a.clip = d->clip_coef;
   a.state = d->chunk_state;
   a.cms = d->chunk_mv_start;
-  if (d->g_dtype == DXA_BF16) hipLaunchKernelGGL(adamw_k<bf16_t>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(adamw_k<float>, dim3((unsigned)d->n_chunks), dim3(256), 0, (hipStream_t)stream, a);
+  a.n_chunks = (int)d->n_chunks;
+  // DXA_ADAMW_GRID=<n>: at most n workgroups, each walking chunks n apart (the overlapped update's footprint on the CUs)
+  static const int grid_cap = getenv("DXA_ADAMW_GRID") ? atoi(getenv("DXA_ADAMW_GRID")) : 0;
+  const unsigned grid = grid_cap > 0 && (int64_t)grid_cap < d->n_chunks ? (unsigned)grid_cap : (unsigned)d->n_chunks;
+  if (d->g_dtype == DXA_BF16) hipLaunchKernelGGL(adamw_k<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(adamw_k<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }

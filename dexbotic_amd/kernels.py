@@ -1027,3 +1027,45 @@ def dit_blocks_timed_out(stream: Optional["torch.cuda.Stream"] = None) -> bool:
     L.check(lib.dxa_dit_blocks_status(stream.cuda_stream if stream is not None else _stream(), C.byref(flag)),
             "dxa_dit_blocks_status")
     return bool(flag.value)
+
+
+# ------------------------------------------------------------------------------------------- persistent decode step
+DECODE_FUSED_MAX_WIDTH = 32768      # csrc/decode_fused.hip ACT_MAX
+DECODE_FUSED_MAX_KEYS = 16383       # ... T_MAX
+
+
+def decode_step_supported(d: int, Hq: int, Hkv: int, D: int, F: int) -> bool:
+    return (D in (64, 128, 256) and d % 8 == 0 and F % 8 == 0 and (Hq * D) % 8 == 0 and Hq % Hkv == 0 and
+            max(d, F, Hq * D) <= DECODE_FUSED_MAX_WIDTH and Hq <= 256)
+
+
+def decode_step(layer_table: torch.Tensor, x_in: torch.Tensor, out: torch.Tensor, final_w: torch.Tensor, cos_row: torch.Tensor,
+                sin_row: torch.Tensor, ws: torch.Tensor, n_layers: int, d: int, Hq: int, Hkv: int, D: int, F: int, slot: int,
+                kv_lo: int, max_len: int, eps: float) -> torch.Tensor:
+    """one new token of one sequence through every decoder layer + final norm in ONE persistent launch (dxa_decode_step);
+    `layer_table`: int64 device tensor of n_layers * 9 pointers (see include/dexbotic_amd.h); the caches are appended in place"""
+    assert layer_table.dtype == torch.int64 and layer_table.numel() == n_layers * 9 and layer_table.is_cuda
+    for t in (x_in, out, final_w):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() == d and t.is_cuda
+    for t in (cos_row, sin_row):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == D // 2 and t.is_cuda
+    q = L.DecodeDesc()
+    q.layers, q.x_in, q.out, q.final_norm_w = _ptr(layer_table), _ptr(x_in), _ptr(out), _ptr(final_w)
+    q.cos_row, q.sin_row = _ptr(cos_row), _ptr(sin_row)
+    q.workspace, q.workspace_bytes = _ptr(ws), ws.numel() * ws.element_size()
+    q.n_layers, q.d, q.Hq, q.Hkv, q.D, q.F = n_layers, d, Hq, Hkv, D, F
+    q.slot, q.kv_lo, q.max_len, q.eps = slot, kv_lo, max_len, float(eps)
+    L.check(lib.dxa_decode_step(C.byref(q), _stream()), "dxa_decode_step")
+    return out
+
+
+def decode_step_workspace(d: int, Hq: int, Hkv: int, D: int, F: int, device) -> torch.Tensor:
+    return torch.empty(lib.dxa_decode_step_workspace(d, Hq, Hkv, D, F), device=device, dtype=torch.uint8)
+
+
+def decode_timed_out(stream: Optional["torch.cuda.Stream"] = None) -> bool:
+    """True if a persistent decode launch on `stream` gave up at a device-wide barrier since the last call (its tokens are
+    garbage).  Synchronises the stream."""
+    flag = C.c_int(0)
+    L.check(lib.dxa_decode_status(stream.cuda_stream if stream is not None else _stream(), C.byref(flag)), "dxa_decode_status")
+    return bool(flag.value)

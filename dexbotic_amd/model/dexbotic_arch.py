@@ -531,6 +531,10 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
             if done or t + 1 == max_new_tokens:
                 break
             logits = K.mm_nt(llm.forward_cached(W_emb[nxt].view(B, 1, -1), cache, pad)[:, -1].contiguous(), W_lm)
+        if cache.fused_steps and K.decode_timed_out():
+            # (the host has synchronised on every token anyway: stopping criteria / eos read the ids)
+            raise RuntimeError("generate(): a persistent decode launch gave up at a device-wide barrier (something else held CUs for "
+                               "seconds); its tokens are garbage — re-run, or set DXA_DECODE_FUSED=0 for the per-op decode step")
         if return_dict_in_generate:
             return GenerateOutput(sequences=seq, logits=tuple(step_logits) if step_logits else None)
         return seq

@@ -139,6 +139,20 @@ class Qwen2Backbone(nn.Module):
         past, total = cache.length, cache.length + S
         if total > cache.max_len:
             raise ValueError(f"KV cache of {cache.max_len} positions cannot take {total}")
+        if B == 1 and S == 1 and past > 0 and inputs_embeds.dtype == torch.bfloat16 and inputs_embeds.is_cuda:
+            fused = self._decode_state(cache)
+            if fused is not None:
+                # ONE persistent launch for the whole decoder pass of the new token (csrc/decode_fused.hip)
+                kv_lo = int(pad[0]) if pad is not None else 0
+                cos_m, sin_m = self.rope_tables(cache.max_len, inputs_embeds.device)
+                c = self.config
+                out = torch.empty(d, device=inputs_embeds.device, dtype=torch.bfloat16)
+                K.decode_step(fused["table"], inputs_embeds.reshape(d).contiguous(), out, fused["final_w"], cos_m[past - kv_lo],
+                              sin_m[past - kv_lo], fused["ws"], c.num_hidden_layers, d, c.num_attention_heads,
+                              c.num_key_value_heads, c.head_dim, c.intermediate_size, past, kv_lo, cache.max_len, c.rms_norm_eps)
+                cache.length = total
+                cache.fused_steps += 1
+                return out.view(1, 1, d)
         cos_all, sin_all = self.rope_tables(total, inputs_embeds.device)
         cos_t, sin_t = cos_all[past:total], sin_all[past:total]
         pos = kv_start = kv_end = None
@@ -172,6 +186,35 @@ class Qwen2Backbone(nn.Module):
         return x.view(B, S, d)
 
 
+    def _decode_state(self, cache: "KVCache"):
+        """pointer table, final-norm weight and workspace of the persistent decode step for this cache (built at the first
+        single-token pass, kept on the cache), or None where the launch does not apply (DXA_DECODE_FUSED=0, widths outside the
+        kernel's limits, a weight that is not 16-byte aligned, fp32 weights): the per-op path above then runs."""
+        import os
+        st, c = self.store, self.config
+        key = st.weights_key()
+        if cache.fused is not None and cache.fused.get("key") == key:
+            return cache.fused["state"]
+        state = None
+        d, F_, D = c.hidden_size, c.intermediate_size, c.head_dim
+        Hq, Hkv = c.num_attention_heads, c.num_key_value_heads
+        if (os.environ.get("DXA_DECODE_FUSED", "1") != "0" and st.shadow is not None and cache.batch == 1 and
+                K.decode_step_supported(d, Hq, Hkv, D, F_) and cache.max_len - 1 <= K.DECODE_FUSED_MAX_KEYS):
+            nq = (Hq + 2 * Hkv) * D
+            ptrs = []
+            for i, sp in enumerate(self.layer_specs):
+                ptrs += [st.w(sp.ln1).data_ptr(), st.w(*sp.qkv_w, shape=(nq, d)).data_ptr(), st.w(*sp.qkv_b, shape=(nq,)).data_ptr(),
+                         st.w(sp.o_w).data_ptr(), st.w(sp.ln2).data_ptr(), st.w(*sp.gu_w, shape=(2 * F_, d)).data_ptr(),
+                         st.w(sp.down_w).data_ptr(), cache.k[i].data_ptr(), cache.v[i].data_ptr()]
+            final_w = st.w(self.p + "norm.weight")
+            if all(p_ % 16 == 0 for p_ in ptrs) and final_w.data_ptr() % 16 == 0:
+                dev = cache.k[0].device
+                state = {"table": torch.tensor(ptrs, dtype=torch.int64).to(dev), "final_w": final_w,
+                         "ws": K.decode_step_workspace(d, Hq, Hkv, D, F_, dev)}
+        cache.fused = {"key": key, "state": state}
+        return state
+
+
 class KVCache:
     """per-layer post-RoPE keys / values, head-major [B, Hkv, max_len, D] (the layout the attention kernels read)"""
 
@@ -179,4 +222,7 @@ class KVCache:
         self.k = [torch.empty((batch, kv_heads, max_len, head_dim), device=device, dtype=dtype) for _ in range(layers)]
         self.v = [torch.empty((batch, kv_heads, max_len, head_dim), device=device, dtype=dtype) for _ in range(layers)]
         self.max_len = max_len
+        self.batch = batch
         self.length = 0
+        self.fused = None          # Qwen2Backbone._decode_state: pointer table / workspace of the persistent decode step
+        self.fused_steps = 0       # single-token passes that ran as one persistent launch

@@ -489,6 +489,32 @@ int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float* t_emb, co
                             float cfg_scale, const void* const* packed_table, int depth, int N, int T1, int H, int heads, int I,
                             float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
 
+/* ---- KV-cached decode step in one persistent launch (csrc/decode_fused.hip) -------------------------------------------------
+ * ONE new token of ONE sequence through every decoder layer and the final RMSNorm — the use_cache=True single-token pass of HF
+ * Qwen2Model that GenerationMixin.generate drives for the discrete-action policies (dexbotic/model/discrete_vla/
+ * discrete_vla_arch.py:24-50, dexbotic/model/dexbotic_arch.py:429-496): a grid of co-resident workgroups walks
+ * [RMSNorm] qkv + bias | RoPE + cache append + attention | o + residual | [RMSNorm] gate / up + SiLU * up | down + residual
+ * per layer with device-wide barriers in between (co-residency contract and watchdog of dxa_dit_blocks_fwd; dxa_decode_status
+ * reports a launch that gave up).  bf16 weights, bf16 rounding points of the unfused kernels, fp32 accumulation.
+ *   layers: DEVICE array of n_layers * 9 pointers — input_layernorm.weight [d], q|k|v weight [(Hq + 2 Hkv) D, d], q|k|v bias,
+ *           o_proj.weight [d, Hq D], post_attention_layernorm.weight [d], gate|up weight [2 F, d], down_proj.weight [d, F] (all
+ *           bf16, 16-byte aligned), key cache and value cache of the layer [Hkv, max_len, D] bf16 (post-RoPE keys).
+ *   x_in [d] bf16: embedding of the new token; out [d] bf16: hidden state after the final norm (final_norm_w [d] bf16).
+ *   cos_row / sin_row [D / 2] fp32: the rotary table row of the token's position.  slot: cache position the new key / value are
+ *   written to; the token attends to the cached positions [kv_lo, slot) and itself.  workspace: dxa_decode_step_workspace bytes,
+ *   256-byte aligned. */
+typedef struct dxa_decode_desc {
+  const void* const* layers;
+  const void* x_in; void* out; const void* final_norm_w;
+  const float* cos_row; const float* sin_row;
+  void* workspace; size_t workspace_bytes;
+  int32_t n_layers, d, Hq, Hkv, D, F, slot, kv_lo, max_len;
+  float eps;
+} dxa_decode_desc;
+size_t dxa_decode_step_workspace(int d, int Hq, int Hkv, int D, int F);
+int dxa_decode_step(const dxa_decode_desc* desc, dxa_stream_t stream);
+int dxa_decode_status(dxa_stream_t stream, int* timed_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,19 @@ def rel_err(a, b) -> float:
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def assert_chunk_close(got, ref, atol: float = 1e-5, rtol: float = 1e-3, what: str = "action chunk") -> None:
+    """element-wise bound on a final action chunk: |got - ref| <= atol + rtol |ref| for EVERY component (rel_err above is a
+    max-norm ratio: a small component may be off by more than 1e-3 of itself and still pass it).  rtol = the tolerance
+    BASELINE.json's north_star states for the predicted chunks; atol = what fp32 rounding leaves on components near zero."""
+    a = np.asarray(got, dtype=np.float64)
+    b = np.asarray(ref, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    excess = np.abs(a - b) - (atol + rtol * np.abs(b))
+    k = int(np.argmax(excess))
+    assert excess.reshape(-1)[k] <= 0, (f"{what}: component {np.unravel_index(k, a.shape)} got {a.reshape(-1)[k]!r} want "
+                                        f"{b.reshape(-1)[k]!r} (atol {atol}, rtol {rtol})")
+
+
 def load_lm_golden(golden_dir, tag="t1"):
     g = np.load(os.path.join(golden_dir, f"lm_{tag}.npz"), allow_pickle=False)
     cfg = CFGS[tag]

@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_field_order():
     from dexbotic_amd import _lib as L
     src = open(HEADER).read()
-    for cname, cls in (("dxa_gemm_desc", L.GemmDesc), ("dxa_attn_desc", L.AttnDesc), ("dxa_adamw_desc", L.AdamWDesc)):
+    for cname, cls in (("dxa_gemm_desc", L.GemmDesc), ("dxa_attn_desc", L.AttnDesc), ("dxa_adamw_desc", L.AdamWDesc),
+                       ("dxa_decode_desc", L.DecodeDesc)):
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname, src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

@@ -10,7 +10,7 @@ from oracle import cogact_oracle as O
 from oracle import memvla_oracle as M
 from oracle.weights import make_weights, weights_crc
 
-from .helpers import product_config, rel_err
+from .helpers import assert_chunk_close, product_config, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -109,6 +109,7 @@ def test_fp32_memvla_inference_episode_matches_reference(golden_dir):
         acts = m.inference_action(T(g["infer_prompt"]), T(g["infer_frames"][f:f + 1]), "True" if f == 0 else "False",
                                   {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms}, noise=T(g["infer_inits"][f]))
         assert rel_err(np.array(acts), g["infer_actions"][f]) < FP32_TOL, f
+        assert_chunk_close(np.array(acts), g["infer_actions"][f], what=f"MemVLA frame {f}")
 
 
 def test_memvla_sampler_graph_replay_equals_eager_launches(golden_dir):
@@ -207,6 +208,7 @@ def test_fp32_memvla_real_size_step_and_episode_match_reference_classes(golden_d
         acts = m.inference_action(T(x["infer_prompt"]), T(x["infer_frames"][f:f + 1]), "True" if f == 0 else "False",
                                   {"cfg_scale": 1.5, "num_ddim_steps": 10, "action_norms": norms}, noise=T(x["infer_inits"][f]))
         assert rel_err(np.array(acts), g["fp32/infer_actions"][f]) < FP32_TOL, f
+        assert_chunk_close(np.array(acts), g["fp32/infer_actions"][f], what=f"MemVLA real-size frame {f}")
 
 
 def test_bf16_memvla_real_size_step_tracks_the_reference_under_autocast(golden_dir):

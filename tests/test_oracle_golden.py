@@ -196,3 +196,36 @@ def test_hybrid_cogact_losses_and_grads_match_reference(golden_dir):
             assert rel(sd[key[5:]].grad.numpy(), g[key]) < 5e-5, key
     gsq = sum(float(v.grad.double().pow(2).sum()) for v in sd.values() if v.grad is not None)
     assert abs(gsq ** 0.5 - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/dexbotic"), reason="needs the reference checkout (build container only)")
+def test_committed_fixtures_regenerate_bit_identically_from_the_live_reference(golden_dir, tmp_path):
+    """The parity chain's first link, kept permanent: the committed generator, run NOW on the reference's own classes, writes
+    cogact_t1.npz / action_bins.npz / diffusion_tables.npz whose every array equals the committed fixture bit for bit (integer keys
+    array_equal, float keys same bytes).  A fixture edited by hand, a generator that drifted, or a reference change shows here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, '/root/reference')\n"
+        "import oracle.gen_golden as G\n"
+        f"G.GOLD = {str(tmp_path)!r}\n"
+        "torch.manual_seed(0); torch.set_num_threads(8)\n"
+        "G.install_timm_shim()\n"
+        "from oracle.cogact_oracle import OracleConfig\n"
+        "G.gen_diffusion_tables(); G.gen_action_bins()\n"
+        "G.gen_cogact('t1', OracleConfig(), seed=1234, B=3, L=12, lengths=[12, 9, 11], views=1)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for name in ("cogact_t1.npz", "action_bins.npz", "diffusion_tables.npz"):
+        new = np.load(os.path.join(str(tmp_path), name), allow_pickle=False)
+        old = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+        assert sorted(new.files) == sorted(old.files), name
+        for k in old.files:
+            a, b = old[k], new[k]
+            assert a.dtype == b.dtype and a.shape == b.shape, (name, k)
+            if a.dtype.kind in "iub" or a.dtype.kind in "US":
+                assert np.array_equal(a, b), (name, k)
+            else:
+                assert a.tobytes() == b.tobytes(), (name, k)

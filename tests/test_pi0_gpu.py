@@ -10,7 +10,7 @@ import torch
 from oracle import pi0_oracle as P
 from oracle.weights import make_weights, weights_crc
 
-from .helpers import rel_err
+from .helpers import assert_chunk_close, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -51,6 +51,7 @@ def test_fp32_pi0_inference_action_matches_reference(golden_dir):
                               noise=T(g["init_noise"]))
     assert tuple(acts.shape) == g["infer_actions"].shape
     assert rel_err(acts.cpu().numpy(), g["infer_actions"]) < FP32_TOL
+    assert_chunk_close(acts.cpu().numpy(), g["infer_actions"], what="pi0 chunk")
 
 
 def test_pi0_sampler_graph_replay_equals_eager_launches(golden_dir):
@@ -197,6 +198,7 @@ def test_fp32_pi0_real_width_step_and_chunk50_inference_match_reference_classes(
                               noise=T(x["init_noise"]))
     assert tuple(acts.shape) == g["fp32/infer_actions"].shape == (2, 50, 32)
     assert rel_err(acts.cpu().numpy(), g["fp32/infer_actions"]) < FP32_TOL
+    assert_chunk_close(acts.cpu().numpy(), g["fp32/infer_actions"], what="pi0 real-width chunk 50")
 
 
 # bf16 compute vs the reference under torch.autocast("cpu", bfloat16) (HF Trainer bf16=True).  The yardstick for "how far apart

@@ -13,7 +13,7 @@ import torch
 
 from oracle.gen_golden_realwidth import GROUPS, REAL
 from oracle.weights import cogact_shapes, make_weights, weights_crc
-from tests.helpers import build_product, rel_err
+from tests.helpers import assert_chunk_close, build_product, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -73,7 +73,9 @@ def test_fp32_real_width_matches_oracle(real):
             n = key[len("fp32/gsamp/"):]
             got = m.store.g(n).reshape(-1)[::997].float().cpu().numpy()
             assert rel_err(got, g[key]) < 1e-3, n
-    assert rel_err(_infer(m, g), g["fp32/infer_samples"]) < 1e-3
+    samples = _infer(m, g)
+    assert rel_err(samples, g["fp32/infer_samples"]) < 1e-3
+    assert_chunk_close(samples, g["fp32/infer_samples"], what="real-width CogACT chunk")
 
 
 def test_bf16_real_width_tracks_bf16_autocast_reference(real):
