@@ -32,7 +32,6 @@ namespace {
 constexpr int SC1 = 16;            // buffer-instruction cache policy: agent scope (gfx94x / gfx95x)
 constexpr unsigned NCTR = 16;      // arrival counters of the device-wide barrier
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr int RG = 16;             // weight rows in flight per wave
 constexpr int MAXR = 160;          // rows (a gate / up pair counts 2) a workgroup folds per pass
 constexpr int ACT_MAX = 32768;     // longest activation vector (elements) staged in LDS: 64 KiB of bf16
 constexpr int T_MAX = ACT_MAX / 2 - 1;   // keys: fp32 scores share the activation buffer
@@ -61,8 +60,16 @@ struct alignas(16) DSmem {
   float wred[16];
 };
 
+// a pointer that is the same in every lane, moved to scalar registers: a buffer descriptor built from a VGPR pointer makes hipcc wrap
+// EVERY buffer instruction in a readfirstlane "waterfall" loop (the table entries come out of a vector load)
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uni(p)), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 __device__ __forceinline__ float ld_bf(__amdgpu_buffer_rsrc_t r, int idx) {      // coherent load of one bf16
   return bf2f(__builtin_amdgcn_raw_buffer_load_b16(r, idx * 2, 0, SC1));
@@ -71,7 +78,27 @@ __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t r, int idx, float v
   __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), r, idx * 2, 0, SC1);
 }
 
+// Tuning build (-DDXA_DEC_STAMPS=<workgroup>): s_memtime of wave 0 of one workgroup at the start of every phase, in front of its
+// barrier and behind it, summed per phase (0 qkv, 1 attention, 2 o, 3 gate / up, 4 down) as [work, barrier] cycles;
+// dxa_decode_debug_stamps() copies the 10 sums out.
+#if defined(DXA_DEC_STAMPS)
+__device__ unsigned long long g_dec_stamps[16];   // [10..13]: attention: request + RoPE | keys | merge + store
+#define DEC_T(v_) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_) :: "memory"); } while (0)
+#define DEC_ATT(i_, a_, b_) do { if (blockIdx.x == DXA_DEC_STAMPS && threadIdx.x == 0) g_dec_stamps[10 + (i_)] += (b_) - (a_); } while (0)
+#define DEC_PHASE_BEGIN() unsigned long long t0_, t1_, t2_; DEC_T(t0_)
+#define DEC_PHASE_SYNC() DEC_T(t1_)
+#define DEC_PHASE_END(ph_) do { DEC_T(t2_); if (blockIdx.x == DXA_DEC_STAMPS && threadIdx.x == 0) { g_dec_stamps[2 * (ph_)] += t1_ - t0_; g_dec_stamps[2 * (ph_) + 1] += t2_ - t1_; } } while (0)
+#else
+#define DEC_T(v_) do { } while (0)
+#define DEC_ATT(i_, a_, b_) do { } while (0)
+#define DEC_PHASE_BEGIN() do { } while (0)
+#define DEC_PHASE_SYNC() do { } while (0)
+#define DEC_PHASE_END(ph_) do { } while (0)
+#endif
 // the barrier of dit_fused.hip (see there for the measurements behind the 16 counters)
+// (round 6 A/B, profiles/r06_decode_prefetch_ab.txt: requesting the next product's first weight block in front of the barrier made
+//  the token 6 % SLOWER — the 28 MB burst of 256 workgroups sits in front of the small activation loads every phase starts with;
+//  the stream is bandwidth-bound, a prefetch adds no bandwidth.  Removed.)
 __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nblk, unsigned& epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -148,6 +175,7 @@ __device__ __forceinline__ void stage_norm(DSmem& s, const bf16_t* x, const bf16
   __syncthreads();
 }
 
+constexpr int RG = 16;             // weight rows in flight per wave
 // This wave's share (its 512-wide K blocks) of the dot products of RG weight rows with s.act; lane-partials folded by a halving
 // butterfly: on return lane l with (l & 3) == 0 holds in `out` the wave's partial of row index
 // 8 bit5(l) + 4 bit4(l) + 2 bit3(l) + bit2(l).  rows[] are row numbers of W (uniform over the wave).
@@ -293,6 +321,33 @@ __device__ __forceinline__ void attention_phase(const DecP& p, DSmem& s, bf16_t*
   const int D = p.D, half = D >> 1, grp = p.Hq / p.Hkv, g = h / grp;
   const int nq = (p.Hq + 2 * p.Hkv) * D;
   const __amdgpu_buffer_rsrc_t rQ = rsrc_of(p.qkv, (size_t)nq * 2);
+  bf16_t* kg = kc + (int64_t)g * p.max_len * D;
+  bf16_t* vg = vc + (int64_t)g * p.max_len * D;
+  // ---- the first AU key groups of this wave are requested BEFORE the RoPE stage (they do not depend on q): the cache rows were
+  //      last touched a token ago (HBM, cold TLB) and arrive while q / k / v come in from the qkv scratch
+  const int T = p.slot - p.kv_lo;
+  const int lpk = D >> 3, kpw = 64 / lpk;              // lanes per key (16 B each), keys per wave load
+  const int kq = lane / lpk, dl = lane % lpk;
+  constexpr int AU = 12;                                // 8 waves x 12 x (64 / lpk) keys per round: 384 at head_dim 128
+  // (buffer loads: one per-lane byte offset + a scalar offset per key group, rows past the last cached key read zeros and are
+  //  never folded; 24 flat addresses would take 48 VGPRs)
+  const __amdgpu_buffer_rsrc_t rK = rsrc_of(kg + (int64_t)p.kv_lo * D, (size_t)T * D * 2);
+  const __amdgpu_buffer_rsrc_t rV = rsrc_of(vg + (int64_t)p.kv_lo * D, (size_t)T * D * 2);
+  u32x4_t kr[AU], vr[AU];
+  auto request = [&](int j0) {
+    const uint32_t voff = (uint32_t)(((j0 + kq) * D + dl * 8) * 2);
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      // (the group offset rides in the VECTOR offset: the descriptor's range check does not see a scalar offset)
+      kr[u] = __builtin_amdgcn_raw_buffer_load_b128(rK, voff + (uint32_t)(u * kpw * D * 2), 0, 0);
+      vr[u] = __builtin_amdgcn_raw_buffer_load_b128(rV, voff + (uint32_t)(u * kpw * D * 2), 0, 0);
+    }
+  };
+  const int j_first = wave * kpw * AU, j_stride = 8 * kpw * AU;
+  unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
+  (void)ta0; (void)ta1; (void)ta2; (void)ta3;
+  DEC_T(ta0);
+  if (j_first < T) request(j_first);
   // ---- RoPE (elementwise.hip rope_k: every product rounded to bf16, cos / sin rounded to bf16)
   if (tid < D) {
     const bool isk = tid >= half;
@@ -309,84 +364,87 @@ __device__ __forceinline__ void attention_phase(const DecP& p, DSmem& s, bf16_t*
     s.vn[t] = ld_bf(rQ, (p.Hq + p.Hkv + g) * D + t);
   }
   __syncthreads();
-  bf16_t* kg = kc + (int64_t)g * p.max_len * D;
-  bf16_t* vg = vc + (int64_t)g * p.max_len * D;
   if (h % grp == 0 && tid < D) {                       // append: read by LATER launches only (this step takes it from LDS)
     kg[(int64_t)p.slot * D + tid] = f2bf(s.kn[tid]);
     vg[(int64_t)p.slot * D + tid] = f2bf(s.vn[tid]);
   }
-  const int T = p.slot - p.kv_lo;                      // cached keys; the new key is score index T
-  float* sc = reinterpret_cast<float*>(s.act);
-  const int lpk = D >> 3, kpw = 64 / lpk;              // lanes per key (16 B each), keys per wave load
-  const int kq = lane / lpk, dl = lane % lpk;
+  // ---- one pass over the cached keys [kv_lo, slot): a lane group of D / 8 lanes owns a key (16 bytes of K and of V per lane), a wave
+  //      has AU such key groups of K AND V in flight at once (a cache of <= 384 keys is ONE round trip; the first form of this phase —
+  //      load, reduce, next — was 9 dependent round trips for the scores and 9 more for P V: 15.7 us of a 115 us layer,
+  //      profiles/r06_decode_stamps.txt) and keeps an online softmax (running max, sum, 8 output dims) per lane group; the new key
+  //      joins wave 0's first group from LDS; the 8 x (64 / lpk) partial states are merged through LDS.
+  DEC_T(ta1);
   float qf[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) qf[e] = s.q[dl * 8 + e];
-  for (int j0 = wave * kpw; j0 < T; j0 += 8 * kpw) {
-    const int j = j0 + kq;
-    float dot = 0.f;
-    if (j < T) {
-      float kf[8];
-      Vec<bf16_t, 8>::ld(kf, kg + (int64_t)(p.kv_lo + j) * D + dl * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dot += qf[e] * kf[e];
-    }
-    for (int o = 1; o < lpk; o <<= 1) dot += __shfl_xor(dot, o, 64);
-    if (dl == 0 && j < T) sc[j] = dot * p.scale;
-  }
-  if (wave == 0) {
-    float dot = 0.f;
-    if (lane < lpk) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dot += qf[e] * s.kn[dl * 8 + e];
-    }
-    for (int o = 1; o < lpk; o <<= 1) dot += __shfl_xor(dot, o, 64);
-    if (lane == 0) sc[T] = dot * p.scale;
-  }
-  __syncthreads();
-  // ---- softmax over T + 1 scores (fp32)
-  float m = -INFINITY;
-  for (int j = tid; j <= T; j += 512) m = fmaxf(m, sc[j]);
-  m = block_reduce(m, s.wred, true);
-  float sum = 0.f;
-  for (int j = tid; j <= T; j += 512) {
-    const float e = expf(sc[j] - m);
-    sc[j] = e;
-    sum += e;
-  }
-  sum = block_reduce(sum, s.wred, false);              // (its barriers also publish the exponentials)
-  // ---- P V
-  float acc[8];
+  for (int e = 0; e < 8; ++e) qf[e] = s.q[dl * 8 + e] * p.scale;
+  float m = -INFINITY, lsum = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int j0 = wave * kpw; j0 < T; j0 += 8 * kpw) {
-    const int j = j0 + kq;
-    if (j < T) {
-      float vf[8];
-      Vec<bf16_t, 8>::ld(vf, vg + (int64_t)(p.kv_lo + j) * D + dl * 8);
-      const float pj = sc[j];
+  auto fold = [&](float sc, const float (&vf)[8]) {   // one key into the lane group's running state
+    const float mn = fmaxf(m, sc);
+    const float so = __expf(m - mn), pj = __expf(sc - mn);   // (m = -inf: so = 0)
+    lsum = lsum * so + pj;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += pj * vf[e];
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] * so + pj * vf[e];
+    m = mn;
+  };
+  for (int j0 = j_first; j0 < T; j0 += j_stride) {
+    float dots[AU];
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dot += qf[2 * e] * __uint_as_float(kr[u][e] << 16) + qf[2 * e + 1] * __uint_as_float(kr[u][e] & 0xffff0000u);
+      dots[u] = dot;
     }
+    for (int o = 1; o < lpk; o <<= 1)                   // the AU reductions side by side (a shuffle is an LDS round trip)
+#pragma unroll
+      for (int u = 0; u < AU; ++u) dots[u] += __shfl_xor(dots[u], o, 64);
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      float vf[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { vf[2 * e] = __uint_as_float(vr[u][e] << 16); vf[2 * e + 1] = __uint_as_float(vr[u][e] & 0xffff0000u); }
+      if (j0 + u * kpw + kq < T) fold(dots[u], vf);
+    }
+    if (j0 + j_stride < T) request(j0 + j_stride);
   }
-  if (wave == 0 && kq == 0) {
-    const float pj = sc[T];
+  if (wave == 0 && kq == 0) {                          // the new token's own key / value
+    float dot = 0.f, vf[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += pj * s.vn[dl * 8 + e];
+    for (int e = 0; e < 8; ++e) { dot += qf[e] * s.kn[dl * 8 + e]; vf[e] = s.vn[dl * 8 + e]; }
+    for (int o = 1; o < lpk; o <<= 1) dot += __shfl_xor(dot, o, 64);
+    fold(dot, vf);                                     // (the shuffles above stay inside the active lane group)
   }
-  for (int o = lpk; o < 64; o <<= 1)
+  DEC_T(ta2);
+  // ---- merge the 8 kpw partial states: maxima, sums and [8 kpw][D] outputs in the (now free) activation buffer; wave 0 turns the
+  //      maxima into weights exp(m_i - M) and the total sum, then D threads add the weighted partial outputs
+  float* mm = reinterpret_cast<float*>(s.act);
+  float* ll = mm + 64;
+  float* oo = ll + 64;
+  const int np = 8 * kpw, slot_id = wave * kpw + kq;
+  if (dl == 0) { mm[slot_id] = m; ll[slot_id] = lsum; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  if (kq == 0)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s.pv[wave][dl * 8 + e] = acc[e];
+  for (int e = 0; e < 8; ++e) oo[slot_id * D + dl * 8 + e] = acc[e];
+  __syncthreads();
+  if (wave == 0) {
+    const float mi = lane < np ? mm[lane] : -INFINITY;
+    const float M = wave_max(mi);
+    const float wi = lane < np ? __expf(mi - M) : 0.f;   // (an empty group: exp(-inf) = 0)
+    const float Lt = wave_sum(lane < np ? ll[lane] * wi : 0.f);
+    if (lane < np) mm[lane] = wi;
+    if (lane == 0) s.wred[0] = Lt;
+  }
   __syncthreads();
   if (tid < D) {
     float o = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) o += s.pv[w][tid];
-    st_bf(rsrc_of(p.ao, (size_t)p.Hq * D * 2), h * D + tid, o / sum);
+#pragma unroll 8
+    for (int i = 0; i < np; ++i) o += oo[i * D + tid] * mm[i];
+    st_bf(rsrc_of(p.ao, (size_t)p.Hq * D * 2), h * D + tid, o / s.wred[0]);
   }
+  DEC_T(ta3);
+  DEC_ATT(0, ta0, ta1); DEC_ATT(1, ta1, ta2); DEC_ATT(2, ta2, ta3);
 }
 
 __global__ __launch_bounds__(512) void decode_step_k(const DecP p) {
@@ -395,28 +453,44 @@ __global__ __launch_bounds__(512) void decode_step_k(const DecP p) {
   unsigned epoch = 0;
   const unsigned nwg = gridDim.x;
   const int nq = (p.Hq + 2 * p.Hkv) * p.D;
+  const int HD = p.Hq * p.D;
   for (int l = 0; l < p.L; ++l) {
     const void* const* lw = p.lp + (size_t)l * 9;
     const bf16_t* xsrc = l == 0 ? p.x_in : p.xres;
     // ---- qkv = RMSNorm(x) W_qkv^T + b
+    { DEC_PHASE_BEGIN();
     stage_norm(s, xsrc, (const bf16_t*)lw[0], p.d, p.eps);
     gemv_plain<EPI_BIAS>(s, (const bf16_t*)lw[1], nq, p.d, (const bf16_t*)lw[2], nullptr, p.qkv, nwg);
+    DEC_PHASE_SYNC();
     grid_sync(p.bar, nwg, epoch);
+    DEC_PHASE_END(0); }
     // ---- attention over the cache
+    { DEC_PHASE_BEGIN();
     attention_phase(p, s, (bf16_t*)lw[7], (bf16_t*)lw[8]);
+    DEC_PHASE_SYNC();
     grid_sync(p.bar, nwg, epoch);
+    DEC_PHASE_END(1); }
     // ---- x = x + o W_o^T
-    stage_plain(s, p.ao, p.Hq * p.D);
-    gemv_plain<EPI_RES>(s, (const bf16_t*)lw[3], p.d, p.Hq * p.D, nullptr, xsrc, p.xres, nwg);
+    { DEC_PHASE_BEGIN();
+    stage_plain(s, p.ao, HD);
+    gemv_plain<EPI_RES>(s, (const bf16_t*)lw[3], p.d, HD, nullptr, xsrc, p.xres, nwg);
+    DEC_PHASE_SYNC();
     grid_sync(p.bar, nwg, epoch);
+    DEC_PHASE_END(2); }
     // ---- a = silu(h W_g^T) * (h W_u^T), h = RMSNorm(x)
+    { DEC_PHASE_BEGIN();
     stage_norm(s, p.xres, (const bf16_t*)lw[4], p.d, p.eps);
     gemv_glu(s, (const bf16_t*)lw[5], p.F, p.d, p.act, nwg);
+    DEC_PHASE_SYNC();
     grid_sync(p.bar, nwg, epoch);
+    DEC_PHASE_END(3); }
     // ---- x = x + a W_d^T
+    { DEC_PHASE_BEGIN();
     stage_plain(s, p.act, p.F);
     gemv_plain<EPI_RES>(s, (const bf16_t*)lw[6], p.d, p.F, nullptr, p.xres, p.xres, nwg);
+    DEC_PHASE_SYNC();
     grid_sync(p.bar, nwg, epoch);
+    DEC_PHASE_END(4); }
   }
   if (blockIdx.x == 0) {
     stage_norm(s, p.L > 0 ? p.xres : p.x_in, p.final_w, p.d, p.eps);
@@ -479,6 +553,8 @@ extern "C" int dxa_decode_step(const dxa_decode_desc* q, dxa_stream_t stream) {
   DXA_CHECK_ARG(q->d % 8 == 0 && q->F % 8 == 0, "dxa_decode_step: hidden and MLP widths must be multiples of 8");
   DXA_CHECK_ARG(q->d <= ACT_MAX && q->F <= ACT_MAX && q->Hq * q->D <= ACT_MAX,
                 "dxa_decode_step: activation vectors of at most %d elements", ACT_MAX);
+  DXA_CHECK_ARG((int64_t)2 * q->F * q->d * 2 < (1ll << 31) && (int64_t)(q->Hq + 2 * q->Hkv) * q->D * q->d * 2 < (1ll << 31),
+                "dxa_decode_step: a weight matrix of 2 GiB or more (32-bit buffer offsets)");
   DXA_CHECK_ARG(q->slot >= 0 && q->slot < q->max_len && q->kv_lo >= 0 && q->kv_lo <= q->slot,
                 "dxa_decode_step: cache slot %d outside [kv_lo %d, max_len %d)", q->slot, q->kv_lo, q->max_len);
   DXA_CHECK_ARG(q->slot - q->kv_lo <= T_MAX, "dxa_decode_step: at most %d cached keys", T_MAX);
@@ -521,6 +597,17 @@ extern "C" int dxa_decode_step(const dxa_decode_desc* q, dxa_stream_t stream) {
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
+
+#if defined(DXA_DEC_STAMPS)
+// tuning build only: [work, barrier] cycle sums per phase since the last call, then zeroed
+extern "C" int dxa_decode_debug_stamps(unsigned long long* out) {
+  DXA_CHECK_HIP(hipDeviceSynchronize());
+  DXA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * 16));
+  unsigned long long z[16] = {0};
+  DXA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamps), z, sizeof(z)));
+  return DXA_OK;
+}
+#endif
 
 // 1 if a decode launch on this stream gave up at a device-wide barrier since the last call (its output is garbage); the barrier
 // state is re-armed.  Synchronises the stream.
