@@ -23,6 +23,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5, 6
 NT, NN, TN = 0, 1, 2
 FILTER_BICUBIC = 3
+FUSE_NONE, FUSE_SWIGLU = 0, 1
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _int = C.c_int
@@ -42,6 +43,7 @@ class GemmDesc(C.Structure):
         ("sA", _i64 * 3), ("sB", _i64 * 3), ("sC", _i64 * 3), ("sR", _i64 * 3), ("sG", _i64 * 3),
         ("epi_f32", _i32), ("mirror", _vp), ("sumsq", _vp),
         ("A2", _vp), ("B2", _vp), ("K2", _i64),
+        ("fuse", _i32), ("ld_aux", _i64),
     ]
 
 

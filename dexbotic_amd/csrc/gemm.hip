@@ -1014,7 +1014,10 @@ template __global__ void gemm_nt_ring_kernel<float, 3, float>(const GemmP);
 // k-rows of such a block would share banks (256-byte pitch): 64-byte chunk q of k-row t sits at chunk q ^ (t & 3).
 // No transposed copy of anything is ever made: the W^T shadow arena and the per-GEMM activation transposes are gone.
 // K need not be a multiple of 64 when every operand is k-strided (rows past K are out of the buffer's range: zeros).
-template <typename TO, typename TE, bool LEAN, bool A_KS, bool B_KS>
+// FUSE = 1 (DXA_FUSE_SWIGLU, bf16 NT lean only): B = [gate ; up] of a gated MLP; the tile's 256 B rows are 128 gate rows and the 128
+// up rows of the same outputs — per wave column wn: 32 gate rows (its block j = 0) and 32 up rows (j = 1) — picked by the DMA source
+// addresses, and the epilogue stores silu(gate) * up (sk_epilogue_swiglu).  Main loop, tiles, K order: unchanged.
+template <typename TO, typename TE, bool LEAN, bool A_KS, bool B_KS, int FUSE = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1078,6 +1081,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
         if constexpr (B_KS) {
           const int gb = n0i + (sig >> 2) * 64 + 32 * h + 8 * (sig & 3);
           voB[h][j] = gb < (int)p.N ? (uint32_t)krow * ldb2 + (uint32_t)gb * 2u : 0x80000000u;
+        } else if constexpr (FUSE == 1) {
+          const int rb = PP_B_ROW0(h, j) + lrow, half_n = (int)(p.N >> 1);
+          const int lc = (n0i >> 1) + (rb >> 6) * 32 + (rb & 31), gb = ((rb >> 5) & 1) * half_n + lc;
+          voB[h][j] = lc < half_n ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
         } else {
           const int rb = PP_B_ROW0(h, j) + lrow, gb = n0i + rb;
           voB[h][j] = gb < (int)p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
@@ -1509,7 +1516,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmP p) {
   if constexpr (LEAN) {
     if (!tile_split_exchange<4>(p, acc, tid, split_j, split_s, tail_i)) return;
     __builtin_amdgcn_sched_barrier(0);
-    sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i, reinterpret_cast<float*>(smem + 8 * 4096), bid);
+    if constexpr (FUSE == 1) sk_epilogue_swiglu<4>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i);
+    else sk_epilogue<TO, TE>(p, acc, smem + wave * 4096, lane, wm, wn, m0i, n0i, reinterpret_cast<float*>(smem + 8 * 4096), bid);
 #if (DXA_PPV & 128)
     __syncthreads();
     if (m0i == 0 && n0i == 0 && lane == 0) {          // the first tile's waves: [wave][8 intervals + K tiles] over the head of C
@@ -1535,6 +1543,7 @@ template __global__ void gemm_pp_kernel<bf16_t, bf16_t, false, false, true>(cons
 template __global__ void gemm_pp_kernel<float, bf16_t, true, false, true>(const GemmP);
 template __global__ void gemm_pp_kernel<float, bf16_t, true, true, true>(const GemmP);
 template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, true, true>(const GemmP);
+template __global__ void gemm_pp_kernel<bf16_t, bf16_t, true, false, false, 1>(const GemmP);     // gate / up + SiLU * up
 
 // =====================================================================================================
 // Fast path 2b (round 4): the ping-pong schedule on a 192-row tile — bf16 NT, K % 64 == 0, both operands K-contiguous.
@@ -1559,7 +1568,7 @@ __device__ unsigned long long g_pp3_stamps[4];
 #else
 #define P3_STAMP(i) do { } while (0)
 #endif
-template <typename TO, typename TE, bool LEAN>
+template <typename TO, typename TE, bool LEAN, int FUSE = 0>
 __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1613,8 +1622,14 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int rb = P3_B_ROW0(h, j) + lrow;
-        const int64_t gb = n0 + rb;
-        voB[h][j] = gb < p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+        if constexpr (FUSE == 1) {          // [gate ; up]: see gemm_pp_kernel
+          const int half_n = (int)(p.N >> 1);
+          const int lc = (int)(n0 >> 1) + (rb >> 6) * 32 + (rb & 31), gb = ((rb >> 5) & 1) * half_n + lc;
+          voB[h][j] = lc < half_n ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+        } else {
+          const int64_t gb = n0 + rb;
+          voB[h][j] = gb < p.N ? (uint32_t)gb * ldb2 + (uint32_t)((lslot ^ ((rb >> 1) & 7)) << 4) : 0x80000000u;
+        }
       }
   }
   const int nk_tot = (int)(p.K / 64);
@@ -1722,7 +1737,8 @@ __global__ __launch_bounds__(512) void gemm_pp3_kernel(const GemmP p) {
   if constexpr (LEAN) {          // C = alpha acc + bias (+ residual) (+ C) over whole 16-byte accesses: the 256-row kernel's epilogue
     if (!tile_split_exchange<3>(p, acc, tid, split_j, split_s, tail_i)) return;
     __builtin_amdgcn_sched_barrier(0);
-    sk_epilogue<TO, TE, 3>(p, acc, smem + wave * 4096, lane, wm, wn, (int)m0, (int)n0, reinterpret_cast<float*>(smem + 8 * 4096), bid);
+    if constexpr (FUSE == 1) sk_epilogue_swiglu<3>(p, acc, smem + wave * 4096, lane, wm, wn, (int)m0, (int)n0);
+    else sk_epilogue<TO, TE, 3>(p, acc, smem + wave * 4096, lane, wm, wn, (int)m0, (int)n0, reinterpret_cast<float*>(smem + 8 * 4096), bid);
   } else {
     tile_finish<TO, 3, TE>(p, acc, smem, tid, lane, wave, wm, wn, l32, lh, m0, n0, split_j, split_s, tail_i);
   }
@@ -1737,6 +1753,7 @@ template __global__ void gemm_pp3_kernel<bf16_t, bf16_t, false>(const GemmP);
 template __global__ void gemm_pp3_kernel<float, bf16_t, false>(const GemmP);
 template __global__ void gemm_pp3_kernel<float, float, true>(const GemmP);      // fp32 epilogue operands (bf16x3 products of the fp32 head)
 template __global__ void gemm_pp3_kernel<float, float, false>(const GemmP);
+template __global__ void gemm_pp3_kernel<bf16_t, bf16_t, true, 1>(const GemmP);                  // gate / up + SiLU * up
 
 // x = hi + lo (two bf16): dst[r] = [hi | hi | lo] (side 0) or [hi | lo | hi] (side 1), 4 elements per thread
 __global__ __launch_bounds__(256) void split3_k(const float* __restrict__ src, int64_t ld, bf16_t* __restrict__ dst,
@@ -1909,6 +1926,20 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   p.aux = (char*)d->aux_out;
   p.G = (const char*)d->mulgrad; p.ldg = d->ldg;
   p.alpha = d->alpha; p.act = d->act; p.accumulate = d->accumulate;
+  p.fuse = d->fuse; p.ldaux = d->ld_aux;
+  if (d->fuse != DXA_FUSE_NONE) {
+    DXA_CHECK_ARG(d->fuse == DXA_FUSE_SWIGLU, "dxa_gemm: unknown fuse mode %d", d->fuse);
+    const int64_t F_ = d->N / 2;
+    DXA_CHECK_ARG(d->layout == DXA_NT && d->in_dtype == DXA_BF16 && d->out_dtype == DXA_BF16 && nbatch == 1 && d->N % 2 == 0 &&
+                  F_ % 8 == 0 && d->K % 64 == 0 && d->K >= 64 && d->M >= 129 && F_ >= 128 && !d->bias && !d->residual && !d->mulgrad &&
+                  d->act == DXA_ACT_NONE && !d->accumulate && !d->mirror && !d->sumsq && !d->epi_f32 && d->K2 == 0,
+                  "dxa_gemm: DXA_FUSE_SWIGLU is a plain bf16 NT product of the MFMA fast path (M >= 129, K %% 64 == 0, F %% 8 == 0)");
+    DXA_CHECK_ARG(aligned_to(d->A, 16) && aligned_to(d->B, 16) && aligned_to(d->C, 8) && d->lda % 8 == 0 && d->ldb % 8 == 0 &&
+                  d->ldc % 4 == 0 && d->ldc >= F_ && (!d->aux_out || (aligned_to(d->aux_out, 8) && d->ld_aux % 4 == 0 && d->ld_aux >= d->N)) &&
+                  ((d->M - 1) * d->ld_aux + d->N) * 2 < (1ll << 31) && ((d->M - 1) * d->lda + d->K) * 2 < (1ll << 31) &&
+                  ((d->N - 1) * d->ldb + d->K) * 2 < (1ll << 31),
+                  "dxa_gemm: DXA_FUSE_SWIGLU needs 16-byte aligned operand rows, 8-byte aligned output rows and operands < 2 GiB");
+  }
   DXA_CHECK_ARG(!d->mirror || (d->out_dtype == DXA_F32 && nbatch == 1), "dxa_gemm: mirror needs an fp32, unbatched output");
   DXA_CHECK_ARG(!d->sumsq || nbatch == 1, "dxa_gemm: sumsq needs an unbatched output");
   p.nb1 = d->nb[1]; p.nb2 = d->nb[2];
@@ -1963,7 +1994,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
   //  54-216 CUs where the 192-row ring kernel's fill 18-72)
   // opt-in (DXA_GEMM_T128_F32EPI=1): parity-green, but the step measured the same with it (255.6 vs 256.2 ms on one box)
   static const bool t128_f32epi = getenv("DXA_GEMM_T128_F32EPI") && atoi(getenv("DXA_GEMM_T128_F32EPI")) != 0;
-  if (!fast_off && !t128_off && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && (!d->epi_f32 || t128_f32epi) &&
+  if (!fast_off && !t128_off && d->fuse == DXA_FUSE_NONE && d->layout == DXA_NT && d->in_dtype == DXA_BF16 && nbatch == 1 && (!d->epi_f32 || t128_f32epi) &&
       d->M >= 64 && d->M <= (d->epi_f32 ? 2048 : t128_max_m) && d->N >= 64 && d->K >= 64 && d->K % 64 == 0 && p.vecA && p.vecB &&
       bytesA < (1ll << 31) && bytesB < (1ll << 31) &&
       (t128_all || (t128_tiles >= 32 && t128_tiles <= NUM_CU && (d->K <= 4096 || d->epi_f32)))) {
@@ -2099,6 +2130,27 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
       else LAUNCH_PP(float, bf16_t, true, false, true);
     } else if (d->layout == DXA_TN) {   // dW = dY^T X: fp32 (accumulating) or bf16 out, plain epilogue
       if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, true, true, true); else LAUNCH_PP(float, bf16_t, true, true, true);
+    } else if (d->fuse == DXA_FUSE_SWIGLU && ai == 4) {
+#define LAUNCH_PPF(FUSE_)                                                                                       \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<bf16_t, bf16_t, true, false, false, FUSE_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);                          \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((gemm_pp_kernel<bf16_t, bf16_t, true, false, false, FUSE_>), fgrid, dim3(512), RING_LDS, st, p); \
+  } while (0)
+      LAUNCH_PPF(1);
+#undef LAUNCH_PPF
+    } else if (d->fuse == DXA_FUSE_SWIGLU) {                   // 192-row tiles
+      static bool attr_f = false;
+      if (!attr_f) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp3_kernel<bf16_t, bf16_t, true, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+        attr_f = true;
+      }
+      hipLaunchKernelGGL((gemm_pp3_kernel<bf16_t, bf16_t, true, 1>), fgrid, dim3(512), RING_LDS, st, p);
     } else if (pp && lean) {
       if (d->epi_f32) LAUNCH_PP(float, float, true, false, false);
       else if (d->out_dtype == DXA_BF16) LAUNCH_PP(bf16_t, bf16_t, true, false, false);
@@ -2133,6 +2185,7 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }
+  DXA_CHECK_ARG(d->fuse == DXA_FUSE_NONE, "dxa_gemm: fuse is only implemented on the bf16 NT MFMA fast path (DXA_GEMM_NO_FAST set?)");
   DXA_CHECK_ARG(!d->epi_f32, "dxa_gemm: epi_f32 is only implemented on the bf16 NT fast path (K %% 32 == 0, M, N >= 64, "
                               "16-byte aligned rows, no batching)");
   // ---- few-row NN (dX of a linear on <= 8 tokens): a stream over W as it lies, K cut into slices, partials in the split scratch

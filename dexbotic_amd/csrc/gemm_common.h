@@ -30,6 +30,7 @@ struct GemmP {
   int* flags;   // per tail tile arrival counter (self-resetting)
   // TN with a second (A2, B2) segment of K2 contraction rows (same lda / ldb): C = A^T B + A2^T B2 (ping-pong kernel only)
   const char* A2; const char* B2; int64_t K2;
+  int fuse; int64_t ldaux;   // dxa_gemm_desc.fuse / ld_aux (gated-MLP epilogue: C = silu(gate) * up, aux = pre-activations)
 };
 }  // namespace dxa_gemm_detail
 
@@ -440,6 +441,82 @@ __device__ __forceinline__ float sk_epilogue_rows(const GemmP& p, f32x16_t (&acc
     }
 #endif
   return ssq;
+}
+// DXA_FUSE_SWIGLU epilogue of one tile (bf16 out).  The operand loads gave the wave's 64 tile columns the meaning
+// [32 gate | 32 up] of the SAME 32 outputs  (n0 / 2 + 32 wn + c, c = 0..31): a lane takes gate and up of 4 outputs from the slab
+// (16-byte units lq and 8 + lq of its row), rounds both to bf16 — the pre-activations as dxa_gemm would have stored them —
+// and stores out = bf16(bf16(silu(g)) * u) (elementwise.hip swiglu_fwd_k, bit for bit) plus, if asked, the two pre-activation
+// pieces: 8-byte stores, 8 lanes = one 64-byte row segment.
+template <int AI = 4>
+__device__ __forceinline__ void sk_epilogue_swiglu(const GemmP& p, f32x16_t (&acc)[AI][2], char* slab, int lane, int wm, int wn,
+                                                   int m0, int n0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int l32 = lane & 31, lh = lane >> 5, r16 = l32 & 15;
+  const int lr = lane >> 3, lq = lane & 7;                 // row of the 8-row instruction, 4-output group
+  const int F = (int)(p.N >> 1);
+  const int nout = (n0 >> 1) + wn * 32 + lq * 4;           // first of the lane's 4 outputs
+  const int rowb = m0 + wm * (32 * AI) + lr;
+  const bool col_ok = nout < F;
+  const uint32_t Mi = (uint32_t)p.M;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((p.M - 1) * p.ldc + F) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux ? p.aux : p.C, 0,
+                                                                      p.aux ? (int)(((p.M - 1) * p.ldaux + p.N) * 2) : 0, 0x00020000);
+  const uint32_t ldcB = (uint32_t)p.ldc * 2u, ldxB = (uint32_t)p.ldaux * 2u;
+  const uint32_t offC0 = (uint32_t)rowb * ldcB + (uint32_t)nout * 2u;
+  const uint32_t offG0 = (uint32_t)rowb * ldxB + (uint32_t)nout * 2u, offU0 = offG0 + (uint32_t)F * 2u;
+  const bool has_aux = p.aux != nullptr;
+  const float alpha = p.alpha;
+  typedef uint32_t u32x2_t_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < AI; ++i)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if ((l32 >> 4) == hh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            *reinterpret_cast<float4*>(slab + r16 * 256 + (((j * 8 + 2 * q + lh) ^ r16) << 4)) = v;
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = lr + 8 * it;                           // row of the 16-row slab
+        const uint32_t rr = (uint32_t)(32 * i + 16 * hh + 8 * it);
+        const bool ok = col_ok && (uint32_t)rowb + rr < Mi;
+        const float4 g4 = *reinterpret_cast<const float4*>(slab + row * 256 + ((lq ^ row) << 4));
+        const float4 u4 = *reinterpret_cast<const float4*>(slab + row * 256 + (((8 + lq) ^ row) << 4));
+        const float g[4] = {rnd<bf16_t>(g4.x * alpha + 0.f), rnd<bf16_t>(g4.y * alpha + 0.f), rnd<bf16_t>(g4.z * alpha + 0.f), rnd<bf16_t>(g4.w * alpha + 0.f)};
+        const float u[4] = {rnd<bf16_t>(u4.x * alpha + 0.f), rnd<bf16_t>(u4.y * alpha + 0.f), rnd<bf16_t>(u4.z * alpha + 0.f), rnd<bf16_t>(u4.w * alpha + 0.f)};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#if defined(DXA_SWIGLU_EXACT)
+          o[e] = rnd<bf16_t>(g[e] / (1.f + expf(-g[e]))) * u[e];
+#else
+          // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf and an IEEE division: the 87 M SiLUs of a training-shape product are
+          // VALU work nothing overlaps in an epilogue (one workgroup per CU) — 36 instead of 100 us per product; against
+          // swiglu_fwd_k the result differs in a few values per million by one bf16 step
+          o[e] = rnd<bf16_t>(g[e] * __builtin_amdgcn_rcpf(1.f + __expf(-g[e]))) * u[e];
+#endif
+        }
+        const u32x2_t_ ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(ov, rC, ok ? offC0 + rr * ldcB : 0x80000000u, 0, 0);
+        if (has_aux) {
+          const u32x2_t_ gv = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+          const u32x2_t_ uv = {pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(gv, rX, ok ? offG0 + rr * ldxB : 0x80000000u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(uv, rX, ok ? offU0 + rr * ldxB : 0x80000000u, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 }
 template <typename TO, typename TE, int AI = 4>
 __device__ __forceinline__ void sk_epilogue(const GemmP& p, f32x16_t (&acc)[AI][2], char* slab, int lane, int wm, int wn,

@@ -264,8 +264,12 @@ class Qwen2LayerFn(_StoreFn):
         lse = K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=True, scale=D ** -0.5, kv_start=kv_start, kv_end=kv_end)
         x2 = K.mm_nt(o.view(M, Hq * D), st.w(sp.o_w), residual=x)
         h2, rstd2 = K.rmsnorm_fwd(x2, st.w(sp.ln2), sp.eps)
-        gu = K.mm_nt(h2, st.w(*sp.gu_w, shape=(2 * F_, d)))
-        a = K.swiglu_fwd(gu)
+        w_gu = st.w(*sp.gu_w, shape=(2 * F_, d))
+        if K.swiglu_gemm_supported(h2, w_gu, keep_pre=True):          # SiLU(gate) * up in the product's own epilogue (opt-in here)
+            a, gu = K.mm_nt_swiglu(h2, w_gu, keep_pre=True)
+        else:
+            gu = K.mm_nt(h2, w_gu)
+            a = K.swiglu_fwd(gu)
         y = K.mm_nt(a, st.w(sp.down_w), residual=x2)
         return y, (rstd1, h1, q, k, v, o, lse, x2, rstd2, h2, gu, a)
 

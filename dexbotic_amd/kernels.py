@@ -268,6 +268,53 @@ def mm_tn(a: torch.Tensor, b: torch.Tensor, *, out=None, out_dtype=None, **kw) -
     return gemm(L.TN, a, b, M, N, K, _row_major(a, "a"), _row_major(b, "b"), out, _row_major(out, "out"), **kw)
 
 
+def swiglu_gemm_supported(x: torch.Tensor, w: torch.Tensor, keep_pre: bool = False) -> bool:
+    """should / can mm_nt_swiglu take this gated-MLP product (dxa_gemm_desc.fuse = DXA_FUSE_SWIGLU)?  bf16, >= 129 rows, K % 64 == 0,
+    F % 8 == 0, F >= 128.  Default: the serving paths (no pre-activations kept: one output stream); the training forward, which also
+    stores the [M, 2F] pre-activations from the epilogue (three 8-byte store streams and 87 M SiLUs that nothing overlaps), measured
+    235.5 against 236.1 ms per step with it — inside the noise, and the product's own rate drops — so it stays on the two-launch
+    form unless DXA_SWIGLU_FUSE=1 (profiles/r06_swiglu_fuse_ab.txt).  DXA_SWIGLU_FUSE=0: two launches everywhere."""
+    import os
+    M, K_ = x.shape
+    F_ = w.shape[0] // 2
+    mode = os.environ.get("DXA_SWIGLU_FUSE", "")
+    if mode == "0" or (keep_pre and mode != "1"):
+        return False
+    return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_cuda and
+            M >= 129 and K_ % 64 == 0 and K_ >= 64 and F_ % 8 == 0 and F_ >= 128 and w.shape[0] % 2 == 0 and
+            x.is_contiguous() and w.is_contiguous() and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and
+            M * 2 * F_ * 2 < (1 << 31) and w.numel() * 2 < (1 << 31))
+
+
+def mm_nt_swiglu(x: torch.Tensor, w: torch.Tensor, keep_pre: bool = True):
+    """gated MLP input half in ONE launch: x [M, K] @ [gate ; up]^T ([2F, K], gate rows first) -> (silu(gate) * up [M, F],
+    pre-activations [M, 2F] or None).  Bit-identical to ``swiglu_fwd(mm_nt(x, w))`` (same tiles, same K order, same rounding points);
+    HF Qwen2MLP (qwen2/modeling_qwen2.py:35-48 under cogact_arch.py:97-106)."""
+    M, K_ = x.shape
+    N = w.shape[0]
+    F_ = N // 2
+    out = torch.empty((M, F_), device=x.device, dtype=x.dtype)
+    pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if keep_pre else None
+    d = L.GemmDesc()
+    d.layout, d.in_dtype, d.out_dtype, d.act = L.NT, L.BF16, L.BF16, L.ACT_NONE
+    d.M, d.N, d.K = M, N, K_
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = _ptr(x), K_, _ptr(w), K_, _ptr(out), F_
+    d.aux_out, d.ld_aux = _ptr(pre), N
+    d.alpha, d.fuse = 1.0, L.FUSE_SWIGLU
+    for i in range(3):
+        d.nb[i] = 1
+    prof = GEMM_PROFILE
+    if prof is not None and prof.wants(L.NT, L.BF16, L.BF16):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm (swiglu)")
+        e1.record()
+        prof.add((L.NT, L.BF16, L.BF16), e0, e1, 2.0 * M * N * K_, float((M * K_ + N * K_) * 2 + M * (N + F_) * 2))
+        return out, pre
+    L.check(lib.dxa_gemm(C.byref(d), _stream()), "dxa_gemm (swiglu)")
+    return out, pre
+
+
 def _ld_kwargs(kw: dict, out: torch.Tensor) -> dict:
     kw = dict(kw)
     if kw.get("residual") is not None:

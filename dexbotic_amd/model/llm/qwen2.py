@@ -179,7 +179,11 @@ class Qwen2Backbone(nn.Module):
                        scale=D ** -0.5, kv_start=kv_start, kv_end=kv_end)
             x2 = K.mm_nt(o.view(B * S, Hq * D), st.w(sp.o_w), residual=x)
             h2, _ = K.rmsnorm_fwd(x2, st.w(sp.ln2), sp.eps)
-            a = K.swiglu_fwd(K.mm_nt(h2, st.w(*sp.gu_w, shape=(2 * F_, d))))
+            w_gu = st.w(*sp.gu_w, shape=(2 * F_, d))
+            if K.swiglu_gemm_supported(h2, w_gu):
+                a, _ = K.mm_nt_swiglu(h2, w_gu, keep_pre=False)
+            else:
+                a = K.swiglu_fwd(K.mm_nt(h2, w_gu))
             x = K.mm_nt(a, st.w(sp.down_w), residual=x2)
         x, _ = K.rmsnorm_fwd(x, st.w(self.p + "norm.weight"), self.config.rms_norm_eps)
         cache.length = total

@@ -63,6 +63,7 @@ int dxa_version(void);
  * Batched over (nb0, nb1, nb2) with element strides per operand (0 = broadcast).
  * Any M/N/K and any leading dimension are accepted; 16-byte aligned rows take the vector path.
  * ---------------------------------------------------------------------------------------------- */
+enum dxa_fuse { DXA_FUSE_NONE = 0, DXA_FUSE_SWIGLU = 1 };
 typedef struct dxa_gemm_desc {
   int32_t layout;    /* dxa_layout */
   int32_t in_dtype;  /* dtype of A, B, bias, residual, mulgrad */
@@ -102,6 +103,15 @@ typedef struct dxa_gemm_desc {
   int64_t K2;         /* gradient accumulation (the reference recipe: 8 episodes x 2 steps, dexbotic/exp/cogact_exp.py:41-46)    */
                       /* is dY1^T X1 + dY2^T X2: HF accumulates it with a read-modify-write of the fp32 gradient per micro-      */
                       /* batch; here the first micro-batch's (dY, X) are kept and the last one writes dW once                     */
+  int32_t fuse;       /* dxa_fuse (0 = none).  DXA_FUSE_SWIGLU: B is the [gate ; up] matrix of a gated MLP, [N = 2 F, K] with the F gate
+                         rows first (HF Qwen2MLP gate_proj / up_proj, qwen2/modeling_qwen2.py:35-48 under cogact_arch.py:97-106);
+                         C [M, F] (ld = ldc) = silu(gate) * up computed in the product's own epilogue from the rounded
+                         pre-activations — bit-identical to dxa_gemm + dxa_swiglu_fwd — and aux_out, if given, the pre-activations
+                         [M, 2 F] (ld = ld_aux) the backward needs.  A tile takes its 128 gate and its 128 up columns of the SAME
+                         128 outputs (the weight rows are picked by the operand loads: nothing is permuted in memory).
+                         bf16 NT products of the MFMA fast path only (M >= 129, K % 64 == 0, F % 8 == 0, no bias / residual /
+                         activation / accumulate): anything else is DXA_ERR_BAD_ARG */
+  int64_t ld_aux;     /* leading dimension of aux_out when fuse != 0 */
 } dxa_gemm_desc;
 int dxa_gemm(const dxa_gemm_desc* d, dxa_stream_t stream);
 int64_t dxa_gemm_sumsq_slots(int64_t M, int64_t N);

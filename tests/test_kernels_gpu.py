@@ -1269,3 +1269,38 @@ def test_tn_two_segments_is_one_product_over_both(M, N, K1, K2, accum):
     # one-pass form keeps a single fp32 accumulation chain; the bound above is what both satisfy
     with pytest.raises(L.DxaError):
         K.mm_nt(r(64, 64), r(64, 64), a2=a2, b2=b2)
+
+
+@pytest.mark.parametrize("M,F_,Kd,split_tail", [(300, 512, 256, False), (600, 1024, 512, False), (543, 520, 192, False),
+                                                (1100, 2056, 320, False), (543, 18944, 3584, False), (4592, 18944, 3584, True)])
+def test_gemm_swiglu_epilogue_is_bit_identical_to_gemm_then_swiglu(M, F_, Kd, split_tail):
+    """dxa_gemm_desc.fuse = DXA_FUSE_SWIGLU (gate / up product with silu(gate) * up in the epilogue, 256- and 192-row tiles, ragged
+    edges, the decoder's real shapes) against mm_nt + swiglu_fwd: the output is swiglu_fwd of the stored pre-activations bit for bit,
+    and the pre-activations are those of the plain product bit for bit — except where a split-K tail exists (the training shape:
+    2664 tiles = 10 rounds of 256 + 104 tail tiles cut along K): the fused tile (128 gate + 128 up columns) and the plain tile (256
+    consecutive columns) put different outputs into the tail tiles, whose fp32 partial sums are added in another order, so a few
+    values land on the neighbouring bf16"""
+    g = torch.Generator(device="cpu").manual_seed(M + F_)
+    x = (torch.randn(M, Kd, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(2 * F_, Kd, generator=g) * (1.5 / math.sqrt(Kd))).to(DEV).to(torch.bfloat16)
+    assert K.swiglu_gemm_supported(x, w, keep_pre=False)
+    pre_ref = K.mm_nt(x, w)
+    out_ref = K.swiglu_fwd(pre_ref)
+    out, pre = K.mm_nt_swiglu(x, w, keep_pre=True)
+    out2, none = K.mm_nt_swiglu(x, w, keep_pre=False)
+    torch.cuda.synchronize()
+    assert none is None
+    mine = K.swiglu_fwd(pre)                                          # the epilogue is swiglu_fwd up to its fast exp / reciprocal
+    off = (out.view(torch.int16) != mine.view(torch.int16)).float().mean().item()
+    step = ((out.float() - mine.float()).abs() / mine.float().abs().clamp_min(1e-6)).max().item()
+    print(f"M {M} F {F_} K {Kd}: {off:.2e} of the outputs differ from swiglu_fwd of the stored pre-activations, by at most {step:.2e}")
+    assert off < 1e-3 and step <= 2 ** -7 * 1.01
+    assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+    if not split_tail:                                                # no tile is cut along K: same summation order everywhere
+        assert torch.equal(pre.view(torch.int16), pre_ref.view(torch.int16))
+    else:
+        differ = (pre.view(torch.int16) != pre_ref.view(torch.int16)).float().mean().item()
+        worst = ((pre.float() - pre_ref.float()).abs() / pre_ref.float().abs().clamp_min(1e-3)).max().item()
+        print(f"M {M} F {F_} K {Kd}: {differ:.2e} of the pre-activations differ, by at most {worst:.2e} relative")
+        assert differ < 2e-2 and worst <= 2 ** -7 * 1.01                                    # one bf16 step
+    assert out_ref.float().abs().max() > 0.05                         # (not a comparison of zeros)
