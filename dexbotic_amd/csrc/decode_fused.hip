@@ -87,7 +87,8 @@ __device__ unsigned long long g_dec_stamps[16];   // [10..13]: attention: reques
 #define DEC_ATT(i_, a_, b_) do { if (blockIdx.x == DXA_DEC_STAMPS && threadIdx.x == 0) g_dec_stamps[10 + (i_)] += (b_) - (a_); } while (0)
 #define DEC_PHASE_BEGIN() unsigned long long t0_, t1_, t2_; DEC_T(t0_)
 #define DEC_PHASE_SYNC() DEC_T(t1_)
-#define DEC_PHASE_END(ph_) do { DEC_T(t2_); if (blockIdx.x == DXA_DEC_STAMPS && threadIdx.x == 0) { g_dec_stamps[2 * (ph_)] += t1_ - t0_; g_dec_stamps[2 * (ph_) + 1] += t2_ - t1_; } } while (0)
+__device__ unsigned long long g_dec_wg[5][256];     // work cycles of EVERY workgroup per phase (who are the stragglers?)
+#define DEC_PHASE_END(ph_) do { DEC_T(t2_); if (threadIdx.x == 0 && blockIdx.x < 256) g_dec_wg[ph_][blockIdx.x] += t1_ - t0_; if (blockIdx.x == DXA_DEC_STAMPS && threadIdx.x == 0) { g_dec_stamps[2 * (ph_)] += t1_ - t0_; g_dec_stamps[2 * (ph_) + 1] += t2_ - t1_; } } while (0)
 #else
 #define DEC_T(v_) do { } while (0)
 #define DEC_ATT(i_, a_, b_) do { } while (0)
@@ -599,6 +600,13 @@ extern "C" int dxa_decode_step(const dxa_decode_desc* q, dxa_stream_t stream) {
 }
 
 #if defined(DXA_DEC_STAMPS)
+extern "C" int dxa_decode_debug_wg(unsigned long long* out) {      // tuning build only: [5][256] work cycles per workgroup, then zeroed
+  DXA_CHECK_HIP(hipDeviceSynchronize());
+  DXA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_wg), sizeof(unsigned long long) * 5 * 256));
+  static unsigned long long z[5 * 256];
+  DXA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dec_wg), z, sizeof(z)));
+  return DXA_OK;
+}
 // tuning build only: [work, barrier] cycle sums per phase since the last call, then zeroed
 extern "C" int dxa_decode_debug_stamps(unsigned long long* out) {
   DXA_CHECK_HIP(hipDeviceSynchronize());

@@ -251,8 +251,9 @@ class Qwen2LayerFn(_StoreFn):
     x + o_proj(attn(rope(qkv(rmsnorm(x))))) ; then + down(silu(gate)*up) of rmsnorm."""
 
     @staticmethod
-    def _run(st: ParamStore, sp: Qwen2LayerSpec, x, cos_t, sin_t, kv_start, kv_end):
-        """the layer's forward launches -> (y, what the backward reads besides x)"""
+    def _run(st: ParamStore, sp: Qwen2LayerSpec, x, cos_t, sin_t, kv_start, kv_end, keep: bool = True):
+        """the layer's forward launches -> (y, what the backward reads besides x).  ``keep`` = False (no gradient will be asked
+        for: serving): the gated MLP's pre-activations are not stored and SiLU * up runs in the gate / up product's epilogue"""
         B, S, Hq, Hkv, D, d, F_ = sp.B, sp.S, sp.Hq, sp.Hkv, sp.D, sp.d, sp.F
         M = B * S
         nq = (Hq + 2 * Hkv) * D
@@ -265,8 +266,8 @@ class Qwen2LayerFn(_StoreFn):
         x2 = K.mm_nt(o.view(M, Hq * D), st.w(sp.o_w), residual=x)
         h2, rstd2 = K.rmsnorm_fwd(x2, st.w(sp.ln2), sp.eps)
         w_gu = st.w(*sp.gu_w, shape=(2 * F_, d))
-        if K.swiglu_gemm_supported(h2, w_gu, keep_pre=True):          # SiLU(gate) * up in the product's own epilogue (opt-in here)
-            a, gu = K.mm_nt_swiglu(h2, w_gu, keep_pre=True)
+        if K.swiglu_gemm_supported(h2, w_gu, keep_pre=keep):          # SiLU(gate) * up in the product's own epilogue
+            a, gu = K.mm_nt_swiglu(h2, w_gu, keep_pre=keep)
         else:
             gu = K.mm_nt(h2, w_gu)
             a = K.swiglu_fwd(gu)
@@ -275,7 +276,10 @@ class Qwen2LayerFn(_StoreFn):
 
     @staticmethod
     def forward(ctx, x, anchor, st: ParamStore, sp: Qwen2LayerSpec, cos_t, sin_t, kv_start, kv_end):
-        y, saved = Qwen2LayerFn._run(st, sp, x, cos_t, sin_t, kv_start, kv_end)
+        need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        y, saved = Qwen2LayerFn._run(st, sp, x, cos_t, sin_t, kv_start, kv_end, keep=need)
+        if not need:
+            return y
         ctx.st, ctx.sp = st, sp
         _use(ctx, st, sp.ln1, sp.qkv_w, sp.qkv_b, sp.o_w, sp.ln2, sp.gu_w, sp.down_w)
         ctx.aux = (cos_t, sin_t, kv_start, kv_end)
