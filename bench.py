@@ -677,6 +677,26 @@ def main():
             result["p50_action_inference_ms"] = round(float(np.median(lat)), 2)
             result["action_inference"] = {"n_requests": n_req, "distinct_inputs": len(reqs), "p50_ms": round(float(np.median(lat)), 2),
                                           "p90_ms": round(float(np.percentile(lat, 90)), 2), "min_ms": round(float(lat.min()), 2)}
+            # roofline of the request: algorithmic FLOPs of ONE two-view request (ViT x 2 views +
+            # projector + 28 decoder layers at S = 543 + 10 DDIM steps x CFG pair of DiT-B forwards) over the p50 latency against the
+            # dense bf16 MFMA peak, and the bf16 weight bytes a request must touch at least once over the same time against HBM
+            f_req, s_req = flops_per_sample_fwd(llm.to_dict(), vis.to_dict(), 2, args.s_text, 768, 12, 16, 0)
+            f_dit = 10 * 2 * (12 * (2 * 12 * 768 * 768 * 17 + 4 * 17 * 17 * 768) + 2 * (3584 * 768 + 256 * 768 + 768 * 768))
+            lw = llm.to_dict()
+            dl, fl_, hq, hkv = lw["hidden_size"], lw["intermediate_size"], lw["num_attention_heads"], lw["num_key_value_heads"]
+            w_llm = lw["num_hidden_layers"] * (dl * (hq + 2 * hkv) * (dl // hq) + dl * dl + 3 * dl * fl_)
+            vw = vis.to_dict()
+            w_vit = (vw["num_hidden_layers"] - 1) * (4 * vw["hidden_size"] ** 2 + 2 * vw["hidden_size"] * vw["intermediate_size"])
+            w_bytes = 2.0 * (w_llm + w_vit + vw["hidden_size"] * dl + dl * dl) + 2.0 * 12 * 12 * 768 * 768
+            p50_s = float(np.median(lat)) * 1e-3
+            result["inference_roofline"] = {
+                "bound": "mfma", "achieved": round((f_req + f_dit) / p50_s / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round((f_req + f_dit) / p50_s / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "request_tflop": round((f_req + f_dit) / 1e12, 3), "seq_len": s_req,
+                "weight_stream_tb_s": round(w_bytes / p50_s / 1e12, 3), "weight_gb": round(w_bytes / 1e9, 2),
+                "hbm_frac_of_8_tb_s": round(w_bytes / p50_s / 8e12, 4),
+                "what": "whole request (host launch of the replayed graph + device + result copy) at its p50, not one kernel: the "
+                        "per-kernel table is profiles/r06_infer_kernel_stats.txt"}
             result["config"]["inference_workload"] = ("DB-CogACT bf16 action inference, batch 1, 2 views 224x224, "
                                                       "32-token instruction (S=543), CFG 1.5, 10 DDIM steps, through inference_action (HIP-graph replay from the third request of a shape on)")
             try:

@@ -1243,8 +1243,8 @@ class GradReducer:
 
     def _avg(self, t: torch.Tensor, native_avg: bool) -> None:
         d = self.dist
-        if self.reduce_op == "sum":
-            self._all_reduce(t, d.ReduceOp.SUM)
+        if self.reduce_op == "sum" and not (self.world == 1 and self.native_avg_world1):
+            self._all_reduce(t, d.ReduceOp.SUM)          # (--native-avg at one rank: AVG in body AND tail, the N > 1 AVG sequence)
         elif native_avg:
             self._all_reduce(t, d.ReduceOp.AVG)
         else:                                                    # gloo has no AVG
@@ -1260,12 +1260,14 @@ class GradReducer:
         # buffer (oneRankReduce<FuncPreMulSum>, 43 ms per step for the 30 GB arena) that no multi-rank ring contains
         native_avg = buf.is_cuda and self.backend == "nccl" and (w > 1 or self.native_avg_world1)
         if w == 1 and not self.native_avg_world1:
+            # (through the staging helpers: a forced one-rank gloo run on a GPU arena must not hand device pointers to a backend
+            #  without device collectives — ADVICE r5)
             if self.algo == "allreduce":
-                d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group)
+                self._all_reduce(buf, d.ReduceOp.SUM)
                 self.collectives += 1
             else:
-                d.reduce_scatter_tensor(buf, buf, op=d.ReduceOp.SUM, group=self.group)
-                d.all_gather_into_tensor(buf, buf, group=self.group)
+                self._reduce_scatter(buf, buf, d.ReduceOp.SUM)
+                self._all_gather(buf, buf)
                 self.collectives += 2
             return
         n = buf.numel()
