@@ -57,7 +57,12 @@ class ArenaAdamW(torch.optim.Optimizer):
         if not core.update_due and (core._held or core.micro % core.grad_accum != 0):
             # HF closed a SHORT accumulation group (last batches of an epoch whose length does not divide by
             # gradient_accumulation_steps) without telling training_step its size — transformers 4.51, which the reference
-            # pins, has no Trainer.current_gradient_accumulation_steps: whatever is held or half-accumulated IS the group
+            # pins, has no Trainer.current_gradient_accumulation_steps: whatever is held or half-accumulated IS the group.
+            # Two consequences, both confined to that last short group of an epoch under 4.51: the held micro-batches'
+            # forward / backward run HERE, after training_step already returned 0 for them, so HF's logged tr_loss misses their
+            # share (the update itself is exact: test_hf_trainer_gpu's short-group case); and an out-of-memory error in that pass
+            # surfaces from optimizer.step() — close_short_group restores grad_accum / micro in its finally block, the step's
+            # gradient arena is left as the next begin_step() finds and overwrites it.
             core.close_short_group()
         with torch.no_grad():
             self._apply()

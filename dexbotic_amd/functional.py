@@ -244,6 +244,7 @@ class Qwen2LayerSpec:
     d: int = 0
     F: int = 0
     eps: float = 1e-6
+    grad_mode: bool = True     # grad mode of the caller of the current forward (Qwen2Backbone.forward records it)
 
 
 class Qwen2LayerFn(_StoreFn):
@@ -276,7 +277,9 @@ class Qwen2LayerFn(_StoreFn):
 
     @staticmethod
     def forward(ctx, x, anchor, st: ParamStore, sp: Qwen2LayerSpec, cos_t, sin_t, kv_start, kv_end):
-        need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        # will a backward come?  (needs_input_grad reports requires_grad of the inputs whatever the grad mode of the caller: a served
+        #  model keeps its parameters trainable, so the caller's grad mode — recorded by Qwen2Backbone.forward — decides too)
+        need = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and getattr(sp, "grad_mode", True)
         y, saved = Qwen2LayerFn._run(st, sp, x, cos_t, sin_t, kv_start, kv_end, keep=need)
         if not need:
             return y

@@ -112,8 +112,9 @@ class Qwen2Backbone(nn.Module):
         cos_t, sin_t = self.rope_tables(S, inputs_embeds.device)
         st = self.store
         x = inputs_embeds.reshape(B * S, d)
+        grad_mode = torch.is_grad_enabled()      # (read HERE: inside an autograd Function's forward it is always off)
         for sp in self.layer_specs:
-            sp.B, sp.S = B, S
+            sp.B, sp.S, sp.grad_mode = B, S, grad_mode
             x = Fn.Qwen2LayerFn.apply(x, st.params[sp.ln1], st, sp, cos_t, sin_t, kv_start, kv_end)
         x = Fn.NormFn.apply(x, st.params[self.p + "norm.weight"], st, "rms", self.p + "norm.weight", None,
                             self.config.rms_norm_eps)
