@@ -111,9 +111,12 @@ def test_bf16_pi0_inference_tracks_reference(golden_dir):
                               images=T(g["images"]), image_masks=T(g["image_masks"]), diffusion_steps=10,
                               noise=T(g["init_noise"]))
     # the reference samples in fp32 (pi0_exp.py:347-353); bf16 compute is the training dtype.  Ten Euler steps through a
-    # random-weight tiny model amplify rounding, so this is a sanity bound on the relative L2 error, not a parity claim
+    # random-weight tiny model amplify rounding, so this is a sanity bound on the relative L2 error, not a parity claim (the bf16
+    # parity claim is the real-width test below, held to the reference under autocast).  Measured 5.5e-2 on the MI355X: bound 1.5 x that
     a, r = acts.cpu().numpy().astype(np.float64), g["infer_actions"].astype(np.float64)
-    assert np.linalg.norm(a - r) / np.linalg.norm(r) < 0.15
+    d = np.linalg.norm(a - r) / np.linalg.norm(r)
+    print(f"toy pi0 bf16 sampler vs fp32 reference: relative L2 {d:.3e}")
+    assert d < 8.5e-2
 
 
 def test_bf16_siglip_tower_head_dim_72_padded_attention():
