@@ -34,7 +34,7 @@ constexpr unsigned NCTR = 16;      // arrival counters of the device-wide barrie
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 constexpr int MAXR = 160;          // rows (a gate / up pair counts 2) a workgroup folds per pass
 constexpr int ACT_MAX = 32768;     // longest activation vector (elements) staged in LDS: 64 KiB of bf16
-constexpr int T_MAX = ACT_MAX / 2 - 1;   // keys: fp32 scores share the activation buffer
+constexpr int T_MAX = ACT_MAX / 2 - 1;   // cached keys per sequence (descriptor sizes and loop counters are 32-bit; nothing is staged per key)
 constexpr int D_MAX = 256;
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -53,10 +53,9 @@ struct DecP {
 };
 
 struct alignas(16) DSmem {
-  bf16_t act[ACT_MAX];            // activation vector of the running product | fp32 scores of the attention phase
+  bf16_t act[ACT_MAX];            // activation vector of the running product | the attention phase's partial softmax states
   float red[8][MAXR];
   float q[D_MAX], kn[D_MAX], vn[D_MAX];
-  float pv[8][D_MAX];
   float wred[16];
 };
 
