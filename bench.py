@@ -626,7 +626,7 @@ def main():
         # HBM bytes per launch of that kernel come from the committed rocprofv3 PMC passes over this same command
         # (separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, checked on a known byte count)
         traffic = None
-        pmc_path = next((pth for pth in (os.path.join(ROOT, "profiles", f"r0{r}_pmc.json") for r in (5, 4, 3, 2)) if os.path.exists(pth)), None)
+        pmc_path = next((pth for pth in (os.path.join(ROOT, "profiles", f"r0{r}_pmc.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(pth)), None)
         pmc_commit = None
         if pmc_path and in_dt == L.BF16:
             with open(pmc_path) as f:

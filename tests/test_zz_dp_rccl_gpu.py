@@ -53,7 +53,7 @@ def test_two_rank_model_step_over_rccl(tmp_path, comm_dtype):
     D.check_against_single_process(tmp_path, variants, *ref, n_ref=n_ref, pairs=pairs)
 
 
-def _real_width_worker(rank, world, port, tmp):
+def _real_width_worker(rank, world, port, tmp, backend="nccl"):
     """one optimizer step at the BASELINE widths (4 decoder layers, 3 ViT layers, bf16 compute, bf16 exchange), 2 episodes per rank,
     replicated and sharded: both must leave identical parameters on both ranks"""
     import datetime
@@ -62,14 +62,18 @@ def _real_width_worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
-                            device_id=torch.device("cuda", rank))
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300),
+                                device_id=torch.device("cuda", rank))
+    else:                      # both ranks on the one GPU of the box; the reducer stages every slice through host memory
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     try:
         import bench
         from dexbotic_amd.engine import OptimConfig
         from dexbotic_amd.trainer import NativeTrainer
-        dev = torch.device("cuda", rank)
+        dev = torch.device("cuda", rank if backend == "nccl" else 0)
         args = types.SimpleNamespace(llm_layers=4, vit_layers=3, dtype="bfloat16")
         out = {}
         for shard in (False, True):
@@ -108,7 +112,24 @@ def test_real_width_step_sharded_equals_replicated_over_rccl(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_real_width_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_real_width_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+    r0, r1 = np.load(tmp_path / "real_rank0.npz"), np.load(tmp_path / "real_rank1.npz")
+    assert np.array_equal(r0["master"], r1["master"]) and float(r0["csum"]) == float(r1["csum"])
+
+
+def test_real_width_step_sharded_equals_replicated_two_ranks_on_one_gpu(tmp_path):
+    """the same real-width check EXECUTED on the 1-GPU lease (round 6): two processes share cuda:0, the process group is gloo and the
+    reducer stages each slice through host memory (as tests/test_zz_dp2_gpu.py does at the toy widths) — 4 decoder layers at the 7 B
+    widths + CLIP-L layers + DiT-B, bf16 compute, bf16 exchange, two optimizer steps: the sharded optimizer step (reduce-scatter ->
+    own-shard AdamW -> all-gather of the bf16 weights) leaves BIT-IDENTICAL masters and shadows to the replicated step on both ranks"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_real_width_worker, args=(2, port, str(tmp_path), "gloo"), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
     r0, r1 = np.load(tmp_path / "real_rank0.npz"), np.load(tmp_path / "real_rank1.npz")
     assert np.array_equal(r0["master"], r1["master"]) and float(r0["csum"]) == float(r1["csum"])
