@@ -30,6 +30,12 @@ pi0)     # exact per-step kernel table of the pi0 fine-tune step
   cd $R
   python profiles/rocpd_stats.py --per-step gpurun_out/prof/pi1_results.db 3 gpurun_out/prof/pi3_results.db 5 > gpurun_out/r06_pi0_train_per_step_kernel_stats.txt 2>&1
   grep "^{" gpurun_out/r06_pi0_3.log | cut -c1-300; head -26 gpurun_out/r06_pi0_train_per_step_kernel_stats.txt | cut -c1-160 ;;
+memvla)  # exact per-step kernel table of the MemVLA fine-tune step (difference of traces with 1 and 3 timed steps)
+  cd /tmp; export TMPDIR=/tmp
+  for n in 1 3; do SKIP_INFER=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o mem$n -- python $R/scripts/memvla_bench.py $n > $R/gpurun_out/r06_memvla_$n.log 2>&1; done
+  cd $R
+  python profiles/rocpd_stats.py --per-step gpurun_out/prof/mem1_results.db 1 gpurun_out/prof/mem3_results.db 3 > gpurun_out/r06_memvla_train_per_step_kernel_stats.txt 2>&1
+  grep "^{" gpurun_out/r06_memvla_3.log | cut -c1-300; head -26 gpurun_out/r06_memvla_train_per_step_kernel_stats.txt | cut -c1-160 ;;
 decode)  # per-TOKEN kernel table of the KV-cached greedy decode: difference of traces with 9 and 33 new tokens (11 generations of n tokens each: 8 and 32 single-token passes per generation)
   cd /tmp; export TMPDIR=/tmp
   for n in 9 33; do rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o de$n -- python $R/scripts/decode_bench.py $n > $R/gpurun_out/r06_decode_$n.log 2>&1; done
