@@ -64,6 +64,25 @@ def test_no_cpu_fallback():
     assert "layout" in L.last_error()
 
 
+def test_new_entry_points_reject_bad_arguments_with_a_message():
+    """round 6's entry points refuse what they cannot run instead of launching (no GPU needed: the checks come first)"""
+    from dexbotic_amd import _lib as L
+    q = L.DecodeDesc()
+    assert L.lib.dxa_decode_step(q, None) == -1 and "null pointer" in L.last_error()
+    assert L.lib.dxa_decode_step_workspace(3584, 28, 4, 128, 18944) == 2 * (3584 + 4608 + 3584 + 18944)      # bf16, 128-element pads
+    assert L.lib.dxa_decode_step_workspace(0, 28, 4, 128, 18944) == 0
+    d = L.GemmDesc()
+    d.layout, d.in_dtype, d.out_dtype, d.M, d.N, d.K = L.NT, L.BF16, L.BF16, 64, 512, 256
+    d.nb[0] = d.nb[1] = d.nb[2] = 1
+    d.A = d.B = d.C = 4096                                   # (never dereferenced: the fuse check fails first)
+    d.lda = d.ldb = 256
+    d.ldc = 256
+    d.fuse = L.FUSE_SWIGLU
+    assert L.lib.dxa_gemm(d, None) == -1 and "DXA_FUSE_SWIGLU" in L.last_error()          # 64 rows: not the MFMA fast path
+    d.fuse = 7
+    assert L.lib.dxa_gemm(d, None) == -1 and "unknown fuse mode" in L.last_error()
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "dexbotic_amd")
     for dp, _, files in os.walk(pkg):
