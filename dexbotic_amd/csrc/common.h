@@ -108,12 +108,26 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// tanh through v_exp_f32 / v_rcp_f32: 1 - 2 / (1 + e^{2u}); exact limits at +-inf, absolute error ~2e-7 (it is only ever added to 1 or
+// squared below).  tanhf is ~20 VALU instructions; the GeGLU backward of pi0's 16384-wide MLP evaluates it 428 M times per layer and
+// was VALU-co-bound with it (237 us per launch against 150 for the same bytes in swiglu_bwd_k).
+__device__ __forceinline__ float fast_tanhf(float u) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u));
+}
+
+// logistic function through v_exp_f32 / v_rcp_f32 (1 ulp each; exact limits).  Used ONLY where an epilogue's VALU time is exposed (the
+// serving-side gate / up epilogue, the decode step).  Tried in swiglu_fwd_k / swiglu_bwd_k / SiLU / quick-GELU as well (round 6): the
+// step did not move (232.8 vs 232.9 ms) and three real-width bf16 tests left their bounds (1.5 x the observed distance to the reference
+// under autocast: one bf16 step in a few pre-activations per million is enough) — reverted; GELU-tanh keeps fast_tanhf (pi0 + 3 %, all
+// bounds held).
+__device__ __forceinline__ float fast_sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case DXA_ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     case DXA_ACT_GELU_TANH: {
       const float k = 0.79788456080286535588f;  // sqrt(2/pi)
-      return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+      return 0.5f * x * (1.f + fast_tanhf(k * (x + 0.044715f * x * x * x)));
     }
     case DXA_ACT_QUICK_GELU: return x / (1.f + expf(-1.702f * x));
     case DXA_ACT_SILU: return x / (1.f + expf(-x));
@@ -132,7 +146,7 @@ __device__ __forceinline__ float act_grad(int act, float x) {
     case DXA_ACT_GELU_TANH: {
       const float k = 0.79788456080286535588f;
       const float u = k * (x + 0.044715f * x * x * x);
-      const float t = tanhf(u);
+      const float t = fast_tanhf(u);
       const float du = k * (1.f + 3.f * 0.044715f * x * x);
       return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
     }

@@ -494,14 +494,10 @@ __device__ __forceinline__ void sk_epilogue_swiglu(const GemmP& p, f32x16_t (&ac
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-#if defined(DXA_SWIGLU_EXACT)
-          o[e] = rnd<bf16_t>(g[e] / (1.f + expf(-g[e]))) * u[e];
-#else
-          // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf and an IEEE division: the 87 M SiLUs of a training-shape product are
-          // VALU work nothing overlaps in an epilogue (one workgroup per CU) — 36 instead of 100 us per product; against
-          // swiglu_fwd_k the result differs in a few values per million by one bf16 step
-          o[e] = rnd<bf16_t>(g[e] * __builtin_amdgcn_rcpf(1.f + __expf(-g[e]))) * u[e];
-#endif
+          // (fast_sigmoidf — v_exp_f32 + v_rcp_f32 — where swiglu_fwd_k has expf and an IEEE division: the SiLUs of a product are VALU
+          //  work nothing overlaps in an epilogue, one workgroup per CU; against swiglu_fwd_k a result may differ by one bf16 step in a
+          //  few values per million, none on the test data)
+          o[e] = rnd<bf16_t>(g[e] * fast_sigmoidf(g[e])) * u[e];
         }
         const u32x2_t_ ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
         __builtin_amdgcn_raw_buffer_store_b64(ov, rC, ok ? offC0 + rr * ldcB : 0x80000000u, 0, 0);
