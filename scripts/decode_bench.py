@@ -113,7 +113,7 @@ def main():
                           "weight_bytes_per_token": 14.14e9,
                           "weight_stream_tb_s": round(14.14e9 * 1e-9 / med(ev_ms), 2),
                           "hbm_frac_of_8_tb_s": round(14.14e9 * 1e-9 / med(ev_ms) / 8.0, 3),
-                          "roofline": {"bound": "hbm", "achieved": round(14.14e9 * 1e-9 / med(ev_ms) / 1e3, 3), "peak": 8.0, "unit": "TB/s",
+                          "roofline": {"bound": "hbm", "achieved": round(14.14e9 * 1e-9 / med(ev_ms), 3), "peak": 8.0, "unit": "TB/s",
                                        "frac": round(14.14e9 * 1e-9 / med(ev_ms) / 8.0, 3),
                                        "traffic": 14.32e9 if fused_on else None,
                                        "traffic_source": "profiles/r06_decode_pmc.txt (rocprofv3 --pmc FETCH_SIZE x 2: decode_step_k 13.22 GB + "
