@@ -109,6 +109,8 @@ SIGNATURES = {
     "dxa_colsum": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _int, _vp, _sz, _vp]),
     "dxa_rope_split": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "dxa_rope_merge": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "dxa_rope_split_at": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "dxa_rope_merge_at": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "dxa_attn_fwd": (_int, [C.POINTER(AttnDesc), _vp]),
     "dxa_attn_fwd_workspace": (_sz, [C.POINTER(AttnDesc)]),
     "dxa_attn_fwd_ws": (_int, [C.POINTER(AttnDesc), _vp, _sz, _vp]),

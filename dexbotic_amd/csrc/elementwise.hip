@@ -15,7 +15,7 @@ template <typename T, bool MERGE, int VEC = 4>
 __global__ __launch_bounds__(TPB) void rope_k(const T* __restrict__ tok, T* __restrict__ tok_out,
                                               T* __restrict__ q, T* __restrict__ k, T* __restrict__ v,
                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                              const int32_t* __restrict__ pos, int B, int S, int Hq, int Hkv, int D) {
+                                              const int32_t* __restrict__ pos, int B, int S, int Hq, int Hkv, int D, int Sc, int s0) {
   const int HS = Hq + 2 * Hkv, half = D / 2, qn = half / VEC;
   const int64_t total = (int64_t)B * S * HS * qn;
   const int64_t ld = (int64_t)HS * D;
@@ -27,9 +27,11 @@ __global__ __launch_bounds__(TPB) void rope_k(const T* __restrict__ tok, T* __re
     const int d0 = qd * VEC;
     T* hm;  // head-major row of this (b, head, s)
     bool rot = true;
-    if (hs < Hq) hm = q + (((int64_t)b * Hq + hs) * S + s) * D;
-    else if (hs < Hq + Hkv) hm = k + (((int64_t)b * Hkv + (hs - Hq)) * S + s) * D;
-    else { hm = v + (((int64_t)b * Hkv + (hs - Hq - Hkv)) * S + s) * D; rot = false; }
+    // head-major tensors hold Sc >= S positions per (b, head); this call's S tokens sit at positions s0 .. s0 + S - 1 (Sc = S, s0 = 0:
+    // tensors of their own; otherwise a slice of a tensor several calls share: pi0's two experts, a key / value cache)
+    if (hs < Hq) hm = q + (((int64_t)b * Hq + hs) * Sc + s0 + s) * D;
+    else if (hs < Hq + Hkv) hm = k + (((int64_t)b * Hkv + (hs - Hq)) * Sc + s0 + s) * D;
+    else { hm = v + (((int64_t)b * Hkv + (hs - Hq - Hkv)) * Sc + s0 + s) * D; rot = false; }
     const int64_t toff = t * ld + (int64_t)hs * D;
     float c[VEC], sn[VEC];
 #pragma unroll
@@ -477,40 +479,51 @@ inline bool ok_dtype(int d) { return d == DXA_F32 || d == DXA_BF16; }
 
 #define ST ((hipStream_t)stream)
 
-extern "C" int dxa_rope_split(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
-                              const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int dtype, dxa_stream_t stream) {
+extern "C" int dxa_rope_split_at(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
+                                 const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int S_cap, int s0, int dtype, dxa_stream_t stream) {
   DXA_CHECK_ARG(qkv && q && k && v && cos_t && sin_t && ok_dtype(dtype), "dxa_rope_split: bad args");
   DXA_CHECK_ARG(D % 8 == 0, "dxa_rope_split: head_dim must be a multiple of 8 (got %d)", D);
+  DXA_CHECK_ARG(s0 >= 0 && S >= 0 && s0 + S <= S_cap, "dxa_rope_split: positions %d .. %d outside the %d the head-major tensors hold", s0, s0 + S, S_cap);
   const int64_t total = (int64_t)B * S * (Hq + 2 * Hkv) * (D / 8);
   if (total == 0) return DXA_OK;
   dim3 grid(dxa_grid1d(total, TPB));
   const bool wide = dtype == DXA_BF16 && D % 16 == 0 && al(qkv, 16) && al(q, 16) && al(k, 16) && al(v, 16);
   if (wide)
-    hipLaunchKernelGGL((rope_k<bf16_t, false, 8>), dim3(dxa_grid1d(total / 2, TPB)), dim3(TPB), 0, ST, (const bf16_t*)qkv, (bf16_t*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
+    hipLaunchKernelGGL((rope_k<bf16_t, false, 8>), dim3(dxa_grid1d(total / 2, TPB)), dim3(TPB), 0, ST, (const bf16_t*)qkv, (bf16_t*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S_cap, s0);
   else if (dtype == DXA_BF16)
-    hipLaunchKernelGGL((rope_k<bf16_t, false>), grid, dim3(TPB), 0, ST, (const bf16_t*)qkv, (bf16_t*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
+    hipLaunchKernelGGL((rope_k<bf16_t, false>), grid, dim3(TPB), 0, ST, (const bf16_t*)qkv, (bf16_t*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S_cap, s0);
   else
-    hipLaunchKernelGGL((rope_k<float, false>), grid, dim3(TPB), 0, ST, (const float*)qkv, (float*)nullptr, (float*)q, (float*)k, (float*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
+    hipLaunchKernelGGL((rope_k<float, false>), grid, dim3(TPB), 0, ST, (const float*)qkv, (float*)nullptr, (float*)q, (float*)k, (float*)v, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S_cap, s0);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
+extern "C" int dxa_rope_split(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
+                              const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int dtype, dxa_stream_t stream) {
+  return dxa_rope_split_at(qkv, q, k, v, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S, 0, dtype, stream);
+}
+extern "C" int dxa_rope_merge_at(const void* dq, const void* dk, const void* dv, void* dqkv, const float* cos_t,
+                                 const float* sin_t, const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int S_cap, int s0,
+                                 int dtype, dxa_stream_t stream) {
+  DXA_CHECK_ARG(dq && dk && dv && dqkv && cos_t && sin_t && ok_dtype(dtype), "dxa_rope_merge: bad args");
+  DXA_CHECK_ARG(D % 8 == 0, "dxa_rope_merge: head_dim must be a multiple of 8 (got %d)", D);
+  DXA_CHECK_ARG(s0 >= 0 && S >= 0 && s0 + S <= S_cap, "dxa_rope_merge: positions %d .. %d outside the %d the head-major tensors hold", s0, s0 + S, S_cap);
+  const int64_t total = (int64_t)B * S * (Hq + 2 * Hkv) * (D / 8);
+  if (total == 0) return DXA_OK;
+  dim3 grid(dxa_grid1d(total, TPB));
+  const bool wide = dtype == DXA_BF16 && D % 16 == 0 && al(dqkv, 16) && al(dq, 16) && al(dk, 16) && al(dv, 16);
+  if (wide)
+    hipLaunchKernelGGL((rope_k<bf16_t, true, 8>), dim3(dxa_grid1d(total / 2, TPB)), dim3(TPB), 0, ST, (const bf16_t*)nullptr, (bf16_t*)dqkv, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S_cap, s0);
+  else if (dtype == DXA_BF16)
+    hipLaunchKernelGGL((rope_k<bf16_t, true>), grid, dim3(TPB), 0, ST, (const bf16_t*)nullptr, (bf16_t*)dqkv, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S_cap, s0);
+  else
+    hipLaunchKernelGGL((rope_k<float, true>), grid, dim3(TPB), 0, ST, (const float*)nullptr, (float*)dqkv, (float*)dq, (float*)dk, (float*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S_cap, s0);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
 extern "C" int dxa_rope_merge(const void* dq, const void* dk, const void* dv, void* dqkv, const float* cos_t,
                               const float* sin_t, const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int dtype,
                               dxa_stream_t stream) {
-  DXA_CHECK_ARG(dq && dk && dv && dqkv && cos_t && sin_t && ok_dtype(dtype), "dxa_rope_merge: bad args");
-  DXA_CHECK_ARG(D % 8 == 0, "dxa_rope_merge: head_dim must be a multiple of 8 (got %d)", D);
-  const int64_t total = (int64_t)B * S * (Hq + 2 * Hkv) * (D / 8);
-  if (total == 0) return DXA_OK;
-  dim3 grid(dxa_grid1d(total, TPB));
-  const bool wide = dtype == DXA_BF16 && D % 16 == 0 && al(dqkv, 16) && al(dq, 16) && al(dk, 16) && al(dv, 16);
-  if (wide)
-    hipLaunchKernelGGL((rope_k<bf16_t, true, 8>), dim3(dxa_grid1d(total / 2, TPB)), dim3(TPB), 0, ST, (const bf16_t*)nullptr, (bf16_t*)dqkv, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
-  else if (dtype == DXA_BF16)
-    hipLaunchKernelGGL((rope_k<bf16_t, true>), grid, dim3(TPB), 0, ST, (const bf16_t*)nullptr, (bf16_t*)dqkv, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
-  else
-    hipLaunchKernelGGL((rope_k<float, true>), grid, dim3(TPB), 0, ST, (const float*)nullptr, (float*)dqkv, (float*)dq, (float*)dk, (float*)dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D);
-  DXA_CHECK_LAUNCH();
-  return DXA_OK;
+  return dxa_rope_merge_at(dq, dk, dv, dqkv, cos_t, sin_t, pos, B, S, Hq, Hkv, D, S, 0, dtype, stream);
 }
 
 extern "C" int dxa_swiglu_fwd(const void* gu, void* out, int64_t rows, int64_t F, int dtype, dxa_stream_t stream) {

@@ -914,6 +914,20 @@ class GemmaLayerSpec:
     eps: float
 
 
+def _gemma_norm_w(st: ParamStore, name: str) -> torch.Tensor:
+    """fp32 (1 + w) of a GemmaRMSNorm weight, computed once per state of the weights (forward and backward of a step share it; the
+    two aten launches per use were 290 launches of a pi0 step)"""
+    key = st.weights_key()
+    cache = st.__dict__.setdefault("_gemma_norm_cache", {})
+    if cache.get("key") != key:
+        cache.clear()
+        cache["key"] = key
+    w = cache.get(name)
+    if w is None:
+        w = cache[name] = st.w(name).float() + 1.0
+    return w
+
+
 class Pi0MotLayerFn(_StoreFn):
     """One layer of the pi0 mixture of transformers (pi0_arch.py:130-216) for its two experts at once: per expert
     GemmaRMSNorm -> fused q/k/v -> RoPE; ONE attention over the concatenated tokens with the block-prefix mask; per
@@ -927,12 +941,17 @@ class Pi0MotLayerFn(_StoreFn):
         B, S0, S1, Hq, Hkv, D = geom
         nq = (Hq + 2 * Hkv) * D
         xs, Ss, poss = (x0, x1), (S0, S1), (pos0, pos1)
-        h1, rstd1, qs, ks, vs = [], [], [], [], []
+        h1, rstd1 = [], []
+        # both experts' RoPE launches write straight into ONE q / k / v (round 6: no concatenation around the shared attention call)
+        q = torch.empty((B, Hq, S0 + S1, D), device=x0.device, dtype=x0.dtype)
+        k = torch.empty((B, Hkv, S0 + S1, D), device=x0.device, dtype=x0.dtype)
+        v = torch.empty((B, Hkv, S0 + S1, D), device=x0.device, dtype=x0.dtype)
+        off = 0
         for x, sp, S, pos in zip(xs, sps, Ss, poss):
-            h, r = K.rmsnorm_fwd(x, st.w(sp.ln1).float() + 1.0, sp.eps)
-            q, k, v = K.rope_split(K.mm_nt(h, st.w(*sp.qkv, shape=(nq, sp.d))), cos_t, sin_t, pos, B, S, Hq, Hkv, D)
-            h1.append(h); rstd1.append(r); qs.append(q); ks.append(k); vs.append(v)
-        q, k, v = torch.cat(qs, 2), torch.cat(ks, 2), torch.cat(vs, 2)
+            h, r = K.rmsnorm_fwd(x, _gemma_norm_w(st, sp.ln1), sp.eps)
+            K.rope_split_into(K.mm_nt(h, st.w(*sp.qkv, shape=(nq, sp.d))), q, k, v, off, cos_t, sin_t, pos, B, S, Hq, Hkv, D)
+            off += S
+            h1.append(h); rstd1.append(r)
         o = torch.empty((B, S0 + S1, Hq, D), device=x0.device, dtype=x0.dtype)
         lse = K.attn_fwd(q, k, v, o.permute(0, 2, 1, 3), causal=False, scale=D ** -0.5, q_limit=q_limit, key_valid=key_valid)
         ys, saved = [], []
@@ -945,7 +964,7 @@ class Pi0MotLayerFn(_StoreFn):
                 saved += [a, a.new_empty(0), a.new_empty(0), a.new_empty(0), a.new_empty(0), a.new_empty(0)]
                 continue
             r = K.mm_nt(a, st.w(sp.o), residual=x)
-            h2, rs2 = K.rmsnorm_fwd(r, st.w(sp.ln2).float() + 1.0, sp.eps)
+            h2, rs2 = K.rmsnorm_fwd(r, _gemma_norm_w(st, sp.ln2), sp.eps)
             gu = K.mm_nt(h2, st.w(*sp.gu, shape=(2 * sp.F, sp.d)))
             act = K.glu_fwd(gu, L.ACT_GELU_TANH)
             ys.append(K.mm_nt(act, st.w(sp.down), residual=r))
@@ -1001,7 +1020,7 @@ class Pi0MotLayerFn(_StoreFn):
             dh2 = _dx(st, sp.gu, (2 * sp.F, sp.d), dgu)
             _wgrad(st, sp.gu, dgu, h2, (2 * sp.F, sp.d))
             tr = st.trainable(sp.ln2)
-            dr, _ = K.rmsnorm_bwd(dh2, r, st.w(sp.ln2).float() + 1.0, rs2, dw_out=st.g(sp.ln2) if tr else None,
+            dr, _ = K.rmsnorm_bwd(dh2, r, _gemma_norm_w(st, sp.ln2), rs2, dw_out=st.g(sp.ln2) if tr else None,
                                   accumulate=st.accum_flag(sp.ln2), want_dw=tr, residual=dy)
             if tr:
                 st.mark_written(sp.ln2)
@@ -1017,14 +1036,12 @@ class Pi0MotLayerFn(_StoreFn):
         dxs = []
         off = 0
         for i, (sp, Sn, pos) in enumerate(zip(sps, Ss, poss)):
-            sl = slice(off, off + Sn)
+            dqkv = K.rope_merge_from(dq, dk, dv, off, cos_t, sin_t, pos, B, Sn, Hq, Hkv, D)      # (no slicing copies)
             off += Sn
-            dqkv = K.rope_merge(dq[:, :, sl].contiguous(), dk[:, :, sl].contiguous(), dv[:, :, sl].contiguous(),
-                                cos_t, sin_t, pos, B, Sn, Hq, Hkv, D)
             dh = _dx(st, sp.qkv, (nq, sp.d), dqkv)
             _wgrad(st, sp.qkv, dqkv, h1[i], (nq, sp.d))
             tr = st.trainable(sp.ln1)
-            dxn, _ = K.rmsnorm_bwd(dh, xs[i], st.w(sp.ln1).float() + 1.0, rstd1[i], dw_out=st.g(sp.ln1) if tr else None,
+            dxn, _ = K.rmsnorm_bwd(dh, xs[i], _gemma_norm_w(st, sp.ln1), rstd1[i], dw_out=st.g(sp.ln1) if tr else None,
                                    accumulate=st.accum_flag(sp.ln1), want_dw=tr, residual=drs[i])
             if tr:
                 st.mark_written(sp.ln1)

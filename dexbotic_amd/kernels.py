@@ -486,6 +486,26 @@ def rope_split(qkv: torch.Tensor, cos_t, sin_t, pos, B, S, Hq, Hkv, D, k_out=Non
     return q, k, v
 
 
+def rope_split_into(qkv: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, s0: int, cos_t, sin_t, pos, B, S, Hq, Hkv, D) -> None:
+    """rope_split writing its S tokens at positions s0 .. s0 + S - 1 of SHARED contiguous q [B, Hq, S_cap, D], k / v [B, Hkv, S_cap, D]"""
+    S_cap = q.shape[2]
+    assert qkv.is_contiguous() and qkv.shape == (B * S, (Hq + 2 * Hkv) * D)
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and q.shape == (B, Hq, S_cap, D) and \
+        k.shape == (B, Hkv, S_cap, D) == v.shape and q.dtype == k.dtype == v.dtype == qkv.dtype
+    L.check(lib.dxa_rope_split_at(_ptr(qkv), _ptr(q), _ptr(k), _ptr(v), _ptr(cos_t), _ptr(sin_t), _ptr(pos), B, S, Hq, Hkv, D,
+                                  S_cap, s0, dt(qkv), _stream()), "dxa_rope_split_at")
+
+
+def rope_merge_from(dq, dk, dv, s0: int, cos_t, sin_t, pos, B, S, Hq, Hkv, D):
+    """rope_merge of positions s0 .. s0 + S - 1 of SHARED contiguous dq [B, Hq, S_cap, D], dk / dv [B, Hkv, S_cap, D]"""
+    S_cap = dq.shape[2]
+    assert dq.is_contiguous() and dk.is_contiguous() and dv.is_contiguous() and dq.shape == (B, Hq, S_cap, D)
+    dqkv = torch.empty((B * S, (Hq + 2 * Hkv) * D), device=dq.device, dtype=dq.dtype)
+    L.check(lib.dxa_rope_merge_at(_ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqkv), _ptr(cos_t), _ptr(sin_t), _ptr(pos), B, S, Hq, Hkv, D,
+                                  S_cap, s0, dt(dq), _stream()), "dxa_rope_merge_at")
+    return dqkv
+
+
 def rope_merge(dq, dk, dv, cos_t, sin_t, pos, B, S, Hq, Hkv, D):
     assert dq.is_contiguous() and dk.is_contiguous() and dv.is_contiguous()
     dqkv = torch.empty((B * S, (Hq + 2 * Hkv) * D), device=dq.device, dtype=dq.dtype)

@@ -166,6 +166,13 @@ int dxa_rope_split(const void* qkv, void* q, void* k, void* v, const float* cos_
 int dxa_rope_merge(const void* dq, const void* dk, const void* dv, void* dqkv, const float* cos_t,
                    const float* sin_t, const int32_t* pos, int B, int S, int Hq, int Hkv, int D,
                    int dtype, dxa_stream_t stream);
+/* The same with head-major tensors that hold S_cap >= S positions per (batch, head): this call's S tokens are positions
+ * s0 .. s0 + S - 1 of them (several calls fill / read ONE q, k, v — the two experts of pi0's mixture layer, pi0_arch.py:130-216,
+ * whose tokens share one attention call: no concatenation / slicing copies around it). */
+int dxa_rope_split_at(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t, const int32_t* pos, int B,
+                      int S, int Hq, int Hkv, int D, int S_cap, int s0, int dtype, dxa_stream_t stream);
+int dxa_rope_merge_at(const void* dq, const void* dk, const void* dv, void* dqkv, const float* cos_t, const float* sin_t,
+                      const int32_t* pos, int B, int S, int Hq, int Hkv, int D, int S_cap, int s0, int dtype, dxa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention.  Replaces torch SDPA at HF:qwen2/modeling_qwen2.py:143-235 (causal + key padding, GQA),
