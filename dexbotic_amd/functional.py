@@ -195,11 +195,17 @@ def _wgrad_product(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor,
         K.mm_tn(dy2d, x2d, out=out, accumulate=accumulate, mirror=mirror, sumsq=ssq, **kw2)
 
 
+_SKIP_BGRAD = os.environ.get("DXA_TUNE_SKIP_BGRAD") == "1"
+
+
 def _bgrad(st: ParamStore, names, dy2d: torch.Tensor) -> None:
     names = _names(names)
     if not all(st.trainable(n) for n in names):
         return
     n = sum(st.slots[nm].numel for nm in names)
+    if _SKIP_BGRAD:            # tuning only (WRONG gradients): what the step would cost if the bias column sums were free
+        st.mark_written(*names)
+        return
     side = st.wgrad_stream if st.bgrad_on_side else None
     if side is None:
         K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
