@@ -854,6 +854,76 @@ struct AttnBwdP {
   char* dv; int64_t dv_sb, dv_sh, dv_ss;
 };
 
+// fp32 attention BACKWARD of the diffusion heads (17 tokens per sample, 12 - 16 heads of 64: DiT.forward's timm Attention,
+// dexbotic/model/cogact/action_model/dit.py:137-162 under ActionModel.loss, action_models.py:102-125): the generic path below is five
+// batched exact-fp32 products and three elementwise launches per attention call (8 launches of 25 - 35 us for 18 K FLOPs per head).
+// Here ONE workgroup per (sample, head) keeps q, k, v, dO in LDS and walks S = q k^T, P = exp(scale S - lse), dP = dO v^T,
+// delta_i = sum_j P_ij dP_ij (= rowsum(dO * O)), dS = P (dP - delta) scale, dQ = dS k, dK = dS^T q, dV = P^T dO with plain fp32 FMAs.
+// No masks, no dropout, G = 1, Sq, Sk <= 32, D <= 64 (D % 4 == 0): 33 KiB of LDS.
+constexpr int SB_MAXT = 32, SB_MAXD = 64;
+__global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
+  const AttnP& p = bp.f;
+  __shared__ float sq[SB_MAXT][SB_MAXD + 1], sk[SB_MAXT][SB_MAXD + 1], sv[SB_MAXT][SB_MAXD + 1], sdo[SB_MAXT][SB_MAXD + 1];
+  __shared__ float sP[SB_MAXT][SB_MAXT + 1], sD[SB_MAXT][SB_MAXT + 1], sdelta[SB_MAXT];
+  const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const int Sq = p.Sq, Sk = p.Sk, D = p.D, D4 = D >> 2;
+  const float* q = reinterpret_cast<const float*>(p.q) + b * p.q_sb + h * p.q_sh;
+  const float* k = reinterpret_cast<const float*>(p.k) + b * p.k_sb + h * p.k_sh;
+  const float* v = reinterpret_cast<const float*>(p.v) + b * p.v_sb + h * p.v_sh;
+  const float* d_o = reinterpret_cast<const float*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
+  for (int it = tid; it < Sq * D4; it += 256) {
+    const int i = it / D4, d = (it - i * D4) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(q + (int64_t)i * p.q_ss + d);
+    const float4 g = *reinterpret_cast<const float4*>(d_o + (int64_t)i * bp.do_ss + d);
+    sq[i][d] = a.x; sq[i][d + 1] = a.y; sq[i][d + 2] = a.z; sq[i][d + 3] = a.w;
+    sdo[i][d] = g.x; sdo[i][d + 1] = g.y; sdo[i][d + 2] = g.z; sdo[i][d + 3] = g.w;
+  }
+  for (int it = tid; it < Sk * D4; it += 256) {
+    const int j = it / D4, d = (it - j * D4) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(k + (int64_t)j * p.k_ss + d);
+    const float4 g = *reinterpret_cast<const float4*>(v + (int64_t)j * p.v_ss + d);
+    sk[j][d] = a.x; sk[j][d + 1] = a.y; sk[j][d + 2] = a.z; sk[j][d + 3] = a.w;
+    sv[j][d] = g.x; sv[j][d + 1] = g.y; sv[j][d + 2] = g.z; sv[j][d + 3] = g.w;
+  }
+  __syncthreads();
+  const float* lse = p.lse + ((int64_t)b * p.Hq + h) * Sq;
+  for (int it = tid; it < Sq * Sk; it += 256) {
+    const int i = it / Sk, j = it - i * Sk;
+    float s = 0.f, dp = 0.f;
+    for (int d = 0; d < D; ++d) { s += sq[i][d] * sk[j][d]; dp += sdo[i][d] * sv[j][d]; }
+    sP[i][j] = expf(s * p.scale - lse[i]);
+    sD[i][j] = dp;
+  }
+  __syncthreads();
+  if (tid < Sq) {
+    float t = 0.f;
+    for (int j = 0; j < Sk; ++j) t += sP[tid][j] * sD[tid][j];
+    sdelta[tid] = t;
+  }
+  __syncthreads();
+  for (int it = tid; it < Sq * Sk; it += 256) {
+    const int i = it / Sk, j = it - i * Sk;
+    sD[i][j] = sP[i][j] * (sD[i][j] - sdelta[i]) * p.scale;          // dS
+  }
+  __syncthreads();
+  float* dq = reinterpret_cast<float*>(bp.dq) + b * bp.dq_sb + h * bp.dq_sh;
+  float* dk = reinterpret_cast<float*>(bp.dk) + b * bp.dk_sb + h * bp.dk_sh;
+  float* dv = reinterpret_cast<float*>(bp.dv) + b * bp.dv_sb + h * bp.dv_sh;
+  for (int it = tid; it < Sq * D; it += 256) {
+    const int i = it / D, d = it - i * D;
+    float a = 0.f;
+    for (int j = 0; j < Sk; ++j) a += sD[i][j] * sk[j][d];
+    dq[(int64_t)i * bp.dq_ss + d] = a;
+  }
+  for (int it = tid; it < Sk * D; it += 256) {
+    const int j = it / D, d = it - j * D;
+    float a = 0.f, c = 0.f;
+    for (int i = 0; i < Sq; ++i) { a += sD[i][j] * sq[i][d]; c += sP[i][j] * sdo[i][d]; }
+    dk[(int64_t)j * bp.dk_ss + d] = a;
+    dv[(int64_t)j * bp.dv_ss + d] = c;
+  }
+}
+
 template <int D, int NW, int DV = D>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
@@ -1459,6 +1529,25 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     else { LAUNCH_BWD(64, 64); LAUNCH_DKV(64, 64, 4, true); }
 #undef LAUNCH_BWD
 #undef LAUNCH_DKV
+    DXA_CHECK_LAUNCH();
+    return DXA_OK;
+  }
+  // head-sized fp32 attention without masks (the DiT heads' training backward): one launch (DXA_ATTN_NO_SMALL_BWD: the generic path)
+  static const bool small_bwd_off = getenv("DXA_ATTN_NO_SMALL_BWD") != nullptr;
+  if (!small_bwd_off && !d->force_generic && d->dtype == DXA_F32 && d->Hq == d->Hkv && !d->causal && !d->kv_start && !d->kv_end &&
+      !d->q_limit && !d->key_valid && !d->drop_mask && d->Sq <= SB_MAXT && d->Sk <= SB_MAXT && d->D <= SB_MAXD && d->D % 4 == 0 &&
+      d->lse && d->Hq <= 65535 && d->B <= 65535 &&
+      ((uintptr_t)d->q % 16 == 0) && ((uintptr_t)d->k % 16 == 0) && ((uintptr_t)d->v % 16 == 0) && ((uintptr_t)d->d_o % 16 == 0) &&
+      d->q_ss % 4 == 0 && d->k_ss % 4 == 0 && d->v_ss % 4 == 0 && d->do_ss % 4 == 0 && d->q_sh % 4 == 0 && d->k_sh % 4 == 0 &&
+      d->v_sh % 4 == 0 && d->do_sh % 4 == 0 && d->q_sb % 4 == 0 && d->k_sb % 4 == 0 && d->v_sb % 4 == 0 && d->do_sb % 4 == 0) {
+    AttnBwdP bp;
+    bp.f = make_params(d);
+    bp.delta = nullptr;
+    bp.d_o = (const char*)d->d_o; bp.do_sb = d->do_sb; bp.do_sh = d->do_sh; bp.do_ss = d->do_ss;
+    bp.dq = (char*)d->dq; bp.dq_sb = d->dq_sb; bp.dq_sh = d->dq_sh; bp.dq_ss = d->dq_ss;
+    bp.dk = (char*)d->dk; bp.dk_sb = d->dk_sb; bp.dk_sh = d->dk_sh; bp.dk_ss = d->dk_ss;
+    bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
+    hipLaunchKernelGGL(attn_bwd_small_f32_k, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(256), 0, (hipStream_t)stream, bp);
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }

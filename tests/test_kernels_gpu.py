@@ -430,7 +430,8 @@ ATTN_CASES = [
 
 
 @pytest.mark.parametrize("dtype,force_generic", [(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, True),
-                                                 (torch.float32, 2), (torch.bfloat16, 2)])      # 2: the materialised forward
+                                                 (torch.float32, 2), (torch.bfloat16, 2),       # 2: the materialised forward
+                                                 (torch.float32, False)])     # fp32 default dispatch: the head-sized one-launch kernels (DiT-like case)
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_attention_fwd_bwd(dtype, force_generic, case):
     B, Hq, Hkv, S, D, causal, padded, head_major = case
