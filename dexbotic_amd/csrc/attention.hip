@@ -854,12 +854,13 @@ struct AttnBwdP {
   char* dv; int64_t dv_sb, dv_sh, dv_ss;
 };
 
-// fp32 attention BACKWARD of the diffusion heads (17 tokens per sample, 12 - 16 heads of 64: DiT.forward's timm Attention,
-// dexbotic/model/cogact/action_model/dit.py:137-162 under ActionModel.loss, action_models.py:102-125): the generic path below is five
-// batched exact-fp32 products and three elementwise launches per attention call (8 launches of 25 - 35 us for 18 K FLOPs per head).
-// Here ONE workgroup per (sample, head) keeps q, k, v, dO in LDS and walks S = q k^T, P = exp(scale S - lse), dP = dO v^T,
-// delta_i = sum_j P_ij dP_ij (= rowsum(dO * O)), dS = P (dP - delta) scale, dQ = dS k, dK = dS^T q, dV = P^T dO with plain fp32 FMAs.
-// No masks, no dropout, G = 1, Sq, Sk <= 32, D <= 64 (D % 4 == 0): 33 KiB of LDS.
+// fp32 attention BACKWARD of the diffusion heads (17 query tokens per sample, 12 - 16 heads of 64, 17 keys — or MemVLA's 256 perceptual
+// keys: DiT.forward's timm Attention, dexbotic/model/cogact/action_model/dit.py:137-162 under ActionModel.loss, action_models.py:102-125;
+// memvla/action_model/dit.py:136-185): the generic path below is five batched exact-fp32 products and three elementwise launches per
+// attention call (8 launches of 25 - 35 us for 18 K FLOPs per head).  Here ONE workgroup per (sample, head) keeps q and dO in LDS and
+// walks the keys in chunks of 32 twice: pass 1  S = q k^T, P = exp(scale S - lse), dP = dO v^T -> delta_i = sum_j P_ij dP_ij
+// (= rowsum(dO * O)); pass 2 the same again -> dS = P (dP - delta) scale, dQ += dS k (registers), dK = dS^T q, dV = P^T dO of the chunk.
+// Plain fp32 FMAs.  No masks, no dropout, G = 1, Sq <= 32, D <= 64 (D % 4 == 0): 34 KiB of LDS.
 constexpr int SB_MAXT = 32, SB_MAXD = 64;
 __global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
@@ -871,6 +872,10 @@ __global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
   const float* k = reinterpret_cast<const float*>(p.k) + b * p.k_sb + h * p.k_sh;
   const float* v = reinterpret_cast<const float*>(p.v) + b * p.v_sb + h * p.v_sh;
   const float* d_o = reinterpret_cast<const float*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
+  float* dq = reinterpret_cast<float*>(bp.dq) + b * bp.dq_sb + h * bp.dq_sh;
+  float* dk = reinterpret_cast<float*>(bp.dk) + b * bp.dk_sb + h * bp.dk_sh;
+  float* dv = reinterpret_cast<float*>(bp.dv) + b * bp.dv_sb + h * bp.dv_sh;
+  const float* lse = p.lse + ((int64_t)b * p.Hq + h) * Sq;
   for (int it = tid; it < Sq * D4; it += 256) {
     const int i = it / D4, d = (it - i * D4) * 4;
     const float4 a = *reinterpret_cast<const float4*>(q + (int64_t)i * p.q_ss + d);
@@ -878,49 +883,80 @@ __global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
     sq[i][d] = a.x; sq[i][d + 1] = a.y; sq[i][d + 2] = a.z; sq[i][d + 3] = a.w;
     sdo[i][d] = g.x; sdo[i][d + 1] = g.y; sdo[i][d + 2] = g.z; sdo[i][d + 3] = g.w;
   }
-  for (int it = tid; it < Sk * D4; it += 256) {
-    const int j = it / D4, d = (it - j * D4) * 4;
-    const float4 a = *reinterpret_cast<const float4*>(k + (int64_t)j * p.k_ss + d);
-    const float4 g = *reinterpret_cast<const float4*>(v + (int64_t)j * p.v_ss + d);
-    sk[j][d] = a.x; sk[j][d + 1] = a.y; sk[j][d + 2] = a.z; sk[j][d + 3] = a.w;
-    sv[j][d] = g.x; sv[j][d + 1] = g.y; sv[j][d + 2] = g.z; sv[j][d + 3] = g.w;
+  if (tid < SB_MAXT) sdelta[tid] = 0.f;
+  auto load_chunk = [&](int j0, int nj) {              // keys j0 .. j0 + nj - 1 into sk / sv
+    for (int it = tid; it < nj * D4; it += 256) {
+      const int j = it / D4, d = (it - j * D4) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(k + (int64_t)(j0 + j) * p.k_ss + d);
+      const float4 g = *reinterpret_cast<const float4*>(v + (int64_t)(j0 + j) * p.v_ss + d);
+      sk[j][d] = a.x; sk[j][d + 1] = a.y; sk[j][d + 2] = a.z; sk[j][d + 3] = a.w;
+      sv[j][d] = g.x; sv[j][d + 1] = g.y; sv[j][d + 2] = g.z; sv[j][d + 3] = g.w;
+    }
+  };
+  auto probs = [&](int nj) {                           // sP = P, sD = dP of the chunk
+    for (int it = tid; it < Sq * nj; it += 256) {
+      const int i = it / nj, j = it - i * nj;
+      float s_ = 0.f, dp = 0.f;
+      for (int d = 0; d < D; ++d) { s_ += sq[i][d] * sk[j][d]; dp += sdo[i][d] * sv[j][d]; }
+      sP[i][j] = expf(s_ * p.scale - lse[i]);
+      sD[i][j] = dp;
+    }
+  };
+  // ---- pass 1: delta
+  for (int j0 = 0; j0 < Sk; j0 += SB_MAXT) {
+    const int nj = min(SB_MAXT, Sk - j0);
+    __syncthreads();
+    load_chunk(j0, nj);
+    __syncthreads();
+    probs(nj);
+    __syncthreads();
+    if (tid < Sq) {
+      float t = 0.f;
+      for (int j = 0; j < nj; ++j) t += sP[tid][j] * sD[tid][j];
+      sdelta[tid] += t;
+    }
   }
-  __syncthreads();
-  const float* lse = p.lse + ((int64_t)b * p.Hq + h) * Sq;
-  for (int it = tid; it < Sq * Sk; it += 256) {
-    const int i = it / Sk, j = it - i * Sk;
-    float s = 0.f, dp = 0.f;
-    for (int d = 0; d < D; ++d) { s += sq[i][d] * sk[j][d]; dp += sdo[i][d] * sv[j][d]; }
-    sP[i][j] = expf(s * p.scale - lse[i]);
-    sD[i][j] = dp;
+  // ---- pass 2: dS, dQ (accumulated in registers: element it = tid + 256 r of [Sq, D]), dK / dV per chunk
+  constexpr int QR = SB_MAXT * SB_MAXD / 256;
+  float accq[QR];
+#pragma unroll
+  for (int r = 0; r < QR; ++r) accq[r] = 0.f;
+  for (int j0 = 0; j0 < Sk; j0 += SB_MAXT) {
+    const int nj = min(SB_MAXT, Sk - j0);
+    __syncthreads();
+    if (Sk > SB_MAXT) {                                 // (a single chunk is still in LDS from pass 1)
+      load_chunk(j0, nj);
+      __syncthreads();
+      probs(nj);
+      __syncthreads();
+    }
+    for (int it = tid; it < Sq * nj; it += 256) {
+      const int i = it / nj, j = it - i * nj;
+      sD[i][j] = sP[i][j] * (sD[i][j] - sdelta[i]) * p.scale;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < QR; ++r) {
+      const int it = tid + 256 * r;
+      if (it < Sq * D) {
+        const int i = it / D, d = it - i * D;
+        float a = accq[r];
+        for (int j = 0; j < nj; ++j) a += sD[i][j] * sk[j][d];
+        accq[r] = a;
+      }
+    }
+    for (int it = tid; it < nj * D; it += 256) {
+      const int j = it / D, d = it - j * D;
+      float a = 0.f, c = 0.f;
+      for (int i = 0; i < Sq; ++i) { a += sD[i][j] * sq[i][d]; c += sP[i][j] * sdo[i][d]; }
+      dk[(int64_t)(j0 + j) * bp.dk_ss + d] = a;
+      dv[(int64_t)(j0 + j) * bp.dv_ss + d] = c;
+    }
   }
-  __syncthreads();
-  if (tid < Sq) {
-    float t = 0.f;
-    for (int j = 0; j < Sk; ++j) t += sP[tid][j] * sD[tid][j];
-    sdelta[tid] = t;
-  }
-  __syncthreads();
-  for (int it = tid; it < Sq * Sk; it += 256) {
-    const int i = it / Sk, j = it - i * Sk;
-    sD[i][j] = sP[i][j] * (sD[i][j] - sdelta[i]) * p.scale;          // dS
-  }
-  __syncthreads();
-  float* dq = reinterpret_cast<float*>(bp.dq) + b * bp.dq_sb + h * bp.dq_sh;
-  float* dk = reinterpret_cast<float*>(bp.dk) + b * bp.dk_sb + h * bp.dk_sh;
-  float* dv = reinterpret_cast<float*>(bp.dv) + b * bp.dv_sb + h * bp.dv_sh;
-  for (int it = tid; it < Sq * D; it += 256) {
-    const int i = it / D, d = it - i * D;
-    float a = 0.f;
-    for (int j = 0; j < Sk; ++j) a += sD[i][j] * sk[j][d];
-    dq[(int64_t)i * bp.dq_ss + d] = a;
-  }
-  for (int it = tid; it < Sk * D; it += 256) {
-    const int j = it / D, d = it - j * D;
-    float a = 0.f, c = 0.f;
-    for (int i = 0; i < Sq; ++i) { a += sD[i][j] * sq[i][d]; c += sP[i][j] * sdo[i][d]; }
-    dk[(int64_t)j * bp.dk_ss + d] = a;
-    dv[(int64_t)j * bp.dv_ss + d] = c;
+#pragma unroll
+  for (int r = 0; r < QR; ++r) {
+    const int it = tid + 256 * r;
+    if (it < Sq * D) dq[(int64_t)(it / D) * bp.dq_ss + (it % D)] = accq[r];
   }
 }
 
@@ -1535,7 +1571,7 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
   // head-sized fp32 attention without masks (the DiT heads' training backward): one launch (DXA_ATTN_NO_SMALL_BWD: the generic path)
   static const bool small_bwd_off = getenv("DXA_ATTN_NO_SMALL_BWD") != nullptr;
   if (!small_bwd_off && !d->force_generic && d->dtype == DXA_F32 && d->Hq == d->Hkv && !d->causal && !d->kv_start && !d->kv_end &&
-      !d->q_limit && !d->key_valid && !d->drop_mask && d->Sq <= SB_MAXT && d->Sk <= SB_MAXT && d->D <= SB_MAXD && d->D % 4 == 0 &&
+      !d->q_limit && !d->key_valid && !d->drop_mask && d->Sq <= SB_MAXT && d->Sk <= 4096 && d->D <= SB_MAXD && d->D % 4 == 0 &&
       d->lse && d->Hq <= 65535 && d->B <= 65535 &&
       ((uintptr_t)d->q % 16 == 0) && ((uintptr_t)d->k % 16 == 0) && ((uintptr_t)d->v % 16 == 0) && ((uintptr_t)d->d_o % 16 == 0) &&
       d->q_ss % 4 == 0 && d->k_ss % 4 == 0 && d->v_ss % 4 == 0 && d->do_ss % 4 == 0 && d->q_sh % 4 == 0 && d->k_sh % 4 == 0 &&

@@ -1305,3 +1305,28 @@ def test_gemm_swiglu_epilogue_is_bit_identical_to_gemm_then_swiglu(M, F_, Kd, sp
         print(f"M {M} F {F_} K {Kd}: {differ:.2e} of the pre-activations differ, by at most {worst:.2e} relative")
         assert differ < 2e-2 and worst <= 2 ** -7 * 1.01                                    # one bf16 step
     assert out_ref.float().abs().max() > 0.05                         # (not a comparison of zeros)
+
+
+@pytest.mark.parametrize("Sq,Sk", [(17, 17), (17, 256), (32, 70), (5, 33)])
+def test_attention_small_f32_backward_one_launch(Sq, Sk, monkeypatch):
+    """the head-sized fp32 attention backward (attn_bwd_small_f32_k: the DiT heads' 17 x 17 and MemVLA's 17 x 256 perceptual attention,
+    one launch, keys in chunks of 32) against double-precision autograd and against the generic eight-launch path"""
+    B, H, D = 3, 4, 64
+    scale = D ** -0.5
+    q, k, v = rnd(B, H, Sq, D, dtype=torch.float32, seed=90), rnd(B, H, Sk, D, dtype=torch.float32, seed=91), rnd(B, H, Sk, D, dtype=torch.float32, seed=92)
+    do = rnd(B, H, Sq, D, dtype=torch.float32, seed=93)
+    o = torch.empty(B, H, Sq, D, device=DEV, dtype=torch.float32)
+    lse = K.attn_fwd(q, k, v, o, causal=False, scale=scale)
+    qr, kr, vr = (t.double().detach().clone().requires_grad_(True) for t in (q, k, v))
+    pr = torch.softmax(qr @ kr.transpose(-1, -2) * scale, -1)
+    (pr @ vr).backward(do.double())
+    outs = {}
+    for generic in (False, True):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=False, scale=scale, force_generic=generic)
+        assert_close(dq, qr.grad, 1e-4, 1e-4, "dq")
+        assert_close(dk, kr.grad, 1e-4, 2e-4, "dk")
+        assert_close(dv, vr.grad, 1e-4, 2e-4, "dv")
+        outs[generic] = (dq, dk, dv)
+    for a, b_ in zip(outs[False], outs[True]):
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-6
