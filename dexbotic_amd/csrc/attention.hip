@@ -855,17 +855,22 @@ struct AttnBwdP {
 };
 
 // fp32 attention BACKWARD of the diffusion heads (17 query tokens per sample, 12 - 16 heads of 64, 17 keys — or MemVLA's 256 perceptual
-// keys: DiT.forward's timm Attention, dexbotic/model/cogact/action_model/dit.py:137-162 under ActionModel.loss, action_models.py:102-125;
-// memvla/action_model/dit.py:136-185): the generic path below is five batched exact-fp32 products and three elementwise launches per
-// attention call (8 launches of 25 - 35 us for 18 K FLOPs per head).  Here ONE workgroup per (sample, head) keeps q and dO in LDS and
-// walks the keys in chunks of 32 twice: pass 1  S = q k^T, P = exp(scale S - lse), dP = dO v^T -> delta_i = sum_j P_ij dP_ij
-// (= rowsum(dO * O)); pass 2 the same again -> dS = P (dP - delta) scale, dQ += dS k (registers), dK = dS^T q, dV = P^T dO of the chunk.
-// Plain fp32 FMAs.  No masks, no dropout, G = 1, Sq <= 32, D <= 64 (D % 4 == 0): 34 KiB of LDS.
-constexpr int SB_MAXT = 32, SB_MAXD = 64;
-__global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
+// keys under the 4 x 17 queries of a sample's diffusion repeats: DiT.forward's timm Attention, dexbotic/model/cogact/action_model/
+// dit.py:137-162 under ActionModel.loss, action_models.py:102-125; memvla/action_model/dit.py:136-185): the generic path below is five
+// batched exact-fp32 products and three elementwise launches per attention call (8 launches of 25 - 35 us for 18 K FLOPs per head).
+// Here ONE workgroup per (sample, head) walks queries and keys in chunks of 32 through LDS:
+//   pass 1  per (query chunk, key chunk): S = q k^T, P = exp(scale S - lse), dP = dO v^T -> delta_i += sum_j P_ij dP_ij (= rowsum(dO * O));
+//   pass 2  per key chunk, per query chunk: the same again -> dS = P (dP - delta) scale; dQ += dS k (registers, all queries),
+//           dK += dS^T q, dV += P^T dO (registers, this key chunk), written when the key chunk is done.
+// Plain fp32 FMAs.  No masks, no dropout, G = 1, Sq <= 96, D <= 64 (D % 4 == 0): 34 KiB of LDS.
+constexpr int SB_MAXT = 32, SB_MAXD = 64, SB_MAXQ = 96;
+// NT threads: 256 for one query chunk (4 workgroups a CU when samples x heads >= 1024), 1024 for the merged repeats (samples x heads = 256:
+// one workgroup a CU — the same 16 waves a CU either way; the products read every operand from LDS and need the waves to hide it).
+template <int NT>
+__global__ __launch_bounds__(NT) void attn_bwd_small_f32_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
   __shared__ float sq[SB_MAXT][SB_MAXD + 1], sk[SB_MAXT][SB_MAXD + 1], sv[SB_MAXT][SB_MAXD + 1], sdo[SB_MAXT][SB_MAXD + 1];
-  __shared__ float sP[SB_MAXT][SB_MAXT + 1], sD[SB_MAXT][SB_MAXT + 1], sdelta[SB_MAXT];
+  __shared__ float sP[SB_MAXT][SB_MAXT + 1], sD[SB_MAXT][SB_MAXT + 1], sdelta[SB_MAXQ];
   const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
   const int Sq = p.Sq, Sk = p.Sk, D = p.D, D4 = D >> 2;
   const float* q = reinterpret_cast<const float*>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -876,16 +881,17 @@ __global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
   float* dk = reinterpret_cast<float*>(bp.dk) + b * bp.dk_sb + h * bp.dk_sh;
   float* dv = reinterpret_cast<float*>(bp.dv) + b * bp.dv_sb + h * bp.dv_sh;
   const float* lse = p.lse + ((int64_t)b * p.Hq + h) * Sq;
-  for (int it = tid; it < Sq * D4; it += 256) {
-    const int i = it / D4, d = (it - i * D4) * 4;
-    const float4 a = *reinterpret_cast<const float4*>(q + (int64_t)i * p.q_ss + d);
-    const float4 g = *reinterpret_cast<const float4*>(d_o + (int64_t)i * bp.do_ss + d);
-    sq[i][d] = a.x; sq[i][d + 1] = a.y; sq[i][d + 2] = a.z; sq[i][d + 3] = a.w;
-    sdo[i][d] = g.x; sdo[i][d + 1] = g.y; sdo[i][d + 2] = g.z; sdo[i][d + 3] = g.w;
-  }
-  if (tid < SB_MAXT) sdelta[tid] = 0.f;
-  auto load_chunk = [&](int j0, int nj) {              // keys j0 .. j0 + nj - 1 into sk / sv
-    for (int it = tid; it < nj * D4; it += 256) {
+  auto load_q = [&](int i0, int ni) {                  // queries i0 .. i0 + ni - 1 (and their dO rows) into sq / sdo
+    for (int it = tid; it < ni * D4; it += NT) {
+      const int i = it / D4, d = (it - i * D4) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(q + (int64_t)(i0 + i) * p.q_ss + d);
+      const float4 g = *reinterpret_cast<const float4*>(d_o + (int64_t)(i0 + i) * bp.do_ss + d);
+      sq[i][d] = a.x; sq[i][d + 1] = a.y; sq[i][d + 2] = a.z; sq[i][d + 3] = a.w;
+      sdo[i][d] = g.x; sdo[i][d + 1] = g.y; sdo[i][d + 2] = g.z; sdo[i][d + 3] = g.w;
+    }
+  };
+  auto load_kv = [&](int j0, int nj) {                 // keys j0 .. j0 + nj - 1 into sk / sv
+    for (int it = tid; it < nj * D4; it += NT) {
       const int j = it / D4, d = (it - j * D4) * 4;
       const float4 a = *reinterpret_cast<const float4*>(k + (int64_t)(j0 + j) * p.k_ss + d);
       const float4 g = *reinterpret_cast<const float4*>(v + (int64_t)(j0 + j) * p.v_ss + d);
@@ -893,69 +899,96 @@ __global__ __launch_bounds__(256) void attn_bwd_small_f32_k(const AttnBwdP bp) {
       sv[j][d] = g.x; sv[j][d + 1] = g.y; sv[j][d + 2] = g.z; sv[j][d + 3] = g.w;
     }
   };
-  auto probs = [&](int nj) {                           // sP = P, sD = dP of the chunk
-    for (int it = tid; it < Sq * nj; it += 256) {
+  auto probs = [&](int i0, int ni, int nj) {           // sP = P, sD = dP of the (query chunk, key chunk) in LDS
+    for (int it = tid; it < ni * nj; it += NT) {
       const int i = it / nj, j = it - i * nj;
       float s_ = 0.f, dp = 0.f;
       for (int d = 0; d < D; ++d) { s_ += sq[i][d] * sk[j][d]; dp += sdo[i][d] * sv[j][d]; }
-      sP[i][j] = expf(s_ * p.scale - lse[i]);
+      sP[i][j] = expf(s_ * p.scale - lse[i0 + i]);
       sD[i][j] = dp;
     }
   };
+  const bool one_q = Sq <= SB_MAXT, one_k = Sk <= SB_MAXT;       // a single chunk stays in LDS: no reload
+  if (tid < SB_MAXQ) sdelta[tid] = 0.f;
   // ---- pass 1: delta
-  for (int j0 = 0; j0 < Sk; j0 += SB_MAXT) {
-    const int nj = min(SB_MAXT, Sk - j0);
+  for (int i0 = 0; i0 < Sq; i0 += SB_MAXT) {
+    const int ni = min(SB_MAXT, Sq - i0);
     __syncthreads();
-    load_chunk(j0, nj);
-    __syncthreads();
-    probs(nj);
-    __syncthreads();
-    if (tid < Sq) {
-      float t = 0.f;
-      for (int j = 0; j < nj; ++j) t += sP[tid][j] * sD[tid][j];
-      sdelta[tid] += t;
+    load_q(i0, ni);
+    for (int j0 = 0; j0 < Sk; j0 += SB_MAXT) {
+      const int nj = min(SB_MAXT, Sk - j0);
+      __syncthreads();
+      load_kv(j0, nj);
+      __syncthreads();
+      probs(i0, ni, nj);
+      __syncthreads();
+      if (tid < ni) {
+        float t = 0.f;
+        for (int j = 0; j < nj; ++j) t += sP[tid][j] * sD[tid][j];
+        sdelta[i0 + tid] += t;
+      }
     }
   }
-  // ---- pass 2: dS, dQ (accumulated in registers: element it = tid + 256 r of [Sq, D]), dK / dV per chunk
-  constexpr int QR = SB_MAXT * SB_MAXD / 256;
+  // ---- pass 2: dQ of every query in registers (element it = tid + NT r of [Sq, D]); dK / dV of the key chunk in registers
+  constexpr int QR = SB_MAXQ * SB_MAXD / NT, KR = SB_MAXT * SB_MAXD / NT;
   float accq[QR];
 #pragma unroll
   for (int r = 0; r < QR; ++r) accq[r] = 0.f;
   for (int j0 = 0; j0 < Sk; j0 += SB_MAXT) {
     const int nj = min(SB_MAXT, Sk - j0);
-    __syncthreads();
-    if (Sk > SB_MAXT) {                                 // (a single chunk is still in LDS from pass 1)
-      load_chunk(j0, nj);
-      __syncthreads();
-      probs(nj);
-      __syncthreads();
-    }
-    for (int it = tid; it < Sq * nj; it += 256) {
-      const int i = it / nj, j = it - i * nj;
-      sD[i][j] = sP[i][j] * (sD[i][j] - sdelta[i]) * p.scale;
-    }
-    __syncthreads();
+    float acck[KR], accv[KR];
 #pragma unroll
-    for (int r = 0; r < QR; ++r) {
-      const int it = tid + 256 * r;
-      if (it < Sq * D) {
-        const int i = it / D, d = it - i * D;
-        float a = accq[r];
-        for (int j = 0; j < nj; ++j) a += sD[i][j] * sk[j][d];
-        accq[r] = a;
+    for (int r = 0; r < KR; ++r) { acck[r] = 0.f; accv[r] = 0.f; }
+    __syncthreads();
+    if (!one_k) load_kv(j0, nj);
+    for (int i0 = 0; i0 < Sq; i0 += SB_MAXT) {
+      const int ni = min(SB_MAXT, Sq - i0);
+      if (!(one_q && one_k)) {                          // (one chunk of each: sq / sdo / sk / sv / sP / sD are those of pass 1)
+        __syncthreads();
+        if (!one_q) load_q(i0, ni);
+        __syncthreads();
+        probs(i0, ni, nj);
+      }
+      __syncthreads();
+      for (int it = tid; it < ni * nj; it += NT) {
+        const int i = it / nj, j = it - i * nj;
+        sD[i][j] = sP[i][j] * (sD[i][j] - sdelta[i0 + i]) * p.scale;          // dS
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < QR; ++r) {
+        const int it = tid + NT * r;
+        const int i = it / D - i0, d = it % D;
+        if (it < Sq * D && i >= 0 && i < ni) {
+          float a = accq[r];
+          for (int j = 0; j < nj; ++j) a += sD[i][j] * sk[j][d];
+          accq[r] = a;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        const int it = tid + NT * r;
+        if (it < nj * D) {
+          const int j = it / D, d = it - j * D;
+          float a = acck[r], c = accv[r];
+          for (int i = 0; i < ni; ++i) { a += sD[i][j] * sq[i][d]; c += sP[i][j] * sdo[i][d]; }
+          acck[r] = a; accv[r] = c;
+        }
       }
     }
-    for (int it = tid; it < nj * D; it += 256) {
-      const int j = it / D, d = it - j * D;
-      float a = 0.f, c = 0.f;
-      for (int i = 0; i < Sq; ++i) { a += sD[i][j] * sq[i][d]; c += sP[i][j] * sdo[i][d]; }
-      dk[(int64_t)(j0 + j) * bp.dk_ss + d] = a;
-      dv[(int64_t)(j0 + j) * bp.dv_ss + d] = c;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const int it = tid + NT * r;
+      if (it < nj * D) {
+        const int j = it / D, d = it - j * D;
+        dk[(int64_t)(j0 + j) * bp.dk_ss + d] = acck[r];
+        dv[(int64_t)(j0 + j) * bp.dv_ss + d] = accv[r];
+      }
     }
   }
 #pragma unroll
   for (int r = 0; r < QR; ++r) {
-    const int it = tid + 256 * r;
+    const int it = tid + NT * r;
     if (it < Sq * D) dq[(int64_t)(it / D) * bp.dq_ss + (it % D)] = accq[r];
   }
 }
@@ -1571,7 +1604,7 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
   // head-sized fp32 attention without masks (the DiT heads' training backward): one launch (DXA_ATTN_NO_SMALL_BWD: the generic path)
   static const bool small_bwd_off = getenv("DXA_ATTN_NO_SMALL_BWD") != nullptr;
   if (!small_bwd_off && !d->force_generic && d->dtype == DXA_F32 && d->Hq == d->Hkv && !d->causal && !d->kv_start && !d->kv_end &&
-      !d->q_limit && !d->key_valid && !d->drop_mask && d->Sq <= SB_MAXT && d->Sk <= 4096 && d->D <= SB_MAXD && d->D % 4 == 0 &&
+      !d->q_limit && !d->key_valid && !d->drop_mask && d->Sq <= SB_MAXQ && d->Sk <= 4096 && d->D <= SB_MAXD && d->D % 4 == 0 &&
       d->lse && d->Hq <= 65535 && d->B <= 65535 &&
       ((uintptr_t)d->q % 16 == 0) && ((uintptr_t)d->k % 16 == 0) && ((uintptr_t)d->v % 16 == 0) && ((uintptr_t)d->d_o % 16 == 0) &&
       d->q_ss % 4 == 0 && d->k_ss % 4 == 0 && d->v_ss % 4 == 0 && d->do_ss % 4 == 0 && d->q_sh % 4 == 0 && d->k_sh % 4 == 0 &&
@@ -1583,7 +1616,8 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     bp.dq = (char*)d->dq; bp.dq_sb = d->dq_sb; bp.dq_sh = d->dq_sh; bp.dq_ss = d->dq_ss;
     bp.dk = (char*)d->dk; bp.dk_sb = d->dk_sb; bp.dk_sh = d->dk_sh; bp.dk_ss = d->dk_ss;
     bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
-    hipLaunchKernelGGL(attn_bwd_small_f32_k, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(256), 0, (hipStream_t)stream, bp);
+    if (d->Sq > SB_MAXT) hipLaunchKernelGGL(attn_bwd_small_f32_k<1024>, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(1024), 0, (hipStream_t)stream, bp);
+    else hipLaunchKernelGGL(attn_bwd_small_f32_k<256>, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(256), 0, (hipStream_t)stream, bp);
     DXA_CHECK_LAUNCH();
     return DXA_OK;
   }

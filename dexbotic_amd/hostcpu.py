@@ -9,7 +9,7 @@ queue.  The rocprofv3 trace shows it as ONE 22 - 65 ms hole between two arbitrar
 unchanged: POST /process_frame p50 22.3 ms, p90 55.5 ms, every third request.  With the pool inside the quota: p90 22.4 ms.
 
 The serving entry point (serve.InferenceServer) calls limit_host_threads() once; training goes through it as well
-(trainer.NativeTrainer) because the feeder's pinned staging copies are ATen-parallel too.  Nothing here touches the GPU path.
+(trainer.NativeTrainer.__init__) because the feeder's pinned staging copies are ATen-parallel too.  Nothing here touches the GPU path.
 """
 from __future__ import annotations
 

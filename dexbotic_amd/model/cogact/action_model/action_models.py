@@ -84,7 +84,7 @@ class ActionModel(nn.Module):
 
     def loss(self, x: torch.Tensor, z: torch.Tensor, reduction: str = "mean", *, noise: Optional[torch.Tensor] = None,
              timestep: Optional[torch.Tensor] = None, drop_ids: Optional[torch.Tensor] = None,
-             sample_weight: Optional[torch.Tensor] = None, per_token: Optional[torch.Tensor] = None):
+             sample_weight: Optional[torch.Tensor] = None, per_token: Optional[torch.Tensor] = None, per_repeat: int = 1):
         """x (N,T,A) ground-truth chunk, z (N,1,token) condition.  The three random draws of the reference
         (action_models.py:106-109 noise/timestep, dit.py:85-87 CFG drop) can be injected for parity tests;
         otherwise they come from torch's device RNG exactly where the reference draws them."""
@@ -100,7 +100,8 @@ class ActionModel(nn.Module):
         if drop_ids is None and self.training and self.net.class_dropout_prob > 0:
             drop_ids = torch.rand(x.shape[0], device=x.device) < self.net.class_dropout_prob
         x_t = self.diffusion.q_sample(x, timestep, noise)
-        noise_pred = self.net(x_t, timestep, z, drop_ids=drop_ids, per_token=per_token)   # per_token: MemVLA
+        # per_token: MemVLA; per_repeat R: x / z are R stacked repeats of the per_token.shape[0] distinct samples (DiT.forward)
+        noise_pred = self.net(x_t, timestep, z, drop_ids=drop_ids, per_token=per_token, per_repeat=per_repeat)
         assert noise_pred.shape == noise.shape == x.shape
         if sample_weight is not None:
             return Fn.MseLossRowsFn.apply(noise_pred, noise.float(), sample_weight)

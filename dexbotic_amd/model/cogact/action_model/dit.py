@@ -119,11 +119,14 @@ class DiT(nn.Module):
         return self._freqs[key]
 
     def _block_with_per_attn(self, st, k: int, hcur: torch.Tensor, pe: torch.Tensor, N: int, T1: int,
-                             kv: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             kv: Optional[torch.Tensor] = None, R: int = 1) -> torch.Tensor:
         """memvla DiTBlock (memvla/action_model/dit.py:175-187): x + attn(norm1 x); x + MHA(norm3 x, per, per);
         x + mlp(norm2 x) — composed from the small autograd pieces (the fused VitBlockFn has no slot for the middle
         term).  nn.MultiheadAttention's packed in_proj: rows [:h] on the queries, rows [h:] on the perceptual tokens
-        (functional.PackedInProjFn).  ``kv``: the sampler's per-request [k | v] of this block (precompute_per_kv)."""
+        (functional.PackedInProjFn).  ``kv``: the sampler's per-request [k | v] of this block (precompute_per_kv).
+        ``R`` > 1 (forward(per_repeat=R)): ``pe`` holds the N / R distinct samples and the rows of ``hcur`` are sample-major
+        with a sample's R diffusion repeats adjacent — the perceptual attention is not causal, so the R x T1 queries of a
+        sample form one query sequence over that sample's keys."""
         b, h, H = f"{self.p}blocks.{k}.", self.hidden_size, self.num_heads
         D, anchor = h // H, self._anchor()
         if kv is not None:
@@ -142,9 +145,10 @@ class DiT(nn.Module):
         hn, hr = Fn.ForkFn.apply(hcur)
         y3 = Fn.NormFn.apply(hn, anchor, st, "ln", b + "norm3.weight", b + "norm3.bias", 1e-6)
         P_ = pe.shape[1]
-        qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(N * P_, h), anchor, st, b + "per_attn.in_proj_weight",
-                                          b + "per_attn.in_proj_bias", h)            # q [N*T1, h], [k | v] [N*P, 2h]
-        o2 = Fn.AttnPackedFn.apply(qf.view(N, T1, H, D), kvf.view(N, P_, 2, H, D)).reshape(N * T1, h)
+        Nk = N // R
+        qf, kvf = Fn.PackedInProjFn.apply(y3, pe.reshape(Nk * P_, h), anchor, st, b + "per_attn.in_proj_weight",
+                                          b + "per_attn.in_proj_bias", h)            # q [N*T1, h], [k | v] [Nk*P, 2h]
+        o2 = Fn.AttnPackedFn.apply(qf.view(Nk, R * T1, H, D), kvf.view(Nk, P_, 2, H, D)).reshape(N * T1, h)
         hcur = Fn.AddFn.apply(hr, lin(o2, b + "per_attn.out_proj.weight", b + "per_attn.out_proj.bias"))
         hn, hr = Fn.ForkFn.apply(hcur)
         y2 = Fn.NormFn.apply(hn, anchor, st, "ln", None, None, 1e-6)
@@ -244,14 +248,26 @@ class DiT(nn.Module):
             self._packed_table(Fp32View(self.store))
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, z: torch.Tensor, drop_ids: Optional[torch.Tensor] = None,
-                train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None, per_kv: Optional[list] = None):
+                train: Optional[bool] = None, per_token: Optional[torch.Tensor] = None, per_kv: Optional[list] = None,
+                per_repeat: int = 1):
         """x (N,T,A) noisy actions, t (N,) timesteps, z (N,1,token) conditions -> eps_hat (N,T,A).
-        ``drop_ids`` (N,) bool/uint8: classifier-free-guidance token drop (drawn by the caller in train mode)."""
+        ``drop_ids`` (N,) bool/uint8: classifier-free-guidance token drop (drawn by the caller in train mode).
+        ``per_repeat`` = R > 1: the batch is R diffusion repeats of N / R samples stacked repeat-major (x.repeat(R, 1, 1) order,
+        memvla_arch.py:515-519) and ``per_token`` holds the N / R DISTINCT perceptual sequences — the reference repeats them R
+        times and projects every copy in each of the blocks (24 x [R N/R P, 1024] x [2048, 1024]^T on identical rows); here the
+        embedding and the per-block key/value projections run once per distinct sample.  The samples are walked sample-major
+        inside (one row permutation of the tiny inputs, undone on the output): same values, R x fewer projection rows."""
         from .... import kernels as K
         st = Fp32View(self.store)
         p, h = self.p, self.hidden_size
         N, T, A = x.shape
         anchor = self._anchor()
+        R = int(per_repeat) if (self.use_per_attn and per_token is not None) else 1
+        if R > 1:
+            assert N % R == 0 and per_token.shape[0] == N // R, (N, R, tuple(per_token.shape))
+            perm, inv = self._repeat_perm(N, R, x.device)
+            x, t, z = x[perm], t[perm], z[perm]
+            drop_ids = None if drop_ids is None else drop_ids[perm]
         x = x.float().contiguous()
         xe = Fn.LinearFn.apply(x, anchor, st, p + "x_embedder.linear.weight", p + "x_embedder.linear.bias",
                                L.ACT_NONE, None)                                        # (N,T,h)
@@ -274,7 +290,7 @@ class DiT(nn.Module):
             pes = [None] * self.depth if pe is None else \
                 (Fn.ForkFn.apply(pe, self.depth) if (torch.is_grad_enabled() and pe.requires_grad) else [pe] * self.depth)
             for k in range(self.depth):
-                hcur = self._block_with_per_attn(st, k, hcur, pes[k], N, T + 1, None if per_kv is None else per_kv[k])
+                hcur = self._block_with_per_attn(st, k, hcur, pes[k], N, T + 1, None if per_kv is None else per_kv[k], R)
         elif self._use_fused_blocks(N, T + 1):
             # inference, one request: every block in ONE persistent launch (csrc/dit_fused.hip)
             self.used_fused = True
@@ -288,7 +304,17 @@ class DiT(nn.Module):
         hcur = Fn.NormFn.apply(hcur.reshape(N * (T + 1), h), anchor, st, "ln", None, None, 1e-6)
         out = Fn.LinearFn.apply(hcur, anchor, st, p + "final_layer.linear.weight", p + "final_layer.linear.bias",
                                 L.ACT_NONE, None)
-        return out.view(N, T + 1, A)[:, 1:, :]
+        out = out.view(N, T + 1, A)[:, 1:, :]
+        return out[inv] if R > 1 else out
+
+    def _repeat_perm(self, N: int, R: int, device):
+        """row n' = b R + r of the sample-major walk <- row n = r (N/R) + b of the caller's repeat-major batch, and its inverse"""
+        key = (N, R, str(device))
+        tabs = self.__dict__.setdefault("_perm_tabs", {})
+        if key not in tabs:
+            perm = torch.arange(N).view(R, N // R).t().reshape(-1)
+            tabs[key] = (perm.to(device), torch.argsort(perm).to(device))
+        return tabs[key]
 
     # ---- the whole sampler in one launch ---------------------------------------------------------------------------
     def fused_sampler_ok(self, N: int, T1: int) -> bool:

@@ -16,6 +16,7 @@ reference also hands dropout_p to SDPA in eval (stochastic inference); eval is d
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -370,9 +371,16 @@ class MemVLAForCausalLM(CogACTForCausalLM):
             A, T = self.config.action_dim, self.config.chunk_size
             acts = actions.reshape(actions.size(0), -1, A).float()[:, :T, :]
             R = repeated_diffusion_steps
+            # the reference repeats the perceptual tokens with the actions (:515-519) and projects all R copies in every DiT block;
+            # the head takes the B distinct sequences and the repeat count instead (DiT.forward per_repeat: same values, the
+            # embedding and the 24 key/value projections on B x P rows instead of R x B x P).  DXA_MEMVLA_PER_REPEAT=1: as written there
+            if os.environ.get("DXA_MEMVLA_PER_REPEAT", "0") == "1":
+                per_kw = dict(per_token=per.float().repeat(R, 1, 1))
+            else:
+                per_kw = dict(per_token=per.float(), per_repeat=R)
             loss = self.model.action_head_module.loss(
-                acts.repeat(R, 1, 1), cog.float().repeat(R, 1, 1), per_token=per.float().repeat(R, 1, 1),
-                noise=kwargs.get("noise"), timestep=kwargs.get("timesteps"), drop_ids=kwargs.get("drop_ids"))
+                acts.repeat(R, 1, 1), cog.float().repeat(R, 1, 1), noise=kwargs.get("noise"), timestep=kwargs.get("timesteps"),
+                drop_ids=kwargs.get("drop_ids"), **per_kw)
         return CausalLMOutputDexbotic(loss=loss, logits=hidden, hidden_states=(hidden,))
 
     @torch.no_grad()

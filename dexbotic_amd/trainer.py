@@ -72,6 +72,10 @@ class NativeTrainer:
                  native_avg_world1: bool = False, coalesce_micro_batches: Optional[bool] = None, grad_reduce_op: str = "sum",
                  shard_optimizer: Optional[bool] = None, emulate_world: int = 0, gather_overlap: bool = True):
         import torch.distributed as dist
+        from . import hostcpu
+        # torch's intra-op pool inside the cgroup's CPU quota (hostcpu.py: a pool sized by the host's 256 CPUs under a 16-CPU quota
+        # gets the launching thread throttled in the middle of a step); DXA_HOST_THREADS=0 leaves torch alone
+        self.host_threads = hostcpu.limit_host_threads()
         self.model = model
         # shard_optimizer: the sharded optimizer step under data parallelism (engine.ShardPlan — the reference's default DeepSpeed
         # ZeRO config partitions optimizer state and update, base_exp.py:229 / zero3.json): reduce-scatter of the gradients, sum(g^2)

@@ -39,13 +39,18 @@ def main():
     for _ in range(2):
         loss = tr.step(batch)
     torch.cuda.synchronize()
+    from dexbotic_amd import hostcpu
+    th0 = hostcpu.throttle_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    th1 = hostcpu.throttle_stats()
     res = {"metric": "samples/sec MemVLA fine-tune", "value": round(B / dt, 2), "ms_per_step": round(1e3 * dt, 1), "batch": B,
-           "loss": round(float(loss), 4), "params_billion": round(m.store.total / 1e9, 3)}
+           "loss": round(float(loss), 4), "params_billion": round(m.store.total / 1e9, 3), "host_threads": tr.host_threads,
+           "cgroup_throttled_periods": th1.get("nr_throttled", 0) - th0.get("nr_throttled", 0),
+           "cgroup_periods": th1.get("nr_periods", 0) - th0.get("nr_periods", 0)}
     if os.environ.get("SKIP_INFER"):
         print(json.dumps(res), flush=True)
         return

@@ -1307,10 +1307,10 @@ def test_gemm_swiglu_epilogue_is_bit_identical_to_gemm_then_swiglu(M, F_, Kd, sp
     assert out_ref.float().abs().max() > 0.05                         # (not a comparison of zeros)
 
 
-@pytest.mark.parametrize("Sq,Sk", [(17, 17), (17, 256), (32, 70), (5, 33)])
+@pytest.mark.parametrize("Sq,Sk", [(17, 17), (17, 256), (32, 70), (5, 33), (68, 256), (96, 40), (33, 17), (65, 31)])
 def test_attention_small_f32_backward_one_launch(Sq, Sk, monkeypatch):
     """the head-sized fp32 attention backward (attn_bwd_small_f32_k: the DiT heads' 17 x 17 and MemVLA's 17 x 256 perceptual attention,
-    one launch, keys in chunks of 32) against double-precision autograd and against the generic eight-launch path"""
+    one launch, queries and keys in chunks of 32; 68 = the 4 x 17 queries of a MemVLA sample's diffusion repeats) against double-precision autograd and against the generic eight-launch path"""
     B, H, D = 3, 4, 64
     scale = D ** -0.5
     q, k, v = rnd(B, H, Sq, D, dtype=torch.float32, seed=90), rnd(B, H, Sk, D, dtype=torch.float32, seed=91), rnd(B, H, Sk, D, dtype=torch.float32, seed=92)

@@ -59,6 +59,29 @@ def test_fp32_memvla_training_step_matches_reference(golden_dir):
             assert abs(st.g(key[6:]).double().norm().item() - gn) < FP32_TOL * gn + 1e-6 * float(g["grad_norm"]), key
 
 
+def test_memvla_distinct_perceptual_tokens_equal_the_repeated_ones(golden_dir, monkeypatch):
+    """the head projects the perceptual keys / values of the B distinct samples (DiT.forward per_repeat) where the reference
+    projects R repeated copies (memvla_arch.py:515-519): same loss, same gradients up to the fp32 summation order"""
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DXA_MEMVLA_PER_REPEAT", mode)
+        g, cfg, m = build(golden_dir, "float32", True)
+        m.train()
+        st = m.store
+        st.set_expected(m.unused_parameter_names())
+        st.begin_step()
+        out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]), actions=T(g["actions"]),
+                indexes=[list(map(int, r)) for r in g["indexes"]], noise=T(g["noise"]), timesteps=T(g["timesteps"]),
+                drop_ids=T(g["drop_u"]) < 0.1)
+        out.loss.backward()
+        res[mode] = (out.loss.item(), {k[5:]: st.g(k[5:]).float().cpu().numpy().copy() for k in g.files if k.startswith("grad/")})
+    (l_rep, g_rep), (l_one, g_one) = res["1"], res["0"]
+    assert abs(l_rep - l_one) <= 2e-6 * abs(l_rep), (l_rep, l_one)
+    worst = max(rel_err(g_one[k], g_rep[k]) for k in g_rep)
+    print(f"loss {l_one:.8f} / {l_rep:.8f}; worst gradient distance {worst:.2e} over {len(g_rep)} tensors")
+    assert worst < 2e-5
+
+
 def test_fp32_memvla_training_step_with_retrieval_dropout_matches_reference(golden_dir):
     """retrieval_dropout = 0.1 = how the reference always trains (memvla_arch.py:83, 99-105, 120-123): attention-weight
     dropout inside the attention kernels (dxa_attn_desc.drop_mask) and the two FFN dropouts, with the masks of the golden
