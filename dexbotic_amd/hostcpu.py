@@ -86,3 +86,17 @@ def limit_host_threads(reserve: int = 2, cap: Optional[int] = None, share: Optio
     if n < torch.get_num_threads():
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+def upload(a, device, non_blocking: bool = True):
+    """small host array (numpy or CPU tensor) -> ``device`` through PINNED memory with a non-blocking copy.  A pageable source
+    (``torch.from_numpy(x).to(dev)``) makes the copy wait until the stream has drained: in the middle of a forward the launching
+    thread loses everything it is ahead of the GPU, and what follows runs host-bound (profiles/r06_host_uploads.txt: MemVLA's step
+    359 -> 323 ms for two 128-byte uploads).  The pinned block comes from torch's caching host allocator, which keeps it alive
+    until the copy has run."""
+    import numpy as np
+    import torch
+    t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    if torch.device(device).type == "cuda" and not t.is_pinned():
+        t = t.pin_memory()
+    return t.to(device, non_blocking=non_blocking)

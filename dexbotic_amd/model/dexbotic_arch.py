@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import hostcpu
 from .. import kernels as K
 from ..constants import IGNORE_INDEX
 from ..engine import ParamStore, attach_parameters, building
@@ -467,7 +468,7 @@ class DexboticForCausalLM(NativePreTrainedMixin, nn.Module):
         shifted[:, :-1] = lab[:, 1:]
         n_valid = int((shifted != IGNORE_INDEX).sum())
         loss, logits = Fn.LmHeadLossFn.apply(hidden, self.store.params["lm_head.weight"], self.store, "lm_head.weight",
-                                             torch.from_numpy(shifted.reshape(-1)).to(hidden.device), n_valid)
+                                             hostcpu.upload(shifted.reshape(-1), hidden.device), n_valid)
         return CausalLMOutputDexbotic(loss=loss, logits=logits, hidden_states=(hidden,))
 
     def unused_parameter_names(self) -> List[str]:

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 from ... import _lib as L
 from ... import functional as Fn
+from ... import hostcpu
 from ... import kernels as K
 from ...engine import ParamStore
 from ..cogact.cogact_arch import CogActConfig, CogActModel, CogACTForCausalLM
@@ -360,11 +361,17 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         loss = None
         if attention_mask is not None and actions is not None:
             plan = self.model._last_plan
-            idx = torch.from_numpy(np.arange(B, dtype=np.int64) * S + plan.last_index).to(hidden.device)
+            pageable = os.environ.get("DXA_MEMVLA_PAGEABLE_UPLOAD", "0") == "1"       # (measurement switch: the round-5 uploads)
+            idx = plan.dev(hidden.device)["last_flat"] if not pageable else \
+                torch.from_numpy(np.arange(B, dtype=np.int64) * S + plan.last_index).to(hidden.device)
             cog = Fn.GatherRowsFn.apply(hidden.reshape(B * S, d), idx).to(hidden.dtype).view(B, 1, d)
             per = self.model.per_compr(vision_proj.reshape(B, -1, d))
             eids = [tuple(int(v) for v in item[:2]) for item in indexes]
-            ts = torch.tensor([float(item[2]) for item in indexes], dtype=torch.float32).to(hidden.device, non_blocking=True)
+            # from PINNED memory: a pageable source makes the copy wait for the stream to drain — here, at the end of the decoder's
+            # forward, that throws away the 60 ms the launching thread is ahead and leaves the bank's ~2,400 small launches
+            # host-bound (profiles/r06_host_uploads.txt)
+            ts = torch.tensor([float(item[2]) for item in indexes], dtype=torch.float32)
+            ts = ts.to(hidden.device, non_blocking=True) if pageable else hostcpu.upload(ts, hidden.device)
             bank = self.model.per_cog_mem_bank
             cog = bank.process_batch_cog(cog, eids, ts)
             per = bank.process_batch_per(per, eids, ts)
@@ -399,7 +406,7 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         B, d = hidden.shape[0], hidden.shape[-1]
         cog = hidden[:, -1, :].unsqueeze(1).contiguous()
         per = self.model.per_compr(vision_proj.reshape(B, -1, d))
-        ts = torch.tensor([float(self.cur_timestep)], dtype=torch.float32).to(dev)
+        ts = hostcpu.upload(torch.tensor([float(self.cur_timestep)], dtype=torch.float32), dev)    # (pinned: no wait for the prefill)
         self.cur_timestep += 1
         cog = bank.process_batch_cog(cog, [(0, 0)], ts)
         per = bank.process_batch_per(per, [(0, 0)], ts)

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ... import functional as Fn
+from ... import hostcpu
 from ... import kernels as K
 from ...engine import ParamStore
 from ..dexbotic_arch import (ActionOutputForCausalLM, CausalLMOutputDexbotic, NativePreTrainedMixin, _DTYPES, _hf_config_base,
@@ -175,8 +176,24 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
     def encode_images(self, images: torch.Tensor) -> torch.Tensor:
         return self.model.mm_projector(self.model.mm_vision_tower(images))
 
-    def embed_prefix(self, input_ids, attention_mask, images, image_masks):
-        """-> tokens [B, P, d] (compute dtype), input_mask np.bool [B, P], ar_mask np.bool [P] (all False)"""
+    @staticmethod
+    def _to_dev(a: np.ndarray, device) -> torch.Tensor:
+        """small host array -> device through pinned memory, non-blocking (hostcpu.upload: a pageable source would make the copy wait
+        for the stream to drain)"""
+        return hostcpu.upload(a, device)
+
+    def prefix_mask(self, attention_mask, image_masks) -> np.ndarray:
+        """input_mask np.bool [B, CAM * T + L] of embed_prefix from the two host-side masks alone (T = tokens per camera): the
+        training step computes every mask and position of the mixture BEFORE it launches the vision tower — fetching a device
+        mask with .cpu() afterwards waits for the tower, and the 7 ms of numpy that follow run with the GPU idle"""
+        T = self.model.mm_vision_tower.num_patches
+        im = np.asarray(image_masks.cpu() if torch.is_tensor(image_masks) else image_masks, dtype=bool)
+        am = np.asarray(attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask, dtype=bool)
+        return np.concatenate([np.repeat(im, T, axis=1), am], axis=1)
+
+    def embed_prefix(self, input_ids, attention_mask, images, image_masks, input_mask: Optional[np.ndarray] = None):
+        """-> tokens [B, P, d] (compute dtype), input_mask np.bool [B, P], ar_mask np.bool [P] (all False).
+        ``input_mask``: prefix_mask(...) computed by the caller beforehand."""
         B, CAM = images.shape[:2]
         dev, cdt = self.store.device, self.store.compute_dtype
         # all cameras in one tower pass: [B, CAM, ...] -> camera-major tokens like the reference's per-camera loop
@@ -185,9 +202,11 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         img_tok = feats.view(CAM, B, T, -1).permute(1, 0, 2, 3).reshape(B, CAM * T, -1)
         txt = self.model.llm.embed(input_ids.to(dev))
         tokens = torch.cat([img_tok.to(cdt), txt.to(cdt)], dim=1)
-        im = np.asarray(image_masks.cpu() if torch.is_tensor(image_masks) else image_masks, dtype=bool)
-        am = np.asarray(attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask, dtype=bool)
-        input_mask = np.concatenate([np.repeat(im, T, axis=1), am], axis=1)
+        if input_mask is None:
+            im = np.asarray(image_masks.cpu() if torch.is_tensor(image_masks) else image_masks, dtype=bool)
+            am = np.asarray(attention_mask.cpu() if torch.is_tensor(attention_mask) else attention_mask, dtype=bool)
+            input_mask = np.concatenate([np.repeat(im, T, axis=1), am], axis=1)
+        assert input_mask.shape[1] == tokens.shape[1], (input_mask.shape, tokens.shape)
         return tokens, input_mask, np.zeros(tokens.shape[1], dtype=bool)
 
     def embed_suffix(self, states: torch.Tensor, noisy_actions: torch.Tensor, time: Optional[np.ndarray], te: Optional[torch.Tensor] = None):
@@ -200,7 +219,7 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
                                                              f"model.{n}.bias", act, None)
         state_tok = lin(states.to(cdt), "state_proj").view(B, 1, da)
         if te is None:
-            te = torch.from_numpy(posemb_sincos(time, da)).to(device=st.device, dtype=cdt)      # [B, da]
+            te = self._to_dev(posemb_sincos(time, da), st.device).to(cdt)                       # [B, da]
         act_tok = lin(noisy_actions.to(cdt).reshape(B * c.chunk_size, -1), "action_in_proj").view(B, c.chunk_size, da)
         h = torch.cat([act_tok, te[:, None, :].expand(B, c.chunk_size, da)], dim=-1).reshape(B * c.chunk_size, 2 * da)
         h = lin(h.contiguous(), "action_time_mlp_in", L.ACT_SILU)
@@ -217,8 +236,7 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         (keys are ordered, cumsum non-decreasing), key_valid[b,j] = input_mask.  Invalid queries get limit 0."""
         lim = (k_cum[:, None, :] <= q_cum[:, :, None]).sum(-1).astype(np.int32)
         lim[~q_valid] = 0
-        return (torch.from_numpy(np.ascontiguousarray(lim)).to(device),
-                torch.from_numpy(np.ascontiguousarray(k_valid.astype(np.uint8))).to(device))
+        return Pi0ForCausalLM._to_dev(lim, device), Pi0ForCausalLM._to_dev(k_valid.astype(np.uint8), device)
 
     @torch.no_grad()
     def _mot_forward(self, xs: List[Optional[torch.Tensor]], positions: Optional[np.ndarray], q_limit: torch.Tensor,
@@ -237,8 +255,7 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         offs = np.cumsum([0] + lens)
         if pos_parts is None:              # (the sampler hands in device tensors: nothing host-side inside its captured loop)
             rope = experts[0].rope_tables(int(positions.max()) + 1, dev)
-            pos_parts = [torch.from_numpy(np.ascontiguousarray(positions[:, offs[i]:offs[i + 1]].astype(np.int32))).to(dev).reshape(-1)
-                         for i in range(len(live))]
+            pos_parts = [self._to_dev(positions[:, offs[i]:offs[i + 1]].astype(np.int32), dev).reshape(-1) for i in range(len(live))]
         cos_t, sin_t = rope
         hs = [x.reshape(B * n, -1).contiguous() for (_, x), n in zip(live, lens)]
         cache = []
@@ -291,8 +308,8 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         geom = (B, P, Sx, c.num_attention_heads, c.num_key_value_heads, c.head_dim)
         dev = st.device
         cos_t, sin_t = llm.rope_tables(int(positions.max()) + 1, dev)
-        pos0 = torch.from_numpy(np.ascontiguousarray(positions[:, :P].astype(np.int32))).to(dev).reshape(-1)
-        pos1 = torch.from_numpy(np.ascontiguousarray(positions[:, P:].astype(np.int32))).to(dev).reshape(-1)
+        pos0 = self._to_dev(positions[:, :P].astype(np.int32), dev).reshape(-1)
+        pos1 = self._to_dev(positions[:, P:].astype(np.int32), dev).reshape(-1)
         x0 = ptok.reshape(B * P, -1).contiguous()
         x1 = stok.reshape(B * Sx, -1).contiguous()
         n = c.num_hidden_layers
@@ -317,15 +334,21 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         time = kwargs.get("time")
         time = (np.random.beta(1.5, 1.0, size=B) * 0.999 + 0.001).astype(np.float32) if time is None else \
             np.asarray(time.cpu() if torch.is_tensor(time) else time, dtype=np.float32)
-        te = torch.from_numpy(time).to(dev)[:, None, None]
-        x_t = te * noise + (1 - te) * acts
-        u_t = noise - acts
-        ptok, pmask, par = self.embed_prefix(input_ids, attention_mask, images, image_masks)
-        stok, smask, sar = self.embed_suffix(states.to(dev).float(), x_t, time)
+        # every mask and position of the mixture first: they depend on the two input masks only (the suffix is all valid), the
+        # device masks are fetched while the stream still holds the previous step's tail, and the numpy below runs under it
+        pmask = self.prefix_mask(attention_mask, image_masks)
+        smask = np.ones((B, 1 + c.chunk_size), dtype=bool)
+        sar = np.array([True, True] + [False] * (c.chunk_size - 1))
         input_mask = np.concatenate([pmask, smask], axis=1)
-        cum = np.broadcast_to(np.cumsum(np.concatenate([par, sar]).astype(np.int64)), input_mask.shape)
+        cum = np.broadcast_to(np.cumsum(np.concatenate([np.zeros(pmask.shape[1], dtype=bool), sar]).astype(np.int64)), input_mask.shape)
         q_limit, key_valid = self._mask_tensors(cum, input_mask, cum, input_mask, dev)
         positions = np.cumsum(input_mask, axis=1) - 1
+        te = self._to_dev(time, dev)[:, None, None]
+        x_t = te * noise + (1 - te) * acts
+        u_t = noise - acts
+        ptok, pmask2, par = self.embed_prefix(input_ids, attention_mask, images, image_masks, input_mask=pmask)
+        stok, smask2, sar2 = self.embed_suffix(states.to(dev).float(), x_t, time)
+        assert smask2.shape == smask.shape and np.array_equal(sar2, sar) and not par.any()
         st = self.store
         if torch.is_grad_enabled():
             suf = self._mot_train(ptok, stok, positions, q_limit, key_valid)
@@ -348,12 +371,12 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         dt = -1.0 / diffusion_steps
         noise = kwargs.get("noise")
         x = (torch.randn(B, c.chunk_size, c.action_dim, device=dev) if noise is None else noise.to(dev)).float().contiguous()
-        ptok, pmask, par = self.embed_prefix(input_ids, attention_mask, images, image_masks)
-        pcum = np.broadcast_to(np.cumsum(par.astype(np.int64)), pmask.shape)
-        q_limit, key_valid = self._mask_tensors(pcum, pmask, pcum, pmask, dev)
+        # host side first (masks, positions, the schedule's time embeddings: they depend on the input masks only), uploaded through
+        # pinned memory — then the device work of the request is enqueued without a single wait on the stream
+        pmask = self.prefix_mask(attention_mask, image_masks)
+        pcum = np.zeros(pmask.shape, dtype=np.int64)
+        p_limit, p_valid = self._mask_tensors(pcum, pmask, pcum, pmask, dev)
         ppos = np.cumsum(pmask, axis=1) - 1
-        _, cache = self._mot_forward([ptok, None], ppos, q_limit, key_valid, collect=True)
-        states_d = states.to(dev).float().contiguous()
         # ---- the Euler loop: everything that does not depend on x is prepared once (masks, positions, RoPE tables, the time
         #      embeddings of the whole schedule), the loop itself is tensors in / tensors out and is replayed as ONE HIP graph
         #      (graphs.GraphCache): 10 steps x 18 layers x ~14 tiny launches are host-bound when issued from Python
@@ -366,14 +389,18 @@ class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
         q_limit, key_valid = self._mask_tensors(scum, smask, k_cum, k_valid, dev)
         fpos = pmask.sum(-1)[:, None] + np.cumsum(smask, axis=-1) - 1
         rope = self.model.llm.rope_tables(int(fpos.max()) + 1, dev)
-        pos = torch.from_numpy(np.ascontiguousarray(fpos.astype(np.int32))).to(dev).reshape(-1)
+        pos = self._to_dev(fpos.astype(np.int32), dev).reshape(-1)
         times, time = [], np.float32(1.0)
         while time > -dt / 2:                                             # the reference's float32 schedule (pi0_arch.py:470-489)
             times.append(time)
             time = np.float32(time + np.float32(dt))
         da = c.action_config.hidden_size
-        te_table = torch.from_numpy(np.stack([posemb_sincos(np.full(B, t, dtype=np.float32), da) for t in times])
-                                    ).to(device=dev, dtype=st.compute_dtype)                      # [steps, B, da]
+        te_table = self._to_dev(np.stack([posemb_sincos(np.full(B, t, dtype=np.float32), da) for t in times]), dev
+                                ).to(st.compute_dtype)                                            # [steps, B, da]
+        ptok, _, par = self.embed_prefix(input_ids, attention_mask, images, image_masks, input_mask=pmask)
+        assert not par.any()
+        _, cache = self._mot_forward([ptok, None], ppos, p_limit, p_valid, collect=True)
+        states_d = states.to(dev).float().contiguous()
         n_layers = len(cache)
 
         P_len, Sx = int(cache[0][0].shape[2]), int(smask.shape[1])

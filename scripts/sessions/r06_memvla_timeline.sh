@@ -5,6 +5,6 @@ R=$PWD; O=$R/gpurun_out/r06_memvla_dedup; mkdir -p $O $R/gpurun_out/prof
 export TMPDIR=/tmp; cd /tmp
 SKIP_INFER=1 timeout 900 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/memvla_bench.py 3 > $O/timeline_run.log 2>&1
 cd $R
-python scripts/step_timeline.py gpurun_out/prof/tl_results.db > $O/step_timeline.txt 2>&1
+python scripts/step_timeline.py gpurun_out/prof/tl_results.db > $O/step_timeline.txt 2>&1; grep -A 45 "per 10 ms window" $O/step_timeline.txt
 rm -rf gpurun_out/prof
-head -70 $O/step_timeline.txt | cut -c1-170
+

@@ -101,6 +101,23 @@ def main(path, marker="adamw_k"):
     print(f"{'idle after kernel':70s} {'gaps':>6s} {'idle_ms':>9s} {'avg_us':>8s}")
     for n, (c, v) in sorted(by_prev.items(), key=lambda x: -x[1][1])[:25]:
         print(f"{n:70s} {c:6d} {v / 1e6:9.3f} {v / 1e3 / c:8.1f}")
+    # where in the step the queue runs dry: idle time and launches per 10 ms window of the step
+    W = 10_000_000
+    nwin = int(dur // W) + 1
+    idle_w, launch_w = [0.0] * nwin, [0] * nwin
+    for g in gaps:
+        a, b = g[1] - t0, g[2] - t0
+        w = int(a // W)
+        while a < b and w < nwin:
+            e = min(b, (w + 1) * W)
+            idle_w[w] += e - a
+            a, w = e, w + 1
+    for r in m:
+        launch_w[min(nwin - 1, int((r[1] - t0) // W))] += 1
+    print("\n# per 10 ms window of the step: launches on the main stream, idle ms (a window with many launches and much idle = host-bound)")
+    for w in range(nwin):
+        bar = "#" * int(round(idle_w[w] / W * 40))
+        print(f"  +{w * 10:4d} ms  launches {launch_w[w]:5d}  idle {idle_w[w] / 1e6:6.2f} ms  {bar}")
     print("\n# the 25 largest gaps: length, what ran before / after on the main stream, what the OTHER streams ran meanwhile")
     for g in sorted(gaps, key=lambda x: -x[0])[:25]:
         mean = [o for o in others if o[2] > g[1] and o[1] < g[2]]
