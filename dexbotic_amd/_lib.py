@@ -169,6 +169,9 @@ SIGNATURES = {
     "dxa_dit_sample_fwd": (_int, [_vp] * 9 + [_int, _int, _int, _int, _f32, _vp, _int, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "dxa_dit_bf16_pack_bytes": (_sz, [_int, _int, _int]),
     "dxa_dit_bf16_pack": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _vp]),
+    "dxa_dit_bf16_pack_per_bytes": (_sz, [_int, _int, _int]),
+    "dxa_dit_bf16_pack_per": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _vp]),
+    "dxa_dit_sample_bf16_per_fwd": (_int, [_vp] * 9 + [_int, _int, _int, _int, _f32, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "dxa_dit_sample_bf16_workspace": (_sz, [_int, _int, _int]),
     "dxa_dit_sample_bf16_fwd": (_int, [_vp] * 9 + [_int, _int, _int, _int, _f32, _vp, _int, _int, _int, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "dxa_decode_step_workspace": (_sz, [_int, _int, _int, _int, _int]),

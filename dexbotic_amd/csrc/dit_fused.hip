@@ -45,7 +45,7 @@ struct alignas(16) Smem {
   float q[MAXT][HD], k[MAXT][HD + 4], v[MAXT][HD], p[MAXT][MAXT + 1];
   int last;
 #if defined(DXA_DIT_STAMPS)
-  unsigned long long stamp[5][8], ts[8];    // tuning build: cycles per segment of each phase type, summed by wave 0 of workgroup DXA_DIT_STAMPS
+  unsigned long long stamp[6][8], ts[8];    // tuning build: cycles per segment of each phase type, summed by wave 0 of workgroup DXA_DIT_STAMPS
 #endif
 };
 
@@ -54,7 +54,7 @@ struct alignas(16) Smem {
 // phase: 0 entry -> operands loaded and MFMAs retired, 1 -> partials of all waves in LDS, 2 -> epilogue stores issued,
 // 3 -> stores acknowledged (vmcnt(0)) and the workgroup assembled, 4 -> device-wide barrier left.
 #if defined(DXA_DIT_STAMPS)
-__device__ unsigned long long g_dit_stamps[5][8];
+__device__ unsigned long long g_dit_stamps[6][8];
 #define DIT_STAMP(s_, i_) do { if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); (s_).ts[i_] = t_; } } while (0)
 #define DIT_STAMP_AFTER(s_, i_, v_) do { if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x == 0) { unsigned long long t_; const unsigned d_ = __builtin_amdgcn_readfirstlane(__float_as_uint(v_)); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "s"(d_) : "memory"); (s_).ts[i_] = t_; } } while (0)
 #define DIT_STAMP_FOLD(s_, ph_, n_) do { if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x == 0) { for (int i_ = 0; i_ < (n_); ++i_) (s_).stamp[ph_][i_] += (s_).ts[i_ + 1] - (s_).ts[i_]; (s_).stamp[ph_][7] += 1; } } while (0)
@@ -571,13 +571,13 @@ __global__ __launch_bounds__(512) void dit_blocks_fused_k(const DitP p) {
   const Act h(p.h, (size_t)p.M * p.H), qkv(p.qkv, (size_t)p.M * 3 * p.H), o(p.o, (size_t)p.M * p.H), a(p.a, (size_t)p.M * p.I),
       part(p.part, (size_t)SMAX * p.M * p.H);
 #if defined(DXA_DIT_STAMPS)
-  if (threadIdx.x < 40) s.stamp[threadIdx.x / 8][threadIdx.x % 8] = 0ull;
+  if (threadIdx.x < 48) s.stamp[threadIdx.x / 8][threadIdx.x % 8] = 0ull;
   __syncthreads();
 #endif
   walk_blocks(p, s, epoch, nblk, 0u, h, qkv, o, a, part);
 #if defined(DXA_DIT_STAMPS)
   __syncthreads();
-  if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x < 40) g_dit_stamps[threadIdx.x / 8][threadIdx.x % 8] = s.stamp[threadIdx.x / 8][threadIdx.x % 8];
+  if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x < 48) g_dit_stamps[threadIdx.x / 8][threadIdx.x % 8] = s.stamp[threadIdx.x / 8][threadIdx.x % 8];
 #endif
   // Leave the counters zeroed for the next launch on this stream (like the split-K flags of the ring GEMM): every
   // workgroup has passed the last barrier when it gets here, so the LAST one out may clear them.  Agent-scope atomic
@@ -643,10 +643,11 @@ extern "C" int dxa_dit_blocks_status(dxa_stream_t stream, int* timed_out) {
 }
 
 #if defined(DXA_DIT_STAMPS)
-// tuning build only: the segment sums of the LAST dit_blocks_fwd launch, [5 phase types][8] (entry 7 = number of phases summed)
+// tuning build only: the segment sums of the LAST dit_blocks_fwd launch, [6 phase types][8] (entry 7 = number of phases summed;
+// type 5 = the perceptual attention: keys / values requested + q in LDS | scores | row softmax | P V | merge + store | barrier)
 extern "C" int dxa_dit_debug_stamps(unsigned long long* out) {
   DXA_CHECK_HIP(hipDeviceSynchronize());
-  DXA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dit_stamps), sizeof(unsigned long long) * 40));
+  DXA_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dit_stamps), sizeof(unsigned long long) * 48));
   return DXA_OK;
 }
 #endif
@@ -807,9 +808,12 @@ struct Buf {                       // an activation / workspace array behind a b
 struct DitBfP {
   float *h, *qkv, *stats, *part;   // h [M][H] fp32 residual stream; qkv [M][3H] fp32; stats [Mp][H/16][2]; part [S][H/16][Mp][16]
   bf16_t *hb, *ob, *ab;            // [K/32][Mp][32] bf16 operand tiles: bf16(h), attention output, gelu(fc1)
-  const void* const* w;            // [depth][10]: qkv_wp, qkv_b, proj_wp, proj_b, fc1_wp, fc1_b, fc2_wp, fc2_b, qkv_wsum, fc1_wsum
+  const void* const* w;            // [depth][wstride]: qkv_wp, qkv_b, proj_wp, proj_b, fc1_wp, fc1_b, fc2_wp, fc2_b, qkv_wsum, fc1_wsum
+                                   // (+ with perceptual attention, wstride 16: q_wp, q_b, q_wsum — norm3's affine folded in —, out_wp, out_b)
+  const float* kv;                 // perceptual attention: the request's projected keys / values [depth][N][P][2][H] fp32 (P = 0: none)
   unsigned *bar, *cnt_proj, *cnt_fc2;
   int M, Mp, N, T1, H, heads, I, depth;
+  int P, wstride;
   int s_proj, s_fc2;
   float eps, scale;
   int dbg;
@@ -1043,10 +1047,176 @@ __device__ __forceinline__ void attention_bf(const DitBfP& p, Smem& s, const BfB
   }
 }
 
+// MemVLA's perceptual cross attention inside the sampler (nn.MultiheadAttention over the perceptual tokens, memvla/action_model/dit.py:
+// 158-185): q = the block's projection of norm3(h) [M][H] fp32 (at the start of the qkv array, row stride H), keys / values = the
+// request's cached projections kv [N][P][2][H] fp32 — written before the launch, read-only in it: plain cached loads.
+// One workgroup per (sample, head, group of <= 8 query rows), the rows of a group at once, so a key / value row is read once per group
+// (the first form — one wave per (row, head), every wave walking all P keys — re-read them T1 times through the vector L1: 77 us a
+// phase, 18.5 of the sampler's 30 ms; all rows in one workgroup: 26 us, bound by the LDS reads of the query rows — every wave
+// broadcasts every row; profiles/r06_memvla_sampler.txt).  Wave w owns keys [w P/8, (w+1) P/8):
+//   scores   lane = (key, half of the head width): its half K row in registers (8 x 16-byte loads), the T1 query rows broadcast from
+//            LDS, the two halves joined by one cross-lane add;
+//   softmax  scaled scores -> LDS [key][row]; lane r then walks row r of the wave's tile for its max and sum (a cross-lane reduction
+//            per row is ten dependent permutes: 17 rows of them were most of the phase), probabilities back in place;
+//   P V      lane = column: a value row is one 256-byte line, T1 accumulators a lane;
+//   merge    the eight waves' (max, sum, partial output) per row through LDS, flash-attention style; output -> the bf16 operand
+//            tiles of the output projection (ob).
+struct PerOperands { float4 kr[8]; float vr[32]; };      // a lane's half key row and its column of the wave's value rows
+constexpr int PER_TP = 8;           // query rows a workgroup takes, padded to a multiple of 4
+constexpr int PER_MAXT = 24;        // tokens per sample with perceptual attention (three row groups of 8)
+// work item = (sample, head, group of <= 8 query rows).  The row groups of one (sample, head) read the same keys / values: they are
+// dealt to workgroups whose ids are congruent mod 8 — one XCD, one L2 (workgroups go round-robin over the 8 XCDs) — and to workgroups
+// that have no tile of the query projection (the first H / 16 have one): those request their keys / values while the projection runs.
+__device__ __forceinline__ int per_first_item(const DitBfP& p) {
+  const int shift = (p.H / 16) % (int)gridDim.x;
+  return ((int)blockIdx.x + (int)gridDim.x - shift) % (int)gridDim.x;
+}
+__device__ __forceinline__ int per_items(const DitBfP& p) { return ((p.N * p.heads + 7) & ~7) * ((p.T1 + PER_TP - 1) / PER_TP); }
+__device__ __forceinline__ bool per_decode(const DitBfP& p, int item, int& n, int& hd, int& r0, int& nr) {      // false: a hole of the padding
+  const int npair = p.N * p.heads, nrg = (p.T1 + PER_TP - 1) / PER_TP, npair8 = (npair + 7) & ~7, rper = (p.T1 + nrg - 1) / nrg;   // 17 rows: 6, 6, 5
+  const int pr = item % npair8, rg = item / npair8;
+  if (item >= npair8 * nrg || pr >= npair) return false;
+  n = pr / p.heads; hd = pr - n * p.heads; r0 = rg * rper; nr = min(rper, p.T1 - r0);
+  return true;
+}
+__device__ __forceinline__ void per_load(const DitBfP& p, const float* __restrict__ kv, int n, int hd, PerOperands& q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, key = lane & 31, half = lane >> 5;
+  const int KW = p.P >> 3, ld = 2 * p.H;
+  const float* kbase = kv + (size_t)n * p.P * ld + hd * HD;
+  const float4* krow = reinterpret_cast<const float4*>(kbase + (size_t)(wave * KW + (key < KW ? key : 0)) * ld + half * 32);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) q.kr[c] = krow[c];
+  const float* vbase = kbase + p.H + (size_t)(wave * KW) * ld + lane;
+#pragma unroll
+  for (int jj = 0; jj < 32; ++jj) q.vr[jj] = jj < KW ? vbase[(size_t)jj * ld] : 0.f;
+}
+
+__device__ __forceinline__ void per_attention_bf(const DitBfP& p, Smem& s, const BfBufs& b, const float* __restrict__ kv,
+                                                 PerOperands& ops, bool preloaded) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int KW = p.P >> 3, T1 = p.T1;                           // KW = keys per wave: 8 .. 32
+  // LDS: the phase owns everything in front of Smem::last — [ q: TP x 64 | (max, sum): 8 x TP x 2 | A: scores / probabilities 8 x 32 x TP,
+  // then (after the P V loop) the waves' partial outputs 8 x TP x 64 ]
+  float* const sq = reinterpret_cast<float*>(&s.red[0][0][0][0]);
+  float* const sml = sq + PER_TP * HD;
+  float* const sA = sml + 8 * PER_TP * 2;
+  static_assert((PER_TP * HD + 8 * PER_TP * 2 + 8 * PER_TP * HD) * sizeof(float) <= offsetof(Smem, last), "per_attention_bf: LDS plan");
+  static_assert(32 * PER_TP <= PER_TP * HD, "per_attention_bf: the probabilities fit under the partial outputs");
+  float* const pw = sA + wave * 32 * PER_TP;
+  const int key = lane & 31, half = lane >> 5;
+  const int first = per_first_item(p);
+  for (int item = first; item < per_items(p); item += gridDim.x) {
+    int n, hd, r0, nr;
+    if (!per_decode(p, item, n, hd, r0, nr)) continue;     // (uniform per workgroup)
+    // this wave's key rows (half a row a lane) and value rows (one column a lane): requested before the barrier in front of this phase
+    // (per_load in walk_blocks_bf) or, for a second item of the workgroup, first thing here — they do not depend on q
+    if (!(preloaded && item == first)) per_load(p, kv, n, hd, ops);
+    const bool kval = key < KW;
+    const float4* kr = ops.kr;
+    const float* vr = ops.vr;
+    if (tid < nr * 16) {
+      const int i = tid >> 4, d4 = tid & 15;
+      *reinterpret_cast<float4*>(sq + i * HD + d4 * 4) = b.qkv.ld16f((uint32_t)(((size_t)(n * T1 + r0 + i) * p.H + hd * HD + d4 * 4) * 4));
+    }
+    __syncthreads();
+    DIT_STAMP(s, 1);
+    float pv[PER_TP];
+#pragma unroll
+    for (int i = 0; i < PER_TP; ++i) {
+      pv[i] = 0.f;
+      if (i < nr) {
+        const float4* qr = reinterpret_cast<const float4*>(sq + i * HD + half * 32);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          const float4 q0 = qr[c], q1 = qr[c + 1];
+          a0 += (q0.x * kr[c].x + q0.y * kr[c].y) + (q0.z * kr[c].z + q0.w * kr[c].w);
+          a1 += (q1.x * kr[c + 1].x + q1.y * kr[c + 1].y) + (q1.z * kr[c + 1].z + q1.w * kr[c + 1].w);
+        }
+        float sc = a0 + a1;
+        sc += __shfl_xor(sc, 32, 64);
+        pv[i] = kval ? sc * p.scale : -INFINITY;
+      }
+    }
+    if (half == 0) {                                       // scaled scores -> LDS [key][row] (rows nr .. TP-1: zeros, and they stay zeros)
+#pragma unroll
+      for (int i = 0; i < PER_TP; i += 4) *reinterpret_cast<float4*>(pw + key * PER_TP + i) = make_float4(pv[i], pv[i + 1], pv[i + 2], pv[i + 3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    DIT_STAMP(s, 2);
+    // the wave's softmax statistics: lane r takes row r of its 32 x TP score tile — 32 independent LDS reads, then registers (a
+    // cross-lane reduction per row is ten dependent permutes).  Keys past KW hold -inf: probability 0.
+    if (lane < nr) {
+      float sv[32];
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) sv[jj] = pw[jj * PER_TP + lane];
+      float mx = sv[0];
+#pragma unroll
+      for (int jj = 1; jj < 32; ++jj) mx = fmaxf(mx, sv[jj]);
+      float sum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) {
+        sv[jj] = __expf(sv[jj] - mx);
+        sum += sv[jj];
+        pw[jj * PER_TP + lane] = sv[jj];
+      }
+      sml[(wave * PER_TP + lane) * 2] = mx;
+      sml[(wave * PER_TP + lane) * 2 + 1] = sum;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    DIT_STAMP(s, 3);
+    // ---- P V over this wave's keys: lane = column
+    float o[PER_TP];
+#pragma unroll
+    for (int i = 0; i < PER_TP; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) {
+      if (jj < KW) {
+        const float v = vr[jj];
+#pragma unroll
+        for (int i = 0; i < PER_TP; i += 4) {
+          const float4 p4 = *reinterpret_cast<const float4*>(pw + jj * PER_TP + i);
+          o[i] += p4.x * v; o[i + 1] += p4.y * v; o[i + 2] += p4.z * v; o[i + 3] += p4.w * v;
+        }
+      }
+    }
+    DIT_STAMP_AFTER(s, 4, o[0] + o[1]);
+    __syncthreads();                                       // every wave is done with its probabilities: A becomes the partial outputs
+    float* const so = sA + wave * PER_TP * HD;
+#pragma unroll
+    for (int i = 0; i < PER_TP; ++i)
+      if (i < nr) so[i * HD + lane] = o[i];
+    __syncthreads();
+    if (tid < nr * 16) {                                   // merge: thread = (row, four columns)
+      const int i = tid >> 4, d = (tid & 15) * 4;
+      float M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) M = fmaxf(M, sml[(w * PER_TP + i) * 2]);
+      float Lsum = 0.f;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const float f = __expf(sml[(w * PER_TP + i) * 2] - M);
+        Lsum += f * sml[(w * PER_TP + i) * 2 + 1];
+        const float4 t = *reinterpret_cast<const float4*>(sA + (w * PER_TP + i) * HD + d);
+        acc.x += f * t.x; acc.y += f * t.y; acc.z += f * t.z; acc.w += f * t.w;
+      }
+      const float inv = 1.f / Lsum;
+      b.ob.st8(tile_off(p.Mp, n * T1 + r0 + i, hd * HD + d), pack_bf16x2(acc.x * inv, acc.y * inv), pack_bf16x2(acc.z * inv, acc.w * inv));
+    }
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ void walk_blocks_bf(const DitBfP& p, Smem& s, const BfBufs& b, unsigned& epoch, unsigned nblk, unsigned base) {
   const bool work = p.dbg != 1, sync = p.dbg != 2;
   for (int blk = 0; blk < p.depth; ++blk) {
-    const void* const* w = p.w + blk * 10;
+    const void* const* w = p.w + blk * p.wstride;
+    const bool per = p.P > 0;
+    // the K-sliced output projections count arrivals per column block: with perceptual attention TWO products per block use cnt_proj
+    const unsigned tgt_proj = per ? (2u * (base + (unsigned)blk) + 1u) * p.s_proj : (base + (unsigned)blk + 1u) * p.s_proj;
     DIT_STAMP(s, 0);
     if (work) gemm_bf<BF_QKV>(p, s, b, b.hb, p.H, w[0], w[1], w[8], 3 * p.H, 1, nullptr, 0);
     DIT_STAMP(s, 3);
@@ -1058,10 +1228,31 @@ __device__ __forceinline__ void walk_blocks_bf(const DitBfP& p, Smem& s, const B
     if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
     DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 1, 5);
     DIT_STAMP(s, 0);
-    if (work) gemm_bf<BF_RES>(p, s, b, b.ob, p.H, w[2], w[3], nullptr, p.H, p.s_proj, p.cnt_proj, (base + (unsigned)blk + 1u) * p.s_proj);
+    if (work) gemm_bf<BF_RES>(p, s, b, b.ob, p.H, w[2], w[3], nullptr, p.H, p.s_proj, p.cnt_proj, tgt_proj);
     DIT_STAMP(s, 3);
     if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
     DIT_STAMP(s, 5); DIT_STAMP_FOLD(s, 2, 5);
+    if (per) {
+      // x + MHA(norm3 x, per, per): q = (norm3 folded into the packed q rows of in_proj) | attention over the cached keys / values | out_proj
+      if (work) gemm_bf<BF_QKV>(p, s, b, b.hb, p.H, w[10], w[11], w[12], p.H, 1, nullptr, 0);
+      // the keys / values of this workgroup's first attention item: in flight (or, for the workgroups without a projection tile,
+      // already here) when the barrier opens — a cold 128 KB of them costs 5 us after it (profiles/r06_memvla_sampler.txt)
+      const float* kvb = p.kv + (size_t)blk * p.N * p.P * 2 * p.H;
+      PerOperands ops;
+      bool pre = false;
+      if (work && p.dbg != 3 && p.dbg != 7) {
+        int n_, hd_, r0_, nr_;
+        if (per_decode(p, per_first_item(p), n_, hd_, r0_, nr_)) { per_load(p, kvb, n_, hd_, ops); pre = true; }
+      }
+      if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+      DIT_STAMP(s, 0);
+      if (work && p.dbg != 3) per_attention_bf(p, s, b, kvb, ops, pre);
+      DIT_STAMP(s, 5);
+      if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+      DIT_STAMP(s, 6); DIT_STAMP_FOLD(s, 5, 6);
+      if (work) gemm_bf<BF_RES>(p, s, b, b.ob, p.H, w[13], w[14], nullptr, p.H, p.s_proj, p.cnt_proj, tgt_proj + (unsigned)p.s_proj);
+      if (sync) grid_sync(p.bar, nblk, epoch, true, &s);
+    }
     DIT_STAMP(s, 0);
     if (work) gemm_bf<BF_FC1>(p, s, b, b.hb, p.H, w[4], w[5], w[9], p.I, 1, nullptr, 0);
     DIT_STAMP(s, 3);
@@ -1094,7 +1285,7 @@ __global__ __launch_bounds__(512) void dit_sample_bf16_k(const DitSampleBfP sp) 
   const Act xin(sp.x, (size_t)nx), xpp(sp.xpp, (size_t)2 * nx), epsg(sp.eps, (size_t)p.M * MAXA), hact(p.h, (size_t)p.M * p.H);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if defined(DXA_DIT_STAMPS)
-  if (threadIdx.x < 40) s.stamp[threadIdx.x / 8][threadIdx.x % 8] = 0ull;
+  if (threadIdx.x < 48) s.stamp[threadIdx.x / 8][threadIdx.x % 8] = 0ull;
   __syncthreads();
 #endif
   auto load_x = [&](int step) {          // as in dit_sample_fused_k
@@ -1177,7 +1368,7 @@ __global__ __launch_bounds__(512) void dit_sample_bf16_k(const DitSampleBfP sp) 
   if (blockIdx.x == 0) load_x(sp.steps);
 #if defined(DXA_DIT_STAMPS)
   __syncthreads();
-  if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x < 40) g_dit_stamps[threadIdx.x / 8][threadIdx.x % 8] = s.stamp[threadIdx.x / 8][threadIdx.x % 8];
+  if (blockIdx.x == DXA_DIT_STAMPS && threadIdx.x < 48) g_dit_stamps[threadIdx.x / 8][threadIdx.x % 8] = s.stamp[threadIdx.x / 8][threadIdx.x % 8];
 #endif
   if (threadIdx.x == 0) {                 // leave_clean
     unsigned* exit_cnt = p.bar + 48;
@@ -1195,47 +1386,71 @@ __global__ __launch_bounds__(512) void dit_sample_bf16_k(const DitSampleBfP sp) 
 }
 
 // ---- weight packing: one workgroup per (block, matrix, 16 output columns); thread (r = tid / 16, t = tid % 16) walks row nb * 16 + r
-struct PackP { const float* const* w; char* arena; const void** table; int depth, H, I; size_t per_block, off[6]; };
+// With perceptual attention (per = 1; `w` is then [depth][14]: + in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, norm3.weight,
+// norm3.bias; the table [depth][16]) two more matrices per block: the QUERY rows of nn.MultiheadAttention's packed in_proj with norm3's
+// affine folded in — W'[n][k] = W[n][k] gamma[k], b'[n] = b[n] + sum_k W[n][k] beta[k], so the phase's plain-LayerNorm identity
+// rs (x W'^T - mu sum_k W') + b' is norm3(x) W^T + b — and out_proj.
+struct PackP { const float* const* w; char* arena; const void** table; int depth, H, I, per, wst, tst; size_t per_block, off[10]; };
 __global__ __launch_bounds__(256) void dit_bf16_pack_k(const PackP q) {
-  const int nbq = 3 * q.H / 16, nbp = q.H / 16, nb1 = q.I / 16, nb2 = q.H / 16, per_blk = nbq + nbp + nb1 + nb2;
+  const int nbq = 3 * q.H / 16, nbp = q.H / 16, nb1 = q.I / 16, nb2 = q.H / 16, nbx = q.per ? q.H / 16 : 0;
+  const int per_blk = nbq + nbp + nb1 + nb2 + 2 * nbx;
   const int blk = blockIdx.x / per_blk;
   int r0 = blockIdx.x - blk * per_blk, mat, K;
-  if (r0 < nbq) { mat = 0; K = q.H; } else if ((r0 -= nbq) < nbp) { mat = 1; K = q.H; } else if ((r0 -= nbp) < nb1) { mat = 2; K = q.H; } else { r0 -= nb1; mat = 3; K = q.I; }
+  if (r0 < nbq) { mat = 0; K = q.H; } else if ((r0 -= nbq) < nbp) { mat = 1; K = q.H; } else if ((r0 -= nbp) < nb1) { mat = 2; K = q.H; }
+  else if ((r0 -= nb1) < nb2) { mat = 3; K = q.I; } else if ((r0 -= nb2) < nbx) { mat = 4; K = q.H; } else { r0 -= nbx; mat = 5; K = q.H; }
   const int nb = r0, tid = threadIdx.x, r = tid >> 4, t = tid & 15, npc = K / 32;
-  const float* W = q.w[blk * 8 + 2 * mat];
+  const int wsrc[6] = {0, 2, 4, 6, 8, 10};
+  const float* W = q.w[blk * q.wst + wsrc[mat]];
   char* base = q.arena + (size_t)blk * q.per_block;
-  const size_t woff[4] = {q.off[0], q.off[2], q.off[3], q.off[5]};
+  const size_t woff[6] = {q.off[0], q.off[2], q.off[3], q.off[5], q.off[6], q.off[9]};
   bf16_t* out = reinterpret_cast<bf16_t*>(base + woff[mat]);
-  float sum = 0.f;
+  float sum = 0.f, bfold = 0.f;
   const float* row = W + (size_t)(nb * 16 + r) * K;
+  const float* gam = mat == 4 ? q.w[blk * q.wst + 12] : nullptr;
+  const float* bet = mat == 4 ? q.w[blk * q.wst + 13] : nullptr;
   for (int k4 = t; k4 < K / 4; k4 += 16) {
-    const float4 v = *reinterpret_cast<const float4*>(row + 4 * k4);
+    float4 v = *reinterpret_cast<const float4*>(row + 4 * k4);
+    if (mat == 4) {
+      const float4 g = *reinterpret_cast<const float4*>(gam + 4 * k4), be = *reinterpret_cast<const float4*>(bet + 4 * k4);
+      bfold += (v.x * be.x + v.y * be.y) + (v.z * be.z + v.w * be.w);
+      v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+    }
     const uint32_t lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
     sum += (__uint_as_float(lo << 16) + __uint_as_float(lo & 0xffff0000u)) + (__uint_as_float(hi << 16) + __uint_as_float(hi & 0xffff0000u));
     const int k = 4 * k4, pc = k >> 5, sl = k & 31;
     *reinterpret_cast<uint2*>(out + (((size_t)nb * npc + pc) * 16 + r) * 32 + sl) = make_uint2(lo, hi);
   }
 #pragma unroll
-  for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  for (int o = 8; o >= 1; o >>= 1) { sum += __shfl_xor(sum, o, 64); bfold += __shfl_xor(bfold, o, 64); }
   if (t == 0 && (mat == 0 || mat == 2)) reinterpret_cast<float*>(base + (mat == 0 ? q.off[1] : q.off[4]))[nb * 16 + r] = sum;
-  if (blockIdx.x % per_blk == 0 && tid < 10) {
+  if (t == 0 && mat == 4) {
+    reinterpret_cast<float*>(base + q.off[7])[nb * 16 + r] = sum;
+    reinterpret_cast<float*>(base + q.off[8])[nb * 16 + r] = q.w[blk * q.wst + 9][nb * 16 + r] + bfold;
+  }
+  if (blockIdx.x % per_blk == 0 && tid < q.tst) {
     const void* e;
     switch (tid) {
-      case 0: e = base + q.off[0]; break;  case 1: e = q.w[blk * 8 + 1]; break;
-      case 2: e = base + q.off[2]; break;  case 3: e = q.w[blk * 8 + 3]; break;
-      case 4: e = base + q.off[3]; break;  case 5: e = q.w[blk * 8 + 5]; break;
-      case 6: e = base + q.off[5]; break;  case 7: e = q.w[blk * 8 + 7]; break;
-      case 8: e = base + q.off[1]; break;  default: e = base + q.off[4]; break;
+      case 0: e = base + q.off[0]; break;  case 1: e = q.w[blk * q.wst + 1]; break;
+      case 2: e = base + q.off[2]; break;  case 3: e = q.w[blk * q.wst + 3]; break;
+      case 4: e = base + q.off[3]; break;  case 5: e = q.w[blk * q.wst + 5]; break;
+      case 6: e = base + q.off[5]; break;  case 7: e = q.w[blk * q.wst + 7]; break;
+      case 8: e = base + q.off[1]; break;  case 9: e = base + q.off[4]; break;
+      case 10: e = base + q.off[6]; break; case 11: e = base + q.off[8]; break;
+      case 12: e = base + q.off[7]; break; case 13: e = base + q.off[9]; break;
+      case 14: e = q.w[blk * q.wst + 11]; break;
+      default: e = nullptr; break;
     }
-    q.table[blk * 10 + tid] = e;
+    q.table[blk * q.tst + tid] = e;
   }
 }
 
-void bf16_layout(int H, int I, size_t off[6], size_t* per_block) {
+void bf16_layout(int H, int I, int per, size_t off[10], size_t* per_block) {
   size_t o = 0;
   auto put = [&](int i, size_t bytes) { off[i] = o; o += (bytes + 255) / 256 * 256; };
   put(0, (size_t)3 * H * H * 2); put(1, (size_t)3 * H * 4); put(2, (size_t)H * H * 2); put(3, (size_t)I * H * 2); put(4, (size_t)I * 4);
   put(5, (size_t)H * I * 2);
+  for (int i = 6; i < 10; ++i) off[i] = 0;
+  if (per) { put(6, (size_t)H * H * 2); put(7, (size_t)H * 4); put(8, (size_t)H * 4); put(9, (size_t)H * H * 2); }
   *per_block = o;
 }
 size_t bf_ws_bytes(int M, int H, int I, size_t off[8]) {
@@ -1255,26 +1470,41 @@ size_t bf_ws_bytes(int M, int H, int I, size_t off[8]) {
 
 }  // namespace
 
-extern "C" size_t dxa_dit_bf16_pack_bytes(int depth, int H, int I) {
+namespace {
+size_t pack_bytes(int depth, int H, int I, int per) {
   if (depth <= 0 || H <= 0 || I <= 0) return 0;
-  size_t off[6], per = 0;
-  bf16_layout(H, I, off, &per);
-  return per * depth;
+  size_t off[10], pb = 0;
+  bf16_layout(H, I, per, off, &pb);
+  return pb * depth;
 }
-
-extern "C" int dxa_dit_bf16_pack(const float* const* weights, int depth, int H, int I, void* packed, size_t packed_bytes,
-                                 const void** table, dxa_stream_t stream) {
-  DXA_CHECK_ARG(weights && packed && table, "dxa_dit_bf16_pack: null buffer");
-  DXA_CHECK_ARG(depth >= 1 && H % 64 == 0 && I % 64 == 0, "dxa_dit_bf16_pack: needs H, I %% 64 == 0");
-  DXA_CHECK_ARG(packed_bytes >= dxa_dit_bf16_pack_bytes(depth, H, I), "dxa_dit_bf16_pack: arena too small");
-  DXA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) % 256) == 0, "dxa_dit_bf16_pack: the arena must be 256-byte aligned");
+int pack_launch(const char* who, const float* const* weights, int depth, int H, int I, int per, void* packed, size_t packed_bytes,
+                const void** table, dxa_stream_t stream) {
+  DXA_CHECK_ARG(weights && packed && table, "%s: null buffer", who);
+  DXA_CHECK_ARG(depth >= 1 && H % 64 == 0 && I % 64 == 0, "%s: needs H, I %% 64 == 0", who);
+  DXA_CHECK_ARG(packed_bytes >= pack_bytes(depth, H, I, per), "%s: arena too small", who);
+  DXA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) % 256) == 0, "%s: the arena must be 256-byte aligned", who);
   PackP q;
   q.w = weights; q.arena = reinterpret_cast<char*>(packed); q.table = table; q.depth = depth; q.H = H; q.I = I;
-  bf16_layout(H, I, q.off, &q.per_block);
-  const int per_blk = 3 * H / 16 + H / 16 + I / 16 + H / 16;
+  q.per = per; q.wst = per ? 14 : 8; q.tst = per ? 16 : 10;
+  bf16_layout(H, I, per, q.off, &q.per_block);
+  const int per_blk = 3 * H / 16 + H / 16 + I / 16 + H / 16 + (per ? 2 * (H / 16) : 0);
   hipLaunchKernelGGL(dit_bf16_pack_k, dim3(depth * per_blk), dim3(256), 0, (hipStream_t)stream, q);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
+}
+}  // namespace
+
+extern "C" size_t dxa_dit_bf16_pack_bytes(int depth, int H, int I) { return pack_bytes(depth, H, I, 0); }
+extern "C" size_t dxa_dit_bf16_pack_per_bytes(int depth, int H, int I) { return pack_bytes(depth, H, I, 1); }
+
+extern "C" int dxa_dit_bf16_pack(const float* const* weights, int depth, int H, int I, void* packed, size_t packed_bytes,
+                                 const void** table, dxa_stream_t stream) {
+  return pack_launch("dxa_dit_bf16_pack", weights, depth, H, I, 0, packed, packed_bytes, table, stream);
+}
+
+extern "C" int dxa_dit_bf16_pack_per(const float* const* weights, int depth, int H, int I, void* packed, size_t packed_bytes,
+                                     const void** table, dxa_stream_t stream) {
+  return pack_launch("dxa_dit_bf16_pack_per", weights, depth, H, I, 1, packed, packed_bytes, table, stream);
 }
 
 extern "C" size_t dxa_dit_sample_bf16_workspace(int M, int H, int I) {
@@ -1283,11 +1513,13 @@ extern "C" size_t dxa_dit_sample_bf16_workspace(int M, int H, int I) {
   return bf_ws_bytes(M, H, I, off);
 }
 
-extern "C" int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w,
-                                       const float* x_b, const float* final_w, const float* final_b, const float* coef, int steps, int A,
-                                       int nb, int use_cfg, float cfg_scale, const void* const* packed_table, int depth, int N, int T1,
-                                       int H, int heads, int I, float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
-  const char* who = "dxa_dit_sample_bf16_fwd";
+namespace {
+int sample_bf16_launch(const char* who, float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w,
+                       const float* x_b, const float* final_w, const float* final_b, const float* coef, int steps, int A,
+                       int nb, int use_cfg, float cfg_scale, const void* const* packed_table, const float* per_kv, int P, int depth, int N,
+                       int T1, int H, int heads, int I, float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  DXA_CHECK_ARG(P == 0 || (per_kv && P % 64 == 0 && P >= 64 && P <= 256 && T1 <= PER_MAXT),
+                "%s: perceptual attention needs 64 <= P <= 256, P %% 64 == 0, at most %d tokens per sample and the keys / values", who, PER_MAXT);
   DXA_CHECK_ARG(x && z_emb && t_emb && pos && x_w && x_b && final_w && final_b && coef && workspace && packed_table, "%s: null buffer", who);
   DXA_CHECK_ARG(steps >= 1 && A >= 1 && A <= MAXA && nb >= 1 && N == (use_cfg ? 2 * nb : nb),
                 "%s: needs 1 <= action_dim <= %d and N == nb (or 2 nb with guidance)", who, MAXA);
@@ -1311,6 +1543,7 @@ extern "C" int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float
   if (int rc = get_sync_block(st, &tail)) return rc;
   p.bar = tail; p.cnt_proj = tail + 64; p.cnt_fc2 = tail + 128;
   p.w = packed_table;
+  p.kv = per_kv; p.P = P; p.wstride = P > 0 ? 16 : 10;
   p.M = M; p.Mp = (M + 1) & ~1; p.N = N; p.T1 = T1; p.H = H; p.heads = heads; p.I = I; p.depth = depth;
   p.eps = eps; p.scale = 1.f / sqrtf((float)HD);
   static const int dbg = getenv("DXA_DIT_DBG") ? atoi(getenv("DXA_DIT_DBG")) : 0;
@@ -1344,4 +1577,23 @@ extern "C" int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float
   hipLaunchKernelGGL(dit_sample_bf16_k, dim3(grid), dim3(512), 0, st, sp);
   DXA_CHECK_LAUNCH();
   return DXA_OK;
+}
+}  // namespace
+
+extern "C" int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w,
+                                       const float* x_b, const float* final_w, const float* final_b, const float* coef, int steps, int A,
+                                       int nb, int use_cfg, float cfg_scale, const void* const* packed_table, int depth, int N, int T1,
+                                       int H, int heads, int I, float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  return sample_bf16_launch("dxa_dit_sample_bf16_fwd", x, z_emb, t_emb, pos, x_w, x_b, final_w, final_b, coef, steps, A, nb, use_cfg,
+                            cfg_scale, packed_table, nullptr, 0, depth, N, T1, H, heads, I, eps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dxa_dit_sample_bf16_per_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w,
+                                           const float* x_b, const float* final_w, const float* final_b, const float* coef, int steps,
+                                           int A, int nb, int use_cfg, float cfg_scale, const void* const* packed_table,
+                                           const float* per_kv, int P, int depth, int N, int T1, int H, int heads, int I, float eps,
+                                           void* workspace, size_t workspace_bytes, dxa_stream_t stream) {
+  DXA_CHECK_ARG(per_kv != nullptr && P > 0, "dxa_dit_sample_bf16_per_fwd: needs the perceptual keys / values");
+  return sample_bf16_launch("dxa_dit_sample_bf16_per_fwd", x, z_emb, t_emb, pos, x_w, x_b, final_w, final_b, coef, steps, A, nb, use_cfg,
+                            cfg_scale, packed_table, per_kv, P, depth, N, T1, H, heads, I, eps, workspace, workspace_bytes, stream);
 }

@@ -1046,41 +1046,55 @@ def dit_sample_fwd(x: torch.Tensor, z_emb: torch.Tensor, t_emb: torch.Tensor, po
     return x
 
 
-def dit_bf16_pack(weight_table: torch.Tensor, depth: int, H: int, I: int, out=None):
+def dit_bf16_pack(weight_table: torch.Tensor, depth: int, H: int, I: int, out=None, per: bool = False):
     """bf16 operand copy of the DiT blocks' matrices for dit_sample_bf16_fwd (dxa_dit_bf16_pack): returns (arena, table) — keep both
     alive; `table` is the int64 device tensor of depth*10 pointers the sampler takes.  Re-pack when the fp32 weights change
-    (``out=(arena, table)`` re-packs in place)."""
-    assert weight_table.dtype == torch.int64 and weight_table.numel() == depth * 8 and weight_table.is_cuda
-    nbytes = lib.dxa_dit_bf16_pack_bytes(depth, H, I)
+    (``out=(arena, table)`` re-packs in place).  ``per``: the blocks of MemVLA's DiT with perceptual attention (dxa_dit_bf16_pack_per:
+    14 source pointers and 16 table entries per block)."""
+    n_src, n_tab = (14, 16) if per else (8, 10)
+    assert weight_table.dtype == torch.int64 and weight_table.numel() == depth * n_src and weight_table.is_cuda
+    nbytes = (lib.dxa_dit_bf16_pack_per_bytes if per else lib.dxa_dit_bf16_pack_bytes)(depth, H, I)
     if out is not None:
         arena, table = out
-        assert arena.numel() == nbytes and table.numel() == depth * 10
+        assert arena.numel() == nbytes and table.numel() == depth * n_tab
     else:
         arena = torch.empty(nbytes, device=weight_table.device, dtype=torch.uint8)
-        table = torch.empty(depth * 10, device=weight_table.device, dtype=torch.int64)
-    L.check(lib.dxa_dit_bf16_pack(_ptr(weight_table), depth, H, I, _ptr(arena), nbytes, _ptr(table), _stream()), "dxa_dit_bf16_pack")
+        table = torch.empty(depth * n_tab, device=weight_table.device, dtype=torch.int64)
+    fn = lib.dxa_dit_bf16_pack_per if per else lib.dxa_dit_bf16_pack
+    L.check(fn(_ptr(weight_table), depth, H, I, _ptr(arena), nbytes, _ptr(table), _stream()), "dxa_dit_bf16_pack")
     return arena, table
 
 
-def dit_sample_bf16_supported(N: int, T1: int, H: int, heads: int, I: int) -> bool:
-    return N * T1 <= 48 and T1 <= DIT_FUSED_MAX_TOKENS and H == heads * 64 and H <= 1024 and H % 64 == 0 and I % 64 == 0
+def dit_sample_bf16_supported(N: int, T1: int, H: int, heads: int, I: int, P: int = 0) -> bool:
+    """``P``: perceptual keys per sample (MemVLA's DiT; 0 = the plain blocks)"""
+    return (N * T1 <= 48 and T1 <= DIT_FUSED_MAX_TOKENS and H == heads * 64 and H <= 1024 and H % 64 == 0 and I % 64 == 0 and
+            (P == 0 or (P % 64 == 0 and 64 <= P <= 256 and T1 <= 24)))
 
 
 def dit_sample_bf16_fwd(x: torch.Tensor, z_emb: torch.Tensor, t_emb: torch.Tensor, pos: torch.Tensor, x_w: torch.Tensor,
                         x_b: torch.Tensor, final_w: torch.Tensor, final_b: torch.Tensor, coef: torch.Tensor, nb: int, use_cfg: bool,
                         cfg_scale: float, packed_table: torch.Tensor, depth: int, T1: int, H: int, heads: int, I: int,
-                        eps: float) -> torch.Tensor:
+                        eps: float, per_kv: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dit_sample_fwd with bf16 MFMA operands (dxa_dit_sample_bf16_fwd; `packed_table` from dit_bf16_pack): the sampler of a model
-    served in bfloat16; x [nb, T1-1, A] fp32 is updated in place"""
+    served in bfloat16; x [nb, T1-1, A] fp32 is updated in place.  ``per_kv`` [depth, N, P, 2, H] fp32: MemVLA's perceptual attention
+    (dxa_dit_sample_bf16_per_fwd; `packed_table` from dit_bf16_pack(per=True))."""
     steps, A = t_emb.shape[0], x.shape[-1]
     N = z_emb.shape[0]
     for t in (x, z_emb, t_emb, pos, x_w, x_b, final_w, final_b, coef):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
     assert x.shape == (nb, T1 - 1, A) and z_emb.shape == (N, H) and t_emb.shape == (steps, H) and coef.shape == (steps, 4)
     assert pos.shape == (T1, H) and x_w.shape == (H, A) and final_w.shape == (A, H)
-    assert packed_table.dtype == torch.int64 and packed_table.numel() == depth * 10 and packed_table.is_cuda
+    assert packed_table.dtype == torch.int64 and packed_table.numel() == depth * (10 if per_kv is None else 16) and packed_table.is_cuda
     nbytes = lib.dxa_dit_sample_bf16_workspace(N * T1, H, I)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    if per_kv is not None:
+        P_ = per_kv.shape[2]
+        assert per_kv.dtype == torch.float32 and per_kv.is_contiguous() and per_kv.shape == (depth, N, P_, 2, H)
+        L.check(lib.dxa_dit_sample_bf16_per_fwd(_ptr(x), _ptr(z_emb), _ptr(t_emb), _ptr(pos), _ptr(x_w), _ptr(x_b), _ptr(final_w),
+                                                _ptr(final_b), _ptr(coef), steps, A, nb, int(use_cfg), float(cfg_scale),
+                                                _ptr(packed_table), _ptr(per_kv), P_, depth, N, T1, H, heads, I, float(eps), _ptr(ws),
+                                                nbytes, _stream()), "dxa_dit_sample_bf16_per_fwd")
+        return x
     L.check(lib.dxa_dit_sample_bf16_fwd(_ptr(x), _ptr(z_emb), _ptr(t_emb), _ptr(pos), _ptr(x_w), _ptr(x_b), _ptr(final_w),
                                         _ptr(final_b), _ptr(coef), steps, A, nb, int(use_cfg), float(cfg_scale), _ptr(packed_table),
                                         depth, N, T1, H, heads, I, float(eps), _ptr(ws), nbytes, _stream()), "dxa_dit_sample_bf16_fwd")

@@ -184,17 +184,23 @@ class DiT(nn.Module):
         return K.mm_nt(a, W("mlp.fc2.weight"), bias=W("mlp.fc2.bias"), residual=hcur)
 
     @torch.no_grad()
-    def precompute_per_kv(self, per_token: torch.Tensor) -> list:
+    def precompute_per_kv(self, per_token: torch.Tensor, packed: bool = False):
         """inference: the perceptual-token embedding and every block's key/value projection of it depend on the request, not on
         the DDIM step — the sampler computes them once ([N, P, 2, H, D] per block; DiT-L: 24 x [N*P, 1024] x [2048, 1024]^T
         products a step otherwise) and hands them to forward(per_kv=...).  Same kernels on the same operands as the per-step
-        path: the samples are bit-identical."""
+        path: the samples are bit-identical.  ``packed``: ONE tensor [depth, N, P, 2, h] (what the one-launch sampler takes)."""
         from .... import kernels as K
         st = Fp32View(self.store)
         p, h, H = self.p, self.hidden_size, self.num_heads
         N, P_ = per_token.shape[:2]
         pe = K.mm_nt(per_token.float().reshape(N * P_, -1).contiguous(), st.w(p + "per_token_embedder.linear.weight"),
                      bias=st.w(p + "per_token_embedder.linear.bias"))
+        if packed:
+            kv = torch.empty((self.depth, N * P_, 2 * h), device=pe.device, dtype=torch.float32)
+            for k in range(self.depth):
+                K.mm_nt(pe, st.w(f"{p}blocks.{k}.per_attn.in_proj_weight")[h:], bias=st.w(f"{p}blocks.{k}.per_attn.in_proj_bias")[h:],
+                        out=kv[k])
+            return kv.view(self.depth, N, P_, 2, h)
         return [K.mm_nt(pe, st.w(f"{p}blocks.{k}.per_attn.in_proj_weight")[h:],
                         bias=st.w(f"{p}blocks.{k}.per_attn.in_proj_bias")[h:]).view(N, P_, 2, H, h // H)
                 for k in range(self.depth)]
@@ -208,13 +214,18 @@ class DiT(nn.Module):
                 K.dit_blocks_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden))
 
     def _weight_table(self, st) -> torch.Tensor:
-        """device array of the raw fp32 master pointers of every block (the arena never moves)"""
+        """device array of the raw fp32 master pointers of every block (the arena never moves); with perceptual attention 14 per
+        block (dxa_dit_bf16_pack_per's order)"""
         if getattr(self, "_wtab", None) is None:
             ptrs = []
+            names = ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight",
+                     "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+            if self.use_per_attn:
+                names += ("per_attn.in_proj_weight", "per_attn.in_proj_bias", "per_attn.out_proj.weight", "per_attn.out_proj.bias",
+                          "norm3.weight", "norm3.bias")
             for k in range(self.depth):
                 b = f"{self.p}blocks.{k}."
-                for n in ("attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight",
-                          "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"):
+                for n in names:
                     w = st.w(b + n)
                     assert w.dtype == torch.float32 and w.is_contiguous()
                     ptrs.append(w.data_ptr())
@@ -235,10 +246,11 @@ class DiT(nn.Module):
         key = self.store.weights_key()
         ent = getattr(self, "_bf16_pack", None)
         if ent is None:
-            arena, table = K.dit_bf16_pack(self._weight_table(st), self.depth, self.hidden_size, self.mlp_hidden)
+            arena, table = K.dit_bf16_pack(self._weight_table(st), self.depth, self.hidden_size, self.mlp_hidden, per=self.use_per_attn)
             self._bf16_pack = ent = (key, arena, table)
         elif ent[0] != key:
-            K.dit_bf16_pack(self._weight_table(st), self.depth, self.hidden_size, self.mlp_hidden, out=(ent[1], ent[2]))
+            K.dit_bf16_pack(self._weight_table(st), self.depth, self.hidden_size, self.mlp_hidden, out=(ent[1], ent[2]),
+                            per=self.use_per_attn)
             self._bf16_pack = ent = (key, ent[1], ent[2])
         return ent[2]
 
@@ -317,9 +329,17 @@ class DiT(nn.Module):
         return tabs[key]
 
     # ---- the whole sampler in one launch ---------------------------------------------------------------------------
-    def fused_sampler_ok(self, N: int, T1: int) -> bool:
-        return (self._use_fused_blocks(N, T1) and not self.use_per_attn and self.in_channels <= 8 and
-                os.environ.get("DXA_DIT_SAMPLER", "1") != "0")
+    def fused_sampler_ok(self, N: int, T1: int, P: int = 0) -> bool:
+        """``P``: perceptual keys per sample (MemVLA's DiT: only the bf16 sampler has the perceptual-attention phases)"""
+        from .... import kernels as K
+        if self.in_channels > 8 or os.environ.get("DXA_DIT_SAMPLER", "1") == "0":
+            return False
+        if self.use_per_attn:
+            return (P > 0 and not torch.is_grad_enabled() and os.environ.get("DXA_DIT_FUSED", "1") != "0" and
+                    getattr(self, "allow_fused", True) and self.store.device.type == "cuda" and
+                    self.store.compute_dtype == torch.bfloat16 and os.environ.get("DXA_DIT_BF16", "1") != "0" and
+                    K.dit_sample_bf16_supported(N, T1, self.hidden_size, self.num_heads, self.mlp_hidden, P))
+        return self._use_fused_blocks(N, T1)
 
     def _sampler_tables(self, diffusion, device):
         """per (schedule, device): the timesteps in execution order and the three DDIM coefficients per step, rounded to fp32
@@ -339,11 +359,13 @@ class DiT(nn.Module):
         return tabs[key][:2]
 
     @torch.no_grad()
-    def ddim_sample_fused(self, noise: torch.Tensor, z: torch.Tensor, diffusion, cfg_scale: Optional[float]) -> torch.Tensor:
+    def ddim_sample_fused(self, noise: torch.Tensor, z: torch.Tensor, diffusion, cfg_scale: Optional[float],
+                          per_token: Optional[torch.Tensor] = None) -> torch.Tensor:
         """GaussianDiffusion.ddim_sample_loop over forward_with_cfg (diffusion.py:714-794, dit.py:294-311) as ONE persistent
         launch (csrc/dit_fused.hip dit_sample_fused_k): noise [nb, T, A], z [N, 1, token] (N = 2 nb with guidance: [cond; uncond])
         -> the sample [nb, T, A].  What does not depend on x is prepared by three small launches: the z embedding and the
-        timestep embeddings of the whole schedule."""
+        timestep embeddings of the whole schedule.  ``per_token`` [N, P, per_token_size] (MemVLA): the perceptual keys / values of
+        every block are projected once (precompute_per_kv) and the launch attends them in its per-attention phases."""
         from .... import kernels as K
         st = Fp32View(self.store)
         p, h = self.p, self.hidden_size
@@ -359,6 +381,14 @@ class DiT(nn.Module):
         x = noise.float().contiguous().clone()
         self.used_fused = True
         self.store.wait_pending()                  # the kernel reads the masters through raw pointers
+        if self.use_per_attn:
+            assert per_token is not None and per_token.shape[0] == N
+            K.dit_sample_bf16_fwd(x, ze.contiguous(), te.contiguous(), st.w(p + "positional_embedding").reshape(T + 1, h),
+                                  st.w(p + "x_embedder.linear.weight"), st.w(p + "x_embedder.linear.bias"),
+                                  st.w(p + "final_layer.linear.weight"), st.w(p + "final_layer.linear.bias"), coef, nb,
+                                  cfg_scale is not None, float(cfg_scale or 0.0), self._packed_table(st), self.depth, T + 1, h,
+                                  self.num_heads, self.mlp_hidden, 1e-6, per_kv=self.precompute_per_kv(per_token, packed=True))
+            return x
         if self._bf16_sampler(N, T + 1):
             # a model served in bfloat16 multiplies with bf16 operands, like the reference's bf16 head (cogact_exp.py:134-138);
             # residual stream, LayerNorm, attention and accumulation stay fp32 (csrc/dit_fused.hip, dit_sample_bf16_k)

@@ -430,7 +430,14 @@ class MemVLAForCausalLM(CogACTForCausalLM):
         per_token = per.float().repeat(2, 1, 1) if cfg_scale > 1.0 else per.float()
         cfg = model_kwargs.get("cfg_scale")
 
+        fused = inference_args.get("fused_sampler", True) and inference_args.get("cache_per_kv", True) and \
+            head.net.fused_sampler_ok(noise.shape[0], self.config.chunk_size + 1, per_token.shape[1])
+        head.net.used_fused = bool(fused)
+
         def sample(noise, z, per_token):
+            if fused:
+                # bf16 serving: all DDIM steps of the DiT with perceptual attention in ONE persistent launch (csrc/dit_fused.hip)
+                return head.net.ddim_sample_fused(noise[:B], z, head.ddim_diffusion, cfg, per_token=per_token)     # [B, T, A]
             # the perceptual keys/values of the 24 blocks do not depend on the DDIM step: projected once per request
             mk = dict(z=z, per_kv=head.net.precompute_per_kv(per_token)) if inference_args.get("cache_per_kv", True) \
                 else dict(z=z, per_token=per_token)
@@ -443,13 +450,27 @@ class MemVLAForCausalLM(CogACTForCausalLM):
             # the sampler (DiT-L with perceptual attention, ~480 launches per DDIM step) is host-bound: captured once per
             # shape into a HIP graph and replayed (graphs.GraphCache); the stateful memory bank above stays eager host logic
             cache = self.__dict__.setdefault("_sampler_graphs", graphs.GraphCache(dev))
-            samples = cache.run(("ddim", float(cfg_scale), int(num_ddim_steps)), sample,
+            if fused:
+                head.net.refresh_packed()          # the bf16 operand copy a captured launch reads: up to date before a replay
+            run_stream = cache
+            samples = cache.run(("ddim", float(cfg_scale), int(num_ddim_steps), bool(fused)), sample,
                                 dict(noise=noise, z=model_kwargs["z"].contiguous(), per_token=per_token.contiguous()))
         else:
+            run_stream = None
             samples = sample(noise, model_kwargs["z"], per_token)
         if cfg_scale > 1.0:
             samples = samples[:B]
-        return self._denorm(samples[0].cpu().numpy(), action_norms).tolist()
+        host = samples[0].cpu().numpy()
+        if fused and K.dit_blocks_timed_out(run_stream.stream if run_stream is not None else None):
+            # the persistent launch gave up at a barrier (its workgroups were not co-resident: something else held CUs for seconds):
+            # the frame is sampled again block by block, which this process keeps doing from now on.  The memory bank above was
+            # updated once and is not touched again.
+            head.net.allow_fused = False
+            self.__dict__.pop("_sampler_graphs", None)
+            fused = False
+            samples = sample(noise, model_kwargs["z"], per_token)
+            host = (samples[:B] if cfg_scale > 1.0 else samples)[0].cpu().numpy()
+        return self._denorm(host, action_norms).tolist()
 
 
 from ..dexbotic_arch import register_model_with_hf  # noqa: E402

@@ -506,6 +506,25 @@ int dxa_dit_sample_bf16_fwd(float* x, const float* z_emb, const float* t_emb, co
                             float cfg_scale, const void* const* packed_table, int depth, int N, int T1, int H, int heads, int I,
                             float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
 
+/* The bf16 sampler for MemVLA's DiT with perceptual attention (dexbotic/model/memvla/action_model/dit.py:136-185: every block is
+ * x + attn(norm1 x); x + MHA(norm3 x, per, per); x + mlp(norm2 x), and MemVLAForCausalLM.inference_action, memvla_arch.py:666-746,
+ * samples with it): three more phases per block in the same persistent launch — the query projection (the q rows of
+ * nn.MultiheadAttention's packed in_proj, norm3's affine folded into the packed copy), attention of each (row, head) over the
+ * request's P perceptual keys / values, out_proj + residual.
+ *   dxa_dit_bf16_pack_per: `weights` = device array of depth*14 fp32 pointers (the 8 of dxa_dit_bf16_pack, then per_attn.in_proj_weight
+ *   [3H, H], per_attn.in_proj_bias, per_attn.out_proj.weight, per_attn.out_proj.bias, norm3.weight, norm3.bias); `table` = device array
+ *   of depth*16 pointers; arena of dxa_dit_bf16_pack_per_bytes bytes.
+ *   dxa_dit_sample_bf16_per_fwd: + `per_kv` [depth][N][P][2][H] fp32, the keys / values of every block projected from the request's
+ *   perceptual tokens by rows [H:3H] of in_proj (they do not depend on the DDIM step; the caller computes them once per request),
+ *   64 <= P <= 256, P % 64 == 0.  Everything else as dxa_dit_sample_bf16_fwd. */
+size_t dxa_dit_bf16_pack_per_bytes(int depth, int H, int I);
+int dxa_dit_bf16_pack_per(const float* const* weights, int depth, int H, int I, void* packed, size_t packed_bytes, const void** table,
+                          dxa_stream_t stream);
+int dxa_dit_sample_bf16_per_fwd(float* x, const float* z_emb, const float* t_emb, const float* pos, const float* x_w, const float* x_b,
+                                const float* final_w, const float* final_b, const float* coef, int steps, int A, int nb, int use_cfg,
+                                float cfg_scale, const void* const* packed_table, const float* per_kv, int P, int depth, int N, int T1,
+                                int H, int heads, int I, float eps, void* workspace, size_t workspace_bytes, dxa_stream_t stream);
+
 /* ---- KV-cached decode step in one persistent launch (csrc/decode_fused.hip) -------------------------------------------------
  * ONE new token of ONE sequence through every decoder layer and the final RMSNorm — the use_cache=True single-token pass of HF
  * Qwen2Model that GenerationMixin.generate drives for the discrete-action policies (dexbotic/model/discrete_vla/

@@ -850,13 +850,18 @@ def test_dit_blocks_fused(cfg, offset):
 
 
 # ------------------------------------------------------------------------------------------------ bf16-operand DiT sampler
-def _dit_weights(H, I, depth, seed0=50):
+def _dit_weights(H, I, depth, seed0=50, per=False):
+    """``per``: + per_attn.in_proj_weight / in_proj_bias / out_proj.weight / out_proj.bias / norm3.weight / norm3.bias (MemVLA's block)"""
     ws, ptrs = [], []
     for k in range(depth):
         blk = [rnd(3 * H, H, seed=seed0 + 10 * k, scale=H ** -0.5), rnd(3 * H, seed=seed0 + 1 + 10 * k, scale=0.1),
                rnd(H, H, seed=seed0 + 2 + 10 * k, scale=H ** -0.5), rnd(H, seed=seed0 + 3 + 10 * k, scale=0.1),
                rnd(I, H, seed=seed0 + 4 + 10 * k, scale=H ** -0.5), rnd(I, seed=seed0 + 5 + 10 * k, scale=0.1),
                rnd(H, I, seed=seed0 + 6 + 10 * k, scale=I ** -0.5), rnd(H, seed=seed0 + 7 + 10 * k, scale=0.1)]
+        if per:
+            blk += [rnd(3 * H, H, seed=seed0 + 1000 + 10 * k, scale=H ** -0.5), rnd(3 * H, seed=seed0 + 1001 + 10 * k, scale=0.1),
+                    rnd(H, H, seed=seed0 + 1002 + 10 * k, scale=H ** -0.5), rnd(H, seed=seed0 + 1003 + 10 * k, scale=0.1),
+                    (1.0 + rnd(H, seed=seed0 + 1004 + 10 * k, scale=0.2)).contiguous(), rnd(H, seed=seed0 + 1005 + 10 * k, scale=0.2)]
         ws.append(blk)
         ptrs += [w.data_ptr() for w in blk]
     return ws, torch.tensor(ptrs, dtype=torch.int64).to(DEV)
@@ -898,7 +903,7 @@ def test_dit_bf16_pack_is_the_rounded_matrix_in_operand_order(H, I, depth):
     check()
 
 
-def _dit_sampler_restated(x, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, cfg_scale, round_ops):
+def _dit_sampler_restated(x, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, cfg_scale, round_ops, kv=None):
     """float64 restatement of the one-launch sampler (DiT.forward_with_cfg, dit.py:273-311, inside ddim_sample_loop,
     diffusion.py:714-794); round_ops: the products read bf16 weights and bf16 copies of their input activations, LayerNorm is
     folded as rs (bf16(h) W^T - mu sum_k W) like csrc/dit_fused.hip does"""
@@ -910,13 +915,26 @@ def _dit_sampler_restated(x, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, cf
     for s in range(te.shape[0]):
         xe = (x @ xw.double().T + xb.double()).repeat(N // nb, 1, 1)
         h = torch.cat([(te[s].double()[None, :] + ze.double())[:, None, :], xe], 1) + pos.double()[None]
-        for qw, qb, pw, pb, w1, b1, w2, b2 in ws:
+        for bi, (qw, qb, pw, pb, w1, b1, w2, b2, *px) in enumerate(ws):
             mu, rs = ln(h)
             Wq = R(qw)
             qkv = rs * (R(h) @ Wq.T - mu * Wq.sum(1)) + qb.double()
             q, kk, v = qkv.reshape(N, T + 1, 3, heads, 64).permute(2, 0, 3, 1, 4)
             o = (torch.softmax((q @ kk.transpose(-1, -2)) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(N, T + 1, H)
             h = h + R(o) @ R(pw).T + pb.double()
+            if px:
+                # x + MHA(norm3 x, per, per) (memvla/action_model/dit.py:158-185): the query rows of the packed in_proj with norm3's
+                # affine folded in BEFORE the rounding, keys / values = the request's cached projections kv [depth, N, P, 2, H]
+                iw, ib, ow, ob_, g3, b3 = px
+                mu, rs = ln(h)
+                Wf = R(iw[:H].double() * g3.double()[None, :])
+                q2 = rs * (R(h) @ Wf.T - mu * Wf.sum(1)) + (ib[:H].double() + iw[:H].double() @ b3.double())
+                P_ = kv.shape[2]
+                q2 = q2.reshape(N, T + 1, heads, 64).permute(0, 2, 1, 3)
+                k2 = kv[bi, :, :, 0].double().reshape(N, P_, heads, 64).permute(0, 2, 1, 3)
+                v2 = kv[bi, :, :, 1].double().reshape(N, P_, heads, 64).permute(0, 2, 1, 3)
+                o2 = (torch.softmax((q2 @ k2.transpose(-1, -2)) * 0.125, -1) @ v2).permute(0, 2, 1, 3).reshape(N, T + 1, H)
+                h = h + R(o2) @ R(ow).T + ob_.double()
             mu, rs = ln(h)
             W1 = R(w1)
             a = F.gelu(rs * (R(h) @ W1.T - mu * W1.sum(1)) + b1.double(), approximate="tanh")
@@ -962,6 +980,49 @@ def test_dit_sample_bf16_operands(cfg):
     print(f"bf16-operand sampler {cfg}: vs its restatement {d_same:.2e}, vs exact {d_exact:.2e}")
     assert d_same < (5e-4 if depth * steps == 1 else 6e-3), d_same
     assert d_exact < 8e-3, d_exact
+
+
+@pytest.mark.parametrize("cfg", [(1024, 16, 4096, 1, 1, True, 256), (1024, 16, 4096, 24, 10, True, 256), (192, 3, 768, 3, 4, False, 64),
+                                 (128, 2, 512, 2, 3, True, 128)])
+def test_dit_sample_bf16_with_perceptual_attention(cfg):
+    """dxa_dit_sample_bf16_per_fwd — MemVLA's DiT (x + attn(norm1 x); x + MHA(norm3 x, per, per); x + mlp(norm2 x),
+    memvla/action_model/dit.py:136-185) sampled in one launch — against the fp64 restatement of its arithmetic and of the exact
+    sampler, at DiT-L size (1024 wide, 24 blocks, 256 perceptual keys, 10 steps) and at small shapes; the packed query matrix is the
+    rounded W diag(gamma3) with b + W beta3 beside it; run-to-run bit-identical"""
+    H, heads, I, depth, steps, use_cfg, P_ = cfg
+    T, A, nb = 16, 7, 1
+    N = 2 if use_cfg else 1
+    ws, table = _dit_weights(H, I, depth, seed0=350, per=True)
+    x0 = rnd(nb, T, A, seed=7)
+    ze, te, pos = rnd(N, H, seed=8, scale=0.5), rnd(steps, H, seed=9, scale=0.5), rnd(T + 1, H, seed=10, scale=0.1)
+    xw, xb, fw, fb = rnd(H, A, seed=11, scale=0.3), rnd(H, seed=12, scale=0.1), rnd(A, H, seed=13, scale=H ** -0.5), rnd(A, seed=14, scale=0.1)
+    kv = rnd(depth, N, P_, 2, H, seed=15, scale=1.0)
+    ab = torch.linspace(0.05, 0.95, steps + 1, device=DEV, dtype=torch.float64)
+    coef = torch.zeros(steps, 4, device=DEV)
+    coef[:, 0] = (1.0 / ab[:-1]).sqrt().float(); coef[:, 1] = (1.0 / ab[:-1] - 1.0).sqrt().float(); coef[:, 2] = ab[1:].float()
+    assert K.dit_sample_bf16_supported(N, T + 1, H, heads, I, P_)
+    arena, ptab = K.dit_bf16_pack(table, depth, H, I, per=True)
+    # the folded query matrix and bias of block 0
+    e = ptab.cpu().tolist()[:16]
+    iw, ib, g3, b3 = ws[0][8], ws[0][9], ws[0][12], ws[0][13]
+    off = e[10] - arena.data_ptr()
+    got = arena[off: off + H * H * 2].view(torch.bfloat16).view(H // 16, H // 32, 16, 32)
+    want = (iw[:H] * g3[None, :]).to(torch.bfloat16).view(H // 16, 16, H // 32, 32).permute(0, 2, 1, 3)
+    assert torch.equal(got.view(torch.int16), want.contiguous().view(torch.int16))
+    off = e[11] - arena.data_ptr()
+    assert_close(arena[off: off + H * 4].view(torch.float32), ib[:H].double() + iw[:H].double() @ b3.double(), 1e-5, 1e-5, "folded bias")
+    assert e[14] == ws[0][11].data_ptr()
+    outs = [K.dit_sample_bf16_fwd(x0.clone(), ze, te, pos, xw, xb, fw, fb, coef, nb, use_cfg, 1.5, ptab, depth, T + 1, H, heads, I, 1e-6,
+                                  per_kv=kv) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert not K.dit_blocks_timed_out()
+    want = _dit_sampler_restated(x0, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, 1.5 if use_cfg else None, True, kv=kv)
+    exact = _dit_sampler_restated(x0, ze, te, pos, xw, xb, fw, fb, coef, ws, N, heads, 1.5 if use_cfg else None, False, kv=kv)
+    scale = float(exact.abs().max())
+    d_same, d_exact = float((outs[0].double() - want).abs().max()) / scale, float((outs[0].double() - exact).abs().max()) / scale
+    print(f"bf16-operand sampler with perceptual attention {cfg}: vs its restatement {d_same:.2e}, vs exact {d_exact:.2e}")
+    assert d_same < (5e-4 if depth * steps == 1 else 8e-3), d_same
+    assert d_exact < 1.2e-2, d_exact
 
 
 # --------------------------------------------------------------- sum(g^2) out of the dW product's epilogue
