@@ -858,10 +858,9 @@ struct AttnBwdP {
 // keys under the 4 x 17 queries of a sample's diffusion repeats: DiT.forward's timm Attention, dexbotic/model/cogact/action_model/
 // dit.py:137-162 under ActionModel.loss, action_models.py:102-125; memvla/action_model/dit.py:136-185): the generic path below is five
 // batched exact-fp32 products and three elementwise launches per attention call (8 launches of 25 - 35 us for 18 K FLOPs per head).
-// Here ONE workgroup per (sample, head) walks queries and keys in chunks of 32 through LDS:
-//   pass 1  per (query chunk, key chunk): S = q k^T, P = exp(scale S - lse), dP = dO v^T -> delta_i += sum_j P_ij dP_ij (= rowsum(dO * O));
-//   pass 2  per key chunk, per query chunk: the same again -> dS = P (dP - delta) scale; dQ += dS k (registers, all queries),
-//           dK += dS^T q, dV += P^T dO (registers, this key chunk), written when the key chunk is done.
+// Here ONE workgroup per (sample, head) walks queries and keys in chunks of 32 through LDS: delta_i = rowsum(dO_i * O_i) from the forward's
+// output, then per key chunk, per query chunk: S = q k^T, P = exp(scale S - lse), dP = dO v^T, dS = P (dP - delta) scale;
+// dQ += dS k (registers, all queries), dK += dS^T q, dV += P^T dO (registers, this key chunk), written when the key chunk is done.
 // Plain fp32 FMAs.  No masks, no dropout, G = 1, Sq <= 96, D <= 64 (D % 4 == 0): 34 KiB of LDS.
 constexpr int SB_MAXT = 32, SB_MAXD = 64, SB_MAXQ = 96;
 // NT threads: 256 for one query chunk (4 workgroups a CU when samples x heads >= 1024), 1024 for the merged repeats (samples x heads = 256:
@@ -908,28 +907,24 @@ __global__ __launch_bounds__(NT) void attn_bwd_small_f32_k(const AttnBwdP bp) {
       sD[i][j] = dp;
     }
   };
-  const bool one_q = Sq <= SB_MAXT, one_k = Sk <= SB_MAXT;       // a single chunk stays in LDS: no reload
-  if (tid < SB_MAXQ) sdelta[tid] = 0.f;
-  // ---- pass 1: delta
-  for (int i0 = 0; i0 < Sq; i0 += SB_MAXT) {
-    const int ni = min(SB_MAXT, Sq - i0);
-    __syncthreads();
-    load_q(i0, ni);
-    for (int j0 = 0; j0 < Sk; j0 += SB_MAXT) {
-      const int nj = min(SB_MAXT, Sk - j0);
-      __syncthreads();
-      load_kv(j0, nj);
-      __syncthreads();
-      probs(i0, ni, nj);
-      __syncthreads();
-      if (tid < ni) {
-        float t = 0.f;
-        for (int j = 0; j < nj; ++j) t += sP[tid][j] * sD[tid][j];
-        sdelta[i0 + tid] += t;
+  // delta_i = rowsum(dO_i * O_i) from the forward's output (rounds 1 - 6a recomputed it as sum_j P_ij dP_ij in a first pass over every
+  // (query chunk, key chunk): 45 % of the kernel): four lanes per query row
+  const float* o_ = reinterpret_cast<const float*>(p.o) + b * p.o_sb + h * p.o_sh;
+  for (int it = tid; it < ((Sq * 4 + 63) & ~63); it += NT) {
+    const int i = it >> 2, c = it & 3;
+    float t = 0.f;
+    if (i < Sq)
+      for (int d = c * 4; d < D; d += 16) {
+        const float4 g = *reinterpret_cast<const float4*>(d_o + (int64_t)i * bp.do_ss + d);
+        const float4 y = *reinterpret_cast<const float4*>(o_ + (int64_t)i * p.o_ss + d);
+        t += (g.x * y.x + g.y * y.y) + (g.z * y.z + g.w * y.w);
       }
-    }
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (i < Sq && c == 0) sdelta[i] = t;
   }
-  // ---- pass 2: dQ of every query in registers (element it = tid + NT r of [Sq, D]); dK / dV of the key chunk in registers
+  const bool one_q = Sq <= SB_MAXT;                              // a single query chunk stays in LDS across the key chunks
+  // ---- dQ of every query in registers (element it = tid + NT r of [Sq, D]); dK / dV of the key chunk in registers
   constexpr int QR = SB_MAXQ * SB_MAXD / NT, KR = SB_MAXT * SB_MAXD / NT;
   float accq[QR];
 #pragma unroll
@@ -940,15 +935,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_small_f32_k(const AttnBwdP bp) {
 #pragma unroll
     for (int r = 0; r < KR; ++r) { acck[r] = 0.f; accv[r] = 0.f; }
     __syncthreads();
-    if (!one_k) load_kv(j0, nj);
+    load_kv(j0, nj);
     for (int i0 = 0; i0 < Sq; i0 += SB_MAXT) {
       const int ni = min(SB_MAXT, Sq - i0);
-      if (!(one_q && one_k)) {                          // (one chunk of each: sq / sdo / sk / sv / sP / sD are those of pass 1)
-        __syncthreads();
-        if (!one_q) load_q(i0, ni);
-        __syncthreads();
-        probs(i0, ni, nj);
-      }
+      __syncthreads();
+      if (!one_q || j0 == 0) load_q(i0, ni);
+      __syncthreads();
+      probs(i0, ni, nj);
       __syncthreads();
       for (int it = tid; it < ni * nj; it += NT) {
         const int i = it / nj, j = it - i * nj;
@@ -1608,7 +1601,8 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
       d->lse && d->Hq <= 65535 && d->B <= 65535 &&
       ((uintptr_t)d->q % 16 == 0) && ((uintptr_t)d->k % 16 == 0) && ((uintptr_t)d->v % 16 == 0) && ((uintptr_t)d->d_o % 16 == 0) &&
       d->q_ss % 4 == 0 && d->k_ss % 4 == 0 && d->v_ss % 4 == 0 && d->do_ss % 4 == 0 && d->q_sh % 4 == 0 && d->k_sh % 4 == 0 &&
-      d->v_sh % 4 == 0 && d->do_sh % 4 == 0 && d->q_sb % 4 == 0 && d->k_sb % 4 == 0 && d->v_sb % 4 == 0 && d->do_sb % 4 == 0) {
+      d->v_sh % 4 == 0 && d->do_sh % 4 == 0 && d->q_sb % 4 == 0 && d->k_sb % 4 == 0 && d->v_sb % 4 == 0 && d->do_sb % 4 == 0 &&
+      d->o && ((uintptr_t)d->o % 16 == 0) && d->o_ss % 4 == 0 && d->o_sh % 4 == 0 && d->o_sb % 4 == 0) {
     AttnBwdP bp;
     bp.f = make_params(d);
     bp.delta = nullptr;
