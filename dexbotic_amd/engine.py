@@ -104,6 +104,7 @@ class ParamStore:
         # stream).  The trainer turns it on and flushes what a pruned backward left behind.
         self.defer_wgrad = False
         self._wg_stash: Dict[tuple, dict] = {}
+        self._bg_stash: Dict[tuple, dict] = {}     # the same for the bias gradients: one column sum over all consumers' dY (functional._bgrad)
         # bf16 gradient arena (the reference's DeepSpeed bf16 recipe, script/deepspeed/zero3.json "bf16": gradients are bf16,
         # the optimizer keeps fp32 masters): the bf16 dW products write ONLY the bf16 arena (gradc) — half the epilogue bytes and
         # half of AdamW's gradient read.  Gradients other kernels produce (norm weights, biases, embeddings, the fp32 head) land
@@ -149,6 +150,7 @@ class ParamStore:
         # optimizer (torch.optim.AdamW on the arena views) moved the fp32 masters (w(): version counter of the arena).
         self.managed = False
         self._shadow_version: Optional[int] = None
+        self._view_cache: Dict[tuple, torch.Tensor] = {}
         self.native_epoch = 0                      # bumped by every native update of the masters (FusedAdamW): with master._version the
                                                    # key of caches derived from the weights (weights_key())
         self._grad_version: Optional[int] = None
@@ -223,13 +225,21 @@ class ParamStore:
         s0 = self.slots[names[0]]
         if self._pending:
             self.wait_pending(s0.bucket)
+        # the arenas never move and a view is two torch calls (~4 us of the launching thread; MemVLA's step asks for 3,700 of them):
+        # each (arena, names, shape) view is built once
+        key = (id(arena), names, shape if shape is None else tuple(shape))
+        v = self._view_cache.get(key)
+        if v is not None:
+            return v
         n = 0
         for nm in names:                      # must be packed back to back
             s = self.slots[nm]
             assert s.offset == s0.offset + n, f"{names} are not adjacent in the arena"
             n += s.numel
         v = arena[s0.offset:s0.offset + n]
-        return v.view(tuple(shape)) if shape is not None else v.view(s0.shape) if len(names) == 1 else v
+        v = v.view(tuple(shape)) if shape is not None else v.view(s0.shape) if len(names) == 1 else v
+        self._view_cache[key] = v
+        return v
 
     def w(self, *names: str, shape: Optional[Sequence[int]] = None) -> torch.Tensor:
         """compute-dtype weight view (bf16 shadow, or the fp32 master in fp32 mode); several adjacent
@@ -326,19 +336,24 @@ class ParamStore:
 
     def flush_wgrads(self) -> None:
         """weight-gradient products still waiting for a last use that never came (autograd pruned one of the consumers)"""
-        if not self._wg_stash:
+        if not self._wg_stash and not self._bg_stash:
             return
-        from .functional import _wgrad_flush
+        from .functional import _bgrad_flush, _wgrad_flush
         for key in list(self._wg_stash):
             for nm in key:
                 self._uses[nm] = 1
             _wgrad_flush(self, key)
+        for key in list(self._bg_stash):
+            for nm in key:
+                self._uses[nm] = 1
+            _bgrad_flush(self, key)
 
     def drop_pending_wgrads(self) -> None:
         """forget the weight-gradient products and accumulation pairs of a backward that was ABORTED (out of memory in the
         middle of a coalesced pass, trainer.NativeTrainer.micro_step): nothing is launched, nothing is allocated — the pass is
         re-run from begin_step, whose first writes replace whatever the aborted one left in the gradient arenas"""
         self._wg_stash.clear()
+        self._bg_stash.clear()
         self._accum_stash.clear()
         self.join_wgrad()
 

@@ -196,6 +196,7 @@ def _wgrad_product(st: ParamStore, names, dy2d: torch.Tensor, x2d: torch.Tensor,
 
 
 _SKIP_BGRAD = os.environ.get("DXA_TUNE_SKIP_BGRAD") == "1"
+_NO_DEFER_BGRAD = os.environ.get("DXA_NO_DEFER_BGRAD") == "1"      # A/B: one column sum per consumer of a bias (rounds 1 - 6a)
 
 
 def _bgrad(st: ParamStore, names, dy2d: torch.Tensor) -> None:
@@ -206,13 +207,40 @@ def _bgrad(st: ParamStore, names, dy2d: torch.Tensor) -> None:
     if _SKIP_BGRAD:            # tuning only (WRONG gradients): what the step would cost if the bias column sums were free
         st.mark_written(*names)
         return
+    # a bias applied k times in one forward (MemVLA's per-sample retrieval blocks: 16 samples x 2 roles x 11 linears): the k dY are
+    # collected like the weight's (dY, X) pairs (_wgrad) and ONE column sum over all their rows writes db once — k - 1 launches of the
+    # backward's host-bound stretch less per bias (profiles/r06_host_uploads.txt: the bank's backward is issued at 21 us a launch)
+    key = tuple(names)
+    pending = st._uses.get(names[0], 0)
+    acc0 = None
+    if st.defer_wgrad and not _NO_DEFER_BGRAD and (pending > 1 or key in st._bg_stash):
+        ent = st._bg_stash.get(key)
+        if ent is None:
+            ent = st._bg_stash[key] = {"acc0": st.accum_flag(*names), "dy": []}
+        ent["dy"].append(dy2d)
+        if pending > 1:
+            st.mark_written(*names)                      # counts this consumer down; the bucket waits for the last one
+            return
+        ent = st._bg_stash.pop(key)
+        dy2d = ent["dy"][0] if len(ent["dy"]) == 1 else torch.cat(ent["dy"], dim=0)
+        acc0 = ent["acc0"]
+    _bgrad_now(st, names, n, dy2d, st.accum_flag(*names) if acc0 is None else acc0)
+
+
+def _bgrad_flush(st: ParamStore, key: tuple) -> None:
+    ent = st._bg_stash.pop(key)
+    dy = ent["dy"][0] if len(ent["dy"]) == 1 else torch.cat(ent["dy"], dim=0)
+    _bgrad_now(st, key, sum(st.slots[nm].numel for nm in key), dy, ent["acc0"])
+
+
+def _bgrad_now(st: ParamStore, names, n: int, dy2d: torch.Tensor, accumulate: bool) -> None:
     side = st.wgrad_stream if st.bgrad_on_side else None
     if side is None:
-        K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
+        K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=accumulate)
     else:
         side.wait_stream(torch.cuda.current_stream(st.device))
         with torch.cuda.stream(side):
-            K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=st.accum_flag(*names))
+            K.colsum(dy2d, out=st.g(*names, shape=(n,)), accumulate=accumulate)
         dy2d.record_stream(side)
         st._wgrad_pending = True
     st.mark_written(*names)

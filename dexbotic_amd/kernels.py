@@ -128,11 +128,14 @@ def _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb) -> bool:
             and 6 * max(M, N) * K < (1 << 31))
 
 
+_NB1 = (1, 1, 1)
+
+
 def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int,
          out: torch.Tensor, ldc: int, *, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, ldr: int = 0, act: int = L.ACT_NONE,
          aux_out: Optional[torch.Tensor] = None, mulgrad: Optional[torch.Tensor] = None, ldg: int = 0,
-         alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = (1, 1, 1),
+         alpha: float = 1.0, accumulate: bool = False, nb: Sequence[int] = _NB1,
          sA: Sequence[int] = (0, 0, 0), sB: Sequence[int] = (0, 0, 0), sC: Sequence[int] = (0, 0, 0),
          sR: Sequence[int] = (0, 0, 0), sG: Sequence[int] = (0, 0, 0), epi_f32: bool = False,
          mirror: Optional[torch.Tensor] = None, sumsq: Optional[torch.Tensor] = None,
@@ -167,8 +170,11 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
                 or sumsq.numel() != gemm_sumsq_slots(M, N):
             raise L.DxaError("gemm: sumsq must be gemm_sumsq_slots(M, N) contiguous floats (unbatched output)")
         d.sumsq = _ptr(sumsq)
-    for i in range(3):
-        d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
+    if nb is _NB1 or tuple(nb) == (1, 1, 1):         # (a fresh descriptor is zeroed: the strides of an unbatched product stay 0)
+        d.nb[0] = d.nb[1] = d.nb[2] = 1
+    else:
+        for i in range(3):
+            d.nb[i], d.sA[i], d.sB[i], d.sC[i], d.sR[i], d.sG[i] = nb[i], sA[i], sB[i], sC[i], sR[i], sG[i]
     K_all = K
     if a2 is not None:                         # TN: a second pair of operands contracted into the same product
         if layout != L.TN or b2 is None or a2.shape[1] != M or b2.shape[1] != N or a2.shape[0] != b2.shape[0] \
