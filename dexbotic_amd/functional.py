@@ -517,6 +517,13 @@ def _ln_bwd(st: ParamStore, dy, x, wn: Optional[str], bn: Optional[str], mean, r
         dx, _, _ = K.layernorm_bwd(dy, x, None, mean, rstd, residual=residual)
         return dx
     tr = st.trainable(wn)
+    if tr and bn is not None and st.defer_wgrad and not _NO_DEFER_BGRAD and (st._uses.get(wn, 0) > 1 or (wn, bn) in st._bg_stash) and \
+            st.slots[bn].offset == st.slots[wn].offset + st.slots[wn].numel:
+        # an affine LayerNorm applied k times per forward (MemVLA's retrieval blocks): the kernel's per-row-block partial sums
+        # [blocks, dw | db] of the k calls are folded by ONE column sum when the last one arrives (_bgrad's stash) instead of one per call
+        dx, part = K.layernorm_bwd(dy, x, st.w(wn), mean, rstd, residual=residual, return_part=True)
+        _bgrad(st, (wn, bn), part)
+        return dx
     dx, _, _ = K.layernorm_bwd(dy, x, st.w(wn), mean, rstd, dw_out=st.g(wn) if tr else None,
                                db_out=st.g(bn) if tr else None, accumulate=st.accum_flag(wn), want_dw=tr, residual=residual)
     if tr:

@@ -12,10 +12,29 @@ keeps per-stream scratch for the life of the process.
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import os
 from typing import Callable, Dict, Hashable
 
 import torch
+
+
+@contextlib.contextmanager
+def capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
+    """``torch.cuda.graph(graph, stream=stream)`` with Python's cyclic garbage collector held off for the duration of the capture.
+    torch collects once BEFORE the capture begins; a generation-0 collection that the capture's own allocations trigger in the middle
+    of it finalises whatever cyclic garbage earlier code left behind (models, trainers with their side streams and events, older graphs)
+    — destructors that talk to the HIP runtime while a stream is capturing (global capture mode) abort the process (seen once in the GPU
+    suite: `Fatal Python error: Aborted ... Garbage-collecting` inside a captured request, round 6)."""
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream):
+            yield
+    finally:
+        if was_on:
+            gc.enable()
 
 
 def enabled(default: bool = True) -> bool:
@@ -57,7 +76,7 @@ class GraphCache:
                 ent["static"][k].copy_(v, non_blocking=True)
             if ent["graph"] is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.stream):
+                with capture(g, self.stream):
                     ent["out"] = fn(**ent["static"])
                 ent["graph"] = g
             ent["graph"].replay()

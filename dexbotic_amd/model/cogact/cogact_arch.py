@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as Fn
+from ... import graphs
 from ...engine import building
 from ..dexbotic_arch import (ActionOutputForCausalLM, CausalLMOutputDexbotic, DexboticConfig, DexboticForCausalLM,
                              register_with_hf,
@@ -234,7 +235,7 @@ class CogACTForCausalLM(DexboticForCausalLM, ActionOutputForCausalLM):
             ent["plan"].copy_(ent["plan_host"], non_blocking=True)
             if ent["graph"] is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=ent["stream"]):
+                with graphs.capture(g, ent["stream"]):
                     ent["out"], _ = self._sample_actions(ent["images"], ent["plan"], B, S, ent["noise"], cfg_scale,
                                                          num_ddim_steps)
                 ent["graph"] = g

@@ -319,7 +319,8 @@ class MemVLAModel(CogActModel):
 class MemVLAForCausalLM(CogACTForCausalLM):
     config_class = MemVLAConfig
     coalescible_micro_batches = False      # the memory bank walks the batch in order: micro-batches are not interchangeable
-    gradient_side_stream = False           # measured slower here (trainer.NativeTrainer)
+    gradient_side_stream = True            # round 6: 310.7 -> 307.8 ms per step now that the step is GPU-bound (profiles/r06_memvla_hostbound.txt);
+                                           # while its 9,000 launches were host-bound it measured 363 -> 372 (round 4) and was off
 
     def _real_init(self, config: MemVLAConfig):
         self.model = MemVLAModel(config, self.store)

@@ -144,6 +144,9 @@ def posemb_sincos(time: np.ndarray, dim: int, min_period: float = 4e-3, max_peri
 
 class Pi0ForCausalLM(NativePreTrainedMixin, nn.Module, ActionOutputForCausalLM):
     config_class = Pi0Config
+    # trainer.NativeTrainer: the bias gradients' column sums (and any fp32 dW product) beside the dX chain on a side stream:
+    # 250.0 -> 245.3 ms per step, two alternating runs each in one box (profiles/r06_memvla_hostbound.txt)
+    gradient_side_stream = True
 
     def __init__(self, config: Pi0Config, device=None, train: bool = True):
         super().__init__()

@@ -275,8 +275,14 @@ def test_fp32_five_optimizer_steps_follow_the_reference_trajectory(real_ref, tra
 # observed (round 5): losses 2.8e-4 (reference's own gap 7.0e-4), norms 5.1e-4 (4.3e-4), movement of the big matrices 3.9e-2 ..
 # 5.1e-2 (3.4e-2 .. 4.0e-2), k_proj bias 8.7e-3, norm weight 3.4e-3, head 1.5e-2 / 4.5e-2.  Floors = 1.5 x observed where the
 # reference's own gap is smaller than the observation.
+# The k_proj bias is a special case: a constant added to every key moves q.k by a per-query constant, which the softmax ignores — its
+# gradient exists only through RoPE (a different rotation per position) and is the sum of nearly cancelling terms, and AdamW then
+# normalises whatever is left.  Its 5-step movement is therefore decided by last-bit effects anywhere upstream: measured on ONE tree in
+# round 6 (scripts/sessions/r06_kbias.sh), 9.0e-3 with the head's attention backward on the generic kernels, 2.30e-2 with the one-launch
+# kernel, 2.36e-2 with the decoder's few-row products on the 192-row tiles — the same arithmetic in a different summation order each
+# time.  Its floor is the level at which the big matrices' movement is accepted (1.75 x 3.4e-2 .. 4.0e-2), not 1.5 x one realisation.
 TRAJ_BF16_X = 1.75
-TRAJ_BF16_FLOOR = {"losses": 4.5e-4, "norms": 8e-4, "delta": 1.5e-2}
+TRAJ_BF16_FLOOR = {"losses": 4.5e-4, "norms": 8e-4, "delta/model.llm.layers.0.self_attn.k_proj.bias": 6e-2, "delta": 1.5e-2}
 
 
 def test_bf16_five_optimizer_steps_track_the_reference_under_autocast(real_ref, traj_ref):
