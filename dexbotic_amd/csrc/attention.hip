@@ -986,6 +986,168 @@ __global__ __launch_bounds__(NT) void attn_bwd_small_f32_k(const AttnBwdP bp) {
   }
 }
 
+// The same backward for MORE than 32 queries per (sample, head) — MemVLA's perceptual attention: the 4 x 17 rows of a sample's diffusion
+// repeats over its 256 perceptual keys, 16 x 16 (sample, head) pairs, one workgroup of 1024 threads each.  attn_bwd_small_f32_k reads two
+// LDS words per FMA (one thread per output element): 63 MB through a compute unit's LDS per workgroup = the 237 us it took at 128 B/clk.
+// Here every thread keeps a small block of outputs in registers and reads its operands as 16-byte pieces of rows padded to 68 floats:
+//   all (<= 96) queries and their dO rows stay in LDS, keys / values come in chunks of 64;
+//   S, dP:   thread (ti, tj) -> rows ti + 32 r (r < 3) x keys tj, tj + 32: 10 ds_read_b128 per 48 FMAs; P and dS written once;
+//   then     threads 0 .. 511:    dQ rows ti + 32 r x one 4-column piece (registers across the key chunks): 4 reads per 12 FMAs,
+//            threads 512 .. 1023: dK, dV of keys tj, tj + 32 x one 4-column piece:                          6 reads per 16 FMAs.
+// 21 MB of LDS reads per workgroup instead of 63.  The sums run in the same order (d, j, i ascending) as in attn_bwd_small_f32_k:
+// bit-identical results.  139 KiB of dynamic LDS.
+constexpr int S2_QP = 96, S2_KC = 64, S2_LD = 68;
+constexpr int S2_LDS_BYTES = ((4 * S2_QP + 2 * S2_KC) * S2_LD + 2 * S2_QP) * 4;
+__global__ __launch_bounds__(1024) void attn_bwd_small2_f32_k(const AttnBwdP bp) {
+  const AttnP& p = bp.f;
+  extern __shared__ __attribute__((aligned(16))) float s2_mem[];
+  typedef float row_t[S2_LD];
+  row_t* sq = reinterpret_cast<row_t*>(s2_mem);
+  row_t* sdo = sq + S2_QP;
+  row_t* sP = sdo + S2_QP;
+  row_t* sD = sP + S2_QP;
+  row_t* sk = sD + S2_QP;
+  row_t* sv = sk + S2_KC;
+  float* sdelta = reinterpret_cast<float*>(sv + S2_KC);
+  float* slse = sdelta + S2_QP;
+  const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const int Sq = p.Sq, Sk = p.Sk, D = p.D, D4 = D >> 2;
+  const int nrb = (Sq + 31) >> 5;                                // row blocks of 32 queries (<= 3)
+  const float* q = reinterpret_cast<const float*>(p.q) + b * p.q_sb + h * p.q_sh;
+  const float* k = reinterpret_cast<const float*>(p.k) + b * p.k_sb + h * p.k_sh;
+  const float* v = reinterpret_cast<const float*>(p.v) + b * p.v_sb + h * p.v_sh;
+  const float* o_ = reinterpret_cast<const float*>(p.o) + b * p.o_sb + h * p.o_sh;
+  const float* d_o = reinterpret_cast<const float*>(bp.d_o) + b * bp.do_sb + h * bp.do_sh;
+  float* dq = reinterpret_cast<float*>(bp.dq) + b * bp.dq_sb + h * bp.dq_sh;
+  float* dk = reinterpret_cast<float*>(bp.dk) + b * bp.dk_sb + h * bp.dk_sh;
+  float* dv = reinterpret_cast<float*>(bp.dv) + b * bp.dv_sb + h * bp.dv_sh;
+  const float* lse = p.lse + ((int64_t)b * p.Hq + h) * Sq;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // queries, their dO rows (zero rows up to the next multiple of 32), lse, delta_i = rowsum(dO_i * O_i)
+  for (int it = tid; it < nrb * 32 * D4; it += 1024) {
+    const int i = it / D4, d = (it - i * D4) * 4;
+    float4 a = z4, g = z4;
+    if (i < Sq) {
+      a = *reinterpret_cast<const float4*>(q + (int64_t)i * p.q_ss + d);
+      g = *reinterpret_cast<const float4*>(d_o + (int64_t)i * bp.do_ss + d);
+    }
+    *reinterpret_cast<float4*>(&sq[i][d]) = a;
+    *reinterpret_cast<float4*>(&sdo[i][d]) = g;
+  }
+  for (int it = tid; it < ((Sq * 4 + 63) & ~63); it += 1024) {
+    const int i = it >> 2, c = it & 3;
+    float t = 0.f;
+    if (i < Sq)
+      for (int d = c * 4; d < D; d += 16) {
+        const float4 g = *reinterpret_cast<const float4*>(d_o + (int64_t)i * bp.do_ss + d);
+        const float4 y = *reinterpret_cast<const float4*>(o_ + (int64_t)i * p.o_ss + d);
+        t += (g.x * y.x + g.y * y.y) + (g.z * y.z + g.w * y.w);
+      }
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (i < Sq && c == 0) { sdelta[i] = t; slse[i] = lse[i]; }
+  }
+  const int ti = tid >> 5, tj = tid & 31, ti0 = ti & ~1;         // S / dP role
+  const bool q_role = tid < 512;                                 // dQ role | dK, dV role
+  const int t2 = tid & 511, tr = t2 >> 4, tq = (t2 & 15) * 4;    // row (query block row | key) and first column of the 4-column piece
+  const bool col_ok = tq < D;
+  float4 accq[3] = {z4, z4, z4};
+  for (int j0 = 0; j0 < Sk; j0 += S2_KC) {
+    const int nj = min(S2_KC, Sk - j0);
+    __syncthreads();                                             // the previous chunk's readers are done (first pass: q / dO / delta visible)
+    for (int it = tid; it < S2_KC * D4; it += 1024) {
+      const int j = it / D4, d = (it - j * D4) * 4;
+      float4 a = z4, g = z4;
+      if (j < nj) {
+        a = *reinterpret_cast<const float4*>(k + (int64_t)(j0 + j) * p.k_ss + d);
+        g = *reinterpret_cast<const float4*>(v + (int64_t)(j0 + j) * p.v_ss + d);
+      }
+      *reinterpret_cast<float4*>(&sk[j][d]) = a;
+      *reinterpret_cast<float4*>(&sv[j][d]) = g;
+    }
+    __syncthreads();
+    {
+      float sa[3][2], da[3][2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { sa[r][0] = sa[r][1] = da[r][0] = da[r][1] = 0.f; }
+      for (int d = 0; d < D; d += 4) {
+        const float4 k0 = *reinterpret_cast<const float4*>(&sk[tj][d]), k1 = *reinterpret_cast<const float4*>(&sk[tj + 32][d]);
+        const float4 v0 = *reinterpret_cast<const float4*>(&sv[tj][d]), v1 = *reinterpret_cast<const float4*>(&sv[tj + 32][d]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          if (32 * r + ti0 < Sq) {                               // (uniform over the wave: its two rows ti0, ti0 + 1 of this block)
+            const float4 a = *reinterpret_cast<const float4*>(&sq[ti + 32 * r][d]);
+            const float4 g = *reinterpret_cast<const float4*>(&sdo[ti + 32 * r][d]);
+            sa[r][0] += a.x * k0.x; sa[r][0] += a.y * k0.y; sa[r][0] += a.z * k0.z; sa[r][0] += a.w * k0.w;
+            sa[r][1] += a.x * k1.x; sa[r][1] += a.y * k1.y; sa[r][1] += a.z * k1.z; sa[r][1] += a.w * k1.w;
+            da[r][0] += g.x * v0.x; da[r][0] += g.y * v0.y; da[r][0] += g.z * v0.z; da[r][0] += g.w * v0.w;
+            da[r][1] += g.x * v1.x; da[r][1] += g.y * v1.y; da[r][1] += g.z * v1.z; da[r][1] += g.w * v1.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (32 * r + ti0 < Sq) {
+          const int i = ti + 32 * r;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int j = tj + 32 * c;
+            float pr = 0.f, ds = 0.f;
+            if (i < Sq && j < nj) {
+              pr = expf(sa[r][c] * p.scale - slse[i]);
+              ds = pr * (da[r][c] - sdelta[i]) * p.scale;
+            }
+            sP[i][j] = pr;
+            sD[i][j] = ds;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (q_role) {
+      if (col_ok) {
+        for (int j = 0; j < nj; ++j) {
+          const float4 kv = *reinterpret_cast<const float4*>(&sk[j][tq]);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            if (32 * r + tr < Sq) {
+              const float a = sD[tr + 32 * r][j];
+              accq[r].x += a * kv.x; accq[r].y += a * kv.y; accq[r].z += a * kv.z; accq[r].w += a * kv.w;
+            }
+          }
+        }
+      }
+    } else if (col_ok) {
+      float4 ak[2] = {z4, z4}, av[2] = {z4, z4};
+      for (int i = 0; i < Sq; ++i) {
+        const float4 qv = *reinterpret_cast<const float4*>(&sq[i][tq]);
+        const float4 gv = *reinterpret_cast<const float4*>(&sdo[i][tq]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float ds = sD[i][tr + 32 * c], pr = sP[i][tr + 32 * c];
+          ak[c].x += ds * qv.x; ak[c].y += ds * qv.y; ak[c].z += ds * qv.z; ak[c].w += ds * qv.w;
+          av[c].x += pr * gv.x; av[c].y += pr * gv.y; av[c].z += pr * gv.z; av[c].w += pr * gv.w;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = tr + 32 * c;
+        if (j < nj) {
+          *reinterpret_cast<float4*>(dk + (int64_t)(j0 + j) * bp.dk_ss + tq) = ak[c];
+          *reinterpret_cast<float4*>(dv + (int64_t)(j0 + j) * bp.dv_ss + tq) = av[c];
+        }
+      }
+    }
+  }
+  if (q_role && col_ok) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int i = tr + 32 * r;
+      if (r < nrb && i < Sq) *reinterpret_cast<float4*>(dq + (int64_t)i * bp.dq_ss + tq) = accq[r];
+    }
+  }
+}
+
 template <int D, int NW, int DV = D>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_k(const AttnBwdP bp) {
   const AttnP& p = bp.f;
@@ -1610,7 +1772,20 @@ extern "C" int dxa_attn_bwd(const dxa_attn_desc* d, void* workspace, size_t work
     bp.dq = (char*)d->dq; bp.dq_sb = d->dq_sb; bp.dq_sh = d->dq_sh; bp.dq_ss = d->dq_ss;
     bp.dk = (char*)d->dk; bp.dk_sb = d->dk_sb; bp.dk_sh = d->dk_sh; bp.dk_ss = d->dk_ss;
     bp.dv = (char*)d->dv; bp.dv_sb = d->dv_sb; bp.dv_sh = d->dv_sh; bp.dv_ss = d->dv_ss;
-    if (d->Sq > SB_MAXT) hipLaunchKernelGGL(attn_bwd_small_f32_k<1024>, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(1024), 0, (hipStream_t)stream, bp);
+    // more than one chunk of queries: the register-blocked kernel (16-byte aligned dq / dk / dv rows; DXA_ATTN_SMALL_BWD_V1=1: the
+    // one-element-per-thread kernel at 1024 threads, rounds 6a-b)
+    static const bool v1_only = getenv("DXA_ATTN_SMALL_BWD_V1") != nullptr;
+    const bool v2_ok = !v1_only && ((uintptr_t)d->dq % 16 == 0) && ((uintptr_t)d->dk % 16 == 0) && ((uintptr_t)d->dv % 16 == 0) &&
+                       d->dq_ss % 4 == 0 && d->dk_ss % 4 == 0 && d->dv_ss % 4 == 0 && d->dq_sh % 4 == 0 && d->dk_sh % 4 == 0 &&
+                       d->dv_sh % 4 == 0 && d->dq_sb % 4 == 0 && d->dk_sb % 4 == 0 && d->dv_sb % 4 == 0;
+    if (d->Sq > SB_MAXT && v2_ok) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small2_f32_k), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS_BYTES);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_small2_f32_k, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(1024), S2_LDS_BYTES, (hipStream_t)stream, bp);
+    } else if (d->Sq > SB_MAXT) hipLaunchKernelGGL(attn_bwd_small_f32_k<1024>, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(1024), 0, (hipStream_t)stream, bp);
     else hipLaunchKernelGGL(attn_bwd_small_f32_k<256>, dim3((unsigned)d->Hq, (unsigned)d->B), dim3(256), 0, (hipStream_t)stream, bp);
     DXA_CHECK_LAUNCH();
     return DXA_OK;

@@ -1391,3 +1391,28 @@ def test_attention_small_f32_backward_one_launch(Sq, Sk, monkeypatch):
         outs[generic] = (dq, dk, dv)
     for a, b_ in zip(outs[False], outs[True]):
         assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("Sq,Sk,D", [(68, 256, 32), (40, 100, 48), (96, 129, 64)])
+def test_attention_small_f32_backward_register_blocked_token_major(Sq, Sk, D):
+    """more than 32 queries per (sample, head): attn_bwd_small2_f32_k (every thread a block of outputs in registers, 16-byte LDS reads;
+    MemVLA's 68 x 256 perceptual attention) on token-major [B, S, H, D] operands as the DiT blocks hold them, head widths below 64,
+    a ragged last key chunk — against double-precision autograd and the generic path"""
+    B, H = 2, 3
+    scale = D ** -0.5
+    mk = lambda S, seed: rnd(B, S, H, D, dtype=torch.float32, seed=seed).permute(0, 2, 1, 3)
+    q, k, v, do = mk(Sq, 80), mk(Sk, 81), mk(Sk, 82), mk(Sq, 83)
+    o = torch.empty(B, Sq, H, D, device=DEV, dtype=torch.float32).permute(0, 2, 1, 3)
+    lse = K.attn_fwd(q, k, v, o, causal=False, scale=scale)
+    qr, kr, vr = (t.double().detach().clone().requires_grad_(True) for t in (q, k, v))
+    (torch.softmax(qr @ kr.transpose(-1, -2) * scale, -1) @ vr).backward(do.double())
+    outs = {}
+    for generic in (False, True):
+        dq, dk, dv = (torch.full((B, S, H, D), float("nan"), device=DEV).permute(0, 2, 1, 3) for S in (Sq, Sk, Sk))
+        K.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, causal=False, scale=scale, force_generic=generic)
+        assert_close(dq, qr.grad, 1e-4, 1e-4, "dq")
+        assert_close(dk, kr.grad, 1e-4, 2e-4, "dk")
+        assert_close(dv, vr.grad, 1e-4, 2e-4, "dv")
+        outs[generic] = (dq, dk, dv)
+    for a, b_ in zip(outs[False], outs[True]):
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-6
