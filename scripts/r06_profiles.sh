@@ -3,7 +3,7 @@
 #   gpurun -- 'bash scripts/r06_profiles.sh [tests|bench|trace|timeline|infer|pi0|memvla|decode|pmc ...]'
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/prof
 what="${@:-tests bench}"
-B="python $R/bench.py --no-cpu-baseline --no-latency --no-secondary --no-recipe"
+B="python $R/bench.py --no-cpu-baseline --no-latency --no-secondary --no-recipe --no-dp-emulation"   # (the timeline takes the LAST step of the trace: it must be a headline step)
 for w in $what; do case $w in
 tests)   # the GPU suite
   timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v "^ROCm version\|^Hostname\|^Librccl\|^RCCL\|^HIP version" | tail -6 | tee gpurun_out/r06_gpu_tests.txt ;;
