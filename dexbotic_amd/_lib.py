@@ -47,6 +47,10 @@ class GemmDesc(C.Structure):
     ]
 
 
+class Split3Op(C.Structure):
+    _fields_ = [("src", _vp), ("ld", _i64), ("dst", _vp), ("rows", _i64), ("cols", _i64), ("pad", _i64), ("side", _i32), ("transposed", _i32)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("dtype", _i32), ("B", _i32), ("Hq", _i32), ("Hkv", _i32), ("Sq", _i32), ("Sk", _i32), ("D", _i32),
@@ -101,6 +105,7 @@ SIGNATURES = {
     "dxa_gemm": (_int, [C.POINTER(GemmDesc), _vp]),
     "dxa_split3": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp]),
     "dxa_split3_t": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _int, _vp]),
+    "dxa_split3_pair": (_int, [C.POINTER(Split3Op), C.POINTER(Split3Op), _vp]),
     "dxa_rmsnorm_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),
     "dxa_rmsnorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _vp]),
     "dxa_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _int, _vp]),

@@ -2343,6 +2343,87 @@ extern "C" int dxa_split3_t(const float* src, int64_t ld, void* dst, int64_t R, 
   DXA_CHECK_LAUNCH();
   return DXA_OK;
 }
+namespace {
+// both operand splits of one bf16x3 product in one launch: blocks [0, a.nblocks) write operand a, the rest operand b, each with the
+// body of split3_k (grid-stride over its own blocks) or of split3_t_k (its 32 x 32 tiles flattened)
+struct S3Op { const float* src; int64_t ld; bf16_t* dst; int64_t rows, cols, pad; int side, transposed; unsigned nblocks, tiles_x; };
+__global__ __launch_bounds__(256) void split3_pair_k(const S3Op a, const S3Op b) {
+  __shared__ float tile[32][33];
+  const bool first = blockIdx.x < a.nblocks;
+  const S3Op& o = first ? a : b;
+  const unsigned bid = first ? blockIdx.x : blockIdx.x - a.nblocks;
+  if (!o.transposed) {
+    const int64_t c4 = o.cols >> 2;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < o.rows * c4; i += (int64_t)o.nblocks * 256) {
+      const int64_t r = i / c4, c = (i - r * c4) * 4;
+      float x[4];
+      Vec<float, 4>::ld(x, o.src + r * o.ld + c);
+      float hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = bf2f(f2bf(x[e]));
+        lo[e] = x[e] - hi[e];
+      }
+      bf16_t* d = o.dst + r * 3 * o.cols + c;
+      Vec<bf16_t, 4>::st(d, hi);
+      Vec<bf16_t, 4>::st(d + o.cols, o.side == 0 ? hi : lo);
+      Vec<bf16_t, 4>::st(d + 2 * o.cols, o.side == 0 ? lo : hi);
+    }
+    return;
+  }
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t R = o.rows, C_ = o.cols, Rp = o.pad;
+  const int64_t r0 = (int64_t)(bid / o.tiles_x) * 32, c0 = (int64_t)(bid % o.tiles_x) * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C_) ? o.src[r * o.ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C_ && r < Rp) {
+      const float x = tile[tx][ty + 8 * i];
+      const bf16_t hb = f2bf(x);
+      const bf16_t lb = f2bf(x - bf2f(hb));
+      bf16_t* d = o.dst + c * 3 * Rp + r;
+      d[0] = hb;
+      d[Rp] = o.side == 0 ? hb : lb;
+      d[2 * Rp] = o.side == 0 ? lb : hb;
+    }
+  }
+}
+int s3_fill(const dxa_split3_op* u, S3Op* o) {
+  DXA_CHECK_ARG(u && u->rows >= 0 && u->cols >= 0 && (u->side == 0 || u->side == 1) && u->ld >= u->cols, "dxa_split3_pair: bad operand");
+  o->src = u->src; o->ld = u->ld; o->dst = (bf16_t*)u->dst; o->rows = u->rows; o->cols = u->cols; o->pad = u->pad; o->side = u->side;
+  o->transposed = u->transposed != 0; o->nblocks = 0; o->tiles_x = 1;
+  if (u->rows == 0 || u->cols == 0) return DXA_OK;
+  DXA_CHECK_ARG(u->src && u->dst, "dxa_split3_pair: null buffer");
+  if (o->transposed) {
+    DXA_CHECK_ARG(u->pad >= u->rows, "dxa_split3_pair: pad < rows");
+    o->tiles_x = (unsigned)((u->cols + 31) / 32);
+    const int64_t nb = (int64_t)o->tiles_x * ((u->pad + 31) / 32);
+    DXA_CHECK_ARG(nb < (1ll << 30), "dxa_split3_pair: operand too large");
+    o->nblocks = (unsigned)nb;
+  } else {
+    DXA_CHECK_ARG(u->cols % 4 == 0 && u->ld % 4 == 0 && (reinterpret_cast<uintptr_t>(u->src) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(u->dst) % 8) == 0,
+                  "dxa_split3_pair: cols and ld must be multiples of 4 and the buffers 16-byte aligned");
+    o->nblocks = (unsigned)dxa_grid1d(u->rows * (u->cols / 4), 256);
+  }
+  return DXA_OK;
+}
+}  // namespace
+extern "C" int dxa_split3_pair(const dxa_split3_op* a, const dxa_split3_op* b, dxa_stream_t stream) {
+  S3Op oa, ob;
+  if (int rc = s3_fill(a, &oa)) return rc;
+  if (int rc = s3_fill(b, &ob)) return rc;
+  if (oa.nblocks + ob.nblocks == 0) return DXA_OK;
+  hipLaunchKernelGGL(split3_pair_k, dim3(oa.nblocks + ob.nblocks), dim3(256), 0, (hipStream_t)stream, oa, ob);
+  DXA_CHECK_LAUNCH();
+  return DXA_OK;
+}
 extern "C" int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t cols, int side, dxa_stream_t stream) {
   DXA_CHECK_ARG(rows >= 0 && cols >= 0 && (side == 0 || side == 1), "dxa_split3: bad arguments");
   if (rows == 0 || cols == 0) return DXA_OK;

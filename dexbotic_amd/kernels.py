@@ -95,6 +95,38 @@ def split3_t(x: torch.Tensor, pad_to: int, side: int) -> torch.Tensor:
     return out
 
 
+_NO_SPLIT_PAIR = __import__("os").environ.get("DXA_NO_SPLIT_PAIR") == "1"
+
+
+def split3_pair(a: torch.Tensor, a_t: bool, b: torch.Tensor, b_t: bool, pad_to: int = 1, a_dims=None, b_dims=None
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """both operands of one bf16x3 product in ONE launch (dxa_split3_pair): ``a`` as the A operand (hi | hi | lo), ``b`` as the B operand
+    (hi | lo | hi); ``*_t``: the split of the TRANSPOSE ([R, C] -> [C, 3 Rp], Rp = R rounded up to ``pad_to``) as split3_t writes it;
+    ``*_dims`` = (rows, cols, ld) of an operand that is not simply a row-major 2-D tensor (gemm()'s explicit extents)"""
+    if _NO_SPLIT_PAIR:                                 # A/B: one launch per operand (rounds 2 - 6b)
+        res = []
+        for x, t, side, dims in ((a, a_t, 0, a_dims), (b, b_t, 1, b_dims)):
+            res.append(split3_t(x, pad_to, side) if t else split3(x, *(dims if dims is not None else (x.shape[0], x.shape[1], _row_major(x, "x"))), side))
+        return res[0], res[1]
+    ops, outs = [], []
+    for x, t, side, dims in ((a, a_t, 0, a_dims), (b, b_t, 1, b_dims)):
+        R, C_, ld = dims if dims is not None else (x.shape[0], x.shape[1], _row_major(x, "x"))
+        o = L.Split3Op()
+        o.src, o.ld, o.rows, o.cols, o.side, o.transposed = _ptr(x), ld, R, C_, side, int(t)
+        if t:
+            Rp = (R + pad_to - 1) // pad_to * pad_to
+            out = torch.empty((C_, 3 * Rp), device=x.device, dtype=torch.bfloat16)
+            o.pad = Rp
+        else:
+            out = torch.empty((R, 3 * C_), device=x.device, dtype=torch.bfloat16)
+            o.pad = 0
+        o.dst = _ptr(out)
+        ops.append(o)
+        outs.append(out)
+    L.check(lib.dxa_split3_pair(C.byref(ops[0]), C.byref(ops[1]), _stream()), "dxa_split3_pair")
+    return outs[0], outs[1]
+
+
 def _x3_t_ok(M: int, N: int, Kc: int, out: torch.Tensor) -> bool:
     """the split-bf16 NT product is admissible for these extents (same rule as _x3_eligible; Kc = contraction length)"""
     return (F32_GEMM_MODE == "bf16x3" and out.dtype == torch.float32 and M >= 128 and N >= 128 and Kc >= 64 and Kc % 32 == 0
@@ -107,7 +139,7 @@ def mm_tn_f32(a: torch.Tensor, b: torch.Tensor, *, out: torch.Tensor, **kw) -> t
     Kc, M = a.shape
     N = b.shape[1]
     if a.dtype == torch.float32 and b.dtype == torch.float32 and _x3_t_ok(M, N, (Kc + 31) // 32 * 32, out):
-        a3, b3 = split3_t(a, 32, 0), split3_t(b, 32, 1)
+        a3, b3 = split3_pair(a, True, b, True, pad_to=32)
         Kp = a3.shape[1] // 3
         kw = _ld_kwargs(kw, out)
         return gemm(L.NT, a3, b3, M, N, 3 * Kp, 3 * Kp, 3 * Kp, out, _row_major(out, "out"), epi_f32=True, **kw)
@@ -124,7 +156,7 @@ def mm_nn_f32(a: torch.Tensor, b: torch.Tensor, **kw) -> torch.Tensor:
         if out is None:
             out = kw["out"] = torch.empty((M, N), device=a.device, dtype=torch.float32)
         if _x3_t_ok(M, N, Kc, out):
-            a3, b3 = split3(a, M, Kc, Kc, 0), split3_t(b, 1, 1)
+            a3, b3 = split3_pair(a, False, b, True)
             kw2 = _ld_kwargs({k: v for k, v in kw.items() if k != "out"}, out)
             return gemm(L.NT, a3, b3, M, N, 3 * Kc, 3 * Kc, 3 * Kc, out, _row_major(out, "out"), epi_f32=True, **kw2)
     return mm_nt(a, transpose(b, 1), **kw)
@@ -150,7 +182,7 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
          mirror: Optional[torch.Tensor] = None, sumsq: Optional[torch.Tensor] = None,
          a2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None) -> torch.Tensor:
     if not epi_f32 and a2 is None and _x3_eligible(layout, a, b, out, M, N, K, lda, ldb, nb):
-        a3, b3 = split3(a, M, K, lda, 0), split3(b, N, K, ldb, 1)
+        a3, b3 = split3_pair(a, False, b, False, a_dims=(M, K, lda), b_dims=(N, K, ldb))
         return gemm(L.NT, a3, b3, M, N, 3 * K, 3 * K, 3 * K, out, ldc, bias=bias, residual=residual, ldr=ldr, act=act,
                     aux_out=aux_out, mulgrad=mulgrad, ldg=ldg, alpha=alpha, accumulate=accumulate, epi_f32=True,
                     mirror=mirror, sumsq=sumsq)

@@ -127,6 +127,19 @@ int dxa_split3(const float* src, int64_t ld, void* dst, int64_t rows, int64_t co
  * the dX = dY W and dW = dY^T X products of the fp32 heads run as NT products of transposed operands (the backward of the
  * reference's autocast(float32) head, cogact_arch.py:133 / dit.py) */
 int dxa_split3_t(const float* src, int64_t ld, void* dst, int64_t R, int64_t C, int64_t Rp, int side, dxa_stream_t stream);
+/* BOTH operands of one such product in ONE launch (each as dxa_split3 or dxa_split3_t would write it): a product of the fp32 heads is
+ * two operand splits + the MFMA launch, and at 1088 rows a split is a few microseconds of work behind a launch's fixed cost — 1,014 of
+ * MemVLA's and 288 of DB-CogACT's launches per step were operand splits.  transposed == 0: rows x cols of src -> dst [rows, 3 cols]
+ * (pad unused); transposed != 0: src [rows, cols] -> dst [cols, 3 pad], pad >= rows (dxa_split3_t's R, C, Rp). */
+typedef struct dxa_split3_op {
+  const float* src;
+  int64_t ld;
+  void* dst;
+  int64_t rows, cols, pad;
+  int32_t side;       /* 0: (hi, hi, lo) — the A operand; 1: (hi, lo, hi) — the B operand */
+  int32_t transposed;
+} dxa_split3_op;
+int dxa_split3_pair(const dxa_split3_op* a, const dxa_split3_op* b, dxa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.  w/b are [cols] in w_dtype (NULL = no affine).

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header_field_order():
     from dexbotic_amd import _lib as L
     src = open(HEADER).read()
     for cname, cls in (("dxa_gemm_desc", L.GemmDesc), ("dxa_attn_desc", L.AttnDesc), ("dxa_adamw_desc", L.AdamWDesc),
-                       ("dxa_decode_desc", L.DecodeDesc)):
+                       ("dxa_decode_desc", L.DecodeDesc), ("dxa_split3_op", L.Split3Op)):
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname, src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

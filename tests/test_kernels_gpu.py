@@ -1393,6 +1393,27 @@ def test_attention_small_f32_backward_one_launch(Sq, Sk, monkeypatch):
         assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-6
 
 
+def test_split3_pair_writes_what_the_single_launches_write():
+    """dxa_split3_pair: both operand splits of a bf16x3 product in one launch — plain / transposed in every combination, ragged
+    extents, a padded transposed operand, an explicit leading dimension — bit for bit what dxa_split3 / dxa_split3_t write"""
+    a = rnd(1088, 768, dtype=torch.float32, seed=70)
+    w = rnd(2304, 768, dtype=torch.float32, seed=71)
+    dy = rnd(1088, 2304, dtype=torch.float32, seed=72)
+    wide = rnd(300, 520, dtype=torch.float32, seed=73)
+    a3, w3 = K.split3_pair(a, False, w, False)
+    assert torch.equal(a3, K.split3(a, 1088, 768, 768, 0)) and torch.equal(w3, K.split3(w, 2304, 768, 768, 1))
+    d3, wt3 = K.split3_pair(dy, False, w, True)                                    # dX = dY W as an NT product against W^T
+    assert torch.equal(d3, K.split3(dy, 1088, 2304, 2304, 0)) and torch.equal(wt3, K.split3_t(w, 1, 1))
+    dt3, at3 = K.split3_pair(dy, True, a, True, pad_to=32)                        # dW = dY^T X
+    assert torch.equal(dt3, K.split3_t(dy, 32, 0)) and torch.equal(at3, K.split3_t(a, 32, 1))
+    assert dt3.shape == (2304, 3 * 1088)
+    r3, s3 = K.split3_pair(wide, True, wide, False, pad_to=32, b_dims=(200, 256, 520))
+    assert r3.shape == (520, 3 * 320) and torch.equal(r3, K.split3_t(wide, 32, 0))
+    assert torch.equal(s3, K.split3(wide, 200, 256, 520, 1))
+    e3, f3 = K.split3_pair(a[:0], False, w, False)                                 # an empty operand is skipped, the other one written
+    assert e3.numel() == 0 and torch.equal(f3, w3)
+
+
 @pytest.mark.parametrize("Sq,Sk,D", [(68, 256, 32), (40, 100, 48), (96, 129, 64)])
 def test_attention_small_f32_backward_register_blocked_token_major(Sq, Sk, D):
     """more than 32 queries per (sample, head): attn_bwd_small2_f32_k (every thread a block of outputs in registers, 16-byte LDS reads;

@@ -82,6 +82,44 @@ def test_memvla_distinct_perceptual_tokens_equal_the_repeated_ones(golden_dir, m
     assert worst < 2e-5
 
 
+def test_memvla_deferred_gradient_folds_equal_the_per_consumer_writes(golden_dir):
+    """what NativeTrainer turns on (ParamStore.defer_wgrad): a parameter the retrieval blocks apply once per sample collects its
+    consumers' (dY, X) pairs, bias dY and LayerNorm partial sums and writes dW / db / (dgamma, dbeta) with ONE product / column sum
+    each (functional._wgrad, _bgrad, _ln_bwd) — against one read-modify-write of the gradient per consumer: same gradients up to the
+    fp32 summation order, every multiply-used slot written, nothing left in the stashes"""
+    res = {}
+    for defer in (False, True):
+        g, cfg, m = build(golden_dir, "float32", True)
+        m.train()
+        st = m.store
+        st.defer_wgrad = defer
+        st.set_expected(m.unused_parameter_names())
+        st.begin_step()
+        out = m(input_ids=T(g["input_ids"]), attention_mask=T(g["attention_mask"]), images=T(g["images"]), actions=T(g["actions"]),
+                indexes=[list(map(int, r)) for r in g["indexes"]], noise=T(g["noise"]), timesteps=T(g["timesteps"]),
+                drop_ids=T(g["drop_u"]) < 0.1)
+        out.loss.backward()
+        assert not st._wg_stash and not st._bg_stash, (list(st._wg_stash), list(st._bg_stash))     # every last consumer arrived
+        st.flush_wgrads()
+        torch.cuda.synchronize()
+        res[defer] = {n: st.g(n).float().cpu().numpy().copy() for n in st.slots if st.grad_written[n]}
+    assert set(res[False]) == set(res[True])
+    bank = [n for n in res[True] if "retrieval_blocks" in n or "gate_fusion" in n or "timestep_embedders" in n]
+    assert any(n.endswith("attn_norm.weight") for n in bank) and any(n.endswith(".bias") for n in bank)
+    # scale of a slot = its own largest gradient, for a bias at least its weight's: the k_proj biases (a constant added to every key
+    # of a softmax: zero gradient) and the last bias of the time embedding (a constant per memory entry) are sums that cancel to
+    # ~1e-11 where the weight's gradient is ~1e-4 — rounding noise, different under every summation order
+    worst = 0.0
+    for n, b in res[False].items():
+        scale = float(np.abs(b).max())
+        if n.endswith(".bias") and n[:-4] + "weight" in res[False]:
+            scale = max(scale, float(np.abs(res[False][n[:-4] + "weight"]).max()))
+        if scale > 0:
+            worst = max(worst, float(np.abs(res[True][n] - b).max()) / scale)
+    print(f"{len(res[True])} gradient slots, {len(bank)} of the memory bank; worst distance deferred vs per consumer {worst:.2e}")
+    assert worst < 2e-5
+
+
 def test_fp32_memvla_training_step_with_retrieval_dropout_matches_reference(golden_dir):
     """retrieval_dropout = 0.1 = how the reference always trains (memvla_arch.py:83, 99-105, 120-123): attention-weight
     dropout inside the attention kernels (dxa_attn_desc.drop_mask) and the two FFN dropouts, with the masks of the golden
