@@ -3,6 +3,8 @@ the MI355X: with ``ParamStore.recompute`` the decoder / vision / pi0 layer Funct
 forward launches inside their backward.  Same kernels in the same order, so the bar is BIT-identical losses and gradient
 arenas against the resident-activation step, fp32 and bf16, plus a lower peak of live device memory at a depth where the kept
 activations dominate."""
+import gc
+
 import numpy as np
 import pytest
 import torch
@@ -20,7 +22,8 @@ def _cogact_step(cfg, w, dtype, b, recompute):
     if recompute:
         m.gradient_checkpointing_enable()
     m.store.begin_step()
-    torch.cuda.synchronize()
+    gc.collect()                       # cyclic garbage of earlier tests (models, graphs) must not be freed in the middle of the measured forward:
+    torch.cuda.synchronize()           # in the whole suite `held` came out NEGATIVE once the collector's timing moved (round 6)
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
     out = m(**b)
