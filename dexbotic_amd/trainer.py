@@ -161,7 +161,7 @@ class NativeTrainer:
         # but a 16-bit dW beside the next dX shares the CUs with it: each launch then takes 400-500 us and the per-launch roofline
         # of section 5 stops meaning anything); 0: everything on the compute stream.  Default per model (``gradient_side_stream``):
         # on for DB-CogACT and — since round 6, when its 7,200 launches stopped being host-bound: 310.7 -> 307.8 ms — for MemVLA
-        # (round 4, 9,000 host-bound launches: 363 -> 372 ms with it, a cross-stream dependency per product) and pi0 (250.0 -> 245.3 ms).
+        # (round 4, 9,000 host-bound launches: 363 -> 372 ms with it, a cross-stream dependency per product) and pi0 (250.0 -> 245.3 ms; round 4, before its host-side waits were removed: 271.3 vs 270.1, profiles/r04_wgrad_stream_pi0.txt).
         mode = os.environ.get("DXA_WGRAD_STREAM", "3" if getattr(model, "gradient_side_stream", False) else "0")
         if mode != "0" and self.store.device.type == "cuda":
             self.store.wgrad_stream = torch.cuda.Stream(device=self.store.device)
