@@ -2087,7 +2087,11 @@ int gemm_dispatch(const dxa_gemm_desc* d, dxa_stream_t stream, bool* mirrored, b
       // the last round would leave NUM_CU - tail CUs idle: cut its tiles along K (>= 16 slabs per piece)
       // (measured: each fp32 partial slot costs ~0.25 us of write-through traffic, so short K does not pay)
       static const int min_nk = getenv("DXA_SPLIT_MIN_NK") ? atoi(getenv("DXA_SPLIT_MIN_NK")) : 64;
-      static const int min_piece = getenv("DXA_SPLIT_MIN_PIECE") ? atoi(getenv("DXA_SPLIT_MIN_PIECE")) : 16;
+      // (min_piece: K slabs of 32 per piece.  16 — rounds 1 - 6 — cut the tail tiles of the step's products and the fp32 head's dW products
+      //  into up to 6 - 7 pieces of 512-deep K; at >= 32 slabs (1024-deep pieces, <= 3 of them at K = 3584) the step is 1.8 - 2.6 ms
+      //  shorter, MemVLA's 2.8 ms, the 287-row request's gate/up 126 -> 119 us: a piece's fp32 partial costs its write-through and read-back
+      //  whoever adds it up (profiles/r06_split_dist.txt).  24: -1.0 ms, 48: -1.3, 64: level, no split at all: +7.5 — profiles/r06_split_knobs.txt)
+      static const int min_piece = getenv("DXA_SPLIT_MIN_PIECE") ? atoi(getenv("DXA_SPLIT_MIN_PIECE")) : 32;
       static const int max_split = getenv("DXA_SPLIT_MAX") ? atoi(getenv("DXA_SPLIT_MAX")) : 8;
       const int s = nk_tot >= min_nk ? std::min(std::min(NUM_CU / tail, max_split), nk_tot / min_piece) : 1;
       if (s >= 2) {
