@@ -340,3 +340,30 @@ def test_adamw_leaves_untouched_embedding_chunks_alone_and_nothing_changes(golde
             assert (st[0] == 2).any() and (st[2][cand] == 1).any()
         else:
             assert (st[2][cand] == 1).all()                                  # decayed every step: never skipped, never promoted
+
+
+def test_graph_capture_holds_the_garbage_collector_off():
+    """graphs.capture: Python's cyclic collector must not run while a stream is capturing (destructors of older models / trainers /
+    graphs that talk to the HIP runtime abort the process in global capture mode — seen once in this suite, round 6) and is
+    switched back on afterwards, also when the captured body raises"""
+    import gc
+
+    from dexbotic_amd import graphs
+    s = torch.cuda.Stream()
+    x = torch.zeros(8, device=DEV)
+    assert gc.isenabled()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with graphs.capture(g, s):
+            assert not gc.isenabled()
+            y = x + 1
+    assert gc.isenabled()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 8.0
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="boom"):
+        with torch.cuda.stream(s):
+            with graphs.capture(g2, s):
+                raise RuntimeError("boom")
+    assert gc.isenabled()
